@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden.py -- generates tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN PYTHON.
+
+Runs only in the build container (it reads /root/reference in place and never copies any
+of it); the GPU box uses the committed .npz fixtures.  Recipe = SURVEY.md appendix A:
+
+  1. chdir to /root/reference (datasets/kitti/kitti_dataset.py:17 opens a relative yaml),
+     sys.dont_write_bytecode (tree is read-only);
+  2. register placeholder modules for the un-installable third-party imports
+     (MinkowskiEngine, pytorch3d, open3d, nksr, pycg, tensorboard);
+  3. pytorch3d.ops.{ball_query,knn_points,knn_gather} are OUR restatement of pytorch3d 0.7.7
+     semantics (oracle/oracle.py) -- the only arithmetic in the goldens that is not the
+     reference's own code ("parity unpinned" at that boundary);
+  4. import utils.loc_utils / utils.eval_utils / evaluate (function bodies only) and call
+     them on seeded synthetic inputs.
+
+A fixture is data: inputs + expected outputs.  Usage:  python oracle/gen_golden.py
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402
+from umeregrobust_amd.synth import synth_pair, synth_scene  # noqa: E402
+
+
+def _t(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _stub_ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True):
+    r = orc.ball_query(p1.numpy(), p2.numpy(),
+                       None if lengths1 is None else lengths1.numpy(),
+                       None if lengths2 is None else lengths2.numpy(), K, radius, return_nn)
+    return orc.BallQuery(_t(r.dists), _t(r.idx), _t(r.knn))
+
+
+def _stub_knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **kw):
+    r = orc.knn_points(p1.numpy(), p2.contiguous().numpy(), K, return_nn)
+    return orc.KNN(_t(r.dists), _t(r.idx), _t(r.knn))
+
+
+def _stub_knn_gather(x, idx, lengths=None):
+    return _t(orc.knn_gather(x.numpy(), idx.numpy()))
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Anything:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return _Anything()
+
+        def __call__(self, *a, **k):
+            return _Anything()
+
+    p3d = mod("pytorch3d")
+    p3d.ops = mod("pytorch3d.ops", ball_query=_stub_ball_query, knn_points=_stub_knn_points,
+                  knn_gather=_stub_knn_gather, sample_farthest_points=_Anything())
+    p3d.structures = mod("pytorch3d.structures", Pointclouds=_Anything, padded_to_list=_Anything())
+    me = mod("MinkowskiEngine", MinkowskiNetwork=torch.nn.Module, utils=_Anything(),
+             SparseTensor=_Anything)
+    me.__getattr__ = lambda name: _Anything()
+    me.MinkowskiFunctional = mod("MinkowskiEngine.MinkowskiFunctional")
+    mod("open3d")
+    mod("nksr")
+    pycg = mod("pycg")
+    pycg.vis = mod("pycg.vis")
+    tb = mod("torch.utils.tensorboard", SummaryWriter=_Anything)
+    torch.utils.tensorboard = tb
+
+
+def import_reference():
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    install_stubs()
+    import utils.loc_utils as loc_utils
+    import utils.eval_utils as eval_utils
+    import evaluate
+    return loc_utils, eval_utils, evaluate
+
+
+def unit_feat(rng, pts, d=32):
+    W = 0.2 * rng.standard_normal((3, d))
+    b = rng.uniform(0, 2 * np.pi, d)
+    f = np.sin(pts.astype(np.float64) @ W + b)
+    return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+
+
+def main():
+    loc_utils, eval_utils, evaluate = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+
+    # ---- G1 ball_query (oracle restatement; parity unpinned) + G2 my_ume_generation -------------
+    rng = np.random.RandomState(1)
+    pts = synth_scene(rng, 2048, 0.3).astype(np.float32)
+    kp_idx = rng.choice(2048, 62, replace=False)
+    kpts = np.concatenate([pts[kp_idx],
+                           np.array([[500.0, 500.0, 500.0]], np.float32),      # empty ball
+                           pts[:1] + np.float32(0.01)], axis=0)                # off-lattice query
+    feat = unit_feat(rng, pts)
+    g1 = dict(pts=pts, kpts=kpts, feat=feat)
+    for tag, (K, r) in dict(a=(16, 5.0), b=(750, 5.0), c=(4, 0.6), d=(64, 50.0)).items():
+        bq = orc.ball_query(kpts[None], pts[None], K=K, radius=r, return_nn=True)
+        assert (orc.ball_query_numpy(kpts, pts, K, r) == bq.idx[0]).all()
+        g1[f"K_{tag}"] = np.int64(K)
+        g1[f"r_{tag}"] = np.float32(r)
+        g1[f"idx_{tag}"] = bq.idx[0].astype(np.int32)
+        g1[f"dists_{tag}"] = bq.dists[0]
+        if K <= 64:
+            g1[f"nn_{tag}"] = bq.knn[0]
+        args = SimpleNamespace(ume_max_nn=K, ume_r_nn=r)
+        with torch.no_grad():
+            F = evaluate.my_ume_generation(_t(pts[None]), _t(kpts[None]), _t(feat[None]), args)
+        g1[f"F_{tag}"] = F[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "g12_ballquery_moments.npz"), **g1)
+    print("G1/G2", {k: v.shape for k, v in g1.items() if hasattr(v, "shape") and v.ndim > 0})
+
+    # ---- G3 ume_cdist + argmin ------------------------------------------------------------------
+    rng = np.random.RandomState(3)
+    p = synth_pair(3, N=4096, n_kp=96, kind="test")
+    args = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0)
+    with torch.no_grad():
+        u1 = evaluate.my_ume_generation(_t(p.src_pts[None]), _t(p.src_pts[p.src_inds[:64]][None]),
+                                        _t(p.src_feat[None]), args)
+        # make the first 32 target keypoints physical twins of source keypoints (true matches)
+        tgt_inds = np.concatenate([p.tgt_twin_of_src[p.src_inds[:32]], p.tgt_inds[:64]])
+        u2 = evaluate.my_ume_generation(_t(p.tgt_pts[None]), _t(p.tgt_pts[tgt_inds][None]),
+                                        _t(p.tgt_feat[None]), args)
+        # degenerate rows: a zero UME (empty ball) and a rank-1 UME
+        u1 = u1.clone(); u2 = u2.clone()
+        u1[0, 63] = 0
+        u2[0, 95, :, 1:] = u2[0, 95, :, :1] * 2.0
+        D = loc_utils.ume_cdist(u1, u2)
+    np.savez_compressed(os.path.join(OUT, "g3_ume_cdist.npz"), ume1=u1[0].numpy(), ume2=u2[0].numpy(),
+                        D=D[0].numpy(), argmin=D[0].min(dim=-1)[1].numpy())
+    print("G3", tuple(D.shape), float(D.min()), float(D.max()))
+
+    # ---- G4 batch_estimate_transform_ume_old ----------------------------------------------------
+    with torch.no_grad():
+        G = u1[0, :32]
+        H = u2[0, :32]                      # true twins -> T ~ gt
+        G2 = u1[0, 32:62]
+        H2 = u2[0, 40:70]                   # mismatched pairs (arbitrary but well-defined T)
+        # reflection case: mirror the target moments in x -> det(U Vh) < 0 branch
+        H3 = H.clone()[:8]
+        H3[:, :, 1] = -H3[:, :, 1]
+        Gall = torch.cat([G, G2, G[:8]], 0).contiguous()
+        Hall = torch.cat([H, H2, H3], 0).contiguous()
+        T, Dd = loc_utils.batch_estimate_transform_ume_old(Gall, Hall)
+    np.savez_compressed(os.path.join(OUT, "g4_rtume.npz"), G=Gall.numpy(), H=Hall.numpy(), T=T.numpy(),
+                        D=Dd.numpy(), gt_tform=p.gt_tform)
+    print("G4", tuple(T.shape), "twin T err", float((T[:32] - _t(p.gt_tform)).abs().max()))
+
+    # ---- G5 relative_rotation_error -------------------------------------------------------------
+    rng = np.random.RandomState(5)
+
+    def rotm(axis, deg):
+        axis = np.asarray(axis, np.float64); axis /= np.linalg.norm(axis)
+        a = np.deg2rad(deg)
+        Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(a) * Kx + (1 - np.cos(a)) * Kx @ Kx
+
+    degs = [0.0, 1e-3, 0.5, 1.0, 1.5, 30.0, 90.0, 179.0, 180.0]
+    Ra, Rb = [], []
+    for dg in degs:
+        base = rotm(rng.standard_normal(3), rng.uniform(0, 360))
+        Ra.append(base)
+        Rb.append(rotm(rng.standard_normal(3), dg) @ base)
+    # non-orthonormal by 1e-6 (clamp path) and trace slightly > 3
+    Ra.append(np.eye(3)); Rb.append(np.eye(3) * (1 + 1e-6))
+    Ra.append(np.eye(3)); Rb.append(-np.eye(3) * (1 + 1e-6) + 2 * np.diag([0, 0, 1.0]))
+    Ra = np.stack(Ra).astype(np.float32); Rb = np.stack(Rb).astype(np.float32)
+    rre = eval_utils.relative_rotation_error(_t(Ra), _t(Rb)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_rre.npz"), R=Ra, R_hat=Rb, rre=rre,
+                        deg=np.array(degs, np.float32))
+    print("G5", rre)
+
+    # ---- G6 config-1 pair: whole named path, injected indices --------------------------------------
+    p = synth_pair(6, N=4096, n_kp=512, kind="rot")
+    n_kp = 512
+    tgt_inds = np.concatenate([p.tgt_twin_of_src[p.src_inds[:256]], p.tgt_inds[:256]])
+    args = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0)
+    with torch.no_grad():
+        ume_src = evaluate.my_ume_generation(_t(p.src_pts[None]), _t(p.src_pts[p.src_inds][None]),
+                                             _t(p.src_feat[None]), args)
+        ume_tgt = evaluate.my_ume_generation(_t(p.tgt_pts[None]), _t(p.tgt_pts[tgt_inds][None]),
+                                             _t(p.tgt_feat[None]), args)
+        D = loc_utils.ume_cdist(ume_src, ume_tgt)
+        m = D.min(dim=-1)[1]                                                  # evaluate.py:224
+        ume_d = D[0, torch.arange(n_kp), m[0]]                                # :234
+        a = torch.exp((1 - ume_d) / 0.05)                                     # :235
+        prob = a / a.sum()                                                    # :236
+        np.random.seed(6)
+        cond = np.random.choice(n_kp, 128, replace=False, p=prob.numpy())     # :238
+        Gm = ume_src[0, cond]
+        Hm = ume_tgt[0, m[0, cond]]
+        T, _ = loc_utils.batch_estimate_transform_ume_old(Gm.contiguous(), Hm.contiguous())
+        R_gt = _t(p.gt_tform[None, :3, :3]).expand(T.shape[0], -1, -1)
+        rre = eval_utils.relative_rotation_error(T[:, :3, :3], R_gt)
+        rte = (T[:, :3, 3] - _t(p.gt_tform[:3, 3])).norm(dim=-1)
+    np.savez_compressed(
+        os.path.join(OUT, "g6_pair_k1.npz"),
+        src_pts=p.src_pts, tgt_pts=p.tgt_pts, src_feat=p.src_feat, tgt_feat=p.tgt_feat,
+        gt_tform=p.gt_tform, src_inds=p.src_inds.astype(np.int32), tgt_inds=tgt_inds.astype(np.int32),
+        ume_src=ume_src[0].numpy(), ume_tgt=ume_tgt[0].numpy(),
+        match=m[0].numpy().astype(np.int32), match_d=ume_d.numpy(), prob=prob.numpy(),
+        cond=cond.astype(np.int32), T=T.numpy(), rre=rre.numpy(), rte=rte.numpy())
+    print("G6 matches correct (first 256 twins):", float((m[0, :256] == torch.arange(256)).float().mean()),
+          "| rre med/max", float(rre.median()), float(rre.max()), "| rte med/max", float(rte.median()), float(rte.max()))
+
+    # ---- G7 (f1) FeatureCorrelator / feature_spatial_var / pc_corr ---------------------------------
+    p = synth_pair(7, N=512, n_kp=64, kind="test", voxel=0.6)
+    rng = np.random.RandomState(7)
+    Ts = [p.gt_tform.astype(np.float64)]
+    for i in range(7):
+        dT = np.eye(4)
+        dT[:3, :3] = rotm(rng.standard_normal(3), rng.uniform(0.2, 8.0))
+        dT[:3, 3] = rng.standard_normal(3) * 0.4
+        Ts.append(dT @ p.gt_tform.astype(np.float64))
+    order = rng.permutation(8)
+    Ts = np.stack(Ts)[order].astype(np.float32)
+    with torch.no_grad():
+        fsv = loc_utils.feature_spatial_var(_t(p.src_pts[None]), _t(p.src_feat[None]), knn=50)
+        fc = loc_utils.FeatureCorrelator(sigma=1.5, batch=3, n_hypotheses=10)
+        # scores: re-run the pieces the way feature_corr_hypothesis_test does (loc_utils.py:656-681)
+        sf, tf = _t(p.src_feat[None]), _t(p.tgt_feat[None])
+        mm = torch.mean(torch.concat((sf, tf), dim=1), dim=1)
+        wsf = (sf - mm) * loc_utils.feature_spatial_var(_t(p.src_pts[None]), sf, knn=50).unsqueeze(-1)
+        wtf = (tf - mm) * loc_utils.feature_spatial_var(_t(p.tgt_pts[None]), tf, knn=50).unsqueeze(-1)
+        Tt = _t(Ts)
+        score = loc_utils.pc_corr_cost_pytorch3d(Tt[:, :3, :3], Tt[:, :3, 3], _t(p.src_pts), _t(p.tgt_pts),
+                                                 20, wsf.squeeze(), wtf.squeeze(), 1.5, None,
+                                                 use_norm=False, src_norm=None, tgt_norm=None, dev="cpu")
+        best = fc.feature_corr_hypothesis_test(_t(p.src_pts[None]), _t(p.tgt_pts[None]), sf, tf, Tt)
+    np.savez_compressed(os.path.join(OUT, "g7_feature_corr.npz"), src_pts=p.src_pts, tgt_pts=p.tgt_pts,
+                        src_feat=p.src_feat, tgt_feat=p.tgt_feat, T_hyp=Ts, fsv_src=fsv[0].numpy(),
+                        score=score.numpy(), best_T=best.numpy(), gt_index=np.int64(np.where(order == 0)[0][0]))
+    print("G7 scores", score.numpy(), "best is gt:", bool(torch.allclose(best, _t(Ts[np.where(order == 0)[0][0]]))))
+
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,302 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY (CPU checker for the HIP kernels).
+
+A CPU restatement of UMERegRobust's registration hot path
+(reference evaluate.py:50-60, 206-254; utils/loc_utils.py:8-15, 292-350;
+utils/eval_utils.py:60-76).  Heavy scan loops are plain C (oracle/ume_oracle.c,
+loaded through ctypes); everything else is numpy calling the same LAPACK/BLAS
+classes torch's CPU backend dispatches to, written line-for-line against the
+reference statements it restates (each function cites them).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package (umeregrobust_amd/) never does and has no CPU
+fallback.
+
+Parity status: pinned against the reference's own Python, executed in the build
+container by oracle/gen_golden.py (fixtures in tests/golden/), for every function
+below EXCEPT the pytorch3d ops (ball_query / knn_points / knn_gather): pytorch3d
+0.7.7 is an un-vendored dependency (reference requirements.txt:3) that cannot be
+installed here, so those restate its published semantics -- "parity unpinned" at
+that boundary.
+"""
+import ctypes
+import os
+import subprocess
+from collections import namedtuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libume_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile oracle/ume_oracle.c with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "ume_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libume_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        for name in ("orc_ball_query_f32", "orc_ume_moments_f32", "orc_orthobasis_f64",
+                     "orc_ume_cdist_f64", "orc_knn_points_f32"):
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+BallQuery = namedtuple("BallQuery", "dists idx knn")
+KNN = namedtuple("KNN", "dists idx knn")
+
+
+# ---------------------------------------------------------------------------------------------
+# a1  pytorch3d.ops.ball_query (reference call sites evaluate.py:51, utils/loc_utils.py:383-384)
+# ---------------------------------------------------------------------------------------------
+def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True):
+    """First K points of p2 *in index order* with |p1-p2|^2 < radius^2 (strict, fp32).
+    p1 [B,n1,3], p2 [B,n2,3] -> dists f32 [B,n1,K] (0 pad), idx i64 [B,n1,K] (-1 pad),
+    knn f32 [B,n1,K,3] (0 pad) or None."""
+    p1 = _f32(p1); p2 = _f32(p2)
+    B, n1, _ = p1.shape
+    n2 = p2.shape[1]
+    idx = np.empty((B, n1, K), np.int64)
+    dists = np.empty((B, n1, K), np.float32)
+    nn = np.empty((B, n1, K, 3), np.float32) if return_nn else None
+    for b in range(B):
+        l1 = -1 if lengths1 is None else int(lengths1[b])
+        l2 = -1 if lengths2 is None else int(lengths2[b])
+        rc = lib().orc_ball_query_f32(_p(p1[b]), _p(p2[b]), ctypes.c_int64(n1), ctypes.c_int64(n2),
+                                      ctypes.c_int64(l1), ctypes.c_int64(l2), ctypes.c_int(K),
+                                      ctypes.c_float(radius), _p(idx[b]), _p(dists[b]),
+                                      _p(nn[b]) if return_nn else None)
+        assert rc == 0
+    return BallQuery(dists, idx, nn)
+
+
+def ball_query_numpy(p1, p2, K, radius):
+    """Independent vectorised restatement of the same semantics;
+    used only to cross-check the C loop.  Single batch element: p1 [n1,3], p2 [n2,3]."""
+    p1 = _f32(p1); p2 = _f32(p2)
+    n1, n2 = p1.shape[0], p2.shape[0]
+    r2 = np.float32(radius) * np.float32(radius)
+    idx = np.full((n1, K), -1, np.int64)
+    for s in range(0, n1, 256):
+        q = p1[s:s + 256]
+        dx = q[:, None, 0] - p2[None, :, 0]
+        dy = q[:, None, 1] - p2[None, :, 1]
+        dz = q[:, None, 2] - p2[None, :, 2]
+        d2 = dx * dx
+        d2 = d2 + dy * dy
+        d2 = d2 + dz * dz
+        within = d2 < r2
+        rank = np.cumsum(within, axis=1) - 1
+        keep = within & (rank < K)
+        ii, jj = np.nonzero(keep)
+        idx[s + ii, rank[ii, jj]] = jj
+    return idx
+
+
+# ---------------------------------------------------------------------------------------------
+# pytorch3d.ops.knn_points / knn_gather (utils/loc_utils.py:580-581,623; evaluate.py:272-275)
+# ---------------------------------------------------------------------------------------------
+def knn_points(p1, p2, K=1, return_nn=False):
+    p1 = _f32(p1); p2 = _f32(p2)
+    B, n1, _ = p1.shape
+    n2 = p2.shape[1]
+    dists = np.empty((B, n1, K), np.float32)
+    idx = np.empty((B, n1, K), np.int64)
+    for b in range(B):
+        rc = lib().orc_knn_points_f32(_p(p1[b]), _p(p2[b]), ctypes.c_int64(n1), ctypes.c_int64(n2),
+                                      ctypes.c_int(K), _p(dists[b]), _p(idx[b]))
+        assert rc == 0
+    nn = knn_gather(p2, idx) if return_nn else None
+    return KNN(dists, idx, nn)
+
+
+def knn_gather(x, idx):
+    """x [B,M,U], idx [B,L,K] -> [B,L,K,U]."""
+    x = np.asarray(x)
+    B = x.shape[0]
+    return np.stack([x[b][idx[b]] for b in range(B)], axis=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# a1+a2  evaluate.py:50-60  my_ume_generation
+# ---------------------------------------------------------------------------------------------
+def my_ume_generation(pts, kpts, feat, ume_max_nn=750, ume_r_nn=5.0):
+    """Statement-by-statement numpy restatement (fp32), for small cases.
+    pts [B,N,3], kpts [B,n,3], feat [B,N,32] -> F [B,n,32,4]."""
+    pts = _f32(pts); kpts = _f32(kpts); feat = _f32(feat)
+    _, bq_idxs, bq_nn = ball_query(kpts, pts, K=ume_max_nn, radius=ume_r_nn, return_nn=True)
+    bq_idxs = bq_idxs.copy()
+    bq_idxs[bq_idxs == -1] = pts.shape[1]                                    # evaluate.py:52
+    feat_pad = np.concatenate([feat, np.zeros_like(feat[:, :1, :])], axis=1)  # :53
+    nn_feat = np.stack([feat_pad[b][bq_idxs[b]] for b in range(pts.shape[0])])  # :54-55 [B,n,K,32]
+    nn_feat_t = np.swapaxes(nn_feat, -1, -2)
+    F1 = nn_feat_t @ bq_nn                                                   # :56
+    F0 = nn_feat_t.sum(axis=-1, keepdims=True, dtype=np.float32)             # :57
+    F = np.concatenate([F0, F1], axis=-1)                                    # :58
+    F = F / (F0.sum(axis=-2, keepdims=True, dtype=np.float32) + np.float32(1e-6))  # :59
+    return F.astype(np.float32)
+
+
+def ume_moments(pts, kpts, feat, K=750, radius=5.0, accum="f64", return_count=False):
+    """C loop (OpenMP) version of the same computation for KITTI-sized inputs.
+    Single batch element: pts [N,3], kpts [n,3], feat [N,d].
+    accum='f32' : fp32 accumulation in neighbour order (the reference's arithmetic class)
+    accum='f64' : fp64 accumulation, rounded once (what the HIP kernel computes)."""
+    pts = _f32(pts); kpts = _f32(kpts); feat = _f32(feat)
+    N, n, d = pts.shape[0], kpts.shape[0], feat.shape[1]
+    F = np.empty((n, d, 4), np.float32)
+    cnt = np.empty((n,), np.int32)
+    rc = lib().orc_ume_moments_f32(_p(pts), _p(kpts), _p(feat), ctypes.c_int64(N), ctypes.c_int64(n),
+                                   ctypes.c_int(d), ctypes.c_int(K), ctypes.c_float(radius),
+                                   ctypes.c_int(1 if accum == "f64" else 0), _p(F), _p(cnt))
+    assert rc == 0
+    return (F, cnt) if return_count else F
+
+
+# ---------------------------------------------------------------------------------------------
+# a3  utils/loc_utils.py:8-15  ume_cdist
+# ---------------------------------------------------------------------------------------------
+def _cdist_mm(x1, x2):
+    """torch.cdist(p=2) 'use_mm_for_euclid_dist' path (taken whenever a side has > 25 rows):
+    ||x||^2 + ||y||^2 - 2 x.y by one augmented matmul, clamp_min(0), sqrt -- fp32."""
+    x1 = _f32(x1); x2 = _f32(x2)
+    x1n = (x1 * x1).sum(-1, keepdims=True, dtype=np.float32)
+    x2n = (x2 * x2).sum(-1, keepdims=True, dtype=np.float32)
+    a = np.concatenate([np.float32(-2) * x1, x1n, np.ones_like(x1n)], axis=-1)
+    b = np.concatenate([x2, np.ones_like(x2n), x2n], axis=-1)
+    r = a @ np.swapaxes(b, -1, -2)
+    return np.sqrt(np.maximum(r, np.float32(0)))
+
+
+def ume_cdist(ume1, ume2):
+    """Reference-faithful fp32 restatement: reduced QR -> P = QQ^T -> cdist / sqrt(2).
+    ume1 [B,n1,32,4], ume2 [B,n2,32,4] -> D [B,n1,n2] f32."""
+    ume1 = _f32(ume1); ume2 = _f32(ume2)
+    Q1 = np.linalg.qr(ume1, mode="reduced")[0]                   # loc_utils.py:9
+    P1 = Q1 @ np.swapaxes(Q1, -1, -2)                            # :10
+    Q2 = np.linalg.qr(ume2, mode="reduced")[0]                   # :11
+    P2 = Q2 @ np.swapaxes(Q2, -1, -2)                            # :12
+    B = ume1.shape[0]
+    D = _cdist_mm(P1.reshape(B, P1.shape[1], -1), P2.reshape(B, P2.shape[1], -1))
+    return (D / np.float32(np.sqrt(2))).astype(np.float32)       # :13
+
+
+def ume_cdist_f64(ume1, ume2):
+    """fp64 truth of the same quantity from the same fp32 inputs (Householder in fp64,
+    D = sqrt(max(4 - |Q1^T Q2|_F^2, 0))).  Single batch element [n,32,4]."""
+    ume1 = _f32(ume1); ume2 = _f32(ume2)
+    n1, n2, d = ume1.shape[0], ume2.shape[0], ume1.shape[1]
+    D = np.empty((n1, n2), np.float64)
+    rc = lib().orc_ume_cdist_f64(_p(ume1), _p(ume2), ctypes.c_int64(n1), ctypes.c_int64(n2),
+                                 ctypes.c_int(d), _p(D))
+    assert rc == 0
+    return D
+
+
+def orthobasis_f64(ume):
+    ume = _f32(ume)
+    n, d = ume.shape[0], ume.shape[1]
+    Q = np.empty((n, d, 4), np.float64)
+    rc = lib().orc_orthobasis_f64(_p(ume), ctypes.c_int64(n), ctypes.c_int(d), _p(Q))
+    assert rc == 0
+    return Q
+
+
+# ---------------------------------------------------------------------------------------------
+# a4/a5  evaluate.py:224-245  row arg-min matching and softmax-weighted sub-sampling
+# ---------------------------------------------------------------------------------------------
+def row_argmin(D):
+    """m = D.min(dim=-1)[1] (evaluate.py:224): first index of the row minimum."""
+    return np.argmin(D, axis=-1).astype(np.int64)
+
+
+def match_prob(ume_d, tau):
+    """a = exp((1 - d)/tau); prob = a / a.sum()  (evaluate.py:235-236), fp32."""
+    ume_d = _f32(ume_d)
+    a = np.exp((np.float32(1) - ume_d) / np.float32(tau)).astype(np.float32)
+    return (a / a.sum(dtype=np.float32)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# a6  utils/loc_utils.py:292-350  batch_estimate_transform_ume_old
+# ---------------------------------------------------------------------------------------------
+def batch_estimate_transform_ume_old(G, H, with_dist=True):
+    """G (source UME), H (target UME): f32 [bs,32,4] -> T f32 [bs,4,4] (maps source -> target), D [bs]."""
+    G = _f32(G); H = _f32(H)
+    bs = G.shape[0]
+    f1 = np.float32
+    mg = G[:, :, 0:1]                                            # :304
+    mh = H[:, :, 0:1]                                            # :305
+    g = G[:, :, 1:]                                              # :308
+    h = H[:, :, 1:]                                              # :309
+    mg_square = (mg ** 2).sum(axis=1, keepdims=True, dtype=np.float32) + f1(1e-16)  # :312
+    mg_mh = (mg * mh).sum(axis=1, keepdims=True, dtype=np.float32)                   # :313
+    gmg = (g * mg).sum(axis=1, keepdims=True, dtype=np.float32)                      # :314
+    hmg = (h * mg).sum(axis=1, keepdims=True, dtype=np.float32)                      # :315
+    wlc = gmg / (mg_square + f1(1e-16))                          # :319
+    wrc = hmg / (mg_mh + f1(1e-16))                              # :320
+    left = g - wlc * mg                                          # :322
+    right = h - wrc * mh                                         # :323
+    M = np.swapaxes(right, 2, 1) @ left                          # :325
+    U, S, VH = np.linalg.svd(np.swapaxes(M, 2, 1))               # :326
+    Q = np.tile(np.eye(3, dtype=np.float32), (bs, 1, 1))         # :327
+    Q[:, 2, 2] = np.sign(np.linalg.det(U @ VH))                  # :328
+    R = (U @ Q @ VH).astype(np.float32)                          # :329
+    b2 = wrc - wlc @ R                                           # :332
+    T = np.tile(np.eye(4, dtype=np.float32), (bs, 1, 1))         # :347
+    T[:, :3, :3] = np.swapaxes(R, 2, 1)                          # :348 (via D_R[:,1:,1:] = R)
+    T[:, :3, 3] = b2[:, 0, :]                                    # :349
+    D = None
+    if with_dist:
+        H_orth = np.linalg.qr(H, mode="reduced")[0]              # :338
+        H_HT = H_orth @ np.swapaxes(H_orth, 1, 2)                # :339
+        G_orth = np.linalg.qr(G, mode="reduced")[0]              # :341
+        G_GT = G_orth @ np.swapaxes(G_orth, 1, 2)                # :342
+        D = (f1(0.707) * np.linalg.norm(H_HT - G_GT, ord="fro", axis=(1, 2))).astype(np.float32)  # :344
+    return T.astype(np.float32), D
+
+
+# ---------------------------------------------------------------------------------------------
+# a7  utils/eval_utils.py:60-76  relative_rotation_error
+# ---------------------------------------------------------------------------------------------
+def relative_rotation_error(R, R_hat):
+    R = _f32(R); R_hat = _f32(R_hat)
+    delta_R = R_hat @ np.swapaxes(R, 1, 2)                       # :62
+    tr = np.einsum("bii->b", delta_R).astype(np.float32)         # :65
+    tr = np.clip(tr, np.float32(-1), np.float32(3))              # :68
+    err = np.arccos((tr - np.float32(1)) / np.float32(2))        # :71
+    return (err * (np.float32(180) / np.float32(3.141592653589793))).astype(np.float32)  # :74
+
+
+# ---------------------------------------------------------------------------------------------
+# whole named path for one pair (evaluate.py:206-254), injected indices instead of host RNG
+# ---------------------------------------------------------------------------------------------
+def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds, cond=None,
+                  K=750, radius=5.0, accum="f32"):
+    """Returns dict(ume_src, ume_tgt, match, match_d, T).  Arrays are single-pair (no batch dim).
+    cond: indices kept by the tau-weighted sub-sampling (evaluate.py:238); None = keep all."""
+    src_kp = _f32(src_pts)[src_inds]
+    tgt_kp = _f32(tgt_pts)[tgt_inds]
+    ume_src = ume_moments(src_pts, src_kp, src_feat, K, radius, accum)
+    ume_tgt = ume_moments(tgt_pts, tgt_kp, tgt_feat, K, radius, accum)
+    D = ume_cdist(ume_src[None], ume_tgt[None])[0]
+    m = row_argmin(D)
+    d = D[np.arange(D.shape[0]), m]
+    sel = np.arange(D.shape[0]) if cond is None else np.asarray(cond)
+    T, _ = batch_estimate_transform_ume_old(ume_src[sel], ume_tgt[m[sel]], with_dist=False)
+    return dict(ume_src=ume_src, ume_tgt=ume_tgt, match=m, match_d=d.astype(np.float32), T=T)

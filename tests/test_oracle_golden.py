@@ -1,0 +1,129 @@
+"""CPU: pins the oracle (oracle/oracle.py + ume_oracle.c) to golden vectors produced by the
+reference's own Python (oracle/gen_golden.py).  No GPU, no /root/reference at run time."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.conftest import load_golden
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_ball_query_c_vs_numpy_vs_golden(tag):
+    g = load_golden("g12_ballquery_moments.npz")
+    K, r = int(g[f"K_{tag}"]), float(g[f"r_{tag}"])
+    bq = orc.ball_query(g["kpts"][None], g["pts"][None], K=K, radius=r, return_nn=True)
+    # bit-exact indices: C loop == vectorised numpy restatement == committed fixture
+    assert np.array_equal(bq.idx[0], g[f"idx_{tag}"].astype(np.int64))
+    assert np.array_equal(orc.ball_query_numpy(g["kpts"], g["pts"], K, r), bq.idx[0])
+    assert np.array_equal(bq.dists[0], g[f"dists_{tag}"])
+    if f"nn_{tag}" in g:
+        assert np.array_equal(bq.knn[0], g[f"nn_{tag}"])
+    # semantics: ascending indices, -1 padding at the tail, empty ball row is all -1
+    idx = bq.idx[0]
+    for row in idx:
+        v = row[row >= 0]
+        assert np.all(np.diff(v) > 0)
+        assert np.all(row[len(v):] == -1)
+    assert np.all(idx[62] == -1)          # keypoint at (500,500,500)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_moments_vs_reference(tag):
+    """my_ume_generation (reference evaluate.py:50-60) golden vs the three oracle forms."""
+    g = load_golden("g12_ballquery_moments.npz")
+    K, r = int(g[f"K_{tag}"]), float(g[f"r_{tag}"])
+    F_ref = g[f"F_{tag}"]
+    F_np = orc.my_ume_generation(g["pts"][None], g["kpts"][None], g["feat"][None], K, r)[0]
+    F_32 = orc.ume_moments(g["pts"], g["kpts"], g["feat"], K, r, accum="f32")
+    F_64, cnt = orc.ume_moments(g["pts"], g["kpts"], g["feat"], K, r, accum="f64", return_count=True)
+    assert np.array_equal(cnt, (g[f"idx_{tag}"] >= 0).sum(-1))
+    # scale per keypoint: entries are O(|p|) after normalisation; compare relative to the row max
+    scale = np.abs(F_ref).max(axis=(1, 2), keepdims=True) + 1e-30
+    for F in (F_np, F_32, F_64):
+        err = np.abs(F - F_ref) / scale
+        assert err.max() < 2e-4, err.max()
+        assert np.median(err) < 2e-6
+    # empty ball -> exact zeros in every form (0 / 1e-6)
+    for F in (F_ref, F_np, F_32, F_64):
+        assert np.all(F[62] == 0)
+
+
+def well_conditioned(ume, max_cond=1e6):
+    s = np.linalg.svd(ume.astype(np.float64), compute_uv=False)
+    return s[:, -1] * max_cond > s[:, 0]
+
+
+def test_ume_cdist_vs_reference():
+    g = load_golden("g3_ume_cdist.npz")
+    D = orc.ume_cdist(g["ume1"][None], g["ume2"][None])[0]
+    D64 = orc.ume_cdist_f64(g["ume1"], g["ume2"])
+    # Rank-deficient UMEs (flat-ground balls: every neighbour on one lattice z => rank 3; the
+    # injected zero / rank-1 rows) have noise-defined trailing basis vectors in ANY fp32 QR,
+    # the reference's included -> compare only well-conditioned pairs.
+    ok = np.outer(well_conditioned(g["ume1"]), well_conditioned(g["ume2"]))
+    assert ok.mean() > 0.8 and not ok[63].any() and not ok[:, 95].any()
+    # fp32 projector/cdist form has ~1e-3 absolute noise near D ~ 0
+    assert np.abs(D - g["D"])[ok].max() < 3e-3
+    assert np.abs(D64 - g["D"])[ok].max() < 3e-3
+    am = orc.row_argmin(np.where(ok, D, 9.0))
+    am_ref = orc.row_argmin(np.where(ok, g["D"], 9.0))
+    rows = ok.any(axis=1)
+    assert (am[rows] == am_ref[rows]).mean() >= 0.98
+    assert np.array_equal(am[:32], np.arange(32))          # physical twins are the matches
+    assert np.array_equal(orc.row_argmin(D64)[:32], np.arange(32))
+    # zero UME against well-conditioned ones: LAPACK tau = 0 -> Q = I[:, :4]; the fp64
+    # Householder follows the same convention
+    assert np.abs(D64[63] - g["D"][63])[ok[0]].max() < 3e-3
+
+
+def test_rtume_vs_reference():
+    g = load_golden("g4_rtume.npz")
+    T, D = orc.batch_estimate_transform_ume_old(g["G"], g["H"])
+    assert np.abs(T[:, :3, :3] - g["T"][:, :3, :3]).max() < 2e-5
+    # translation noise floor of the fp32 reference itself
+    dt = np.abs(T[:, :3, 3] - g["T"][:, :3, 3])
+    assert dt[:32].max() < 1e-4 and np.median(dt) < 1e-4
+    assert np.all(T[:, 3] == np.array([0, 0, 0, 1], np.float32))
+    assert np.abs(D - g["D"]).max() < 3e-3
+    # first 32 are physical twins: recovers the ground-truth transform
+    assert np.abs(T[:32] - g["gt_tform"]).max() < 2e-4
+    # reflection inputs still give proper rotations (det fix, loc_utils.py:327-329)
+    assert np.allclose(np.linalg.det(T[62:, :3, :3].astype(np.float64)), 1.0, atol=1e-5)
+
+
+def test_rre_vs_reference():
+    g = load_golden("g5_rre.npz")
+    rre = orc.relative_rotation_error(g["R"], g["R_hat"])
+    # acos amplifies 1-ulp trace differences near 0 and 180 deg
+    assert np.abs(rre - g["rre"]).max() < 0.05
+    assert np.abs(rre[2:8] - g["deg"][2:8]).max() < 2e-2
+
+
+def test_pair_k1_whole_path():
+    """Config 1 (BASELINE.json configs[0]): 4k-point pair, known SE(3), injected indices."""
+    g = load_golden("g6_pair_k1.npz")
+    out = orc.register_pair(g["src_pts"], g["tgt_pts"], g["src_feat"], g["tgt_feat"],
+                            g["src_inds"], g["tgt_inds"], cond=g["cond"], accum="f32")
+    assert (out["match"] == g["match"]).mean() >= 0.995
+    same = out["match"] == g["match"]
+    assert np.abs(out["match_d"] - g["match_d"])[same].max() < 3e-3
+    prob = orc.match_prob(g["match_d"], 0.05)
+    assert np.allclose(prob, g["prob"], rtol=1e-4, atol=1e-12)
+    ok = same[g["cond"]]
+    T, Tg = out["T"][ok], g["T"][ok]
+    assert np.abs(T[:, :3, :3] - Tg[:, :3, :3]).max() < 1e-4
+    dt = np.abs(T[:, :3, 3] - Tg[:, :3, 3])
+    assert np.median(dt) < 1e-4 and dt.max() < 2e-3
+    rre = orc.relative_rotation_error(T[:, :3, :3], np.broadcast_to(g["gt_tform"][:3, :3], T[:, :3, :3].shape))
+    assert np.median(rre) < 0.1
+
+
+def test_knn_points_matches_bruteforce():
+    rng = np.random.RandomState(0)
+    a = rng.standard_normal((1, 50, 3)).astype(np.float32)
+    b = rng.standard_normal((1, 200, 3)).astype(np.float32)
+    r = orc.knn_points(a, b, K=7)
+    d2 = ((a[0][:, None, :].astype(np.float64) - b[0][None].astype(np.float64)) ** 2).sum(-1)
+    ref = np.argsort(d2, axis=1, kind="stable")[:, :7]
+    assert np.array_equal(r.idx[0], ref)
+    assert np.all(np.diff(r.dists[0], axis=1) >= 0)
