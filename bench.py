@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the UMERegRobust registration hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one pass of the named hot path over one synthetic
+KITTI-shaped registration pair whose inputs are already resident in HBM: keypoint gather ->
+fused ball-query + UME moments (x2 clouds) -> orthonormal bases -> MFMA subspace-distance GEMM with
+fused row arg-min -> match probabilities -> tau-weighted sub-sampling (host numpy RNG, like the
+reference evaluate.py:238) -> closed-form SE(3) per match -> RRE/RTE of every hypothesis.
+Pairs are independent, so N GPUs run N disjoint pair streams (weak scaling); the only collective
+is the final all-reduce of the metric counters.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="KT", choices=["K1", "KT", "NS", "SY"])
+    ap.add_argument("--kind", default="test", choices=["test", "rot"])
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=1, help="pairs timed by the CPU baseline leg")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    import umeregrobust_amd
+    from umeregrobust_amd import evaluate, ops
+    from umeregrobust_amd.dist import RegistrationMetrics, init_distributed
+    from umeregrobust_amd.synth import CONFIGS, synth_pair
+    from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
+
+    rank, local_rank, world = init_distributed()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    umeregrobust_amd.require_native()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = CONFIGS[a.config]
+    args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path(
+        "nuscenes_test" if a.config == "NS" else "kitti_test"))
+    args.ume_n_samples = cfg["M"]
+    args.filter_by_ume_dist_cond = cfg["filter_by_ume_dist_cond"]
+    n_kp = cfg["n_kp"] if args.filter_by_ume_dist_cond else min(cfg["n_kp"], args.ume_n_samples)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------
+    pool = []
+    for i in range(max(1, a.pool)):
+        p = synth_pair(seed=1000 * rank + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"])
+        t = lambda x: torch.from_numpy(x).to(dev)
+        pool.append(SimpleNamespace(
+            host=p, src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
+            tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
+            R_gt=t(p.gt_tform[:3, :3]).contiguous(), t_gt=t(p.gt_tform[:3, 3]).contiguous()))
+    # neighbour counts (for the algorithmic-bytes roofline), outside the timed region
+    for e in pool:
+        e.mom_bytes = []
+        for pts, inds, feat in ((e.src_pts, e.src_inds, e.src_feat), (e.tgt_pts, e.tgt_inds, e.tgt_feat)):
+            _, cnt = ops.ume_moments(pts, pts[:, inds], feat, args.ume_max_nn, args.ume_r_nn, return_count=True)
+            e.mom_bytes.append(float((140.0 * cnt.double() + 524.0).sum().item()))
+    dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
+
+    rng = np.random.RandomState(1234 + rank)
+    counts = torch.zeros(4, dtype=torch.float64, device=dev)   # hypotheses, ok(1.5,0.6), ok(1.5,0.3), ok(1,0.1)
+    timing = {"moments": [], "dist": []}
+    mom_bytes_log = []
+
+    def step(i, record):
+        e = pool[i % len(pool)]
+        out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=rng,
+                                     src_inds=e.src_inds, tgt_inds=e.tgt_inds, timing=timing if record else None)
+        T = out.rtume_tform[0]
+        rre = ops.rre_deg(T[:, :3, :3].contiguous(), e.R_gt[None].expand(T.shape[0], -1, -1).contiguous())
+        rte = (T[:, :3, 3] - e.t_gt).norm(dim=-1)
+        counts.add_(torch.stack([torch.tensor(float(T.shape[0]), device=dev, dtype=torch.float64),
+                                 ((rre <= 1.5) & (rte <= 0.6)).sum().double(),
+                                 ((rre <= 1.5) & (rte <= 0.3)).sum().double(),
+                                 ((rre <= 1.0) & (rte <= 0.1)).sum().double()]))
+        if record:
+            mom_bytes_log.extend(e.mom_bytes)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i, False)
+    counts.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (48 B class)
+
+    # ---- per-kernel durations measured live with events on the launch stream -----------------------
+    mom_ms = [s.elapsed_time(e_) for s, e_ in timing["moments"]]
+    dist_ms = [s.elapsed_time(e_) for s, e_ in timing["dist"]]
+    mom_total_ms, dist_total_ms = float(np.sum(mom_ms)), float(np.sum(dist_ms))
+    mom_gbs = float(np.sum(mom_bytes_log)) / (mom_total_ms * 1e-3) / 1e9
+    dist_tfs = dist_flops * len(dist_ms) / (dist_total_ms * 1e-3) / 1e12
+    roof_mom = {"kernel": "ume_moments_kernel", "bound": "hbm", "achieved": round(mom_gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
+                "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0)}
+    roof_dist = {"kernel": "ume_dist_kernel", "bound": "mfma", "achieved": round(dist_tfs, 2),
+                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dist_tfs / MFMA_F32_PEAK_TFLOPS, 4),
+                 "traffic": None, "avg_launch_ms": round(float(np.mean(dist_ms)), 4), "launches": len(dist_ms),
+                 "algorithmic_flops_per_launch": dist_flops, "d_used": "512-equivalent (Q-form), fp32 MFMA"}
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")      # filled from rocprofv3 --pmc passes, if present
+    if os.path.exists(pmc):
+        tr = json.load(open(pmc))
+        roof_mom["traffic"] = tr.get("ume_moments_kernel")
+        roof_dist["traffic"] = tr.get("ume_dist_kernel")
+    dominant = roof_mom if mom_total_ms >= dist_total_ms else roof_dist
+
+    total_pairs = a.steps * world
+    c = counts.cpu().numpy()
+    result = {
+        "metric": "registration_pairs_per_s", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.config}: named hot path a1-a7 on synthetic KITTI-shaped pairs "
+                               f"(N={cfg['N']} pts/cloud, {n_kp} keypoints/cloud, K={args.ume_max_nn}, r={args.ume_r_nn} m, "
+                               f"d=32, M={args.ume_n_samples} hypotheses, tau={args.tau}, kind={a.kind})",
+                   "pairs_per_step_per_gpu": 1, "sharding": f"pairs[rank::{world}] (no data-path collective)",
+                   "sampler": "host numpy RNG (reference evaluate.py:238)"},
+        "roofline": dominant,
+        "rooflines": {"ume_moments_kernel": roof_mom, "ume_dist_kernel": roof_dist},
+        "hypothesis_quality": {"hypotheses": int(c[0]), "within_1.5deg_0.6m": round(c[1] / max(c[0], 1), 4),
+                               "within_1.5deg_0.3m": round(c[2] / max(c[0], 1), 4),
+                               "within_1deg_0.1m": round(c[3] / max(c[0], 1), 4),
+                               "note": "fraction of RTUME hypotheses (not selected registrations) inside each gate"},
+    }
+
+    # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.lib()
+        t_cpu = 0.0
+        for i in range(a.cpu_pairs):
+            p = pool[i % len(pool)].host
+            rs = np.random.RandomState(7 + i)
+            tc = time.perf_counter()
+            o = cpu_pair(orc, p, args, rs)
+            t_cpu += time.perf_counter() - tc
+            del o
+        result["cpu_baseline"] = {"value": round(a.cpu_pairs / t_cpu, 4), "unit": "pairs/s", "cores": os.cpu_count(),
+                                  "kind": "port",
+                                  "sample": f"{a.cpu_pairs} full {a.config} pair(s) through oracle.register_pair "
+                                            f"(C/OpenMP scan+moments, numpy LAPACK/BLAS for QR/cdist/SVD), "
+                                            f"{t_cpu:.1f} s wall"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_pair(orc, p, args, rs):
+    """The same named path on the CPU, including the tau-weighted draw (evaluate.py:233-245)."""
+    src_kp = p.src_pts[p.src_inds]
+    tgt_kp = p.tgt_pts[p.tgt_inds]
+    ume_src = orc.ume_moments(p.src_pts, src_kp, p.src_feat, args.ume_max_nn, float(args.ume_r_nn), "f32")
+    ume_tgt = orc.ume_moments(p.tgt_pts, tgt_kp, p.tgt_feat, args.ume_max_nn, float(args.ume_r_nn), "f32")
+    D = orc.ume_cdist(ume_src[None], ume_tgt[None])[0]
+    m = orc.row_argmin(D)
+    d = D[np.arange(D.shape[0]), m]
+    if args.filter_by_ume_dist_cond:
+        prob = orc.match_prob(d, args.tau)
+        cond = rs.choice(D.shape[0], min(D.shape[0], args.ume_n_samples), replace=False, p=prob)
+    else:
+        cond = np.arange(D.shape[0])
+    T, _ = orc.batch_estimate_transform_ume_old(ume_src[cond], ume_tgt[m[cond]], with_dist=False)
+    R_gt = np.broadcast_to(p.gt_tform[:3, :3], T[:, :3, :3].shape)
+    return orc.relative_rotation_error(T[:, :3, :3], R_gt)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/*
+ * umereg.h -- C ABI of the MI355X-native (gfx950) UMERegRobust registration hot path.
+ *
+ * The reference (yuvalH9/UMERegRobust) is pure Python: its "operator interface" for this
+ * path is the function level of evaluate.py / utils/loc_utils.py / utils/eval_utils.py, with
+ * the arithmetic living in un-vendored CUDA libraries (pytorch3d, torch).  Each entry point
+ * below is what a ctypes/cffi binding written for that function would bind; the reference
+ * statement it replaces is cited as file:line relative to the reference tree.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer (HIP global memory) unless the name ends in _host;
+ *     tensors are dense, row-major, batch-first, fp32 values / int64 indices, exactly the
+ *     layouts the reference's torch tensors have;
+ *   - the library never allocates or frees device memory: outputs and workspaces are caller
+ *     owned (size queries: *_workspace_bytes); no global mutable state except the
+ *     thread-local last-error string;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous
+ *     with respect to the host and re-entrant;
+ *   - return value: UMEREG_OK (0) or a negative UMEREG_E* code; umereg_last_error() gives the
+ *     text for the calling thread;
+ *   - there is NO CPU fallback: without a HIP device every compute entry point returns
+ *     UMEREG_ENODEV.
+ */
+#ifndef UMEREG_H
+#define UMEREG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMEREG_ABI_VERSION 1
+#define UMEREG_FEAT_DIM 32 /* evaluate.py:55 hard-codes 32 */
+
+enum {
+    UMEREG_OK = 0,
+    UMEREG_EINVAL = -1, /* bad argument (null pointer, size, unsupported feature dim) */
+    UMEREG_ENODEV = -2, /* no HIP device / wrong architecture */
+    UMEREG_EWORKSPACE = -3, /* workspace too small */
+    UMEREG_ELAUNCH = -4 /* HIP launch / runtime error */
+};
+
+/* Q-basis layouts written by umereg_ume_orthobasis_f32 */
+enum {
+    UMEREG_QLAYOUT_PLAIN = 0, /* [n,32,4] row-major, like torch.linalg.qr(...).Q */
+    UMEREG_QLAYOUT_ROWS = 1,  /* MFMA A-fragment order: source side of the distance GEMM */
+    UMEREG_QLAYOUT_COLS = 2   /* MFMA B-fragment order: target side of the distance GEMM */
+};
+
+int umereg_abi_version(void);
+const char* umereg_last_error(void);
+/* number of visible HIP devices; fills name (may be NULL) with device 0's gcnArchName */
+int umereg_device_count(char* arch_name, size_t arch_name_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1  pytorch3d.ops.ball_query(p1, p2, lengths1, lengths2, K, radius, return_nn)
+ *     reference call sites: evaluate.py:51, utils/loc_utils.py:38,72,100,114,167,184,383-384.
+ * For every query p1[b,i] (i < lengths1[b]) the FIRST K points of p2[b] IN INDEX ORDER with
+ * |p1-p2|^2 < radius^2 (strict; fp32, one rounding per operation, no FMA contraction).
+ *   p1 [B,n1,3]  p2 [B,n2,3]  lengths1/lengths2 int64 [B] or NULL (= full)
+ *   idx   int64 [B,n1,K]  padded with -1
+ *   dists f32   [B,n1,K]  squared distances, padded with 0      (may be NULL)
+ *   nn    f32   [B,n1,K,3] neighbour coordinates, padded with 0 (may be NULL; return_nn)
+ * workspace: umereg_ball_query_workspace_bytes(B, n2).
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_ball_query_workspace_bytes(int B, int n2);
+int umereg_ball_query_f32(const float* p1, const float* p2, const int64_t* lengths1,
+                          const int64_t* lengths2, int B, int n1, int n2, int K, float radius,
+                          int64_t* idx, float* dists, float* nn, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1+a2  evaluate.my_ume_generation(pts, kpts, feat, args)            evaluate.py:50-60
+ *        (the same moment matrix as ume_kp_layer.ume_mat, utils/loc_utils.py:365-372)
+ * Fused ball query (K = args.ume_max_nn, radius = args.ume_r_nn) + feature gather + UME moment
+ * matrix:  F = [sum f, sum f p^T] / (sum_c sum f_c + 1e-6)   ->  F f32 [B,n_kp,32,4].
+ * The 960 MB gathered intermediate of the reference (evaluate.py:54-55) is never formed.
+ * Moments are accumulated in fp64 and rounded once to fp32.
+ *   pts [B,N,3]  kpts [B,n_kp,3]  feat [B,N,32]
+ *   nn_count int32 [B,n_kp]   neighbours used per keypoint (0 => F row is exactly 0)  (may be NULL)
+ *   nn_idx   int64 [B,n_kp,K] the neighbourhood actually used, -1 padded              (may be NULL)
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_ume_moments_workspace_bytes(int B, int N);
+/* layered form of the same call, so a caller can keep the packed table across calls and time the
+ * moment kernel alone: (1) pack pts [B,N,3] into the padded {x,y,z,-} table (`packed`, size =
+ * umereg_ume_moments_workspace_bytes(B,N)); (2) run the fused kernel on it. */
+int umereg_pack_points_f32(const float* pts, int B, int N, void* packed, size_t packed_bytes,
+                           void* stream);
+int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const float* feat, int B,
+                                  int N, int n_kp, int feat_dim, int K, float radius, float* F,
+                                  int32_t* nn_count, int64_t* nn_idx, void* stream);
+int umereg_ume_moments_f32(const float* pts, const float* kpts, const float* feat, int B, int N,
+                           int n_kp, int feat_dim, int K, float radius, float* F,
+                           int32_t* nn_count, int64_t* nn_idx, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3 (first half)  torch.linalg.qr(ume, mode='reduced').Q           utils/loc_utils.py:9,11
+ * Householder orthonormal basis of each 32x4 UME matrix (LAPACK geqr2/org2r conventions,
+ * computed in fp64, stored fp32).  The projector QQ^T -- all the reference uses -- is
+ * invariant to QR sign conventions.
+ *   ume [n,32,4] -> Q in `layout`; ROWS pads n to a multiple of 16, COLS to a multiple of 32
+ *   (padding is written as zeros): size = umereg_qbasis_bytes(n, layout).
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_qbasis_bytes(int n, int layout);
+int umereg_ume_orthobasis_f32(const float* ume, int n, int layout, float* Q, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3  utils.loc_utils.ume_cdist(ume1, ume2)                          utils/loc_utils.py:8-15
+ * D[b,i,j] = |Q1 Q1^T - Q2 Q2^T|_F / sqrt(2), evaluated as sqrt(max(4 - |Q1^T Q2|_F^2, 0)) by
+ * an fp32 MFMA GEMM over the 4-column bases (no 1024-wide projector is materialised).
+ *   ume1 [B,n1,32,4]  ume2 [B,n2,32,4]  ->  D f32 [B,n1,n2]
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_ume_cdist_workspace_bytes(int B, int n1, int n2);
+int umereg_ume_cdist_f32(const float* ume1, const float* ume2, int B, int n1, int n2, float* D,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3+a4  D = ume_cdist(...); m = D.min(dim=-1)[1]; ume_d = D[i, m_i]   evaluate.py:215,224,234
+ * Same GEMM with the row arg-min fused into the epilogue: D is never written.
+ *   match_idx int64 [B,n1] (lowest index on ties), match_dist f32 [B,n1]
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_ume_match_workspace_bytes(int B, int n1, int n2);
+/* layered form: bases already orthonormalised by umereg_ume_orthobasis_f32 (Q1 in ROWS layout,
+ * Q2 in COLS layout), one batch element.  D may be NULL (no distance matrix written); match_idx
+ * may be NULL (no arg-min); `keys` is n1 x 8 bytes of scratch, required when match_idx != NULL. */
+int umereg_ume_dist_q_f32(const float* Q1_rows, const float* Q2_cols, int n1, int n2, float* D,
+                          int64_t* match_idx, float* match_dist, void* keys, void* stream);
+int umereg_ume_match_f32(const float* ume1, const float* ume2, int B, int n1, int n2,
+                         int64_t* match_idx, float* match_dist, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a5  a = exp((1 - ume_d)/tau); prob = a / a.sum()                   evaluate.py:235-236
+ *   ume_d f32 [n] -> prob f32 [n].  (The draw itself, np.random.choice(..., p=prob) at
+ *   evaluate.py:238, consumes the HOST numpy RNG and stays on the host.)
+ * ------------------------------------------------------------------------------------------- */
+int umereg_match_prob_f32(const float* ume_d, int n, float tau, float* prob, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6  utils.loc_utils.batch_estimate_transform_ume_old(G, H)         utils/loc_utils.py:292-350
+ * Closed-form SE(3) from a (source G, target H) UME pair; T maps source -> target.
+ *   G_all [nG,32,4], H_all [nH,32,4]; g_index/h_index int64 [n] select the rows used by
+ *   hypothesis k (NULL = identity), which fuses the gathers of evaluate.py:230-231,243-244;
+ *   T f32 [n,4,4];  dist f32 [n] = 0.707 |P_H - P_G|_F (utils/loc_utils.py:338-344; NULL to
+ *   skip -- every live caller discards it).
+ * ------------------------------------------------------------------------------------------- */
+int umereg_rtume_solve_f32(const float* G_all, const float* H_all, const int64_t* g_index,
+                           const int64_t* h_index, int nG, int nH, int n, float* T, float* dist,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a7  utils.eval_utils.relative_rotation_error(R, R_hat)             utils/eval_utils.py:60-76
+ *   R, R_hat f32 [b,3,3] -> degrees f32 [b]
+ * ------------------------------------------------------------------------------------------- */
+int umereg_rre_deg_f32(const float* R, const float* R_hat, int b, float* out_deg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMEREG_H */

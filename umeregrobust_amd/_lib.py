@@ -1,0 +1,77 @@
+"""ctypes loader for csrc/libumereg.so -- the C ABI declared in include/umereg.h.
+
+There is no fallback of any kind: if the shared object is missing or a symbol is absent the
+import of the ops fails loudly, and on a box with a GPU every op raises if the library reports
+an error.
+"""
+import ctypes
+import os
+
+from ._build import LIB_PATH
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/umereg.h one to one
+SIGNATURES = {
+    "umereg_abi_version": (c_int, []),
+    "umereg_last_error": (ctypes.c_char_p, []),
+    "umereg_device_count": (c_int, [ctypes.c_char_p, c_size_t]),
+    "umereg_ball_query_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_ball_query_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_ume_moments_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_ume_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_pack_points_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umereg_ume_moments_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "umereg_ume_dist_q_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    "umereg_qbasis_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_ume_orthobasis_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "umereg_ume_cdist_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "umereg_ume_cdist_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_ume_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "umereg_ume_match_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+    "umereg_match_prob_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "umereg_rtume_solve_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p]),
+    "umereg_rre_deg_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type every symbol.  Raises NativeLibraryError when the .so is absent:
+    build it with `python -c "import __graft_entry__ as g; g.build()"`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run __graft_entry__.build()); umeregrobust_amd has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.umereg_abi_version() != 1:
+        raise NativeLibraryError(f"ABI version mismatch: {lib.umereg_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().umereg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,234 @@
+// rtume.hip -- a6/a7: closed-form SE(3) from a UME pair ("RTUME") and the rotation-error metric.
+// Replaces utils.loc_utils.batch_estimate_transform_ume_old (reference utils/loc_utils.py:292-350)
+// and utils.eval_utils.relative_rotation_error (reference utils/eval_utils.py:60-76).
+//
+// 32 lanes per hypothesis (lane = feature channel), two hypotheses per wavefront.  The reference
+// spends ~15 tiny launches + 3 batched cuSOLVER calls here; this is one launch: 17 group
+// reductions, an analytic 3x3 polar rotation (Jacobi on A^T A), 64 B out.  The gathers of the
+// matched / sub-sampled UME rows (evaluate.py:230-231, 243-244) are folded in through the
+// optional index arrays.  Arithmetic is fp64 on fp32 inputs, rounded once on output.
+#include "householder.h"
+
+namespace umereg {
+
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&B)[3][3], double (&V)[3][3])
+{
+    const double apq = B[P][Q];
+    if (apq == 0.0) return;
+    const double theta = (B[Q][Q] - B[P][P]) / (2.0 * apq);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0);
+    const double s = t * c;
+    constexpr int R = 3 - P - Q;  // the untouched index
+    const double bpp = B[P][P], bqq = B[Q][Q];
+    B[P][P] = bpp - t * apq;
+    B[Q][Q] = bqq + t * apq;
+    B[P][Q] = B[Q][P] = 0.0;
+    const double brp = B[R][P], brq = B[R][Q];
+    B[R][P] = B[P][R] = c * brp - s * brq;
+    B[R][Q] = B[Q][R] = s * brp + c * brq;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double vp = V[r][P], vq = V[r][Q];
+        V[r][P] = c * vp - s * vq;
+        V[r][Q] = s * vp + c * vq;
+    }
+}
+
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// R = U diag(1, 1, det(U Vh)) Vh for A = U S Vh   (utils/loc_utils.py:326-329).
+// With A = sum_i s_i u_i v_i^T this equals u0 v0^T + u1 v1^T + (u0 x u1)(v0 x v1)^T, which needs
+// only the two dominant singular pairs and no sign bookkeeping.
+__device__ void polar_rotation(const double A[3][3], double R[3][3])
+{
+    double B[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) B[p][q] = A[0][p] * A[0][q] + A[1][p] * A[1][q] + A[2][p] * A[2][q];
+    for (int sweep = 0; sweep < 10; ++sweep) {
+        jacobi_rotate<0, 1>(B, V);
+        jacobi_rotate<0, 2>(B, V);
+        jacobi_rotate<1, 2>(B, V);
+    }
+    // pick the two largest eigenvalues (branch-free selects keep everything in registers)
+    const double l0 = B[0][0], l1 = B[1][1], l2 = B[2][2];
+    const int i_min = (l0 <= l1 && l0 <= l2) ? 0 : ((l1 <= l2) ? 1 : 2);
+    double v0[3], v1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        v0[r] = i_min == 0 ? V[r][1] : V[r][0];
+        v1[r] = i_min == 2 ? V[r][1] : V[r][2];
+    }
+    const double la = i_min == 0 ? l1 : l0, lb = i_min == 2 ? l1 : l2;
+    if (lb > la) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { const double tmp = v0[r]; v0[r] = v1[r]; v1[r] = tmp; }
+    }
+    double u0[3], u1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        u0[r] = A[r][0] * v0[0] + A[r][1] * v0[1] + A[r][2] * v0[2];
+        u1[r] = A[r][0] * v1[0] + A[r][1] * v1[1] + A[r][2] * v1[2];
+    }
+    const double n0 = sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+    if (!(n0 > 0.0)) {  // A == 0: any rotation is optimal; LAPACK returns U = V = I -> R = I
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) R[p][q] = p == q ? 1.0 : 0.0;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u0[r] /= n0;
+    const double d01 = u0[0] * u1[0] + u0[1] * u1[1] + u0[2] * u1[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u1[r] -= d01 * u0[r];
+    double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (!(n1 > 1e-150)) {  // rank 1: complete u1 with any unit vector orthogonal to u0
+        const int ax = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0
+                       : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+        double e[3] = {ax == 0 ? 1.0 : 0.0, ax == 1 ? 1.0 : 0.0, ax == 2 ? 1.0 : 0.0};
+        cross3(u0, e, u1);
+        n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u1[r] /= n1;
+    double u2[3], v2[3];
+    cross3(u0, u1, u2);
+    cross3(v0, v1, v2);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) R[p][q] = u0[p] * v0[q] + u1[p] * v1[q] + u2[p] * v2[q];
+}
+
+__global__ __launch_bounds__(256) void rtume_kernel(const float4* __restrict__ G_all,
+                                                    const float4* __restrict__ H_all,
+                                                    const int64_t* __restrict__ g_index,
+                                                    const int64_t* __restrict__ h_index, int n,
+                                                    float* __restrict__ T, float* __restrict__ dist)
+{
+    const int row = threadIdx.x & 31;
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (k >= n) return;  // uniform per 32-lane group
+    const int64_t gi = g_index ? g_index[k] : k;
+    const int64_t hi = h_index ? h_index[k] : k;
+    const float4 gv = G_all[gi * 32 + row];
+    const float4 hv = H_all[hi * 32 + row];
+    const double mg = gv.x, mh = hv.x;                       // utils/loc_utils.py:304-305
+    const double g[3] = {gv.y, gv.z, gv.w};                  // :308
+    const double h[3] = {hv.y, hv.z, hv.w};                  // :309
+    const double mg_square = group32_sum(mg * mg) + 1e-16;   // :312
+    const double mg_mh = group32_sum(mg * mh);               // :313
+    double wlc[3], wrc[3], left[3], right[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        wlc[c] = group32_sum(g[c] * mg) / (mg_square + 1e-16);  // :314,319
+        wrc[c] = group32_sum(h[c] * mg) / (mg_mh + 1e-16);      // :315,320
+        left[c] = g[c] - wlc[c] * mg;                           // :322
+        right[c] = h[c] - wrc[c] * mh;                          // :323
+    }
+    // M = right^T left (:325); the SVD is taken of M^T = left^T right (:326)
+    double A[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) A[p][q] = group32_sum(left[p] * right[q]);
+    double R[3][3];
+    polar_rotation(A, R);
+    // b2 = wrc - wlc @ R (:332);  T[:3,:3] = R^T, T[:3,3] = b2 (:347-349)
+    double b2[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b2[q] = wrc[q] - (wlc[0] * R[0][q] + wlc[1] * R[1][q] + wlc[2] * R[2][q]);
+    if (row < 16) {
+        const int p = row >> 2, q = row & 3;
+        double v = 0.0;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq)
+                if (p == pp && q == qq) v = R[qq][pp];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+            if (p == pp && q == 3) v = b2[pp];
+        if (p == 3) v = q == 3 ? 1.0 : 0.0;
+        T[(size_t)k * 16 + row] = (float)v;
+    }
+    if (dist) {
+        // D = 0.707 |P_H - P_G|_F (:338-344) = 0.707 sqrt(8 - 2 |Qh^T Qg|_F^2)
+        const double ga[4] = {gv.x, gv.y, gv.z, gv.w}, ha[4] = {hv.x, hv.y, hv.z, hv.w};
+        double qg[4], qh[4];
+        householder_q_32x4(ga, qg, row);
+        householder_q_32x4(ha, qh, row);
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double c = group32_sum(qh[p] * qg[q]);
+                s += c * c;
+            }
+        if (row == 0) dist[k] = (float)(0.707 * sqrt(fmax(8.0 - 2.0 * s, 0.0)));
+    }
+}
+
+// a7: relative_rotation_error, fp32 like the reference (utils/eval_utils.py:60-76)
+__global__ void rre_kernel(const float* __restrict__ R, const float* __restrict__ R_hat, int b,
+                           float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b) return;
+    const float* a = R + (size_t)i * 9;
+    const float* c = R_hat + (size_t)i * 9;
+    // trace(R_hat R^T) = sum_pq R_hat[p][q] R[p][q]                         (:62,65)
+    float tr = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) d = d + c[p * 3 + q] * a[p * 3 + q];
+        tr = tr + d;
+    }
+    tr = fminf(fmaxf(tr, -1.0f), 3.0f);                                        // :68
+    const float rad = acosf((tr - 1.0f) / 2.0f);                               // :71
+    out[i] = rad * (180.0f / 3.141592653589793f);                              // :74
+}
+
+}  // namespace umereg
+
+using namespace umereg;
+
+UMEREG_API int umereg_rtume_solve_f32(const float* G_all, const float* H_all, const int64_t* g_index,
+                                      const int64_t* h_index, int nG, int nH, int n, float* T, float* dist,
+                                      void* stream)
+{
+    UMEREG_REQUIRE(G_all && H_all && T, "rtume_solve: null pointer (G/H/T)");
+    UMEREG_REQUIRE(n > 0 && nG > 0 && nH > 0, "rtume_solve: n, nG, nH must be positive (got %d, %d, %d)", n, nG, nH);
+    UMEREG_REQUIRE(g_index || n <= nG, "rtume_solve: n > nG without g_index");
+    UMEREG_REQUIRE(h_index || n <= nH, "rtume_solve: n > nH without h_index");
+    UMEREG_REQUIRE(((uintptr_t)G_all & 15) == 0 && ((uintptr_t)H_all & 15) == 0, "rtume_solve: G/H must be 16-byte aligned");
+    if (int rc = check_device()) return rc;
+    const int groups_per_wg = 256 / 32;
+    hipLaunchKernelGGL(rtume_kernel, dim3((n + groups_per_wg - 1) / groups_per_wg), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)G_all, (const float4*)H_all, g_index, h_index, n, T, dist);
+    UMEREG_CHECK_LAUNCH("rtume_kernel");
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_rre_deg_f32(const float* R, const float* R_hat, int b, float* out_deg, void* stream)
+{
+    UMEREG_REQUIRE(R && R_hat && out_deg, "rre_deg: null pointer");
+    UMEREG_REQUIRE(b > 0, "rre_deg: b must be positive (got %d)", b);
+    if (int rc = check_device()) return rc;
+    hipLaunchKernelGGL(rre_kernel, dim3((b + 255) / 256), dim3(256), 0, (hipStream_t)stream, R, R_hat, b, out_deg);
+    UMEREG_CHECK_LAUNCH("rre_kernel");
+    return UMEREG_OK;
+}

@@ -1,0 +1,295 @@
+"""Torch-facing wrappers over the C ABI (include/umereg.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function marshals raw
+device pointers + sizes into libumereg.so and returns freshly allocated output tensors, like
+the reference's torch/pytorch3d calls do.  Inputs must live on a HIP device ("cuda" in
+PyTorch-ROCm); there is no CPU fallback -- a CPU tensor raises.
+"""
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+
+BallQuery = namedtuple("BallQuery", "dists idx knn")   # pytorch3d's _KNN field names (.dists/.idx/.knn)
+
+QLAYOUT_PLAIN, QLAYOUT_ROWS, QLAYOUT_COLS = 0, 1, 2
+
+_workspaces = {}
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(device, nbytes, tag):
+    """Grow-only scratch buffer per (device, stream, purpose); the C side never allocates."""
+    key = (device.index, _stream_ptr(device), tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; umeregrobust_amd runs on the GPU only "
+                           "(no CPU fallback) -- move inputs to the HIP device")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True):
+    """pytorch3d.ops.ball_query drop-in (reference evaluate.py:51; utils/loc_utils.py:383-384).
+    p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] f32 0-pad, idx [B,n1,K] i64 -1-pad, knn [B,n1,K,3] | None)."""
+    lib = _lib.load()
+    p1 = _dev(p1, "p1"); p2 = _dev(p2, "p2")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3 or p1.shape[0] != p2.shape[0]:
+        raise ValueError(f"ball_query: expected p1 [B,n1,3], p2 [B,n2,3]; got {tuple(p1.shape)}, {tuple(p2.shape)}")
+    B, n1, _ = p1.shape
+    n2 = p2.shape[1]
+    dev = p1.device
+    l1 = None if lengths1 is None else _dev(lengths1, "lengths1", torch.int64)
+    l2 = None if lengths2 is None else _dev(lengths2, "lengths2", torch.int64)
+    idx = torch.empty((B, n1, K), dtype=torch.int64, device=dev)
+    dists = torch.empty((B, n1, K), dtype=torch.float32, device=dev)
+    nn = torch.empty((B, n1, K, 3), dtype=torch.float32, device=dev) if return_nn else None
+    if n1 == 0 or n2 == 0:
+        idx.fill_(-1); dists.zero_()
+        if nn is not None:
+            nn.zero_()
+        return BallQuery(dists, idx, nn)
+    need = lib.umereg_ball_query_workspace_bytes(B, n2)
+    ws = _workspace(dev, need, "bq")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_ball_query_f32(_ptr(p1), _ptr(p2), _ptr(l1), _ptr(l2), B, n1, n2, int(K), float(radius),
+                                       _ptr(idx), _ptr(dists), _ptr(nn), _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_ball_query_f32")
+    return BallQuery(dists, idx, nn)
+
+
+def _timed(timing, dev):
+    """Optional event pair on the launch stream around one kernel (bench.py's roofline leg)."""
+    if timing is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record(torch.cuda.current_stream(dev))
+    return ev
+
+
+def _timed_end(timing, ev, dev):
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(dev))
+        timing.append(ev)
+
+
+def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None):
+    """Fused ball query + gather + UME moment matrix (reference evaluate.py:50-60).
+    pts [B,N,3], kpts [B,n,3], feat [B,N,32] -> F [B,n,32,4] (+ nn_count i32 [B,n], nn_idx i64 [B,n,K]).
+    timing: optional list; receives a (start, end) event pair bracketing the moment kernel alone."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts"); kpts = _dev(kpts, "kpts"); feat = _dev(feat, "feat")
+    if pts.dim() != 3 or kpts.dim() != 3 or feat.dim() != 3:
+        raise ValueError("ume_moments: expected pts [B,N,3], kpts [B,n,3], feat [B,N,32]")
+    B, N, _ = pts.shape
+    n = kpts.shape[1]
+    d = feat.shape[2]
+    if feat.shape[0] != B or feat.shape[1] != N or kpts.shape[0] != B:
+        raise ValueError(f"ume_moments: inconsistent shapes {tuple(pts.shape)}, {tuple(kpts.shape)}, {tuple(feat.shape)}")
+    dev = pts.device
+    F = torch.empty((B, n, d, 4), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B, n), dtype=torch.int32, device=dev) if return_count else None
+    nidx = torch.empty((B, n, K), dtype=torch.int64, device=dev) if return_idx else None
+    if n > 0:
+        need = lib.umereg_ume_moments_workspace_bytes(B, N)
+        ws = _workspace(dev, need, "mom")
+        with torch.cuda.device(dev):
+            rc = lib.umereg_pack_points_f32(_ptr(pts), B, N, _ptr(ws), ws.numel(), _stream_ptr(dev))
+            _lib.check(rc, "umereg_pack_points_f32")
+            ev = _timed(timing, dev)
+            rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(feat), B, N, n, d, int(K),
+                                                   float(radius), _ptr(F), _ptr(cnt), _ptr(nidx), _stream_ptr(dev))
+            _lib.check(rc, "umereg_ume_moments_packed_f32")
+            _timed_end(timing, ev, dev)
+    out = (F,)
+    if return_count:
+        out += (cnt,)
+    if return_idx:
+        out += (nidx,)
+    return out[0] if len(out) == 1 else out
+
+
+def ume_orthobasis(ume, layout=QLAYOUT_PLAIN):
+    """Householder Q of each 32x4 UME (reference utils/loc_utils.py:9,11).  ume [n,32,4]."""
+    lib = _lib.load()
+    ume = _dev(ume, "ume")
+    if ume.dim() != 3 or ume.shape[1:] != (32, 4):
+        raise ValueError(f"ume_orthobasis: expected [n,32,4], got {tuple(ume.shape)}")
+    n = ume.shape[0]
+    dev = ume.device
+    nfloat = lib.umereg_qbasis_bytes(n, layout) // 4
+    Q = torch.empty((nfloat,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.umereg_ume_orthobasis_f32(_ptr(ume), n, int(layout), _ptr(Q), _stream_ptr(dev))
+    _lib.check(rc, "umereg_ume_orthobasis_f32")
+    return Q.view(n, 32, 4) if layout == QLAYOUT_PLAIN else Q
+
+
+def _check_umes(ume1, ume2, who):
+    if ume1.dim() != 4 or ume2.dim() != 4 or ume1.shape[2:] != (32, 4) or ume2.shape[2:] != (32, 4) \
+            or ume1.shape[0] != ume2.shape[0]:
+        raise ValueError(f"{who}: expected ume1 [B,n1,32,4], ume2 [B,n2,32,4]; got {tuple(ume1.shape)}, {tuple(ume2.shape)}")
+
+
+def _dist_q(ume1, ume2, want_D, want_match, timing):
+    lib = _lib.load()
+    ume1 = _dev(ume1, "ume1"); ume2 = _dev(ume2, "ume2")
+    _check_umes(ume1, ume2, "ume_cdist/ume_match")
+    B, n1 = ume1.shape[:2]
+    n2 = ume2.shape[1]
+    dev = ume1.device
+    D = torch.empty((B, n1, n2), dtype=torch.float32, device=dev) if want_D else None
+    m = torch.empty((B, n1), dtype=torch.int64, device=dev) if want_match else None
+    d = torch.empty((B, n1), dtype=torch.float32, device=dev) if want_match else None
+    if n1 == 0 or n2 == 0:
+        if want_match:
+            raise ValueError("ume_match: empty UME set")
+        return D, m, d
+    qa = lib.umereg_qbasis_bytes(n1, QLAYOUT_ROWS)
+    qb = lib.umereg_qbasis_bytes(n2, QLAYOUT_COLS)
+    ws = _workspace(dev, qa + qb + 8 * n1 + 256, "dist")
+    base = ws.data_ptr()
+    st = _stream_ptr(dev)
+    with torch.cuda.device(dev):
+        for b in range(B):
+            _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume1[b]), n1, QLAYOUT_ROWS, base, st), "umereg_ume_orthobasis_f32")
+            _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume2[b]), n2, QLAYOUT_COLS, base + qa, st), "umereg_ume_orthobasis_f32")
+            ev = _timed(timing, dev)
+            rc = lib.umereg_ume_dist_q_f32(base, base + qa, n1, n2, _ptr(D[b]) if want_D else None,
+                                           _ptr(m[b]) if want_match else None, _ptr(d[b]) if want_match else None,
+                                           base + qa + qb if want_match else None, st)
+            _lib.check(rc, "umereg_ume_dist_q_f32")
+            _timed_end(timing, ev, dev)
+    return D, m, d
+
+
+def ume_cdist(ume1, ume2, timing=None):
+    """utils.loc_utils.ume_cdist (reference utils/loc_utils.py:8-15): D [B,n1,n2]."""
+    return _dist_q(ume1, ume2, True, False, timing)[0]
+
+
+def ume_match(ume1, ume2, timing=None):
+    """Fused ume_cdist + row arg-min (reference evaluate.py:215,224,234): (m [B,n1] i64, d [B,n1] f32)."""
+    _, m, d = _dist_q(ume1, ume2, False, True, timing)
+    return m, d
+
+
+def ume_cdist_onecall(ume1, ume2):
+    """Same as ume_cdist through the single-call ABI entry (umereg_ume_cdist_f32)."""
+    lib = _lib.load()
+    ume1 = _dev(ume1, "ume1"); ume2 = _dev(ume2, "ume2")
+    _check_umes(ume1, ume2, "ume_cdist")
+    B, n1 = ume1.shape[:2]
+    n2 = ume2.shape[1]
+    dev = ume1.device
+    D = torch.empty((B, n1, n2), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.umereg_ume_cdist_workspace_bytes(B, n1, n2), "dist1")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_ume_cdist_f32(_ptr(ume1), _ptr(ume2), B, n1, n2, _ptr(D), _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_ume_cdist_f32")
+    return D
+
+
+def ume_match_onecall(ume1, ume2):
+    """Same as ume_match through the single-call ABI entry (umereg_ume_match_f32)."""
+    lib = _lib.load()
+    ume1 = _dev(ume1, "ume1"); ume2 = _dev(ume2, "ume2")
+    _check_umes(ume1, ume2, "ume_match")
+    B, n1 = ume1.shape[:2]
+    n2 = ume2.shape[1]
+    dev = ume1.device
+    m = torch.empty((B, n1), dtype=torch.int64, device=dev)
+    d = torch.empty((B, n1), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.umereg_ume_match_workspace_bytes(B, n1, n2), "dist1")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_ume_match_f32(_ptr(ume1), _ptr(ume2), B, n1, n2, _ptr(m), _ptr(d), _ptr(ws), ws.numel(),
+                                      _stream_ptr(dev))
+    _lib.check(rc, "umereg_ume_match_f32")
+    return m, d
+
+
+def ume_moments_onecall(pts, kpts, feat, K, radius):
+    """Same as ume_moments through the single-call ABI entry (umereg_ume_moments_f32)."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts"); kpts = _dev(kpts, "kpts"); feat = _dev(feat, "feat")
+    B, N, _ = pts.shape
+    n = kpts.shape[1]
+    dev = pts.device
+    F = torch.empty((B, n, feat.shape[2], 4), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.umereg_ume_moments_workspace_bytes(B, N), "mom1")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_ume_moments_f32(_ptr(pts), _ptr(kpts), _ptr(feat), B, N, n, feat.shape[2], int(K), float(radius),
+                                        _ptr(F), None, None, _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_ume_moments_f32")
+    return F
+
+
+def match_prob(ume_d, tau):
+    """a = exp((1 - d)/tau); a / a.sum()  (reference evaluate.py:235-236).  ume_d [n]."""
+    lib = _lib.load()
+    ume_d = _dev(ume_d, "ume_d").view(-1)
+    prob = torch.empty_like(ume_d)
+    dev = ume_d.device
+    with torch.cuda.device(dev):
+        rc = lib.umereg_match_prob_f32(_ptr(ume_d), ume_d.numel(), float(tau), _ptr(prob), _stream_ptr(dev))
+    _lib.check(rc, "umereg_match_prob_f32")
+    return prob
+
+
+def rtume_solve(G, H, g_index=None, h_index=None, with_dist=False):
+    """batch_estimate_transform_ume_old (reference utils/loc_utils.py:292-350) with optional fused
+    row gathers.  G [nG,32,4] (source), H [nH,32,4] (target) -> T [n,4,4] (source -> target), D [n] | None."""
+    lib = _lib.load()
+    G = _dev(G, "G"); H = _dev(H, "H")
+    if G.dim() != 3 or H.dim() != 3 or G.shape[1:] != (32, 4) or H.shape[1:] != (32, 4):
+        raise ValueError(f"rtume_solve: expected [n,32,4] UME matrices, got {tuple(G.shape)}, {tuple(H.shape)}")
+    gi = None if g_index is None else _dev(g_index, "g_index", torch.int64).view(-1)
+    hi = None if h_index is None else _dev(h_index, "h_index", torch.int64).view(-1)
+    if gi is not None and hi is not None and gi.numel() != hi.numel():
+        raise ValueError("rtume_solve: g_index and h_index differ in length")
+    n = gi.numel() if gi is not None else (hi.numel() if hi is not None else G.shape[0])
+    if (gi is None and n > G.shape[0]) or (hi is None and n > H.shape[0]) or \
+            (gi is None and hi is None and G.shape[0] != H.shape[0]):
+        raise ValueError("rtume_solve: index / batch sizes do not agree")
+    dev = G.device
+    T = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
+    D = torch.empty((n,), dtype=torch.float32, device=dev) if with_dist else None
+    if n > 0:
+        with torch.cuda.device(dev):
+            rc = lib.umereg_rtume_solve_f32(_ptr(G), _ptr(H), _ptr(gi), _ptr(hi), G.shape[0], H.shape[0], n, _ptr(T),
+                                            _ptr(D), _stream_ptr(dev))
+        _lib.check(rc, "umereg_rtume_solve_f32")
+    return T, D
+
+
+def rre_deg(R, R_hat):
+    """relative_rotation_error (reference utils/eval_utils.py:60-76): degrees [b]."""
+    lib = _lib.load()
+    R = _dev(R, "R"); R_hat = _dev(R_hat, "R_hat")
+    if R.dim() != 3 or R.shape[1:] != (3, 3) or R_hat.shape != R.shape:
+        raise ValueError(f"rre_deg: expected [b,3,3] pairs, got {tuple(R.shape)}, {tuple(R_hat.shape)}")
+    b = R.shape[0]
+    out = torch.empty((b,), dtype=torch.float32, device=R.device)
+    if b > 0:
+        with torch.cuda.device(R.device):
+            rc = lib.umereg_rre_deg_f32(_ptr(R), _ptr(R_hat), b, _ptr(out), _stream_ptr(R.device))
+        _lib.check(rc, "umereg_rre_deg_f32")
+    return out

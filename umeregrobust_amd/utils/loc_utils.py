@@ -1,0 +1,91 @@
+"""Drop-in counterparts of the hot-path symbols of the reference's utils/loc_utils.py.
+
+Same names, argument order and return shapes as the reference; the arithmetic runs in the HIP
+kernels behind include/umereg.h (via ..ops).  pytorch3d is not a dependency: the ops the
+reference imports from it (ball_query / knn_points / knn_gather, reference utils/loc_utils.py:4)
+are re-provided here with the same namedtuple fields (.dists/.idx/.knn).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ball_query  # noqa: F401  (re-export: `from utils.loc_utils import ball_query` style use)
+
+
+def ume_cdist(ume1, ume2):
+    """reference utils/loc_utils.py:8-15.  ume1 [bs,n1,32,4], ume2 [bs,n2,32,4] -> D [bs,n1,n2].
+    D = |Q1Q1^T - Q2Q2^T|_F / sqrt(2) with Q the reduced-QR basis of each UME matrix."""
+    return ops.ume_cdist(ume1, ume2)
+
+
+def batch_estimate_transform_ume_old(G, H):
+    """reference utils/loc_utils.py:292-350.  G = UME of the SOURCE cloud, H = UME of the TARGET
+    cloud as evaluate.py:248-253 passes them (the reference docstring has them swapped);
+    returns T [bs,4,4] mapping source -> target and D [bs] = 0.707 |P_H - P_G|_F."""
+    if G.dtype != torch.float32 or H.dtype != torch.float32:
+        # the reference raises on fp64 input as well (fp32 torch.eye temporaries, :326,333,347)
+        raise RuntimeError("batch_estimate_transform_ume_old: expected float32 UME matrices")
+    T, D = ops.rtume_solve(G, H, with_dist=True)
+    return T, D
+
+
+def knn_gather(x, idx, lengths=None):
+    """pytorch3d.ops.knn_gather: x [N,M,U], idx [N,L,K] -> [N,L,K,U] (plain device indexing)."""
+    N, L, K = idx.shape
+    U = x.shape[2]
+    return torch.gather(x.unsqueeze(1).expand(-1, L, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, U))
+
+
+def ball_query_gather(pts, idx):
+    """reference utils/loc_utils.py:353-354: gather with index -1 -> zero row."""
+    return knn_gather(torch.cat((torch.zeros((pts.shape[0], 1, pts.shape[-1]), device=pts.device), pts), 1), idx + 1)
+
+
+class ume_kp_layer(nn.Module):
+    """reference utils/loc_utils.py:357-431.  Constructed by evaluate.py:168 and loss.py:124 but
+    never invoked there; kept constructible and runnable on top of the fused kernels."""
+
+    def __init__(self, ume_knn, ume_desc_rad, diag_only=False, n_rand=None):
+        super().__init__()
+        self.ume_knn = ume_knn
+        self.ume_desc_rad = ume_desc_rad
+        self.diag_only = diag_only
+        self.n_rand = n_rand
+
+    def ume_mat(self, points, features, bs, n_kp):
+        """Moment matrix of already-gathered neighbourhoods (:365-372), plain tensor ops.
+        points [bs*n_kp,K,3], features [bs*n_kp,K,d]."""
+        m0 = torch.sum(features, dim=1, keepdim=True)
+        m1 = features.transpose(2, 1) @ points
+        ume_mat = torch.cat((m0.transpose(2, 1), m1), dim=2) / (torch.sum(m0, dim=-1, keepdim=True) + 1e-6)
+        return ume_mat.view(bs, n_kp, *ume_mat.shape[1:])
+
+    def forward(self, source_points, source_features, source_kp, target_points, target_features, target_kp):
+        bs, n_kp = source_kp.shape[0], source_kp.shape[1]
+        # ball query + gather + ume_mat (:383-393) is exactly the fused moments kernel
+        G_all = ops.ume_moments(source_points, source_kp, source_features, self.ume_knn, self.ume_desc_rad)
+        H_all = ops.ume_moments(target_points, target_kp, target_features, self.ume_knn, self.ume_desc_rad)
+        Gf = G_all.reshape(-1, 32, 4)
+        Hf = H_all.reshape(-1, 32, 4)
+        dev = Gf.device
+        if not self.diag_only:
+            b = torch.arange(bs, device=dev)[:, None, None] * n_kp
+            gi = (b + torch.arange(n_kp, device=dev)[None, :, None]).expand(bs, n_kp, n_kp).reshape(-1)
+            hi = (b + torch.arange(n_kp, device=dev)[None, None, :]).expand(bs, n_kp, n_kp).reshape(-1)
+            T, D = ops.rtume_solve(Gf, Hf, gi, hi, with_dist=True)
+            T = T.view(bs, n_kp, n_kp, 4, 4)
+            D = D.view(bs, n_kp, n_kp)
+        else:
+            if self.n_rand is not None:
+                triplets = torch.from_numpy(np.random.choice(np.arange(Gf.shape[0]), (self.n_rand, 3))).to(dev)
+                Gs = Gf[triplets[:, 0]] + Gf[triplets[:, 1]] + Gf[triplets[:, 2]]
+                Hs = Hf[triplets[:, 0]] + Hf[triplets[:, 1]] + Hf[triplets[:, 2]]
+                T, D = ops.rtume_solve(Gs, Hs, with_dist=True)
+                T = T.view(bs, -1, 4, 4)
+                D = D.view(bs, -1)
+            else:
+                T, D = ops.rtume_solve(Gf, Hf, with_dist=True)
+                T = T.view(bs, n_kp, 4, 4)
+                D = D.view(bs, n_kp)
+        return T, D, G_all.unsqueeze(2).squeeze(), H_all.unsqueeze(1).squeeze()
