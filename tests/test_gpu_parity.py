@@ -166,7 +166,8 @@ def test_ume_cdist_golden(gpu):
     assert np.abs(D - D64)[ok].max() < 2e-3               # vs fp64 truth
     far = ok & (D64 > 0.05)                               # away from the sqrt cancellation at D ~ 0
     assert np.abs(D - D64)[far].max() < 2e-5
-    assert np.abs(D - D64).max() < 2e-3                   # rank-deficient rows too (same Householder convention)
+    # zero UME (row 63): LAPACK's tau = 0 convention gives Q = I[:, :4], like torch.linalg.qr
+    assert np.abs(D[63] - D64[63])[ok[0]].max() < 2e-5 and np.abs(D[63] - g["D"][63])[ok[0]].max() < 3e-3
     # fused arg-min == arg-min of the materialised matrix, bit for bit
     m, d = ops.ume_match(T_(g["ume1"], gpu)[None], T_(g["ume2"], gpu)[None])
     assert np.array_equal(N_(m[0]), D.argmin(axis=1))
@@ -199,7 +200,9 @@ def test_ume_cdist_ragged_vs_oracle(gpu, n1, n2):
     assert np.array_equal(N_(m[0][:k]), np.arange(k))
     # asymmetric check (catches a transposed tile write): D(u1,u2) == D(u2,u1)^T
     Dt = N_(ops.ume_cdist(T_(u2, gpu)[None], T_(u1, gpu)[None])[0])
-    assert np.abs(D - Dt.T).max() < 1e-5
+    assert np.abs(D - Dt.T).max() < 2e-3                  # D ~ 0 entries carry sqrt-cancellation noise
+    if (D64 > 0.05).any():
+        assert np.abs(D - Dt.T)[D64 > 0.05].max() < 1e-5
 
 
 def test_ume_cdist_batch(gpu):

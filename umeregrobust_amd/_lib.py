@@ -7,6 +7,12 @@ an error.
 import ctypes
 import os
 
+# torch must come first: PyTorch-ROCm bundles its own libamdhip64.so; loading it before
+# libumereg.so makes our DT_NEEDED libamdhip64.so.7 resolve to THAT runtime, so torch's streams
+# and device pointers are valid inside our kernels.  (Loaded the other way round the process
+# holds two HIP runtimes and ours sees no device.)
+import torch  # noqa: F401
+
 from ._build import LIB_PATH
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
