@@ -46,7 +46,11 @@ enum {
 enum {
     UMEREG_QLAYOUT_PLAIN = 0, /* [n,32,4] row-major, like torch.linalg.qr(...).Q */
     UMEREG_QLAYOUT_ROWS = 1,  /* MFMA A-fragment order: source side of the distance GEMM */
-    UMEREG_QLAYOUT_COLS = 2   /* MFMA B-fragment order: target side of the distance GEMM */
+    UMEREG_QLAYOUT_COLS = 2,  /* MFMA B-fragment order: target side of the distance GEMM */
+    /* split-f16 operands for the fast GEMM: every basis entry is stored as hi = f16(q) and
+     * lo = f16(q - hi): |q| <= 1, so the pair carries q to an absolute error <= 2^-25 */
+    UMEREG_QLAYOUT_ROWS_F16X2 = 3, /* source side; pads n to a multiple of 64 */
+    UMEREG_QLAYOUT_COLS_F16X2 = 4  /* target side; pads n to a multiple of 32 */
 };
 
 int umereg_abi_version(void);
@@ -83,11 +87,14 @@ int umereg_ball_query_f32(const float* p1, const float* p2, const int64_t* lengt
  *   nn_idx   int64 [B,n_kp,K] the neighbourhood actually used, -1 padded              (may be NULL)
  * ------------------------------------------------------------------------------------------- */
 size_t umereg_ume_moments_workspace_bytes(int B, int N);
-/* layered form of the same call, so a caller can keep the packed table across calls and time the
- * moment kernel alone: (1) pack pts [B,N,3] into the padded {x,y,z,-} table (`packed`, size =
- * umereg_ume_moments_workspace_bytes(B,N)); (2) run the fused kernel on it. */
-int umereg_pack_points_f32(const float* pts, int B, int N, void* packed, size_t packed_bytes,
-                           void* stream);
+/* layered form of the same call, so a caller can time the moment kernel alone:
+ * (1) umereg_pack_points_f32 builds the search structure for `radius` in `packed` (size =
+ *     umereg_ume_moments_workspace_bytes(B,N)): packed {x,y,z} table, bounding box, uniform grid
+ *     with cell edge >= radius, points counting-sorted by cell (stable, deterministic);
+ * (2) umereg_ume_moments_packed_f32 runs the fused search + gather + moments kernel on it (same
+ *     radius). */
+int umereg_pack_points_f32(const float* pts, int B, int N, float radius, void* packed,
+                           size_t packed_bytes, void* stream);
 int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const float* feat, int B,
                                   int N, int n_kp, int feat_dim, int K, float radius, float* F,
                                   int32_t* nn_count, int64_t* nn_idx, void* stream);
@@ -101,7 +108,7 @@ int umereg_ume_moments_f32(const float* pts, const float* kpts, const float* fea
  * Householder orthonormal basis of each 32x4 UME matrix (LAPACK geqr2/org2r conventions,
  * computed in fp64, stored fp32).  The projector QQ^T -- all the reference uses -- is
  * invariant to QR sign conventions.
- *   ume [n,32,4] -> Q in `layout`; ROWS pads n to a multiple of 16, COLS to a multiple of 32
+ *   ume [n,32,4] -> Q in `layout`; ROWS pads n to a multiple of 16, COLS to 32, ROWS_F16X2 to 64
  *   (padding is written as zeros): size = umereg_qbasis_bytes(n, layout).
  * ------------------------------------------------------------------------------------------- */
 size_t umereg_qbasis_bytes(int n, int layout);
@@ -131,6 +138,14 @@ int umereg_ume_dist_q_f32(const float* Q1_rows, const float* Q2_cols, int n1, in
 int umereg_ume_match_f32(const float* ume1, const float* ume2, int B, int n1, int n2,
                          int64_t* match_idx, float* match_dist, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same two calls on the f16 MFMA pipe (16x the fp32-MFMA rate): operands in the *_F16X2
+ * layouts, products hi*hi + hi*lo + lo*hi accumulated in fp32 by v_mfma_f32_32x32x16_f16 --
+ * an fp32-class result (operand error <= 2^-25 absolute) several times faster. */
+int umereg_ume_dist_q_f16x2(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, float* D,
+                            int64_t* match_idx, float* match_dist, void* keys, void* stream);
+int umereg_ume_match_f16x2(const float* ume1, const float* ume2, int B, int n1, int n2,
+                           int64_t* match_idx, float* match_dist, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5  a = exp((1 - ume_d)/tau); prob = a / a.sum()                   evaluate.py:235-236

@@ -57,6 +57,35 @@ def test_ball_query_random_vs_oracle(gpu, N, n1, K, r):
     assert out2.knn is None and torch.equal(out2.idx, out.idx)
 
 
+@pytest.mark.parametrize("case", ["dense_smallK", "huge_extent", "one_cell", "flat_line", "far_queries"])
+def test_ball_query_grid_edge_cases(gpu, case):
+    """Geometry that stresses the uniform-grid search: streaming top-K re-selection (hits >> list
+    capacity), axis caps (extent >> 32 cells), a single cell, degenerate extents, queries far
+    outside the bounding box.  Result must stay bit-identical to the linear scan."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(sum(map(ord, case)))
+    K, r = 64, 5.0
+    if case == "dense_smallK":
+        pts = rng.uniform(-6, 6, (40000, 3)); q = pts[rng.choice(40000, 50, replace=False)] + 0.01; K = 8
+    elif case == "huge_extent":
+        pts = rng.uniform(-3000, 3000, (30000, 3)) * np.array([1, 1, 0.01]); q = pts[:60] + 0.5; r = 150.0
+    elif case == "one_cell":
+        pts = rng.uniform(-1, 1, (5000, 3)); q = rng.uniform(-2, 2, (40, 3)); K = 750
+    elif case == "flat_line":
+        pts = np.stack([np.linspace(-400, 400, 20000), np.zeros(20000), np.zeros(20000)], 1)
+        pts = pts[rng.permutation(20000)]; q = pts[:30] + np.array([0.1, 0.2, 0.0]); K = 200
+    else:
+        pts = rng.uniform(-50, 50, (20000, 3)) * np.array([1, 1, 0.05])
+        q = np.concatenate([rng.uniform(-50, 50, (20, 3)) * np.array([1, 1, 0.05]),
+                            [[54.9, 0, 0], [55.1, 0, 0], [-60, -60, 0], [1e6, 0, 0], [0, 0, 4.99], [0, 0, 9]]])
+    pts = pts.astype(np.float32); q = q.astype(np.float32)
+    ref = orc.ball_query(q[None], pts[None], K=K, radius=r, return_nn=True)
+    out = ops.ball_query(T_(q, gpu)[None], T_(pts, gpu)[None], K=K, radius=r, return_nn=True)
+    assert np.array_equal(N_(out.idx), ref.idx)
+    assert np.array_equal(N_(out.dists), ref.dists)
+    assert np.array_equal(N_(out.knn), ref.knn)
+
+
 def test_ball_query_batch_and_lengths(gpu):
     from umeregrobust_amd import ops
     rng = np.random.RandomState(4)
@@ -169,7 +198,7 @@ def test_ume_cdist_golden(gpu):
     # zero UME (row 63): LAPACK's tau = 0 convention gives Q = I[:, :4], like torch.linalg.qr
     assert np.abs(D[63] - D64[63])[ok[0]].max() < 2e-5 and np.abs(D[63] - g["D"][63])[ok[0]].max() < 3e-3
     # fused arg-min == arg-min of the materialised matrix, bit for bit
-    m, d = ops.ume_match(T_(g["ume1"], gpu)[None], T_(g["ume2"], gpu)[None])
+    m, d = ops.ume_match(T_(g["ume1"], gpu)[None], T_(g["ume2"], gpu)[None], precision="f32")
     assert np.array_equal(N_(m[0]), D.argmin(axis=1))
     assert np.array_equal(N_(d[0]), D[np.arange(64), D.argmin(axis=1)])
     rows = ok.any(axis=1)
@@ -195,7 +224,7 @@ def test_ume_cdist_ragged_vs_oracle(gpu, n1, n2):
     D64 = orc.ume_cdist_f64(u1, u2)
     assert np.abs(D - D64).max() < 2e-3
     assert np.abs(D - D64)[D64 > 0.05].max() < 2e-5 if (D64 > 0.05).any() else True
-    m, d = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None])
+    m, d = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f32")
     assert np.array_equal(N_(m[0]), D.argmin(axis=1))
     assert np.array_equal(N_(m[0][:k]), np.arange(k))
     # asymmetric check (catches a transposed tile write): D(u1,u2) == D(u2,u1)^T
@@ -203,6 +232,46 @@ def test_ume_cdist_ragged_vs_oracle(gpu, n1, n2):
     assert np.abs(D - Dt.T).max() < 2e-3                  # D ~ 0 entries carry sqrt-cancellation noise
     if (D64 > 0.05).any():
         assert np.abs(D - Dt.T)[D64 > 0.05].max() < 1e-5
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (63, 33), (64, 32), (65, 31), (250, 1000), (1000, 97), (3000, 2500)])
+def test_ume_dist_f16x2_vs_oracle(gpu, n1, n2):
+    """Split-f16 MFMA path (hi + 2^-11 lo operands, fp32 accumulate): must be fp32-class, i.e. meet the
+    same bounds against the fp64 truth as the exact-fp32 MFMA path, and agree with it on the arg-min."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(n1 * 7 + n2)
+    u1 = rng.standard_normal((n1, 32, 4)).astype(np.float32)
+    u2 = rng.standard_normal((n2, 32, 4)).astype(np.float32)
+    u1[:, :, 1:] += 30.0 * u1[:, :, :1]                  # UME-like: columns nearly collinear (cond ~ 1e2..1e3)
+    u2[:, :, 1:] += 30.0 * u2[:, :, :1]
+    k = min(n1, n2) // 2
+    u2[:k] = u1[:k] @ (np.eye(4) + 0.1 * rng.standard_normal((4, 4))).astype(np.float32)
+    Dh = N_(ops.ume_cdist(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16x2")[0])
+    Df = N_(ops.ume_cdist(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f32")[0])
+    D64 = orc.ume_cdist_f64(u1, u2)
+    assert np.abs(Dh - D64).max() < 2e-3
+    if (D64 > 0.05).any():
+        assert np.abs(Dh - D64)[D64 > 0.05].max() < 2e-5
+        assert np.abs(Dh - Df)[D64 > 0.05].max() < 2e-5
+    mh, dh = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16x2")
+    assert np.array_equal(N_(mh[0]), Dh.argmin(axis=1))          # fused arg-min == arg-min of its own matrix
+    assert np.array_equal(N_(dh[0]), Dh[np.arange(n1), Dh.argmin(axis=1)])
+    assert np.array_equal(N_(mh[0][:k]), np.arange(k))
+    mf, _ = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f32")
+    agree = (N_(mh[0]) == N_(mf[0])).mean()
+    assert agree >= 0.999 or n1 < 100
+    # arg-min of the fp64 truth, where the margin is above the fp32 noise
+    srt = np.sort(D64, axis=1)
+    clear = (srt[:, 1] - srt[:, 0] > 5e-3) if n2 > 1 else np.ones(n1, bool)
+    assert np.array_equal(N_(mh[0])[clear], D64.argmin(axis=1)[clear])
+    # single-call ABI entry
+    lib = __import__("umeregrobust_amd")._lib.load()
+    m1 = torch.empty((1, n1), dtype=torch.int64, device=gpu); d1 = torch.empty((1, n1), device=gpu)
+    ws = torch.empty(lib.umereg_ume_match_workspace_bytes(1, n1, n2), dtype=torch.uint8, device=gpu)
+    a, b = T_(u1, gpu)[None].contiguous(), T_(u2, gpu)[None].contiguous()
+    rc = lib.umereg_ume_match_f16x2(a.data_ptr(), b.data_ptr(), 1, n1, n2, m1.data_ptr(), d1.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and torch.equal(m1, mh) and torch.equal(d1, dh)
 
 
 def test_ume_cdist_batch(gpu):

@@ -28,11 +28,15 @@ SIGNATURES = {
     "umereg_ume_moments_workspace_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ume_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "umereg_pack_points_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umereg_pack_points_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "umereg_ume_moments_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "umereg_ume_dist_q_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    "umereg_ume_dist_q_f16x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
+    "umereg_ume_match_f16x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "umereg_qbasis_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ume_orthobasis_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "umereg_ume_cdist_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

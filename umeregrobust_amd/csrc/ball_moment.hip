@@ -2,104 +2,434 @@
 // for gfx950.  Replaces pytorch3d.ops.ball_query (reference evaluate.py:51) and
 // evaluate.my_ume_generation (reference evaluate.py:50-60).
 //
-// Execution model: one 64-lane wavefront per keypoint, 4 independent wavefronts per workgroup
-// (no workgroup barrier anywhere, so a wave can retire as soon as its keypoint is done).
+// pytorch3d's kernel tests every point against every query (one thread per query, linear scan).
+// Measured here, that scan was 263 of 346 us per KITTI-sized cloud, so the search is restructured
+// around a uniform grid while keeping the result BIT-IDENTICAL to the linear scan:
 //
-//   scan    lanes stride the packed point table {x,y,z,-} (one coalesced 1 KiB dwordx4 load
-//           per 64 points) IN INDEX ORDER; d2 = ((dx*dx)+(dy*dy))+(dz*dz) with one rounding
-//           per operation (this file is compiled with -ffp-contract=off) so the strict
-//           `d2 < r*r` test is bit-identical to the scalar reference loop; hits are
-//           appended in ascending index order with ballot + mbcnt prefix counts into a
-//           per-wave LDS list and the scan stops at K hits ("first K by index").
+//   prep    (5 tiny launches per cloud, all deterministic)
+//           pack [N,3] -> {x,y,z,-} + bounding box (ordered-uint atomicMax) ;
+//           cell id per point, per-workgroup LDS histograms ; exclusive scan over (cell, workgroup) ;
+//           STABLE scatter into cell-sorted order {x,y,z,original index}.
+//           Cell edge >= 1.0001 r, so a ball touches at most 3x3x3 cells, and because cells are
+//           linearised x-fastest the three x-neighbours are ONE contiguous run: 9 runs per query.
+//   search  one 64-lane wavefront per query; lanes stride each run (coalesced 1 KiB dwordx4 loads);
+//           d2 = ((dx*dx)+(dy*dy))+(dz*dz), one rounding per operation (-ffp-contract=off), strict
+//           d2 < r*r: the same predicate, bit for bit, as the reference loop.  "First K by index"
+//           is kept exact by a streaming top-K on the ORIGINAL index: hits are appended to a per-wave
+//           LDS list (ballot + mbcnt); when the list fills, a radix select finds the K-th smallest
+//           index, the list is compacted to those K and later hits above the threshold are dropped.
 //   moments 8 neighbours x 8 channel-quads per step: each lane loads one 16 B slice of a
-//           neighbour's 128 B feature row (1 KiB per wave-load, whole rows) and the
-//           neighbour's xyz, and keeps 4 channels x {1,x,y,z} fp64 accumulators; the 8
-//           neighbour slots are folded with xor-shuffles, the normaliser is a wave reduction,
-//           and the 32x4 fp32 result leaves as 8 lanes x 64 B.
+//           neighbour's 128 B feature row (1 KiB per wave-load, whole rows) and its xyz, and keeps
+//           4 channels x {1,x,y,z} fp64 accumulators; the 8 neighbour slots are folded with
+//           xor-shuffles, the normaliser is a wave reduction, the 32x4 fp32 result leaves as
+//           8 lanes x 64 B.  fp64 accumulation makes the result independent of neighbour order
+//           to ~1e-16, i.e. the correctly rounded fp32 moment matrix.
+//   a1      the ball-query entry point sorts the K kept indices (bitonic, in LDS) to emit
+//           pytorch3d's ascending order, then recomputes dists / nn from them.
 // The reference's [n_kp,K,32] gathered intermediate (960 MB at KITTI size) never exists.
 #include "common.h"
 
 namespace umereg {
 
-constexpr int kWavesPerWG = 4;
-constexpr int kScanUnroll = 4;
-constexpr int kPadPts = kWave * kScanUnroll;  // point table padded to a multiple of this
-constexpr float kFar = 1.0e18f;               // padding coordinate: d2 ~ 3e36, never < r2
+constexpr float kFar = 1.0e18f;     // padding coordinate: d2 ~ 3e36, never < r2
+constexpr int kPadPts = 256;        // packed tables are padded to a multiple of this
+constexpr int kMaxCells = 4096;     // grid cells: <= 32 x 32 x 4
+constexpr int kCapX = 32, kCapY = 32, kCapZ = 4;
+constexpr int kSortWG = 1024;       // points per workgroup in the counting sort
 
-// ---- K0: pack [N,3] -> [Npad] float4 ----------------------------------------------------------
-__global__ void pack_points_kernel(const float* __restrict__ pts, float4* __restrict__ out, int N,
-                                   int Npad)
+// ---- workspace carve-up (per batch element) ---------------------------------------------------
+struct GridWs {
+    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_bbox, total;
+    int Npad, n_wg;
+};
+
+__host__ __device__ inline GridWs grid_ws(int N)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (j >= Npad) return;
-    float4 v = make_float4(kFar, kFar, kFar, 0.f);
-    if (j < N) {
-        const float* p = pts + ((size_t)b * N + j) * 3;
-        v = make_float4(p[0], p[1], p[2], 0.f);
-    }
-    out[(size_t)b * Npad + j] = v;
+    GridWs w;
+    w.Npad = (int)((N + kPadPts - 1) / kPadPts * kPadPts);
+    w.n_wg = (N + kSortWG - 1) / kSortWG;
+    size_t o = 0;
+    w.off_p4o = o;    o += (size_t)w.Npad * 16;
+    w.off_p4s = o;    o += ((size_t)w.Npad + 64) * 16;
+    w.off_cell = o;   o += (size_t)w.Npad * 4;
+    w.off_counts = o; o += (size_t)w.n_wg * kMaxCells * 4;
+    w.off_bases = o;  o += (size_t)w.n_wg * kMaxCells * 4;
+    w.off_start = o;  o += (size_t)(kMaxCells + 64) * 4;
+    w.off_bbox = o;   o += 64;
+    w.total = (o + 255) / 256 * 256;
+    return w;
 }
 
-// ---- the scan: returns min(#hits, K); hit indices (ascending) in lds_idx[0 .. count) -----------
-__device__ __forceinline__ int ball_scan(const float4* __restrict__ P4, int n_eff, float qx, float qy,
-                                         float qz, float r2, int K, int* lds_idx, int lane)
+// ---- grid geometry, recomputed from the bounding box by every kernel that needs it ------------
+struct Grid {
+    float minx, miny, minz, invx, invy, invz;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ unsigned int enc_ord(float f)
 {
-    int count = 0;
-    for (int base = 0; base < n_eff && count < K; base += kPadPts) {
-        float4 p[kScanUnroll];
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ord(unsigned int e)
+{
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+// bbox words: [0..2] = max of ~enc(coord) (i.e. the minimum), [3..5] = max of enc(coord)
+__device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox, float radius)
+{
+    Grid g;
+    const float mn[3] = {dec_ord(~bbox[0]), dec_ord(~bbox[1]), dec_ord(~bbox[2])};
+    const float mx[3] = {dec_ord(bbox[3]), dec_ord(bbox[4]), dec_ord(bbox[5])};
+    const int cap[3] = {kCapX, kCapY, kCapZ};
+    float inv[3];
+    int n[3];
 #pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) p[u] = P4[base + u * kWave + lane];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = fmaxf(mx[a] - mn[a], 0.f);
+        // cell edge: >= 1.0001 r (so |p-q| < r spans at most one cell boundary even after
+        // rounding) and large enough that the axis fits its cap
+        const float cs = fmaxf(radius * 1.0001f, ext / (float)cap[a] * 1.0001f) + 1e-30f;
+        inv[a] = 1.0f / cs;
+        int na = (int)floorf(ext * inv[a]) + 1;
+        n[a] = na < 1 ? 1 : (na > cap[a] ? cap[a] : na);
+    }
+    g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
+    g.invx = inv[0]; g.invy = inv[1]; g.invz = inv[2];
+    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    return g;
+}
+
+__device__ __forceinline__ int cell_axis(float p, float mn, float inv, int n)
+{
+    const float t = (p - mn) * inv;
+    int c = (int)floorf(t);
+    c = c < 0 ? 0 : c;           // also catches NaN -> 0
+    return c > n - 1 ? n - 1 : c;
+}
+
+// ---- K0: pack [N,3] -> [Npad] float4, and the bounding box -------------------------------------
+// Few fat workgroups (grid-stride) so the bounding box costs ~6 atomics per workgroup: thousands of
+// same-address atomics serialise at ~12 ns each and made this kernel 56 us in its first version.
+constexpr int kPackWG = 1024;
+constexpr int kPackMaxBlocks = 32;
+
+__global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __restrict__ pts, char* __restrict__ ws,
+                                                              size_t ws_stride, int N)
+{
+    __shared__ unsigned int red[kPackWG / 64][6];
+    const GridWs w = grid_ws(N);
+    const int b = blockIdx.y;
+    float4* out = reinterpret_cast<float4*>(ws + b * ws_stride + w.off_p4o);
+    unsigned int* bbox = reinterpret_cast<unsigned int*>(ws + b * ws_stride + w.off_bbox);
+    unsigned int e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    for (int j = blockIdx.x * kPackWG + threadIdx.x; j < w.Npad; j += gridDim.x * kPackWG) {
+        float4 v = make_float4(kFar, kFar, kFar, 0.f);
+        if (j < N) {
+            const float* p = pts + ((size_t)b * N + j) * 3;
+            v = make_float4(p[0], p[1], p[2], 0.f);
+            const unsigned int ex = enc_ord(v.x), ey = enc_ord(v.y), ez = enc_ord(v.z);
+            e[0] = max(e[0], ~ex); e[1] = max(e[1], ~ey); e[2] = max(e[2], ~ez);
+            e[3] = max(e[3], ex);  e[4] = max(e[4], ey);  e[5] = max(e[5], ez);
+        }
+        out[j] = v;
+    }
 #pragma unroll
-        for (int u = 0; u < kScanUnroll; ++u) {
-            const int j = base + u * kWave + lane;
-            const float dx = qx - p[u].x;
-            const float dy = qy - p[u].y;
-            const float dz = qz - p[u].z;
-            float d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
-            const bool hit = (d2 < r2) && (j < n_eff);
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull) {  // wave-uniform
-                const int pos = count + mbcnt(m);
-                if (hit && pos < K) lds_idx[pos] = j;
-                count += __popcll(m);
-            }
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned int o = __shfl_xor(e[k], m, kWave);
+            e[k] = o > e[k] ? o : e[k];
         }
     }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = e[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned int v = 0u;
+        for (int wv = 0; wv < kPackWG / 64; ++wv) v = max(v, red[wv][threadIdx.x]);
+        atomicMax(bbox + threadIdx.x, v);   // max is order-independent: deterministic
+    }
+}
+
+// ---- K1: cell ids + per-workgroup histograms --------------------------------------------------
+__global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ ws, size_t ws_stride, int N,
+                                                            float radius)
+{
+    __shared__ int hist[kMaxCells];
+    const GridWs w = grid_ws(N);
+    char* wb = ws + blockIdx.y * ws_stride;
+    const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
+    int* cell_of = reinterpret_cast<int*>(wb + w.off_cell);
+    int* counts = reinterpret_cast<int*>(wb + w.off_counts) + (size_t)blockIdx.x * kMaxCells;
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) hist[c] = 0;
+    __syncthreads();
+    const int j = blockIdx.x * kSortWG + threadIdx.x;
+    if (j < N) {
+        const float4 p = P4o[j];
+        const int c = (cell_axis(p.z, g.minz, g.invz, g.nz) * g.ny + cell_axis(p.y, g.miny, g.invy, g.ny)) * g.nx +
+                      cell_axis(p.x, g.minx, g.invx, g.nx);
+        cell_of[j] = c;
+        atomicAdd(&hist[c], 1);   // integer counts: order-independent
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) counts[c] = hist[c];
+}
+
+// ---- K2: exclusive scan over (cell, workgroup): bases[wg][c] = first slot of (wg, c) within cell c --
+// One workgroup; reads and writes go to different arrays so the per-cell loop over workgroups is a
+// stream of independent loads (a read-modify-write in place serialised ~50 dependent round trips).
+__global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius)
+{
+    __shared__ int tot[kMaxCells];
+    __shared__ int part[1024 / 64];
+    const GridWs w = grid_ws(N);
+    char* wb = ws + blockIdx.y * ws_stride;
+    const int* __restrict__ counts = reinterpret_cast<const int*>(wb + w.off_counts);
+    int* __restrict__ bases = reinterpret_cast<int*>(wb + w.off_bases);
+    int* __restrict__ start = reinterpret_cast<int*>(wb + w.off_start);
+    const Grid gg = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const int n_cells = gg.nx * gg.ny * gg.nz;   // cells beyond this are never populated
+    for (int c = threadIdx.x; c < kMaxCells; c += 1024) {
+        int run = 0;
+        if (c >= n_cells) { tot[c] = 0; continue; }
+        int g = 0;
+        for (; g + 8 <= w.n_wg; g += 8) {
+            int t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = counts[(size_t)(g + u) * kMaxCells + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                bases[(size_t)(g + u) * kMaxCells + c] = run;
+                run += t[u];
+            }
+        }
+        for (; g < w.n_wg; ++g) {
+            const int t = counts[(size_t)g * kMaxCells + c];
+            bases[(size_t)g * kMaxCells + c] = run;
+            run += t;
+        }
+        tot[c] = run;
+    }
+    __syncthreads();
+    // exclusive scan of tot[0..4096): each thread owns 4 consecutive cells
+    const int c0 = threadIdx.x * 4;
+    const int t0 = tot[c0], t1 = tot[c0 + 1], t2 = tot[c0 + 2], t3 = tot[c0 + 3];
+    const int sum = t0 + t1 + t2 + t3;
+    int incl = sum;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_up(incl, m, kWave);
+        if ((int)(threadIdx.x & 63) >= m) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) base += part[k];
+    const int excl = base + incl - sum;
+    start[c0] = excl;
+    start[c0 + 1] = excl + t0;
+    start[c0 + 2] = excl + t0 + t1;
+    start[c0 + 3] = excl + t0 + t1 + t2;
+    if (threadIdx.x == 1023) start[kMaxCells] = excl + sum;
+}
+
+// ---- K3: stable scatter into cell-sorted order ------------------------------------------------
+__global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict__ ws, size_t ws_stride, int N)
+{
+    __shared__ int slot[kMaxCells];
+    const GridWs w = grid_ws(N);
+    char* wb = ws + blockIdx.y * ws_stride;
+    const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
+    float4* P4s = reinterpret_cast<float4*>(wb + w.off_p4s);
+    const int* cell_of = reinterpret_cast<const int*>(wb + w.off_cell);
+    const int* bases = reinterpret_cast<const int*>(wb + w.off_bases) + (size_t)blockIdx.x * kMaxCells;
+    const int* start = reinterpret_cast<const int*>(wb + w.off_start);
+    for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) slot[c] = start[c] + bases[c];
+    __syncthreads();
+    const int j = blockIdx.x * kSortWG + threadIdx.x;
+    const bool valid = j < N;
+    const int c = valid ? cell_of[j] : -1;
+    const int wave = threadIdx.x >> 6;
+    // rank among the lanes of this wave with the same cell and a lower index
+    int rank = 0, n_same = 0;
+    {
+        unsigned long long todo = __ballot(valid);
+        while (todo != 0ull) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lc = __shfl(c, leader, kWave);
+            const unsigned long long same = __ballot(valid && c == lc);
+            if (c == lc) { rank = mbcnt(same); n_same = __popcll(same); }
+            todo &= ~same;
+        }
+    }
+    // waves take turns in index order: slot[] is the running first-free slot of each cell
+    for (int wv = 0; wv < kSortWG / 64; ++wv) {
+        if (wave == wv && valid) {
+            const int pos = slot[c] + rank;
+            float4 p = P4o[j];
+            p.w = __int_as_float(j);
+            P4s[pos] = p;
+        }
+        __syncthreads();
+        if (wave == wv && valid && rank == 0) slot[c] += n_same;
+        __syncthreads();
+    }
+    // tail padding of the sorted table (read, never accepted, by the last chunk of the last run)
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+        P4s[N + threadIdx.x] = make_float4(kFar, kFar, kFar, __int_as_float(0x7fffffff));
+}
+
+// ---- streaming top-K by original index ---------------------------------------------------------
+// K-th smallest (1-based) of lst[0..cnt) -- distinct non-negative ints < 2^nbits -- by radix select.
+__device__ __forceinline__ int select_kth(const int* lst, int cnt, int K, int nbits, int lane)
+{
+    int prefix = 0, need = K;
+    for (int bit = nbits - 1; bit >= 0; --bit) {
+        int zeros = 0;
+        for (int e0 = 0; e0 < cnt; e0 += kWave) {
+            const int e = e0 + lane;
+            const int v = e < cnt ? lst[e] : -1;
+            const bool z = e < cnt && ((v ^ prefix) >> (bit + 1)) == 0 && ((v >> bit) & 1) == 0;
+            zeros += __popcll(__ballot(z));
+        }
+        if (need > zeros) { prefix |= 1 << bit; need -= zeros; }
+    }
+    return prefix;
+}
+
+// keep the entries <= thr (in place); returns the new count
+__device__ __forceinline__ int compact_le(int* lst, int cnt, int thr, int lane)
+{
+    int out = 0;
+    for (int e0 = 0; e0 < cnt; e0 += kWave) {
+        const int e = e0 + lane;
+        const int v = e < cnt ? lst[e] : 0x7fffffff;
+        const bool keep = e < cnt && v <= thr;
+        const unsigned long long m = __ballot(keep);
+        __builtin_amdgcn_wave_barrier();
+        if (keep) lst[out + mbcnt(m)] = v;   // out + prefix <= e: never clobbers an unread entry
+        out += __popcll(m);
+    }
     __builtin_amdgcn_wave_barrier();
-    return count < K ? count : K;
+    return out;
+}
+
+// Grid search for one query.  Returns min(#hits, K); the kept ORIGINAL indices are in
+// lst[0..count) in unspecified (deterministic) order.  lst has capacity cap >= K + 2*64.
+__device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, const int* __restrict__ start,
+                                                const Grid& g, float qx, float qy, float qz, float r2, int K,
+                                                int n_eff, int nbits, int* lst, int cap, int lane)
+{
+    const int cx = cell_axis(qx, g.minx, g.invx, g.nx);
+    const int cy = cell_axis(qy, g.miny, g.invy, g.ny);
+    const int cz = cell_axis(qz, g.minz, g.invz, g.nz);
+    const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < g.nx - 1 ? cx + 1 : g.nx - 1;
+    const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy < g.ny - 1 ? cy + 1 : g.ny - 1;
+    const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz < g.nz - 1 ? cz + 1 : g.nz - 1;
+    int cnt = 0;
+    int thr = n_eff - 1;   // accept original indices <= thr (lengths2: only the first n_eff points exist)
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+            const int cbase = (z * g.ny + y) * g.nx;
+            const int beg = __builtin_amdgcn_readfirstlane(start[cbase + x0]);
+            const int end = __builtin_amdgcn_readfirstlane(start[cbase + x1 + 1]);
+            for (int base = beg; base < end; base += kWave) {
+                const int pos = base + lane;
+                const float4 p = P4s[pos];          // table has 64 entries of tail padding
+                const int oi = __float_as_int(p.w);
+                const float dx = qx - p.x;
+                const float dy = qy - p.y;
+                const float dz = qz - p.z;
+                float d2 = dx * dx;
+                d2 = d2 + dy * dy;
+                d2 = d2 + dz * dz;
+                const bool hit = (pos < end) && (d2 < r2) && (oi <= thr);
+                const unsigned long long m = __ballot(hit);
+                if (m != 0ull) {   // wave-uniform
+                    if (hit) lst[cnt + mbcnt(m)] = oi;
+                    cnt += __popcll(m);
+                    if (cnt > cap - kWave) {   // the next chunk might not fit: keep the K smallest
+                        __builtin_amdgcn_wave_barrier();
+                        thr = select_kth(lst, cnt, K, nbits, lane);
+                        cnt = compact_le(lst, cnt, thr, lane);
+                    }
+                }
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > K) {
+        thr = select_kth(lst, cnt, K, nbits, lane);
+        cnt = compact_le(lst, cnt, thr, lane);
+    }
+    return cnt;
+}
+
+// ascending bitonic sort of lst[0..n_pow2) (entries beyond the live count must hold INT_MAX)
+__device__ __forceinline__ void bitonic_sort(int* lst, int n_pow2, int lane)
+{
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < (n_pow2 >> 1); t += kWave) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const int a = lst[lo], b = lst[hi];
+                if ((a > b) == up) { lst[lo] = b; lst[hi] = a; }
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void sort_kept(int* lst, int count, int lane)
+{
+    int n_pow2 = 64;
+    while (n_pow2 < count) n_pow2 <<= 1;
+    for (int e = count + lane; e < n_pow2; e += kWave) lst[e] = 0x7fffffff;
+    bitonic_sort(lst, n_pow2, lane);
 }
 
 // ---- a1: ball query with idx / dists / nn outputs ---------------------------------------------
-__global__ __launch_bounds__(kWave* kWavesPerWG) void ball_query_kernel(
-    const float4* __restrict__ P4, const float* __restrict__ p1, const int64_t* __restrict__ lengths1,
-    const int64_t* __restrict__ lengths2, int n1, int n2, int Npad, int K, int Kpad, float r2,
-    int64_t* __restrict__ idx, float* __restrict__ dists, float* __restrict__ nn)
+__global__ __launch_bounds__(256) void ball_query_kernel(
+    const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ p1,
+    const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int n1, int n2, int K, int cap,
+    float radius, int64_t* __restrict__ idx, float* __restrict__ dists, float* __restrict__ nn)
 {
     extern __shared__ int lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int b = blockIdx.y;
-    const int i = blockIdx.x * kWavesPerWG + wave;
+    const int i = blockIdx.x * (blockDim.x >> 6) + wave;
     if (i >= n1) return;
-    int* lds_idx = lds + wave * Kpad;
+    int* lst = lds + wave * cap;
+    const GridWs w = grid_ws(n2);
+    const char* wb = ws + b * ws_stride;
+    const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
+    const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    const int* start = reinterpret_cast<const int*>(wb + w.off_start);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
     const int len1 = lengths1 ? (int)lengths1[b] : n1;
     int len2 = lengths2 ? (int)lengths2[b] : n2;
     len2 = len2 < n2 ? len2 : n2;
-    const float4* Pb = P4 + (size_t)b * Npad;
     const float* q = p1 + ((size_t)b * n1 + i) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
+    const float r2 = radius * radius;
+    const int nbits = 32 - __clz(n2 > 1 ? n2 - 1 : 1);
     int count = 0;
-    if (i < len1) count = ball_scan(Pb, len2, qx, qy, qz, r2, K, lds_idx, lane);
+    if (i < len1 && len2 > 0) count = ball_search_grid(P4s, start, g, qx, qy, qz, r2, K, len2, nbits, lst, cap, lane);
+    sort_kept(lst, count, lane);   // pytorch3d emits the kept indices in ascending order
     const size_t row = ((size_t)b * n1 + i) * K;
     for (int e = lane; e < K; e += kWave) {
         int64_t j = -1;
         float d2 = 0.f, x = 0.f, y = 0.f, z = 0.f;
         if (e < count) {
-            const int jj = lds_idx[e];
-            const float4 p = Pb[jj];
+            const int jj = lst[e];
+            const float4 p = P4o[jj];
             const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
             d2 = dx * dx;
             d2 = d2 + dy * dy;
@@ -119,29 +449,36 @@ __global__ __launch_bounds__(kWave* kWavesPerWG) void ball_query_kernel(
 // ---- a1+a2: fused ball query + gather + UME moments -------------------------------------------
 constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave
 
-__global__ __launch_bounds__(kWave* kWavesPerWG) void ume_moments_kernel(
-    const float4* __restrict__ P4, const float* __restrict__ kpts, const float4* __restrict__ feat4,
-    int N, int Npad, int n_kp, int K, int Kpad, float r2, float* __restrict__ F,
+__global__ __launch_bounds__(256) void ume_moments_kernel(
+    const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
+    const float4* __restrict__ feat4, int N, int n_kp, int K, int cap, float radius, float* __restrict__ F,
     int32_t* __restrict__ nn_count, int64_t* __restrict__ nn_idx)
 {
     extern __shared__ int lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int b = blockIdx.y;
-    const int kp = blockIdx.x * kWavesPerWG + wave;
+    const int kp = blockIdx.x * (blockDim.x >> 6) + wave;
     if (kp >= n_kp) return;
-    int* lds_idx = lds + wave * Kpad;
-    const float4* Pb = P4 + (size_t)b * Npad;
+    int* lst = lds + wave * cap;
+    const GridWs w = grid_ws(N);
+    const char* wb = ws + b * ws_stride;
+    const float4* Pb = reinterpret_cast<const float4*>(wb + w.off_p4o);
+    const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    const int* start = reinterpret_cast<const int*>(wb + w.off_start);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
     const float4* fb = feat4 + (size_t)b * N * 8;
     const float* q = kpts + ((size_t)b * n_kp + kp) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
+    const int nbits = 32 - __clz(N > 1 ? N - 1 : 1);
 
-    const int count = ball_scan(Pb, N, qx, qy, qz, r2, K, lds_idx, lane);
+    const int count = ball_search_grid(P4s, start, g, qx, qy, qz, radius * radius, K, N, nbits, lst, cap, lane);
 
     if (nn_count && lane == 0) nn_count[(size_t)b * n_kp + kp] = count;
-    if (nn_idx) {
+    if (nn_idx) {   // optional parity output, ascending like ball_query
+        sort_kept(lst, count, lane);
         int64_t* o = nn_idx + ((size_t)b * n_kp + kp) * K;
-        for (int e = lane; e < K; e += kWave) o[e] = e < count ? (int64_t)lds_idx[e] : (int64_t)-1;
+        for (int e = lane; e < K; e += kWave) o[e] = e < count ? (int64_t)lst[e] : (int64_t)-1;
     }
 
     const int slot = lane >> 3;  // neighbour slot 0..7
@@ -153,7 +490,7 @@ __global__ __launch_bounds__(kWave* kWavesPerWG) void ume_moments_kernel(
         for (int u = 0; u < kMomUnroll; ++u) {
             const int e = e0 + u * 8 + slot;
             const bool v = e < count;
-            const int j = v ? lds_idx[e] : 0;
+            const int j = v ? lst[e] : 0;
             pp[u] = Pb[j];
             ff[u] = fb[(size_t)j * 8 + qd];
             if (!v) ff[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -196,12 +533,37 @@ __global__ __launch_bounds__(kWave* kWavesPerWG) void ume_moments_kernel(
     }
 }
 
-static int launch_pack(const float* pts, float4* P4, int B, int N, int Npad, hipStream_t st)
+// ---- host side ---------------------------------------------------------------------------------
+static int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st)
 {
-    dim3 grid((Npad + 255) / 256, B);
-    hipLaunchKernelGGL(pack_points_kernel, grid, dim3(256), 0, st, pts, P4, N, Npad);
+    const GridWs w = grid_ws(N);
+    for (int b = 0; b < B; ++b) {
+        if (hipMemsetAsync(ws + b * w.total + w.off_bbox, 0, 64, st) != hipSuccess) {
+            set_error("hipMemsetAsync(bbox) failed");
+            return UMEREG_ELAUNCH;
+        }
+    }
+    {
+        int nb = (w.Npad + kPackWG - 1) / kPackWG;
+        nb = nb > kPackMaxBlocks ? kPackMaxBlocks : nb;
+        hipLaunchKernelGGL(pack_points_kernel, dim3(nb, B), dim3(kPackWG), 0, st, pts, ws, w.total, N);
+    }
     UMEREG_CHECK_LAUNCH("pack_points_kernel");
+    hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius);
+    UMEREG_CHECK_LAUNCH("grid_hist_kernel");
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1, B), dim3(1024), 0, st, ws, w.total, N, radius);
+    UMEREG_CHECK_LAUNCH("grid_scan_kernel");
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N);
+    UMEREG_CHECK_LAUNCH("grid_scatter_kernel");
     return UMEREG_OK;
+}
+
+// per-wave LDS list capacity and waves per workgroup for a given K
+static void lds_plan(int K, int* cap, int* waves)
+{
+    const int Kpad = (int)align_up((size_t)K, 64);
+    *cap = 2 * Kpad + 64;
+    *waves = (*cap) * 4 * 4 <= 48 * 1024 ? 4 : ((*cap) * 4 * 2 <= 64 * 1024 ? 2 : 1);
 }
 
 }  // namespace umereg
@@ -211,7 +573,7 @@ using namespace umereg;
 UMEREG_API size_t umereg_ball_query_workspace_bytes(int B, int n2)
 {
     if (B <= 0 || n2 <= 0) return 0;
-    return (size_t)B * align_up((size_t)n2, kPadPts) * sizeof(float4);
+    return (size_t)B * grid_ws(n2).total;
 }
 
 UMEREG_API size_t umereg_ume_moments_workspace_bytes(int B, int N)
@@ -227,37 +589,38 @@ UMEREG_API int umereg_ball_query_f32(const float* p1, const float* p2, const int
     UMEREG_REQUIRE(p1 && p2 && idx, "ball_query: null pointer (p1/p2/idx)");
     UMEREG_REQUIRE(B > 0 && n1 > 0 && n2 > 0, "ball_query: B, n1, n2 must be positive (got %d, %d, %d)", B, n1, n2);
     UMEREG_REQUIRE(K > 0 && K <= 4096, "ball_query: K must be in [1, 4096] (got %d)", K);
+    UMEREG_REQUIRE(radius > 0.f, "ball_query: radius must be positive");
     if (int rc = check_device()) return rc;
-    if (!workspace || workspace_bytes < umereg_ball_query_workspace_bytes(B, n2)) {
-        set_error("ball_query: workspace too small (%zu < %zu)", workspace_bytes,
+    if (!workspace || workspace_bytes < umereg_ball_query_workspace_bytes(B, n2) || ((uintptr_t)workspace & 15)) {
+        set_error("ball_query: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
                   umereg_ball_query_workspace_bytes(B, n2));
         return UMEREG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int Npad = (int)align_up((size_t)n2, kPadPts);
-    float4* P4 = (float4*)workspace;
-    if (int rc = launch_pack(p2, P4, B, n2, Npad, st)) return rc;
-    const int Kpad = (int)align_up((size_t)K, 64);
-    dim3 grid((n1 + kWavesPerWG - 1) / kWavesPerWG, B);
-    const size_t lds = (size_t)kWavesPerWG * Kpad * sizeof(int);
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kWave * kWavesPerWG), lds, st, P4, p1, lengths1,
-                       lengths2, n1, n2, Npad, K, Kpad, radius * radius, idx, dists, nn);
+    if (int rc = launch_prep(p2, (char*)workspace, B, n2, radius, st)) return rc;
+    int cap, waves;
+    lds_plan(K, &cap, &waves);
+    dim3 grid((n1 + waves - 1) / waves, B);
+    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int), st,
+                       (const char*)workspace, grid_ws(n2).total, p1, lengths1, lengths2, n1, n2, K, cap, radius,
+                       idx, dists, nn);
     UMEREG_CHECK_LAUNCH("ball_query_kernel");
     return UMEREG_OK;
 }
 
-UMEREG_API int umereg_pack_points_f32(const float* pts, int B, int N, void* packed, size_t packed_bytes,
-                                      void* stream)
+UMEREG_API int umereg_pack_points_f32(const float* pts, int B, int N, float radius, void* packed,
+                                      size_t packed_bytes, void* stream)
 {
     UMEREG_REQUIRE(pts && packed, "pack_points: null pointer");
     UMEREG_REQUIRE(B > 0 && N > 0, "pack_points: B, N must be positive (got %d, %d)", B, N);
+    UMEREG_REQUIRE(radius > 0.f, "pack_points: radius must be positive");
     if (int rc = check_device()) return rc;
     if (packed_bytes < umereg_ume_moments_workspace_bytes(B, N) || ((uintptr_t)packed & 15)) {
         set_error("pack_points: packed buffer too small or misaligned (%zu < %zu)", packed_bytes,
                   umereg_ume_moments_workspace_bytes(B, N));
         return UMEREG_EWORKSPACE;
     }
-    return launch_pack(pts, (float4*)packed, B, N, (int)align_up((size_t)N, kPadPts), (hipStream_t)stream);
+    return launch_prep(pts, (char*)packed, B, N, radius, (hipStream_t)stream);
 }
 
 UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const float* feat, int B,
@@ -269,16 +632,16 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
                    "ume_moments: feature dim must be 32 like the reference (evaluate.py:55), got %d", feat_dim);
     UMEREG_REQUIRE(B > 0 && N > 0 && n_kp > 0, "ume_moments: B, N, n_kp must be positive (got %d, %d, %d)", B, N, n_kp);
     UMEREG_REQUIRE(K > 0 && K <= 4096, "ume_moments: K must be in [1, 4096] (got %d)", K);
+    UMEREG_REQUIRE(radius > 0.f, "ume_moments: radius must be positive");
     UMEREG_REQUIRE(((uintptr_t)feat & 15) == 0 && ((uintptr_t)F & 15) == 0 && ((uintptr_t)packed & 15) == 0,
                    "ume_moments: packed, feat and F must be 16-byte aligned");
     if (int rc = check_device()) return rc;
-    const int Npad = (int)align_up((size_t)N, kPadPts);
-    const int Kpad = (int)align_up((size_t)K, 64);
-    dim3 grid((n_kp + kWavesPerWG - 1) / kWavesPerWG, B);
-    const size_t lds = (size_t)kWavesPerWG * Kpad * sizeof(int);
-    hipLaunchKernelGGL(ume_moments_kernel, grid, dim3(kWave * kWavesPerWG), lds, (hipStream_t)stream,
-                       (const float4*)packed, kpts, (const float4*)feat, N, Npad, n_kp, K, Kpad, radius * radius, F,
-                       nn_count, nn_idx);
+    int cap, waves;
+    lds_plan(K, &cap, &waves);
+    dim3 grid((n_kp + waves - 1) / waves, B);
+    hipLaunchKernelGGL(ume_moments_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                       (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, (const float4*)feat, N, n_kp, K,
+                       cap, radius, F, nn_count, nn_idx);
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
     return UMEREG_OK;
 }
@@ -294,7 +657,7 @@ UMEREG_API int umereg_ume_moments_f32(const float* pts, const float* kpts, const
                   umereg_ume_moments_workspace_bytes(B, N));
         return UMEREG_EWORKSPACE;
     }
-    if (int rc = umereg_pack_points_f32(pts, B, N, workspace, workspace_bytes, stream)) return rc;
+    if (int rc = umereg_pack_points_f32(pts, B, N, radius, workspace, workspace_bytes, stream)) return rc;
     return umereg_ume_moments_packed_f32(workspace, kpts, feat, B, N, n_kp, feat_dim, K, radius, F, nn_count,
                                          nn_idx, stream);
 }

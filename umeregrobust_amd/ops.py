@@ -13,7 +13,8 @@ from . import _lib
 
 BallQuery = namedtuple("BallQuery", "dists idx knn")   # pytorch3d's _KNN field names (.dists/.idx/.knn)
 
-QLAYOUT_PLAIN, QLAYOUT_ROWS, QLAYOUT_COLS = 0, 1, 2
+QLAYOUT_PLAIN, QLAYOUT_ROWS, QLAYOUT_COLS, QLAYOUT_ROWS_F16X2, QLAYOUT_COLS_F16X2 = 0, 1, 2, 3, 4
+DEFAULT_MATCH_PRECISION = "f16x2"   # "f32": exact-fp32 MFMA; "f16x2": split-f16 MFMA (fp32-class, ~5x faster)
 
 _workspaces = {}
 
@@ -112,7 +113,7 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
         need = lib.umereg_ume_moments_workspace_bytes(B, N)
         ws = _workspace(dev, need, "mom")
         with torch.cuda.device(dev):
-            rc = lib.umereg_pack_points_f32(_ptr(pts), B, N, _ptr(ws), ws.numel(), _stream_ptr(dev))
+            rc = lib.umereg_pack_points_f32(_ptr(pts), B, N, float(radius), _ptr(ws), ws.numel(), _stream_ptr(dev))
             _lib.check(rc, "umereg_pack_points_f32")
             ev = _timed(timing, dev)
             rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(feat), B, N, n, d, int(K),
@@ -149,7 +150,7 @@ def _check_umes(ume1, ume2, who):
         raise ValueError(f"{who}: expected ume1 [B,n1,32,4], ume2 [B,n2,32,4]; got {tuple(ume1.shape)}, {tuple(ume2.shape)}")
 
 
-def _dist_q(ume1, ume2, want_D, want_match, timing):
+def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
     lib = _lib.load()
     ume1 = _dev(ume1, "ume1"); ume2 = _dev(ume2, "ume2")
     _check_umes(ume1, ume2, "ume_cdist/ume_match")
@@ -163,17 +164,23 @@ def _dist_q(ume1, ume2, want_D, want_match, timing):
         if want_match:
             raise ValueError("ume_match: empty UME set")
         return D, m, d
-    qa = lib.umereg_qbasis_bytes(n1, QLAYOUT_ROWS)
-    qb = lib.umereg_qbasis_bytes(n2, QLAYOUT_COLS)
+    if precision not in ("f32", "f16x2"):
+        raise ValueError(f"precision must be 'f32' or 'f16x2', got {precision!r}")
+    half = precision == "f16x2"
+    lay_a = QLAYOUT_ROWS_F16X2 if half else QLAYOUT_ROWS
+    lay_b = QLAYOUT_COLS_F16X2 if half else QLAYOUT_COLS
+    dist_fn = lib.umereg_ume_dist_q_f16x2 if half else lib.umereg_ume_dist_q_f32
+    qa = lib.umereg_qbasis_bytes(n1, lay_a)
+    qb = lib.umereg_qbasis_bytes(n2, lay_b)
     ws = _workspace(dev, qa + qb + 8 * n1 + 256, "dist")
     base = ws.data_ptr()
     st = _stream_ptr(dev)
     with torch.cuda.device(dev):
         for b in range(B):
-            _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume1[b]), n1, QLAYOUT_ROWS, base, st), "umereg_ume_orthobasis_f32")
-            _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume2[b]), n2, QLAYOUT_COLS, base + qa, st), "umereg_ume_orthobasis_f32")
+            _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume1[b]), n1, lay_a, base, st), "umereg_ume_orthobasis_f32")
+            _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume2[b]), n2, lay_b, base + qa, st), "umereg_ume_orthobasis_f32")
             ev = _timed(timing, dev)
-            rc = lib.umereg_ume_dist_q_f32(base, base + qa, n1, n2, _ptr(D[b]) if want_D else None,
+            rc = dist_fn(base, base + qa, n1, n2, _ptr(D[b]) if want_D else None,
                                            _ptr(m[b]) if want_match else None, _ptr(d[b]) if want_match else None,
                                            base + qa + qb if want_match else None, st)
             _lib.check(rc, "umereg_ume_dist_q_f32")
@@ -181,14 +188,15 @@ def _dist_q(ume1, ume2, want_D, want_match, timing):
     return D, m, d
 
 
-def ume_cdist(ume1, ume2, timing=None):
-    """utils.loc_utils.ume_cdist (reference utils/loc_utils.py:8-15): D [B,n1,n2]."""
-    return _dist_q(ume1, ume2, True, False, timing)[0]
+def ume_cdist(ume1, ume2, timing=None, precision="f32"):
+    """utils.loc_utils.ume_cdist (reference utils/loc_utils.py:8-15): D [B,n1,n2].
+    precision 'f32' = exact-fp32 MFMA (default for the materialised matrix), 'f16x2' = split-f16 MFMA."""
+    return _dist_q(ume1, ume2, True, False, timing, precision)[0]
 
 
-def ume_match(ume1, ume2, timing=None):
+def ume_match(ume1, ume2, timing=None, precision=None):
     """Fused ume_cdist + row arg-min (reference evaluate.py:215,224,234): (m [B,n1] i64, d [B,n1] f32)."""
-    _, m, d = _dist_q(ume1, ume2, False, True, timing)
+    _, m, d = _dist_q(ume1, ume2, False, True, timing, precision or DEFAULT_MATCH_PRECISION)
     return m, d
 
 
