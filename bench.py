@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"],
                     help="distance GEMM: split-f16 MFMA (fp32-class operands, default) or exact-fp32 MFMA")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=1, help="pairs timed by the CPU baseline leg")
     return ap.parse_args()
@@ -79,7 +81,7 @@ def main():
         pool.append(SimpleNamespace(
             host=p, src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
             tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
-            R_gt=t(p.gt_tform[:3, :3]).contiguous(), t_gt=t(p.gt_tform[:3, 3]).contiguous()))
+            gt=t(p.gt_tform).contiguous()))
     # neighbour counts (for the algorithmic-bytes roofline), outside the timed region
     for e in pool:
         e.mom_bytes = []
@@ -89,23 +91,35 @@ def main():
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
     rng = np.random.RandomState(1234 + rank)
-    counts = torch.zeros(4, dtype=torch.float64, device=dev)   # hypotheses, ok(1.5,0.6), ok(1.5,0.3), ok(1,0.1)
+    depth = max(1, a.depth)
+    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=rng)
+    # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
+    counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     timing = {"moments": [], "dist": []}
     mom_bytes_log = []
 
-    def step(i, record):
+    def submit(i, record):
         e = pool[i % len(pool)]
-        out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=rng,
-                                     src_inds=e.src_inds, tgt_inds=e.tgt_inds, timing=timing if record else None)
-        T = out.rtume_tform[0]
-        rre = ops.rre_deg(T[:, :3, :3].contiguous(), e.R_gt[None].expand(T.shape[0], -1, -1).contiguous())
-        rte = (T[:, :3, 3] - e.t_gt).norm(dim=-1)
-        counts.add_(torch.stack([torch.tensor(float(T.shape[0]), device=dev, dtype=torch.float64),
-                                 ((rre <= 1.5) & (rte <= 0.6)).sum().double(),
-                                 ((rre <= 1.5) & (rte <= 0.3)).sum().double(),
-                                 ((rre <= 1.0) & (rte <= 0.1)).sum().double()]))
+        h = pipe.submit(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, src_inds=e.src_inds, tgt_inds=e.tgt_inds,
+                        timing=timing if record else None)
+        h.entry = e
         if record:
             mom_bytes_log.extend(e.mom_bytes)
+        return h
+
+    def finish(h):
+        out = pipe.finish(h)                                    # host RNG draw + SE(3) hypotheses
+        with torch.cuda.stream(pipe.stream_of(h)):              # a7 + recall gates, on the device
+            ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, counts[h.slot])
+
+    def run(first, n, record):
+        pending = []
+        for i in range(n):
+            pending.append(submit(first + i, record))
+            if len(pending) >= depth:
+                finish(pending.pop(0))
+        while pending:
+            finish(pending.pop(0))
 
     def fence():
         torch.cuda.synchronize()
@@ -113,20 +127,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i, False)
-    counts.zero_()
+    run(0, a.warmup, False)
+    torch.cuda.synchronize()
+    for c_ in counts:
+        c_.zero_()
     fence()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i, True)
+    run(a.warmup, a.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
+    counts = torch.stack(counts).sum(0).double()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (48 B class)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (32 B)
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     mom_ms = [s.elapsed_time(e_) for s, e_ in timing["moments"]]
@@ -169,7 +184,8 @@ def main():
                                f"(N={cfg['N']} pts/cloud, {n_kp} keypoints/cloud, K={args.ume_max_nn}, r={args.ume_r_nn} m, "
                                f"d=32, M={args.ume_n_samples} hypotheses, tau={args.tau}, kind={a.kind})",
                    "pairs_per_step_per_gpu": 1, "sharding": f"pairs[rank::{world}] (no data-path collective)",
-                   "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision},
+                   "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
+                   "pairs_in_flight": depth},
         "roofline": dominant,
         "rooflines": {"ume_moments_kernel": roof_mom, roof_dist["kernel"]: roof_dist},
         "hypothesis_quality": {"hypotheses": int(c[0]), "within_1.5deg_0.6m": round(c[1] / max(c[0], 1), 4),

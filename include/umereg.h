@@ -154,6 +154,15 @@ int umereg_ume_match_f16x2(const float* ume1, const float* ume2, int B, int n1, 
  * ------------------------------------------------------------------------------------------- */
 int umereg_match_prob_f32(const float* ume_d, int n, float tau, float* prob, void* stream);
 
+/* HOST helper (host pointers, no device work) for the draw itself -- evaluate.py:238,
+ * np.random.choice(n, size, replace=False, p=prob): one round of numpy's legacy weighted
+ * sampling-without-replacement algorithm, bit-identical to numpy given the same uniforms (which the
+ * caller keeps drawing from its RandomState).  See csrc/api.hip for the argument contract. */
+int umereg_host_choice_round(double* p_host, int n, const double* x_host, int k, int64_t* found_host,
+                             int n_uniq, double* cdf_scratch_host, unsigned char* seen_scratch_host);
+/* numpy's pre-draw argument checks in one pass: out[0] = Kahan sum, out[1] = #(p > 0), out[2] = any NaN/negative */
+int umereg_host_choice_check(const double* p_host, int n, double* out3_host);
+
 /* ---------------------------------------------------------------------------------------------
  * a6  utils.loc_utils.batch_estimate_transform_ume_old(G, H)         utils/loc_utils.py:292-350
  * Closed-form SE(3) from a (source G, target H) UME pair; T maps source -> target.
@@ -171,6 +180,20 @@ int umereg_rtume_solve_f32(const float* G_all, const float* H_all, const int64_t
  *   R, R_hat f32 [b,3,3] -> degrees f32 [b]
  * ------------------------------------------------------------------------------------------- */
 int umereg_rre_deg_f32(const float* R, const float* R_hat, int b, float* out_deg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a7 + the recall gates of evaluate.py:304-305, batched over hypotheses and kept on the device:
+ * rre[k] = relative_rotation_error(T[k][:3,:3], gt[:3,:3]) (utils/eval_utils.py:60-76),
+ * rte[k] = |T[k][:3,3] - gt[:3,3]| (evaluate.py:43), and
+ *   counts[0] += n
+ *   counts[1] += #(rre <= 1.5 deg & rte <= 0.6 m)   "N.P" as coded   (evaluate.py:304)
+ *   counts[2] += #(rre <= 1.5 deg & rte <= 0.3 m)   "N.P" as the README states it
+ *   counts[3] += #(rre <= 1   deg & rte <= 0.1 m)   "S.P"            (evaluate.py:305)
+ * counts: uint64 [4], caller-initialised, accumulated with integer atomics (order-independent).
+ *   T f32 [n,4,4], gt_tform f32 [4,4]; rre_deg / rte f32 [n] optional outputs.
+ * ------------------------------------------------------------------------------------------- */
+int umereg_hypothesis_gates_f32(const float* T, const float* gt_tform, int n, uint64_t* counts,
+                                float* rre_deg, float* rte, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,136 @@
+"""CPU: host-side logic of the path (no GPU): the native numpy-identical weighted draw, configs,
+synthetic generator contract, metric accumulation and the 2-rank (gloo) shard + all-reduce."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_choice_noreplace_is_numpy_bit_identical():
+    """evaluate.py:238 -- np.random.choice(n, size, replace=False, p): same indices, order and RNG state."""
+    from umeregrobust_amd.host_rng import choice_noreplace
+    for seed in range(25):
+        rs = np.random.RandomState(seed)
+        if seed % 2:
+            d = np.where(rs.rand(10000) < 0.2, np.abs(rs.normal(0, 0.01, 10000)), rs.uniform(0.3, 1.2, 10000))
+        else:
+            d = rs.rand(10000)
+        a = np.exp((1 - d.astype(np.float32)) / np.float32(0.05)).astype(np.float32)
+        pr = (a / a.sum()).astype(np.float32)
+        if seed % 5 == 0:
+            pr = pr.astype(np.float64)
+            pr /= pr.sum()
+        r1, r2 = np.random.RandomState(100 + seed), np.random.RandomState(100 + seed)
+        c1 = r1.choice(10000, 2500, replace=False, p=pr)
+        c2 = choice_noreplace(r2, 10000, 2500, pr)
+        assert np.array_equal(c1, c2) and c2.dtype == np.int64
+        assert r1.rand() == r2.rand()                       # RNG streams stay in lock-step
+    for n, size in ((5, 5), (7, 3), (1, 1), (100, 99), (17, 9)):
+        pr = np.random.RandomState(n).rand(n)
+        pr /= pr.sum()
+        r1, r2 = np.random.RandomState(3), np.random.RandomState(3)
+        assert np.array_equal(r1.choice(n, size, replace=False, p=pr), choice_noreplace(r2, n, size, pr))
+    # the global numpy stream (what the reference consumes) is supported too
+    np.random.seed(11)
+    c1 = np.random.choice(50, 20, replace=False, p=np.full(50, 0.02))
+    np.random.seed(11)
+    assert np.array_equal(c1, choice_noreplace(np.random, 50, 20, np.full(50, 0.02)))
+
+
+def test_choice_noreplace_errors_like_numpy():
+    from umeregrobust_amd.host_rng import choice_noreplace
+    rs = np.random.RandomState(0)
+    with pytest.raises(ValueError, match="sum to 1"):
+        choice_noreplace(rs, 4, 2, np.array([0.5, 0.5, 0.5, 0.5]))
+    with pytest.raises(ValueError, match="Fewer non-zero"):
+        choice_noreplace(rs, 4, 3, np.array([0.5, 0.5, 0.0, 0.0]))
+    with pytest.raises(ValueError):
+        choice_noreplace(rs, 4, 2, np.array([0.5, np.nan, 0.25, 0.25]))
+    with pytest.raises(ValueError, match="larger sample"):
+        choice_noreplace(rs, 4, 5, np.full(4, 0.25))
+
+
+def test_benchmark_configs_have_reference_keys():
+    from types import SimpleNamespace
+    from umeregrobust_amd.utils.general_utils import BENCHMARK_CONFIGS, benchmark_config_path, update_namespace_from_yaml
+    keys = {"dataset", "split", "data_path", "cache_data_path", "batch_size", "corr_batch_size", "corr_ds",
+            "corr_kernel_sigma", "corr_no_nksr", "device", "filter_by_ume_dist_cond", "hungarian_matching_flag",
+            "max_pc_size", "model_checkpoint_path", "num_samples", "num_workers", "out_ch", "pc_corr_max_size",
+            "pc_size_for_hypothesis_sel", "rtume_nn_max", "rtume_r_nn", "seed", "skip_invalid_entries_flag", "tau",
+            "ume_max_nn", "ume_min_nn", "ume_n_samples", "ume_r_nn"}
+    assert set(BENCHMARK_CONFIGS) == {"kitti_test", "lokitti", "rotkitti", "nuscenes_test", "lonuscenes", "rotnuscenes"}
+    for b in BENCHMARK_CONFIGS:
+        a = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path(b))
+        assert set(vars(a)) == keys
+        assert a.ume_max_nn == 750 and a.ume_r_nn == 5 and a.tau == 0.05 and a.batch_size == 1
+    kt = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("kitti_test"))
+    ns = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("nuscenes_test"))
+    assert kt.filter_by_ume_dist_cond and kt.ume_n_samples == 2500 and kt.max_pc_size == 50000
+    assert (not ns.filter_by_ume_dist_cond) and ns.ume_n_samples == 5000
+
+
+def test_synth_pair_contract():
+    from umeregrobust_amd.synth import synth_pair
+    p = synth_pair(3, N=3000, n_kp=500, kind="rot")
+    assert p.src_pts.shape == (3000, 3) and p.src_pts.dtype == np.float32 and p.src_feat.shape == (3000, 32)
+    assert np.allclose(np.linalg.norm(p.src_feat, axis=1), 1.0, atol=1e-5)
+    R, t = p.gt_tform[:3, :3].astype(np.float64), p.gt_tform[:3, 3].astype(np.float64)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6) and abs(np.linalg.det(R) - 1) < 1e-6
+    tw = p.tgt_twin_of_src
+    assert np.abs(p.src_pts.astype(np.float64) @ R.T + t - p.tgt_pts[tw]).max() < 1e-4     # target = R src + t, re-permuted
+    assert np.array_equal(p.src_feat, p.tgt_feat[tw])                                      # twins share features
+    assert len(np.unique(p.src_inds)) == 500 and p.src_inds.max() < 3000
+    assert len(np.unique(np.round(p.src_pts / 0.3).astype(np.int64), axis=0)) == 3000      # de-duplicated lattice
+    yaw = np.degrees(np.arctan2(R[1, 0], R[0, 0]))
+    assert 29.0 <= abs(yaw) <= 181.0
+    p2 = synth_pair(3, N=3000, n_kp=500, kind="rot")
+    assert np.array_equal(p.src_pts, p2.src_pts) and np.array_equal(p.tgt_inds, p2.tgt_inds)  # seeded
+
+
+def test_registration_metrics_counts():
+    from umeregrobust_amd.dist import RegistrationMetrics, shard_indices
+    m = RegistrationMetrics()
+    m.update([0.5, 1.2, 1.4, 3.0], [0.05, 0.2, 0.5, 0.01])
+    s = m.summary()
+    assert s["n_pairs"] == 4 and s["rr_np_06"] == 75.0 and s["rr_np_03"] == 50.0 and s["rr_sp"] == 25.0
+    assert abs(s["mrre"] - 1.525) < 1e-12
+    assert shard_indices(10, 1, 4) == [1, 5, 9] and sorted(sum((shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["UMEREG_REPO"])
+from umeregrobust_amd.dist import RegistrationMetrics, init_distributed, shard_indices
+rank, local_rank, world = init_distributed(backend="gloo")
+rs = np.random.RandomState(0)
+rre = rs.uniform(0, 3, 101); rte = rs.uniform(0, 0.8, 101)
+m = RegistrationMetrics()
+idx = shard_indices(101, rank, world)
+m.update(rre[idx], rte[idx])
+m.all_reduce()
+ref = RegistrationMetrics(); ref.update(rre, rte)
+assert np.array_equal(m.v[:4], ref.v[:4]), (m.v, ref.v)          # integer counts: exactly the single-process value
+assert np.allclose(m.v[4:], ref.v[4:], rtol=1e-12)
+if rank == 0:
+    print("SHARD_OK", world, m.summary()["rr_np_06"])
+import torch.distributed as dist
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shard_and_allreduce_gloo(world, tmp_path):
+    """N > 1 path on CPU: pairs[rank::world] + the one all-reduce reproduce the single-process metrics exactly."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, UMEREG_REPO=REPO, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29600 + world), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert f"SHARD_OK {world}" in out.stdout

@@ -45,8 +45,11 @@ SIGNATURES = {
     "umereg_ume_match_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
     "umereg_match_prob_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "umereg_host_choice_round": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "umereg_host_choice_check": (c_int, [c_void_p, c_int, c_void_p]),
     "umereg_rtume_solve_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p]),
+    "umereg_hypothesis_gates_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "umereg_rre_deg_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
 }
 

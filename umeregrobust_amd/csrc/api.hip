@@ -53,3 +53,94 @@ UMEREG_API int umereg_device_count(char* arch_name, size_t arch_name_len)
     }
     return n;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// HOST helper for the one host-side step of the path: np.random.choice(n, size, replace=False, p=prob)
+// at reference evaluate.py:238.  numpy's legacy algorithm (numpy/random/mtrand.pyx, RandomState.choice)
+// runs rounds of { x = rand(size - n_uniq); p[found] = 0; cdf = cumsum(p); cdf /= cdf[-1];
+// new = cdf.searchsorted(x, side='right'); keep first occurrences in draw order } until `size`
+// distinct indices are found.  Each round is ~10 small numpy calls (0.57 ms per KITTI pair in total);
+// this does one round in a single pass with identical fp64 arithmetic, so the drawn indices are
+// bit-identical to numpy's given the same uniforms (the caller still draws them from its RandomState).
+//   p     f64 [n]   working copy of the probabilities (entries of found[0..n_uniq) are zeroed here)
+//   x     f64 [k]   uniforms for this round, k = size - n_uniq
+//   found i64 [size] indices found so far; new ones are appended at found[n_uniq...]
+//   cdf   f64 [n], seen u8 [n]: scratch (seen must be zero on entry; it is zero again on return)
+// returns the number of new distinct indices.
+UMEREG_API int umereg_host_choice_round(double* p, int n, const double* x, int k, int64_t* found, int n_uniq,
+                                        double* cdf, unsigned char* seen)
+{
+    if (!p || !x || !found || !cdf || !seen || n <= 0 || k <= 0 || n_uniq < 0) return -1;
+    for (int i = 0; i < n_uniq; ++i) p[found[i]] = 0.0;
+    double run = 0.0;
+    for (int i = 0; i < n; ++i) { run += p[i]; cdf[i] = run; }   // np.cumsum: sequential fp64 adds
+    const double last = cdf[n - 1];
+    // numpy then normalises the whole array (cdf /= cdf[-1]) and binary-searches it.  The quotient
+    // is monotone in cdf[i], so the same answer comes from searching the un-normalised array for
+    // v*last and settling the boundary with the EXACT predicate (cdf[i] / last > v) numpy evaluates:
+    // 2-3 divisions per draw instead of n per round.
+    // Pass 1: searchsorted for every draw, candidates parked in found[n_uniq + d].  The searches are
+    // latency-bound (dependent loads over an 80 KB array), so 8 of them advance in lock-step --
+    // every search has the same length sequence -- to keep 8 loads in flight.
+    int64_t* cand = found + n_uniq;
+    constexpr int W = 8;
+    for (int d0 = 0; d0 < k; d0 += W) {
+        const int w = k - d0 < W ? k - d0 : W;
+        const double* base[W];
+        double t[W];
+        for (int u = 0; u < W; ++u) {
+            const double v = x[d0 + (u < w ? u : 0)];
+            t[u] = v * last;
+            base[u] = cdf;
+        }
+        int len = n;
+        while (len > 1) {
+            const int half = len >> 1;
+            for (int u = 0; u < W; ++u) base[u] = (base[u][half - 1] <= t[u]) ? base[u] + half : base[u];
+            len -= half;
+        }
+        for (int u = 0; u < w; ++u) {
+            const double v = x[d0 + u];
+            int lo = (int)(base[u] - cdf) + (base[u][0] <= t[u] ? 1 : 0);
+            // settle with numpy's exact predicate: first index with cdf[i] / last > v
+            while (lo > 0 && cdf[lo - 1] / last > v) --lo;
+            while (lo < n && !(cdf[lo] / last > v)) ++lo;
+            if (lo >= n) lo = n - 1;   // unreachable for x in [0,1) (cdf[n-1]/last == 1), kept for safety
+            cand[d0 + u] = lo;
+        }
+    }
+    // Pass 2: keep first occurrences in draw order (np.unique(return_index) + sort + take)
+    int n_new = 0;
+    for (int d = 0; d < k; ++d) {
+        const int64_t lo = cand[d];
+        if (!seen[lo]) {
+            seen[lo] = 1;
+            cand[n_new++] = lo;   // n_new <= d: in-place forward compaction
+        }
+    }
+    for (int i = 0; i < n_new; ++i) seen[found[n_uniq + i]] = 0;
+    return n_new;
+}
+
+// one pass over the probabilities for the argument checks numpy performs before drawing:
+// out[0] = sum (Kahan, like numpy's kahan_sum), out[1] = #entries > 0, out[2] = 1 if any NaN / negative
+UMEREG_API int umereg_host_choice_check(const double* p, int n, double* out)
+{
+    if (!p || !out || n <= 0) return -1;
+    double sum = p[0], c = 0.0;
+    long npos = 0;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const double v = p[i];
+        if (!(v >= 0.0)) bad = 1;
+        if (v > 0.0) ++npos;
+        if (i > 0) {
+            const double y = v - c;
+            const double t = sum + y;
+            c = (t - sum) - y;
+            sum = t;
+        }
+    }
+    out[0] = sum; out[1] = (double)npos; out[2] = (double)bad;
+    return 0;
+}

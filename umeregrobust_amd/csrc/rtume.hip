@@ -202,9 +202,60 @@ __global__ void rre_kernel(const float* __restrict__ R, const float* __restrict_
     out[i] = rad * (180.0f / 3.141592653589793f);                              // :74
 }
 
+// a7 over hypotheses + recall gates (evaluate.py:304-305); one thread per hypothesis, one atomic per
+// wave per counter
+__global__ __launch_bounds__(256) void hypothesis_gates_kernel(const float* __restrict__ T, const float* __restrict__ gt,
+                                                               int n, unsigned long long* __restrict__ counts,
+                                                               float* __restrict__ rre_out, float* __restrict__ rte_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = k < n;
+    float rre = 1e30f, rte = 1e30f;
+    if (valid) {
+        const float* t = T + (size_t)k * 16;
+        // relative_rotation_error(R = T[:3,:3], R_hat = gt[:3,:3]): trace(R_hat R^T)      (eval_utils.py:62,65)
+        float tr = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            float d = 0.f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d = d + gt[p * 4 + q] * t[p * 4 + q];
+            tr = tr + d;
+        }
+        tr = fminf(fmaxf(tr, -1.0f), 3.0f);
+        rre = acosf((tr - 1.0f) / 2.0f) * (180.0f / 3.141592653589793f);
+        const float dx = t[3] - gt[3], dy = t[7] - gt[7], dz = t[11] - gt[11];
+        rte = sqrtf(dx * dx + dy * dy + dz * dz);                                         // evaluate.py:43
+        if (rre_out) rre_out[k] = rre;
+        if (rte_out) rte_out[k] = rte;
+    }
+    const unsigned long long m0 = __ballot(valid);
+    const unsigned long long m1 = __ballot(valid && rre <= 1.5f && rte <= 0.6f);
+    const unsigned long long m2 = __ballot(valid && rre <= 1.5f && rte <= 0.3f);
+    const unsigned long long m3 = __ballot(valid && rre <= 1.0f && rte <= 0.1f);
+    if ((threadIdx.x & 63) == 0) {
+        if (m0) atomicAdd(counts + 0, (unsigned long long)__popcll(m0));
+        if (m1) atomicAdd(counts + 1, (unsigned long long)__popcll(m1));
+        if (m2) atomicAdd(counts + 2, (unsigned long long)__popcll(m2));
+        if (m3) atomicAdd(counts + 3, (unsigned long long)__popcll(m3));
+    }
+}
+
 }  // namespace umereg
 
 using namespace umereg;
+
+UMEREG_API int umereg_hypothesis_gates_f32(const float* T, const float* gt_tform, int n, uint64_t* counts,
+                                           float* rre_deg, float* rte, void* stream)
+{
+    UMEREG_REQUIRE(T && gt_tform && counts, "hypothesis_gates: null pointer");
+    UMEREG_REQUIRE(n > 0, "hypothesis_gates: n must be positive (got %d)", n);
+    if (int rc = check_device()) return rc;
+    hipLaunchKernelGGL(hypothesis_gates_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, gt_tform, n,
+                       (unsigned long long*)counts, rre_deg, rte);
+    UMEREG_CHECK_LAUNCH("hypothesis_gates_kernel");
+    return UMEREG_OK;
+}
 
 UMEREG_API int umereg_rtume_solve_f32(const float* G_all, const float* H_all, const int64_t* g_index,
                                       const int64_t* h_index, int nG, int nH, int n, float* T, float* dist,

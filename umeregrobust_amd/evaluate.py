@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .host_rng import choice_noreplace
 from .utils.eval_utils import relative_rotation_error  # noqa: F401
 from .utils.loc_utils import batch_estimate_transform_ume_old, ume_cdist, ume_kp_layer  # noqa: F401
 
@@ -26,31 +27,11 @@ def my_ume_generation(pts, kpts, feat, args):
     return ops.ume_moments(pts, kpts, feat, args.ume_max_nn, args.ume_r_nn)
 
 
-def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src_inds=None, tgt_inds=None,
-                  cond=None, materialize_D=False, timing=None):
-    """The named hot path for one pair (reference evaluate.py:195-254).
-
-    src_pts/tgt_pts [1,N,3], src_feat/tgt_feat [1,N,32] on the GPU.  Host-RNG draws mirror the
-    reference's np.random.choice calls (:199-200, :238) and can be injected (src_inds, tgt_inds,
-    cond) for replay.  Returns a namespace with rtume_tform [1,M,4,4] and the intermediates the
-    downstream stages (hypothesis selection) need.
-    """
-    assert src_pts.shape[0] == 1, "the reference evaluates with batch_size: 1"
+def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D=False, timing=None):
+    """evaluate.py:195-236 up to the match probabilities: everything before the host RNG draw."""
     dev = src_pts.device
-    # Sample keypoints (:195-204)
-    if args.filter_by_ume_dist_cond:
-        num_init_sel = min(10000, min(src_pts.shape[1], tgt_pts.shape[1]))
-    else:
-        num_init_sel = min(min(src_pts.shape[1], tgt_pts.shape[1]), args.ume_n_samples)
-    if src_inds is None:
-        src_inds = rng.choice(src_pts.shape[1], num_init_sel, replace=False)
-    if tgt_inds is None:
-        tgt_inds = rng.choice(tgt_pts.shape[1], num_init_sel, replace=False)
-    src_inds = _index_tensor(src_inds, dev)
-    tgt_inds = _index_tensor(tgt_inds, dev)
     src_keypoint_pts = src_pts[:, src_inds]
     tgt_keypoint_pts = tgt_pts[:, tgt_inds]
-
     # UME matrices (:206-212)
     t_mom = None if timing is None else timing.setdefault("moments", [])
     t_dist = None if timing is None else timing.setdefault("dist", [])
@@ -61,7 +42,6 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src
     ume_tgt = ume_tgt[:, :num_kpts]
     src_keypoint_pts = src_keypoint_pts[:, :num_kpts]
     tgt_keypoint_pts = tgt_keypoint_pts[:, :num_kpts]
-
     # Matches (:215-225).  Hungarian matching (:216-222) is off in every shipped config.
     if getattr(args, "hungarian_matching_flag", False):
         raise NotImplementedError("hungarian_matching_flag: off in all reference configs; host scipy path not wired")
@@ -72,26 +52,111 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src
         ume_d = torch.gather(D, 2, m_tgt.unsqueeze(-1)).squeeze(-1)
     else:
         m_tgt, ume_d = ops.ume_match(ume_src, ume_tgt, timing=t_dist)
-    m_src = torch.arange(num_kpts, device=dev)
+    prob = ops.match_prob(ume_d[0], args.tau) if args.filter_by_ume_dist_cond else None   # (:235-236)
+    return SimpleNamespace(ume_src=ume_src, ume_tgt=ume_tgt, match=m_tgt, match_d=ume_d, prob=prob, D=D,
+                           src_inds=src_inds, tgt_inds=tgt_inds,
+                           num_kpts=num_kpts, src_keypoint_pts=src_keypoint_pts, tgt_keypoint_pts=tgt_keypoint_pts,
+                           dev=dev)
 
-    # tau-weighted sub-sampling of matches (:233-245): the draw consumes the HOST numpy RNG
-    prob = None
+
+def _phase_b(a, args, cond):
+    """evaluate.py:238-254: apply the drawn sub-sample and solve one SE(3) per kept match."""
+    dev = a.dev
+    m_src = torch.arange(a.num_kpts, device=dev)
     if args.filter_by_ume_dist_cond:
-        prob = ops.match_prob(ume_d[0], args.tau)
-        num_matches = min(num_kpts, args.ume_n_samples)
-        if cond is None:
-            cond = rng.choice(num_kpts, num_matches, replace=False, p=prob.cpu().numpy())
         cond_t = _index_tensor(cond, dev)
         g_index = m_src[cond_t]
-        h_index = m_tgt[0][cond_t]
+        h_index = a.match[0][cond_t]
     else:
         g_index = m_src
-        h_index = m_tgt[0]
-
+        h_index = a.match[0]
     # Hypotheses (:248-254); the match gathers (:228-231, 243-244) are fused into the solve
-    T, _ = ops.rtume_solve(ume_src[0], ume_tgt[0], g_index, h_index)
-    rtume_tform = T.view(1, -1, 4, 4)
-    return SimpleNamespace(
-        rtume_tform=rtume_tform, ume_src=ume_src, ume_tgt=ume_tgt, match=m_tgt, match_d=ume_d, prob=prob,
-        cond=cond, g_index=g_index, h_index=h_index, D=D,
-        src_matches_keypoint_pts=src_keypoint_pts[:, g_index], tgt_matches_keypoint_pts=tgt_keypoint_pts[:, h_index])
+    T, _ = ops.rtume_solve(a.ume_src[0], a.ume_tgt[0], g_index, h_index)
+    a.rtume_tform = T.view(1, -1, 4, 4)
+    a.cond, a.g_index, a.h_index = cond, g_index, h_index
+    a.src_matches_keypoint_pts = a.src_keypoint_pts[:, g_index]
+    a.tgt_matches_keypoint_pts = a.tgt_keypoint_pts[:, h_index]
+    return a
+
+
+def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):
+    """Keypoint draws (:195-204): host numpy RNG unless injected."""
+    if args.filter_by_ume_dist_cond:
+        num_init_sel = min(10000, min(src_pts.shape[1], tgt_pts.shape[1]))
+    else:
+        num_init_sel = min(min(src_pts.shape[1], tgt_pts.shape[1]), args.ume_n_samples)
+    if src_inds is None:
+        src_inds = rng.choice(src_pts.shape[1], num_init_sel, replace=False)
+    if tgt_inds is None:
+        tgt_inds = rng.choice(tgt_pts.shape[1], num_init_sel, replace=False)
+    return _index_tensor(src_inds, src_pts.device), _index_tensor(tgt_inds, src_pts.device)
+
+
+def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src_inds=None, tgt_inds=None,
+                  cond=None, materialize_D=False, timing=None):
+    """The named hot path for one pair (reference evaluate.py:195-254).
+
+    src_pts/tgt_pts [1,N,3], src_feat/tgt_feat [1,N,32] on the GPU.  Host-RNG draws mirror the
+    reference's np.random.choice calls (:199-200, :238) and can be injected (src_inds, tgt_inds,
+    cond) for replay.  Returns a namespace with rtume_tform [1,M,4,4] and the intermediates the
+    downstream stages (hypothesis selection) need.
+    """
+    assert src_pts.shape[0] == 1, "the reference evaluates with batch_size: 1"
+    src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds)
+    a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D, timing)
+    if args.filter_by_ume_dist_cond and cond is None:
+        # tau-weighted sub-sampling of matches (:233-245): the draw consumes the HOST numpy RNG
+        num_matches = min(a.num_kpts, args.ume_n_samples)
+        cond = choice_noreplace(rng, a.num_kpts, num_matches, a.prob.cpu().numpy())
+    return _phase_b(a, args, cond)
+
+
+class RegistrationPipeline:
+    """Same computation as register_pair, software-pipelined over consecutive pairs.
+
+    The reference draws the match sub-sample on the host (np.random.choice with p from the device,
+    evaluate.py:238), which costs ~0.6 ms of host time per KITTI-sized pair with the GPU idle.  Here
+    phase A of pair i+1 (moments, distance GEMM, probabilities) is enqueued on a second HIP stream
+    before the host draws for pair i, so the draw overlaps GPU work.  Results are identical to
+    register_pair given the same RNG stream; `submit` and `finish` must be called in order.
+    """
+
+    def __init__(self, args, device, depth=2, rng=np.random):
+        self.args, self.rng, self.depth = args, rng, depth
+        self.dev = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(depth)]
+        self.host_prob = [None] * depth
+        self.last_a_done = None
+        self.n_submitted = 0
+
+    def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None):
+        k = self.n_submitted % self.depth
+        self.n_submitted += 1
+        st = self.streams[k]
+        src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, self.rng, src_inds, tgt_inds)
+        st.wait_stream(torch.cuda.current_stream(self.dev))
+        if self.last_a_done is not None:
+            st.wait_event(self.last_a_done)        # phase A of consecutive pairs stays back-to-back on the GPU
+        with torch.cuda.stream(st):
+            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing)
+            if a.prob is not None:
+                if self.host_prob[k] is None or self.host_prob[k].numel() != a.prob.numel():
+                    self.host_prob[k] = torch.empty(a.prob.numel(), dtype=torch.float32, pin_memory=True)
+                self.host_prob[k].copy_(a.prob, non_blocking=True)
+            a.ready = torch.cuda.Event()
+            a.ready.record(st)
+            self.last_a_done = a.ready
+        a.slot = k
+        return a
+
+    def finish(self, a, cond=None):
+        st = self.streams[a.slot]
+        if self.args.filter_by_ume_dist_cond and cond is None:
+            a.ready.synchronize()
+            num_matches = min(a.num_kpts, self.args.ume_n_samples)
+            cond = choice_noreplace(self.rng, a.num_kpts, num_matches, self.host_prob[a.slot].numpy())
+        with torch.cuda.stream(st):
+            return _phase_b(a, self.args, cond)
+
+    def stream_of(self, a):
+        return self.streams[a.slot]

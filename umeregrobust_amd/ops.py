@@ -301,3 +301,24 @@ def rre_deg(R, R_hat):
             rc = lib.umereg_rre_deg_f32(_ptr(R), _ptr(R_hat), b, _ptr(out), _stream_ptr(R.device))
         _lib.check(rc, "umereg_rre_deg_f32")
     return out
+
+
+def hypothesis_gates(T, gt_tform, counts, return_errors=False):
+    """RRE / RTE of every hypothesis against one ground-truth transform + the recall gates of reference
+    evaluate.py:304-305, accumulated on the device: counts (int64 [4], caller-zeroed) +=
+    [n, #(<=1.5deg,<=0.6m), #(<=1.5deg,<=0.3m), #(<=1deg,<=0.1m)].  T [n,4,4], gt_tform [4,4]."""
+    lib = _lib.load()
+    T = _dev(T, "T"); gt = _dev(gt_tform, "gt_tform")
+    if T.dim() != 3 or T.shape[1:] != (4, 4) or gt.shape != (4, 4):
+        raise ValueError(f"hypothesis_gates: expected T [n,4,4], gt [4,4]; got {tuple(T.shape)}, {tuple(gt.shape)}")
+    if counts.dtype != torch.int64 or counts.numel() < 4 or not counts.is_cuda or not counts.is_contiguous():
+        raise ValueError("hypothesis_gates: counts must be a contiguous int64 device tensor with >= 4 elements")
+    n = T.shape[0]
+    dev = T.device
+    rre = torch.empty((n,), dtype=torch.float32, device=dev) if return_errors else None
+    rte = torch.empty((n,), dtype=torch.float32, device=dev) if return_errors else None
+    if n > 0:
+        with torch.cuda.device(dev):
+            rc = lib.umereg_hypothesis_gates_f32(_ptr(T), _ptr(gt), n, _ptr(counts), _ptr(rre), _ptr(rte), _stream_ptr(dev))
+        _lib.check(rc, "umereg_hypothesis_gates_f32")
+    return (rre, rte) if return_errors else None
