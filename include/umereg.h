@@ -95,9 +95,12 @@ size_t umereg_ume_moments_workspace_bytes(int B, int N);
  *     radius). */
 int umereg_pack_points_f32(const float* pts, int B, int N, float radius, void* packed,
                            size_t packed_bytes, void* stream);
-int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const float* feat, int B,
-                                  int N, int n_kp, int feat_dim, int K, float radius, float* F,
-                                  int32_t* nn_count, int64_t* nn_idx, void* stream);
+int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
+                                  const float* feat, int B, int N, int n_kp, int feat_dim, int K,
+                                  float radius, float* F, int32_t* nn_count, int64_t* nn_idx,
+                                  void* stream);
+/*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers
+ *   `src_pts[0, src_inds]` of evaluate.py:201-202; when non-NULL, kpts may be NULL. */
 int umereg_ume_moments_f32(const float* pts, const float* kpts, const float* feat, int B, int N,
                            int n_kp, int feat_dim, int K, float radius, float* F,
                            int32_t* nn_count, int64_t* nn_idx, void* workspace,
@@ -168,12 +171,14 @@ int umereg_host_choice_check(const double* p_host, int n, double* out3_host);
  * Closed-form SE(3) from a (source G, target H) UME pair; T maps source -> target.
  *   G_all [nG,32,4], H_all [nH,32,4]; g_index/h_index int64 [n] select the rows used by
  *   hypothesis k (NULL = identity), which fuses the gathers of evaluate.py:230-231,243-244;
+ *   h_of_g int64 [nG] (optional, instead of h_index): the match table m[:,1] of evaluate.py:224,
+ *   hypothesis k then pairs G row g = g_index[k] with H row h_of_g[g];
  *   T f32 [n,4,4];  dist f32 [n] = 0.707 |P_H - P_G|_F (utils/loc_utils.py:338-344; NULL to
  *   skip -- every live caller discards it).
  * ------------------------------------------------------------------------------------------- */
 int umereg_rtume_solve_f32(const float* G_all, const float* H_all, const int64_t* g_index,
-                           const int64_t* h_index, int nG, int nH, int n, float* T, float* dist,
-                           void* stream);
+                           const int64_t* h_index, const int64_t* h_of_g, int nG, int nH, int n,
+                           float* T, float* dist, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a7  utils.eval_utils.relative_rotation_error(R, R_hat)             utils/eval_utils.py:60-76

@@ -518,3 +518,21 @@ def test_pipeline_equals_sequential(gpu):
     for h in hs:
         o = pipe2.finish(h)
         assert o.rtume_tform.shape == (1, 300, 4, 4) and torch.isfinite(o.rtume_tform).all()
+
+
+def test_fused_gathers_equal_explicit(gpu):
+    """kp_index (fused evaluate.py:201-202 gather) and h_of_g (fused match-table lookup) give bit-identical results."""
+    from umeregrobust_amd import ops
+    g = load_golden("g6_pair_k1.npz")
+    pts, feat = T_(g["src_pts"], gpu)[None], T_(g["src_feat"], gpu)[None]
+    inds = T_(g["src_inds"].astype(np.int64), gpu)
+    F1 = ops.ume_moments(pts, pts[:, inds], feat, 750, 5.0)
+    F2 = ops.ume_moments(pts, None, feat, 750, 5.0, kp_index=inds)
+    assert torch.equal(F1, F2)
+    G, H = T_(g["ume_src"], gpu), T_(g["ume_tgt"], gpu)
+    match = T_(g["match"].astype(np.int64), gpu)
+    cond = T_(g["cond"].astype(np.int64), gpu)
+    T1, _ = ops.rtume_solve(G, H, cond, match[cond])
+    T2, _ = ops.rtume_solve(G, H, cond, None, h_of_g=match)
+    T3, _ = ops.rtume_solve(G, H, None, None, h_of_g=match)
+    assert torch.equal(T1, T2) and torch.equal(T3[cond], T1)

@@ -29,8 +29,8 @@ SIGNATURES = {
     "umereg_ume_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_pack_points_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
-    "umereg_ume_moments_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "umereg_ume_moments_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                              c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "umereg_ume_dist_q_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "umereg_ume_dist_q_f16x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -47,7 +47,7 @@ SIGNATURES = {
     "umereg_match_prob_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "umereg_host_choice_round": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "umereg_host_choice_check": (c_int, [c_void_p, c_int, c_void_p]),
-    "umereg_rtume_solve_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+    "umereg_rtume_solve_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p]),
     "umereg_hypothesis_gates_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "umereg_rre_deg_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

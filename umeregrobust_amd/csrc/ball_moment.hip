@@ -451,8 +451,8 @@ constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave
 
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
-    const float4* __restrict__ feat4, int N, int n_kp, int K, int cap, float radius, float* __restrict__ F,
-    int32_t* __restrict__ nn_count, int64_t* __restrict__ nn_idx)
+    const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
+    float radius, float* __restrict__ F, int32_t* __restrict__ nn_count, int64_t* __restrict__ nn_idx)
 {
     extern __shared__ int lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -468,8 +468,14 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
     const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
     const float4* fb = feat4 + (size_t)b * N * 8;
-    const float* q = kpts + ((size_t)b * n_kp + kp) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
+    float qx, qy, qz;
+    if (kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
+        const float4 qp = Pb[kp_index[(size_t)b * n_kp + kp]];
+        qx = qp.x; qy = qp.y; qz = qp.z;
+    } else {
+        const float* q = kpts + ((size_t)b * n_kp + kp) * 3;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
     const int nbits = 32 - __clz(N > 1 ? N - 1 : 1);
 
     const int count = ball_search_grid(P4s, start, g, qx, qy, qz, radius * radius, K, N, nbits, lst, cap, lane);
@@ -623,11 +629,11 @@ UMEREG_API int umereg_pack_points_f32(const float* pts, int B, int N, float radi
     return launch_prep(pts, (char*)packed, B, N, radius, (hipStream_t)stream);
 }
 
-UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const float* feat, int B,
-                                             int N, int n_kp, int feat_dim, int K, float radius, float* F,
-                                             int32_t* nn_count, int64_t* nn_idx, void* stream)
+UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
+                                             const float* feat, int B, int N, int n_kp, int feat_dim, int K,
+                                             float radius, float* F, int32_t* nn_count, int64_t* nn_idx, void* stream)
 {
-    UMEREG_REQUIRE(packed && kpts && feat && F, "ume_moments: null pointer (packed/kpts/feat/F)");
+    UMEREG_REQUIRE(packed && (kpts || kp_index) && feat && F, "ume_moments: null pointer (packed/kpts|kp_index/feat/F)");
     UMEREG_REQUIRE(feat_dim == UMEREG_FEAT_DIM,
                    "ume_moments: feature dim must be 32 like the reference (evaluate.py:55), got %d", feat_dim);
     UMEREG_REQUIRE(B > 0 && N > 0 && n_kp > 0, "ume_moments: B, N, n_kp must be positive (got %d, %d, %d)", B, N, n_kp);
@@ -640,8 +646,8 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     lds_plan(K, &cap, &waves);
     dim3 grid((n_kp + waves - 1) / waves, B);
     hipLaunchKernelGGL(ume_moments_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                       (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, (const float4*)feat, N, n_kp, K,
-                       cap, radius, F, nn_count, nn_idx);
+                       (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                       n_kp, K, cap, radius, F, nn_count, nn_idx);
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
     return UMEREG_OK;
 }
@@ -658,6 +664,6 @@ UMEREG_API int umereg_ume_moments_f32(const float* pts, const float* kpts, const
         return UMEREG_EWORKSPACE;
     }
     if (int rc = umereg_pack_points_f32(pts, B, N, radius, workspace, workspace_bytes, stream)) return rc;
-    return umereg_ume_moments_packed_f32(workspace, kpts, feat, B, N, n_kp, feat_dim, K, radius, F, nn_count,
+    return umereg_ume_moments_packed_f32(workspace, kpts, nullptr, feat, B, N, n_kp, feat_dim, K, radius, F, nn_count,
                                          nn_idx, stream);
 }

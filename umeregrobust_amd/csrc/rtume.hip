@@ -113,14 +113,15 @@ __device__ void polar_rotation(const double A[3][3], double R[3][3])
 __global__ __launch_bounds__(256) void rtume_kernel(const float4* __restrict__ G_all,
                                                     const float4* __restrict__ H_all,
                                                     const int64_t* __restrict__ g_index,
-                                                    const int64_t* __restrict__ h_index, int n,
+                                                    const int64_t* __restrict__ h_index,
+                                                    const int64_t* __restrict__ h_of_g, int n,
                                                     float* __restrict__ T, float* __restrict__ dist)
 {
     const int row = threadIdx.x & 31;
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (k >= n) return;  // uniform per 32-lane group
     const int64_t gi = g_index ? g_index[k] : k;
-    const int64_t hi = h_index ? h_index[k] : k;
+    const int64_t hi = h_of_g ? h_of_g[gi] : (h_index ? h_index[k] : k);
     const float4 gv = G_all[gi * 32 + row];
     const float4 hv = H_all[hi * 32 + row];
     const double mg = gv.x, mh = hv.x;                       // utils/loc_utils.py:304-305
@@ -258,18 +259,19 @@ UMEREG_API int umereg_hypothesis_gates_f32(const float* T, const float* gt_tform
 }
 
 UMEREG_API int umereg_rtume_solve_f32(const float* G_all, const float* H_all, const int64_t* g_index,
-                                      const int64_t* h_index, int nG, int nH, int n, float* T, float* dist,
-                                      void* stream)
+                                      const int64_t* h_index, const int64_t* h_of_g, int nG, int nH, int n, float* T,
+                                      float* dist, void* stream)
 {
     UMEREG_REQUIRE(G_all && H_all && T, "rtume_solve: null pointer (G/H/T)");
     UMEREG_REQUIRE(n > 0 && nG > 0 && nH > 0, "rtume_solve: n, nG, nH must be positive (got %d, %d, %d)", n, nG, nH);
     UMEREG_REQUIRE(g_index || n <= nG, "rtume_solve: n > nG without g_index");
-    UMEREG_REQUIRE(h_index || n <= nH, "rtume_solve: n > nH without h_index");
+    UMEREG_REQUIRE(h_index || h_of_g || n <= nH, "rtume_solve: n > nH without h_index / h_of_g");
+    UMEREG_REQUIRE(!(h_index && h_of_g), "rtume_solve: pass h_index or h_of_g, not both");
     UMEREG_REQUIRE(((uintptr_t)G_all & 15) == 0 && ((uintptr_t)H_all & 15) == 0, "rtume_solve: G/H must be 16-byte aligned");
     if (int rc = check_device()) return rc;
     const int groups_per_wg = 256 / 32;
     hipLaunchKernelGGL(rtume_kernel, dim3((n + groups_per_wg - 1) / groups_per_wg), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)G_all, (const float4*)H_all, g_index, h_index, n, T, dist);
+                       (hipStream_t)stream, (const float4*)G_all, (const float4*)H_all, g_index, h_index, h_of_g, n, T, dist);
     UMEREG_CHECK_LAUNCH("rtume_kernel");
     return UMEREG_OK;
 }

@@ -30,18 +30,14 @@ def my_ume_generation(pts, kpts, feat, args):
 def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D=False, timing=None):
     """evaluate.py:195-236 up to the match probabilities: everything before the host RNG draw."""
     dev = src_pts.device
-    src_keypoint_pts = src_pts[:, src_inds]
-    tgt_keypoint_pts = tgt_pts[:, tgt_inds]
-    # UME matrices (:206-212)
+    # UME matrices (:206-212); the keypoint gathers src_pts[0, src_inds] (:201-202) are fused into the kernel
     t_mom = None if timing is None else timing.setdefault("moments", [])
     t_dist = None if timing is None else timing.setdefault("dist", [])
-    ume_src = ops.ume_moments(src_pts, src_keypoint_pts, src_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom)
-    ume_tgt = ops.ume_moments(tgt_pts, tgt_keypoint_pts, tgt_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom)
+    ume_src = ops.ume_moments(src_pts, None, src_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom, kp_index=src_inds)
+    ume_tgt = ops.ume_moments(tgt_pts, None, tgt_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom, kp_index=tgt_inds)
     num_kpts = min(ume_src.shape[1], ume_tgt.shape[1])
     ume_src = ume_src[:, :num_kpts]
     ume_tgt = ume_tgt[:, :num_kpts]
-    src_keypoint_pts = src_keypoint_pts[:, :num_kpts]
-    tgt_keypoint_pts = tgt_keypoint_pts[:, :num_kpts]
     # Matches (:215-225).  Hungarian matching (:216-222) is off in every shipped config.
     if getattr(args, "hungarian_matching_flag", False):
         raise NotImplementedError("hungarian_matching_flag: off in all reference configs; host scipy path not wired")
@@ -54,29 +50,50 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
         m_tgt, ume_d = ops.ume_match(ume_src, ume_tgt, timing=t_dist)
     prob = ops.match_prob(ume_d[0], args.tau) if args.filter_by_ume_dist_cond else None   # (:235-236)
     return SimpleNamespace(ume_src=ume_src, ume_tgt=ume_tgt, match=m_tgt, match_d=ume_d, prob=prob, D=D,
-                           src_inds=src_inds, tgt_inds=tgt_inds,
-                           num_kpts=num_kpts, src_keypoint_pts=src_keypoint_pts, tgt_keypoint_pts=tgt_keypoint_pts,
-                           dev=dev)
+                           src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=num_kpts, dev=dev,
+                           src_pts=src_pts, tgt_pts=tgt_pts)
+
+
+class PairResult(SimpleNamespace):
+    """Namespace of one pair's results; the matched keypoint coordinates the reference materialises
+    (evaluate.py:228-229, 240-241) are gathered only if somebody reads them."""
+
+    @property
+    def src_keypoint_pts(self):
+        return self.src_pts[:, self.src_inds[:self.num_kpts]]
+
+    @property
+    def tgt_keypoint_pts(self):
+        return self.tgt_pts[:, self.tgt_inds[:self.num_kpts]]
+
+    @property
+    def h_index(self):
+        return self.match[0][self.g_index]
+
+    @property
+    def src_matches_keypoint_pts(self):
+        return self.src_keypoint_pts[:, self.g_index]
+
+    @property
+    def tgt_matches_keypoint_pts(self):
+        return self.tgt_keypoint_pts[:, self.h_index]
 
 
 def _phase_b(a, args, cond):
     """evaluate.py:238-254: apply the drawn sub-sample and solve one SE(3) per kept match."""
     dev = a.dev
-    m_src = torch.arange(a.num_kpts, device=dev)
     if args.filter_by_ume_dist_cond:
-        cond_t = _index_tensor(cond, dev)
-        g_index = m_src[cond_t]
-        h_index = a.match[0][cond_t]
+        g_index = _index_tensor(cond, dev)          # m[:,0] is arange (:225), so src rows = cond itself
     else:
-        g_index = m_src
-        h_index = a.match[0]
-    # Hypotheses (:248-254); the match gathers (:228-231, 243-244) are fused into the solve
-    T, _ = ops.rtume_solve(a.ume_src[0], a.ume_tgt[0], g_index, h_index)
-    a.rtume_tform = T.view(1, -1, 4, 4)
-    a.cond, a.g_index, a.h_index = cond, g_index, h_index
-    a.src_matches_keypoint_pts = a.src_keypoint_pts[:, g_index]
-    a.tgt_matches_keypoint_pts = a.tgt_keypoint_pts[:, h_index]
-    return a
+        g_index = None
+    # Hypotheses (:248-254); the match gathers (:228-231, 243-244) are fused into the solve through the
+    # match table (target row of source row g = match[g])
+    T, _ = ops.rtume_solve(a.ume_src[0], a.ume_tgt[0], g_index, None, h_of_g=a.match[0])
+    out = PairResult(**vars(a))
+    out.rtume_tform = T.view(1, -1, 4, 4)
+    out.cond = cond
+    out.g_index = g_index if g_index is not None else torch.arange(a.num_kpts, device=dev)
+    return out
 
 
 def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):

@@ -92,19 +92,30 @@ def _timed_end(timing, ev, dev):
         timing.append(ev)
 
 
-def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None):
+def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None, kp_index=None):
     """Fused ball query + gather + UME moment matrix (reference evaluate.py:50-60).
     pts [B,N,3], kpts [B,n,3], feat [B,N,32] -> F [B,n,32,4] (+ nn_count i32 [B,n], nn_idx i64 [B,n,K]).
-    timing: optional list; receives a (start, end) event pair bracketing the moment kernel alone."""
+    timing: optional list; receives a (start, end) event pair bracketing the moment kernel alone.
+    kp_index: optional int64 [B,n] -- keypoints as indices into pts (kpts may then be None): the gather
+    `pts[0, inds]` of reference evaluate.py:201-202 fused into the kernel."""
     lib = _lib.load()
-    pts = _dev(pts, "pts"); kpts = _dev(kpts, "kpts"); feat = _dev(feat, "feat")
-    if pts.dim() != 3 or kpts.dim() != 3 or feat.dim() != 3:
+    pts = _dev(pts, "pts"); feat = _dev(feat, "feat")
+    if kp_index is not None:
+        kp_index = _dev(kp_index, "kp_index", torch.int64)
+        kp_index = kp_index.view(pts.shape[0], -1)
+        kpts = None
+        n = kp_index.shape[1]
+    else:
+        kpts = _dev(kpts, "kpts")
+        if kpts.dim() != 3 or kpts.shape[0] != pts.shape[0]:
+            raise ValueError("ume_moments: expected kpts [B,n,3]")
+        n = kpts.shape[1]
+    if pts.dim() != 3 or feat.dim() != 3:
         raise ValueError("ume_moments: expected pts [B,N,3], kpts [B,n,3], feat [B,N,32]")
     B, N, _ = pts.shape
-    n = kpts.shape[1]
     d = feat.shape[2]
-    if feat.shape[0] != B or feat.shape[1] != N or kpts.shape[0] != B:
-        raise ValueError(f"ume_moments: inconsistent shapes {tuple(pts.shape)}, {tuple(kpts.shape)}, {tuple(feat.shape)}")
+    if feat.shape[0] != B or feat.shape[1] != N:
+        raise ValueError(f"ume_moments: inconsistent shapes {tuple(pts.shape)}, {tuple(feat.shape)}")
     dev = pts.device
     F = torch.empty((B, n, d, 4), dtype=torch.float32, device=dev)
     cnt = torch.empty((B, n), dtype=torch.int32, device=dev) if return_count else None
@@ -116,7 +127,7 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
             rc = lib.umereg_pack_points_f32(_ptr(pts), B, N, float(radius), _ptr(ws), ws.numel(), _stream_ptr(dev))
             _lib.check(rc, "umereg_pack_points_f32")
             ev = _timed(timing, dev)
-            rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(feat), B, N, n, d, int(K),
+            rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(kp_index), _ptr(feat), B, N, n, d, int(K),
                                                    float(radius), _ptr(F), _ptr(cnt), _ptr(nidx), _stream_ptr(dev))
             _lib.check(rc, "umereg_ume_moments_packed_f32")
             _timed_end(timing, ev, dev)
@@ -262,28 +273,32 @@ def match_prob(ume_d, tau):
     return prob
 
 
-def rtume_solve(G, H, g_index=None, h_index=None, with_dist=False):
+def rtume_solve(G, H, g_index=None, h_index=None, with_dist=False, h_of_g=None):
     """batch_estimate_transform_ume_old (reference utils/loc_utils.py:292-350) with optional fused
-    row gathers.  G [nG,32,4] (source), H [nH,32,4] (target) -> T [n,4,4] (source -> target), D [n] | None."""
+    row gathers.  G [nG,32,4] (source), H [nH,32,4] (target) -> T [n,4,4] (source -> target), D [n] | None.
+    h_of_g (int64 [nG], instead of h_index): the match table; hypothesis k pairs G[g_index[k]] with H[h_of_g[g_index[k]]]."""
     lib = _lib.load()
     G = _dev(G, "G"); H = _dev(H, "H")
     if G.dim() != 3 or H.dim() != 3 or G.shape[1:] != (32, 4) or H.shape[1:] != (32, 4):
         raise ValueError(f"rtume_solve: expected [n,32,4] UME matrices, got {tuple(G.shape)}, {tuple(H.shape)}")
     gi = None if g_index is None else _dev(g_index, "g_index", torch.int64).view(-1)
     hi = None if h_index is None else _dev(h_index, "h_index", torch.int64).view(-1)
+    hg = None if h_of_g is None else _dev(h_of_g, "h_of_g", torch.int64).view(-1)
+    if hg is not None and (hi is not None or hg.numel() != G.shape[0]):
+        raise ValueError("rtume_solve: h_of_g must have one entry per G row and excludes h_index")
     if gi is not None and hi is not None and gi.numel() != hi.numel():
         raise ValueError("rtume_solve: g_index and h_index differ in length")
     n = gi.numel() if gi is not None else (hi.numel() if hi is not None else G.shape[0])
-    if (gi is None and n > G.shape[0]) or (hi is None and n > H.shape[0]) or \
-            (gi is None and hi is None and G.shape[0] != H.shape[0]):
+    if (gi is None and n > G.shape[0]) or (hi is None and hg is None and n > H.shape[0]) or \
+            (gi is None and hi is None and hg is None and G.shape[0] != H.shape[0]):
         raise ValueError("rtume_solve: index / batch sizes do not agree")
     dev = G.device
     T = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
     D = torch.empty((n,), dtype=torch.float32, device=dev) if with_dist else None
     if n > 0:
         with torch.cuda.device(dev):
-            rc = lib.umereg_rtume_solve_f32(_ptr(G), _ptr(H), _ptr(gi), _ptr(hi), G.shape[0], H.shape[0], n, _ptr(T),
-                                            _ptr(D), _stream_ptr(dev))
+            rc = lib.umereg_rtume_solve_f32(_ptr(G), _ptr(H), _ptr(gi), _ptr(hi), _ptr(hg), G.shape[0], H.shape[0], n,
+                                            _ptr(T), _ptr(D), _stream_ptr(dev))
         _lib.check(rc, "umereg_rtume_solve_f32")
     return T, D
 
