@@ -42,6 +42,8 @@ def parse():
                     help="distance GEMM: split-f16 MFMA (fp32-class operands, default) or exact-fp32 MFMA")
     ap.add_argument("--depth", type=int, default=2,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
+    ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
+                    help="run source and target clouds as two launches instead of one batch of 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=1, help="pairs timed by the CPU baseline leg")
     return ap.parse_args()
@@ -82,12 +84,17 @@ def main():
             host=p, src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
             tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
             gt=t(p.gt_tform).contiguous()))
+        e = pool[-1]
+        e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
+            if a.batch_clouds else None
     # neighbour counts (for the algorithmic-bytes roofline), outside the timed region
     for e in pool:
-        e.mom_bytes = []
+        per_cloud = []
         for pts, inds, feat in ((e.src_pts, e.src_inds, e.src_feat), (e.tgt_pts, e.tgt_inds, e.tgt_feat)):
             _, cnt = ops.ume_moments(pts, pts[:, inds], feat, args.ume_max_nn, args.ume_r_nn, return_count=True)
-            e.mom_bytes.append(float((140.0 * cnt.double() + 524.0).sum().item()))
+            per_cloud.append(float((140.0 * cnt.double() + 524.0).sum().item()))
+        # one moment-kernel launch covers both clouds when they are batched, one cloud otherwise
+        e.mom_bytes = [sum(per_cloud)] if e.pair is not None else per_cloud
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
     rng = np.random.RandomState(1234 + rank)
@@ -101,7 +108,7 @@ def main():
     def submit(i, record):
         e = pool[i % len(pool)]
         h = pipe.submit(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, src_inds=e.src_inds, tgt_inds=e.tgt_inds,
-                        timing=timing if record else None)
+                        timing=timing if record else None, pair=e.pair)
         h.entry = e
         if record:
             mom_bytes_log.extend(e.mom_bytes)
@@ -185,7 +192,7 @@ def main():
                                f"d=32, M={args.ume_n_samples} hypotheses, tau={args.tau}, kind={a.kind})",
                    "pairs_per_step_per_gpu": 1, "sharding": f"pairs[rank::{world}] (no data-path collective)",
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
-                   "pairs_in_flight": depth},
+                   "pairs_in_flight": depth, "clouds_per_moment_launch": 2 if a.batch_clouds else 1},
         "roofline": dominant,
         "rooflines": {"ume_moments_kernel": roof_mom, roof_dist["kernel"]: roof_dist},
         "hypothesis_quality": {"hypotheses": int(c[0]), "within_1.5deg_0.6m": round(c[1] / max(c[0], 1), 4),

@@ -97,8 +97,13 @@ int umereg_pack_points_f32(const float* pts, int B, int N, float radius, void* p
                            size_t packed_bytes, void* stream);
 int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
                                   const float* feat, int B, int N, int n_kp, int feat_dim, int K,
-                                  float radius, float* F, int32_t* nn_count, int64_t* nn_idx,
-                                  void* stream);
+                                  float radius, int ordered, float* F, int32_t* nn_count,
+                                  int64_t* nn_idx, void* stream);
+/*   ordered != 0: process keypoints in the cell-sorted, XCD-sliced order that
+ *   umereg_ume_keypoint_order wrote into `packed` for these same keypoints (results are unchanged;
+ *   only cache locality differs).  Requires n_kp <= N rounded up to 256. */
+int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
+                              int n_kp, float radius, void* stream);
 /*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers
  *   `src_pts[0, src_inds]` of evaluate.py:201-202; when non-NULL, kpts may be NULL. */
 int umereg_ume_moments_f32(const float* pts, const float* kpts, const float* feat, int B, int N,

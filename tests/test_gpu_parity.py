@@ -536,3 +536,24 @@ def test_fused_gathers_equal_explicit(gpu):
     T2, _ = ops.rtume_solve(G, H, cond, None, h_of_g=match)
     T3, _ = ops.rtume_solve(G, H, None, None, h_of_g=match)
     assert torch.equal(T1, T2) and torch.equal(T3[cond], T1)
+
+
+def test_batched_pair_equals_separate_clouds(gpu):
+    """Source and target cloud as one batch of 2 (PairBatch) == two separate launches, bit for bit."""
+    from types import SimpleNamespace
+    from umeregrobust_amd import evaluate
+    from umeregrobust_amd.synth import synth_pair
+    args = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0, filter_by_ume_dist_cond=True, ume_n_samples=200, tau=0.05)
+    p = synth_pair(77, N=7000, n_kp=900, kind="rot")
+    t = lambda a: T_(a, gpu)[None]
+    dp = (t(p.src_pts), t(p.tgt_pts), t(p.src_feat), t(p.tgt_feat))
+    si, ti = T_(p.src_inds, gpu), T_(p.tgt_inds, gpu)
+    ref = evaluate.register_pair(*dp, args, rng=np.random.RandomState(1), src_inds=si, tgt_inds=ti)
+    pair = evaluate.PairBatch.from_clouds(*dp, si, ti)
+    assert pair is not None and pair.pts.shape == (2, 7000, 3)
+    pipe = evaluate.RegistrationPipeline(args, gpu, depth=2, rng=np.random.RandomState(1))
+    out = pipe.finish(pipe.submit(*dp, pair=pair))
+    torch.cuda.synchronize()
+    assert torch.equal(ref.ume_src, out.ume_src) and torch.equal(ref.ume_tgt, out.ume_tgt)
+    assert torch.equal(ref.match, out.match) and torch.equal(ref.rtume_tform, out.rtume_tform)
+    assert np.array_equal(ref.cond, out.cond)

@@ -30,7 +30,8 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_pack_points_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "umereg_ume_moments_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                              c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                              c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "umereg_ume_keypoint_order": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "umereg_ume_dist_q_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "umereg_ume_dist_q_f16x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

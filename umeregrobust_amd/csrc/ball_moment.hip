@@ -36,10 +36,11 @@ constexpr int kPadPts = 256;        // packed tables are padded to a multiple of
 constexpr int kMaxCells = 4096;     // grid cells: <= 32 x 32 x 4
 constexpr int kCapX = 32, kCapY = 32, kCapZ = 4;
 constexpr int kSortWG = 1024;       // points per workgroup in the counting sort
+constexpr int kScanUnroll = 4;      // 64-point chunks in flight per wave in the grid search
 
 // ---- workspace carve-up (per batch element) ---------------------------------------------------
 struct GridWs {
-    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_bbox, total;
+    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_bbox, off_kperm, total;
     int Npad, n_wg;
 };
 
@@ -56,6 +57,7 @@ __host__ __device__ inline GridWs grid_ws(int N)
     w.off_bases = o;  o += (size_t)w.n_wg * kMaxCells * 4;
     w.off_start = o;  o += (size_t)(kMaxCells + 64) * 4;
     w.off_bbox = o;   o += 64;
+    w.off_kperm = o;  o += (size_t)w.Npad * 4;   // keypoint processing order (n_kp <= Npad)
     w.total = (o + 255) / 256 * 256;
     return w;
 }
@@ -338,25 +340,36 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
             const int cbase = (z * g.ny + y) * g.nx;
             const int beg = __builtin_amdgcn_readfirstlane(start[cbase + x0]);
             const int end = __builtin_amdgcn_readfirstlane(start[cbase + x1 + 1]);
-            for (int base = beg; base < end; base += kWave) {
-                const int pos = base + lane;
-                const float4 p = P4s[pos];          // table has 64 entries of tail padding
-                const int oi = __float_as_int(p.w);
-                const float dx = qx - p.x;
-                const float dy = qy - p.y;
-                const float dz = qz - p.z;
-                float d2 = dx * dx;
-                d2 = d2 + dy * dy;
-                d2 = d2 + dz * dz;
-                const bool hit = (pos < end) && (d2 < r2) && (oi <= thr);
-                const unsigned long long m = __ballot(hit);
-                if (m != 0ull) {   // wave-uniform
-                    if (hit) lst[cnt + mbcnt(m)] = oi;
-                    cnt += __popcll(m);
-                    if (cnt > cap - kWave) {   // the next chunk might not fit: keep the K smallest
-                        __builtin_amdgcn_wave_barrier();
-                        thr = select_kth(lst, cnt, K, nbits, lane);
-                        cnt = compact_le(lst, cnt, thr, lane);
+            // kScanUnroll chunks per trip, loads issued together: a serial load -> test -> load chain
+            // left the wave waiting on L2 latency for half of its lifetime (SQ_WAIT_ANY 49 %)
+            for (int base = beg; base < end; base += kWave * kScanUnroll) {
+                float4 pv[kScanUnroll];
+#pragma unroll
+                for (int u = 0; u < kScanUnroll; ++u) {
+                    const int pos = base + u * kWave + lane;
+                    pv[u] = P4s[pos < end ? pos : end - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < kScanUnroll; ++u) {
+                    const int pos = base + u * kWave + lane;
+                    const float4 p = pv[u];
+                    const int oi = __float_as_int(p.w);
+                    const float dx = qx - p.x;
+                    const float dy = qy - p.y;
+                    const float dz = qz - p.z;
+                    float d2 = dx * dx;
+                    d2 = d2 + dy * dy;
+                    d2 = d2 + dz * dz;
+                    const bool hit = (pos < end) && (d2 < r2) && (oi <= thr);
+                    const unsigned long long m = __ballot(hit);
+                    if (m != 0ull) {   // wave-uniform
+                        if (hit) lst[cnt + mbcnt(m)] = oi;
+                        cnt += __popcll(m);
+                        if (cnt > cap - kWave) {   // the next chunk might not fit: keep the K smallest
+                            __builtin_amdgcn_wave_barrier();
+                            thr = select_kth(lst, cnt, K, nbits, lane);
+                            cnt = compact_le(lst, cnt, thr, lane);
+                        }
                     }
                 }
             }
@@ -446,23 +459,93 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
     }
 }
 
+// ---- keypoint processing order ---------------------------------------------------------------------
+// Keypoints arrive in random order (np.random.choice), so consecutive wavefronts gather from all over
+// the 6.4 MB feature table: every XCD's 4 MiB L2 sees the whole table (measured: 58 % L2 hits,
+// 226 MB of fabric traffic per launch for 8 MB of unique data).  Sorting the keypoints by grid cell
+// and giving each XCD one contiguous slab of that order (workgroup b runs on XCD b % 8) shrinks an
+// XCD's working set to its slab plus a one-cell halo, and makes the 4 waves of a workgroup walk the
+// same runs (L1 hits).  Only the ORDER in which keypoints are processed changes -- each keypoint's
+// result is independent of it -- so this pass may use atomics freely.
+__global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, size_t ws_stride,
+                                                         const float* __restrict__ kpts,
+                                                         const int64_t* __restrict__ kp_index, int N, int n_kp,
+                                                         float radius)
+{
+    __shared__ int cnt[kMaxCells];
+    __shared__ int part[1024 / 64];
+    const GridWs w = grid_ws(N);
+    char* wb = ws + blockIdx.y * ws_stride;
+    const int b = blockIdx.y;
+    const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
+    int* perm = reinterpret_cast<int*>(wb + w.off_kperm);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    for (int c = threadIdx.x; c < kMaxCells; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    auto cell_of_kp = [&](int k) {
+        float x, y, z;
+        if (kp_index) {
+            const float4 p = P4o[kp_index[(size_t)b * n_kp + k]];
+            x = p.x; y = p.y; z = p.z;
+        } else {
+            const float* q = kpts + ((size_t)b * n_kp + k) * 3;
+            x = q[0]; y = q[1]; z = q[2];
+        }
+        return (cell_axis(z, g.minz, g.invz, g.nz) * g.ny + cell_axis(y, g.miny, g.invy, g.ny)) * g.nx +
+               cell_axis(x, g.minx, g.invx, g.nx);
+    };
+    for (int k = threadIdx.x; k < n_kp; k += 1024) atomicAdd(&cnt[cell_of_kp(k)], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..4096): 4 consecutive cells per thread
+    const int c0 = threadIdx.x * 4;
+    const int t0 = cnt[c0], t1 = cnt[c0 + 1], t2 = cnt[c0 + 2], t3 = cnt[c0 + 3];
+    const int sum = t0 + t1 + t2 + t3;
+    int incl = sum;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_up(incl, m, kWave);
+        if ((int)(threadIdx.x & 63) >= m) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) base += part[k];
+    const int excl = base + incl - sum;
+    __syncthreads();
+    cnt[c0] = excl; cnt[c0 + 1] = excl + t0; cnt[c0 + 2] = excl + t0 + t1; cnt[c0 + 3] = excl + t0 + t1 + t2;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_kp; k += 1024) perm[atomicAdd(&cnt[cell_of_kp(k)], 1)] = k;
+}
+
 // ---- a1+a2: fused ball query + gather + UME moments -------------------------------------------
-constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave
+constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 measured no faster, and costs 2 waves/SIMD)
 
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
-    float radius, float* __restrict__ F, int32_t* __restrict__ nn_count, int64_t* __restrict__ nn_idx)
+    float radius, int ordered, float* __restrict__ F, int32_t* __restrict__ nn_count,
+    int64_t* __restrict__ nn_idx)
 {
     extern __shared__ int lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int b = blockIdx.y;
-    const int kp = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (kp >= n_kp) return;
-    int* lst = lds + wave * cap;
     const GridWs w = grid_ws(N);
     const char* wb = ws + b * ws_stride;
+    int kp;
+    if (ordered) {
+        // XCD-aware: workgroup `blockIdx.x` runs on XCD blockIdx.x % 8 (observed dispatch rule, used
+        // for speed only); give XCD x the x-th contiguous slab of the cell-sorted keypoint order.
+        const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
+        const int lblk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        const int slot = lblk * (blockDim.x >> 6) + wave;
+        if (slot >= n_kp) return;
+        kp = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(wb + w.off_kperm)[slot]);
+    } else {
+        kp = blockIdx.x * (blockDim.x >> 6) + wave;
+        if (kp >= n_kp) return;
+    }
+    int* lst = lds + wave * cap;
     const float4* Pb = reinterpret_cast<const float4*>(wb + w.off_p4o);
     const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
@@ -629,9 +712,23 @@ UMEREG_API int umereg_pack_points_f32(const float* pts, int B, int N, float radi
     return launch_prep(pts, (char*)packed, B, N, radius, (hipStream_t)stream);
 }
 
+UMEREG_API int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
+                                         int n_kp, float radius, void* stream)
+{
+    UMEREG_REQUIRE(packed && (kpts || kp_index), "keypoint_order: null pointer");
+    UMEREG_REQUIRE(B > 0 && N > 0 && n_kp > 0, "keypoint_order: B, N, n_kp must be positive");
+    UMEREG_REQUIRE(n_kp <= grid_ws(N).Npad, "keypoint_order: n_kp (%d) exceeds the order buffer (%d)", n_kp, grid_ws(N).Npad);
+    if (int rc = check_device()) return rc;
+    hipLaunchKernelGGL(kp_order_kernel, dim3(1, B), dim3(1024), 0, (hipStream_t)stream, (char*)packed, grid_ws(N).total,
+                       kpts, kp_index, N, n_kp, radius);
+    UMEREG_CHECK_LAUNCH("kp_order_kernel");
+    return UMEREG_OK;
+}
+
 UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
                                              const float* feat, int B, int N, int n_kp, int feat_dim, int K,
-                                             float radius, float* F, int32_t* nn_count, int64_t* nn_idx, void* stream)
+                                             float radius, int ordered, float* F, int32_t* nn_count, int64_t* nn_idx,
+                                             void* stream)
 {
     UMEREG_REQUIRE(packed && (kpts || kp_index) && feat && F, "ume_moments: null pointer (packed/kpts|kp_index/feat/F)");
     UMEREG_REQUIRE(feat_dim == UMEREG_FEAT_DIM,
@@ -647,7 +744,7 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     dim3 grid((n_kp + waves - 1) / waves, B);
     hipLaunchKernelGGL(ume_moments_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
                        (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                       n_kp, K, cap, radius, F, nn_count, nn_idx);
+                       n_kp, K, cap, radius, ordered, F, nn_count, nn_idx);
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
     return UMEREG_OK;
 }
@@ -664,6 +761,9 @@ UMEREG_API int umereg_ume_moments_f32(const float* pts, const float* kpts, const
         return UMEREG_EWORKSPACE;
     }
     if (int rc = umereg_pack_points_f32(pts, B, N, radius, workspace, workspace_bytes, stream)) return rc;
-    return umereg_ume_moments_packed_f32(workspace, kpts, nullptr, feat, B, N, n_kp, feat_dim, K, radius, F, nn_count,
-                                         nn_idx, stream);
+    const int ordered = n_kp <= grid_ws(N).Npad && n_kp >= 64;
+    if (ordered)
+        if (int rc = umereg_ume_keypoint_order(workspace, kpts, nullptr, B, N, n_kp, radius, stream)) return rc;
+    return umereg_ume_moments_packed_f32(workspace, kpts, nullptr, feat, B, N, n_kp, feat_dim, K, radius, ordered, F,
+                                         nn_count, nn_idx, stream);
 }

@@ -27,14 +27,22 @@ def my_ume_generation(pts, kpts, feat, args):
     return ops.ume_moments(pts, kpts, feat, args.ume_max_nn, args.ume_r_nn)
 
 
-def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D=False, timing=None):
+def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D=False, timing=None,
+             pair=None):
     """evaluate.py:195-236 up to the match probabilities: everything before the host RNG draw."""
     dev = src_pts.device
     # UME matrices (:206-212); the keypoint gathers src_pts[0, src_inds] (:201-202) are fused into the kernel
     t_mom = None if timing is None else timing.setdefault("moments", [])
     t_dist = None if timing is None else timing.setdefault("dist", [])
-    ume_src = ops.ume_moments(src_pts, None, src_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom, kp_index=src_inds)
-    ume_tgt = ops.ume_moments(tgt_pts, None, tgt_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom, kp_index=tgt_inds)
+    if pair is not None:
+        # both clouds of the pair as ONE batch of 2 through every kernel (same arithmetic per cloud; half
+        # the launches, twice the parallelism for the small grid-building kernels)
+        ume_both = ops.ume_moments(pair.pts, None, pair.feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom,
+                                   kp_index=pair.inds)
+        ume_src, ume_tgt = ume_both[0:1], ume_both[1:2]
+    else:
+        ume_src = ops.ume_moments(src_pts, None, src_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom, kp_index=src_inds)
+        ume_tgt = ops.ume_moments(tgt_pts, None, tgt_feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom, kp_index=tgt_inds)
     num_kpts = min(ume_src.shape[1], ume_tgt.shape[1])
     ume_src = ume_src[:, :num_kpts]
     ume_tgt = ume_tgt[:, :num_kpts]
@@ -52,6 +60,24 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
     return SimpleNamespace(ume_src=ume_src, ume_tgt=ume_tgt, match=m_tgt, match_d=ume_d, prob=prob, D=D,
                            src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=num_kpts, dev=dev,
                            src_pts=src_pts, tgt_pts=tgt_pts)
+
+
+class PairBatch:
+    """A registration pair laid out as a batch of two clouds: pts [2,N,3], feat [2,N,32], inds [2,n_kp]
+    (row 0 = source, row 1 = target).  Requires both clouds to have the same N and keypoint count, which
+    is what the reference's collate (`max_pc_size`) and keypoint draw (`num_init_sel`) produce."""
+
+    def __init__(self, pts, feat, inds):
+        assert pts.dim() == 3 and pts.shape[0] == 2 and feat.shape[:2] == pts.shape[:2] and inds.shape[0] == 2
+        self.pts, self.feat, self.inds = pts.contiguous(), feat.contiguous(), inds.contiguous().to(torch.int64)
+
+    @classmethod
+    def from_clouds(cls, src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds):
+        """Stacks two [1,N,*] clouds (one device copy); returns None if their shapes differ."""
+        if src_pts.shape != tgt_pts.shape or src_inds.shape != tgt_inds.shape:
+            return None
+        return cls(torch.cat([src_pts, tgt_pts], 0), torch.cat([src_feat, tgt_feat], 0),
+                   torch.stack([src_inds.view(-1), tgt_inds.view(-1)], 0))
 
 
 class PairResult(SimpleNamespace):
@@ -146,16 +172,21 @@ class RegistrationPipeline:
         self.last_a_done = None
         self.n_submitted = 0
 
-    def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None):
+    def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None, pair=None):
+        """pair: optional PairBatch holding the same clouds/keypoints as a batch of 2 (then the per-cloud
+        arguments are only used for their shapes and as views for downstream consumers)."""
         k = self.n_submitted % self.depth
         self.n_submitted += 1
         st = self.streams[k]
-        src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, self.rng, src_inds, tgt_inds)
+        if pair is not None:
+            src_inds, tgt_inds = pair.inds[0], pair.inds[1]
+        else:
+            src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, self.rng, src_inds, tgt_inds)
         st.wait_stream(torch.cuda.current_stream(self.dev))
         if self.last_a_done is not None:
             st.wait_event(self.last_a_done)        # phase A of consecutive pairs stays back-to-back on the GPU
         with torch.cuda.stream(st):
-            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing)
+            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair)
             if a.prob is not None:
                 if self.host_prob[k] is None or self.host_prob[k].numel() != a.prob.numel():
                     self.host_prob[k] = torch.empty(a.prob.numel(), dtype=torch.float32, pin_memory=True)

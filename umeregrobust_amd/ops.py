@@ -14,6 +14,7 @@ from . import _lib
 BallQuery = namedtuple("BallQuery", "dists idx knn")   # pytorch3d's _KNN field names (.dists/.idx/.knn)
 
 QLAYOUT_PLAIN, QLAYOUT_ROWS, QLAYOUT_COLS, QLAYOUT_ROWS_F16X2, QLAYOUT_COLS_F16X2 = 0, 1, 2, 3, 4
+ORDER_KEYPOINTS = True   # process keypoints in cell-sorted, XCD-sliced order (cache locality only)
 DEFAULT_MATCH_PRECISION = "f16x2"   # "f32": exact-fp32 MFMA; "f16x2": split-f16 MFMA (fp32-class, ~5x faster)
 
 _workspaces = {}
@@ -126,9 +127,15 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
         with torch.cuda.device(dev):
             rc = lib.umereg_pack_points_f32(_ptr(pts), B, N, float(radius), _ptr(ws), ws.numel(), _stream_ptr(dev))
             _lib.check(rc, "umereg_pack_points_f32")
+            ordered = int(ORDER_KEYPOINTS and 64 <= n <= (N + 255) // 256 * 256)
+            if ordered:
+                rc = lib.umereg_ume_keypoint_order(_ptr(ws), _ptr(kpts), _ptr(kp_index), B, N, n, float(radius),
+                                                   _stream_ptr(dev))
+                _lib.check(rc, "umereg_ume_keypoint_order")
             ev = _timed(timing, dev)
             rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(kp_index), _ptr(feat), B, N, n, d, int(K),
-                                                   float(radius), _ptr(F), _ptr(cnt), _ptr(nidx), _stream_ptr(dev))
+                                                   float(radius), ordered, _ptr(F), _ptr(cnt), _ptr(nidx),
+                                                   _stream_ptr(dev))
             _lib.check(rc, "umereg_ume_moments_packed_f32")
             _timed_end(timing, ev, dev)
     out = (F,)
