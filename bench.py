@@ -42,6 +42,8 @@ def parse():
                     help="distance GEMM: split-f16 MFMA (fp32-class operands, default) or exact-fp32 MFMA")
     ap.add_argument("--depth", type=int, default=2,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
+    ap.add_argument("--threaded-draw", action="store_true",
+                    help="host RNG draw on a worker thread (overlaps kernel enqueues too); use --depth 3")
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +101,7 @@ def main():
 
     rng = np.random.RandomState(1234 + rank)
     depth = max(1, a.depth)
-    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=rng)
+    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=rng, threaded_draw=a.threaded_draw)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     timing = {"moments": [], "dist": []}
@@ -192,7 +194,7 @@ def main():
                                f"d=32, M={args.ume_n_samples} hypotheses, tau={args.tau}, kind={a.kind})",
                    "pairs_per_step_per_gpu": 1, "sharding": f"pairs[rank::{world}] (no data-path collective)",
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
-                   "pairs_in_flight": depth, "clouds_per_moment_launch": 2 if a.batch_clouds else 1},
+                   "pairs_in_flight": depth, "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1},
         "roofline": dominant,
         "rooflines": {"ume_moments_kernel": roof_mom, roof_dist["kernel"]: roof_dist},
         "hypothesis_quality": {"hypotheses": int(c[0]), "within_1.5deg_0.6m": round(c[1] / max(c[0], 1), 4),

@@ -480,21 +480,27 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     int* perm = reinterpret_cast<int*>(wb + w.off_kperm);
     const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const int* cell_of = reinterpret_cast<const int*>(wb + w.off_cell);
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) cnt[c] = 0;
     __syncthreads();
     auto cell_of_kp = [&](int k) {
-        float x, y, z;
-        if (kp_index) {
-            const float4 p = P4o[kp_index[(size_t)b * n_kp + k]];
-            x = p.x; y = p.y; z = p.z;
-        } else {
-            const float* q = kpts + ((size_t)b * n_kp + k) * 3;
-            x = q[0]; y = q[1]; z = q[2];
-        }
-        return (cell_axis(z, g.minz, g.invz, g.nz) * g.ny + cell_axis(y, g.miny, g.invy, g.ny)) * g.nx +
-               cell_axis(x, g.minx, g.invx, g.nx);
+        if (kp_index) return cell_of[kp_index[(size_t)b * n_kp + k]];   // the point's cell, from the hist pass
+        const float* q = kpts + ((size_t)b * n_kp + k) * 3;
+        return (cell_axis(q[2], g.minz, g.invz, g.nz) * g.ny + cell_axis(q[1], g.miny, g.invy, g.ny)) * g.nx +
+               cell_axis(q[0], g.minx, g.invx, g.nx);
     };
-    for (int k = threadIdx.x; k < n_kp; k += 1024) atomicAdd(&cnt[cell_of_kp(k)], 1);
+    // each thread's cells are kept in registers between the count pass and the scatter pass
+    constexpr int kKeep = 16;
+    int mine[kKeep];
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u) {
+        const int k = threadIdx.x + u * 1024;
+        mine[u] = k < n_kp ? cell_of_kp(k) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u)
+        if (mine[u] >= 0) atomicAdd(&cnt[mine[u]], 1);
+    for (int k = threadIdx.x + kKeep * 1024; k < n_kp; k += 1024) atomicAdd(&cnt[cell_of_kp(k)], 1);
     __syncthreads();
     // exclusive scan of cnt[0..4096): 4 consecutive cells per thread
     const int c0 = threadIdx.x * 4;
@@ -514,7 +520,10 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
     __syncthreads();
     cnt[c0] = excl; cnt[c0 + 1] = excl + t0; cnt[c0 + 2] = excl + t0 + t1; cnt[c0 + 3] = excl + t0 + t1 + t2;
     __syncthreads();
-    for (int k = threadIdx.x; k < n_kp; k += 1024) perm[atomicAdd(&cnt[cell_of_kp(k)], 1)] = k;
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u)
+        if (mine[u] >= 0) perm[atomicAdd(&cnt[mine[u]], 1)] = threadIdx.x + u * 1024;
+    for (int k = threadIdx.x + kKeep * 1024; k < n_kp; k += 1024) perm[atomicAdd(&cnt[cell_of_kp(k)], 1)] = k;
 }
 
 // ---- a1+a2: fused ball query + gather + UME moments -------------------------------------------

@@ -164,11 +164,20 @@ class RegistrationPipeline:
     register_pair given the same RNG stream; `submit` and `finish` must be called in order.
     """
 
-    def __init__(self, args, device, depth=2, rng=np.random):
+    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False):
+        """threaded_draw: run the host draw (event wait + choice) on one worker thread, in submission
+        order, so it also overlaps the main thread's kernel enqueues (the native draw releases the GIL).
+        Use depth >= 3 with it.  The worker is then the only consumer of `rng` between submit and finish,
+        so inject the keypoint indices (or draw them from a different generator)."""
         self.args, self.rng, self.depth = args, rng, depth
+        self.pool = None
+        if threaded_draw:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="umereg-draw")
         self.dev = torch.device(device)
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(depth)]
         self.host_prob = [None] * depth
+        self.host_cond = [None] * depth
         self.last_a_done = None
         self.n_submitted = 0
 
@@ -195,15 +204,31 @@ class RegistrationPipeline:
             a.ready.record(st)
             self.last_a_done = a.ready
         a.slot = k
+        a.draw = None
+        if self.pool is not None and self.args.filter_by_ume_dist_cond:
+            a.draw = self.pool.submit(self._draw, a)
         return a
+
+    def _draw(self, a):
+        a.ready.synchronize()
+        num_matches = min(a.num_kpts, self.args.ume_n_samples)
+        return choice_noreplace(self.rng, a.num_kpts, num_matches, self.host_prob[a.slot].numpy())
 
     def finish(self, a, cond=None):
         st = self.streams[a.slot]
         if self.args.filter_by_ume_dist_cond and cond is None:
-            a.ready.synchronize()
-            num_matches = min(a.num_kpts, self.args.ume_n_samples)
-            cond = choice_noreplace(self.rng, a.num_kpts, num_matches, self.host_prob[a.slot].numpy())
+            cond = a.draw.result() if a.draw is not None else self._draw(a)
         with torch.cuda.stream(st):
+            if self.args.filter_by_ume_dist_cond and not isinstance(cond, torch.Tensor):
+                # upload through pinned memory: a pageable-source copy blocks the host for tens of microseconds
+                c = np.asarray(cond, dtype=np.int64)
+                k = a.slot
+                if self.host_cond[k] is None or self.host_cond[k].numel() != c.size:
+                    self.host_cond[k] = torch.empty(c.size, dtype=torch.int64, pin_memory=True)
+                self.host_cond[k].numpy()[:] = c
+                out = _phase_b(a, self.args, self.host_cond[k].to(self.dev, non_blocking=True))
+                out.cond = c
+                return out
             return _phase_b(a, self.args, cond)
 
     def stream_of(self, a):
