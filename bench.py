@@ -46,6 +46,9 @@ def parse():
                     help="host RNG draw on a worker thread (overlaps kernel enqueues too); use --depth 3")
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
+    ap.add_argument("--dist-backend", default=None, help="(testing) torch.distributed backend override, e.g. gloo")
+    ap.add_argument("--force-device", type=int, default=None,
+                    help="(testing) put every rank on this device index, to exercise the N>1 path on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=1, help="pairs timed by the CPU baseline leg")
     return ap.parse_args()
@@ -63,7 +66,9 @@ def main():
     from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
 
     ops.DEFAULT_MATCH_PRECISION = a.precision
-    rank, local_rank, world = init_distributed()
+    if a.force_device is not None:
+        os.environ["LOCAL_RANK"] = str(a.force_device)
+    rank, local_rank, world = init_distributed(backend=a.dist_backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     umeregrobust_amd.require_native()
