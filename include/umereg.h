@@ -205,6 +205,43 @@ int umereg_rre_deg_f32(const float* R, const float* R_hat, int b, float* out_deg
 int umereg_hypothesis_gates_f32(const float* T, const float* gt_tform, int n, uint64_t* counts,
                                 float* rre_deg, float* rte, void* stream);
 
+/* =============================================================================================
+ * hypothesis selection (FeatureCorrelator, utils/loc_utils.py:579-681)
+ * ============================================================================================= */
+
+/* pytorch3d.ops.knn_points(p1, p2, K)   -- utils/loc_utils.py:580,623; evaluate.py:272,274
+ * Exact K nearest points of p2[b] for every p1[b,i]: squared distances ascending, ties towards the
+ * lower index (upstream leaves tie order unspecified).  K <= min(64, n2).
+ *   p1 [B,n1,3]  p2 [B,n2,3]  ->  dists f32 [B,n1,K], idx int64 [B,n1,K] */
+size_t umereg_knn_workspace_bytes(int B, int n2);
+int umereg_knn_points_f32(const float* p1, const float* p2, int B, int n1, int n2, int K, float* dists,
+                          int64_t* idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* feature_spatial_var(pts, feat, knn)   -- utils/loc_utils.py:579-585
+ * out[b,i] = mean over the knn-1 nearest OTHER points j of |feat[b,i] - feat[b,j]|_2 (self-kNN,
+ * idx[:, :, 1:]); fused kNN + gather + norm, nothing of size [N,knn,32] is formed.
+ *   pts [B,N,3], feat [B,N,32] -> out f32 [B,N]; workspace: umereg_knn_workspace_bytes(B, N) */
+int umereg_feature_spatial_var_f32(const float* pts, const float* feat, int B, int N, int feat_dim, int knn,
+                                   float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* weighted features of feature_corr_hypothesis_test -- utils/loc_utils.py:661,664-665
+ *   m = mean over the points of BOTH clouds;  out = (feat - m) * weight[:, None]
+ * workspace >= 16 KiB (partial column sums, reduced in a fixed order). */
+int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
+                                      const float* tgt_w, int Ns, int Nt, float* src_out, float* tgt_out,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* pc_corr_cost_pytorch3d for all hypotheses -- utils/loc_utils.py:592-637
+ *   score[h] = (1/Ns) sum_n sum_{k<K} cauchy(|R_h p_n + t_h - q_jk|, sigma) <src_wfeat[n], tgt_wfeat[jk]>
+ * with jk the K nearest target points of the transformed source point and
+ * cauchy(e, s) = 1 / (1 + (e/s)^2).  Fused transform + exact kNN + correlation; the reference's
+ * [batch,Ns,K,32] gathered tensor is never formed.
+ *   src_pts [Ns,3], tgt_pts [Nt,3], src_wfeat [Ns,32], tgt_wfeat [Nt,32], T [M,4,4] -> scores f32 [M] */
+size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M);
+int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
+                           const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
+                           float* scores, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -300,3 +300,59 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds, cond
     sel = np.arange(D.shape[0]) if cond is None else np.asarray(cond)
     T, _ = batch_estimate_transform_ume_old(ume_src[sel], ume_tgt[m[sel]], with_dist=False)
     return dict(ume_src=ume_src, ume_tgt=ume_tgt, match=m, match_d=d.astype(np.float32), T=T)
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8(f1)  utils/loc_utils.py:579-681  hypothesis selection by feature correlation
+# ---------------------------------------------------------------------------------------------
+def feature_spatial_var(pts, feat, knn=10):
+    """utils/loc_utils.py:579-585.  pts [B,N,3], feat [B,N,32] -> [B,N] fp32."""
+    pts = _f32(pts); feat = _f32(feat)
+    q_nn_to_p = knn_points(pts, pts, K=knn)                                   # :580
+    nn_feat = knn_gather(feat, q_nn_to_p.idx[:, :, 1:])                        # :581
+    nn_feat_diff = feat[:, :, None, :] - nn_feat                               # :582
+    nn_feat_diff_norm = np.linalg.norm(nn_feat_diff, axis=-1)                  # :583
+    return nn_feat_diff_norm.mean(axis=-1, dtype=np.float32).astype(np.float32)   # :584
+
+
+def cauchy_kernel(e, k=0.1):
+    """utils/loc_utils.py:588-589."""
+    return 1 / (1 + (e / k) ** 2)
+
+
+def pc_corr_cost(R, t, source_points, target_points, k, source_vals, target_vals, sigma):
+    """pc_corr_cost_pytorch3d + pc_corr_pytorch3d + pc_corr (utils/loc_utils.py:592-637), P=None, use_norm=False.
+    R [b,3,3], t [b,3], source_points [Ns,3], target_points [Nt,3], vals [N,32] -> score [b] fp32."""
+    R = _f32(R); t = _f32(t); sp = _f32(source_points); tp = _f32(target_points)
+    vp = _f32(source_vals); vq = _f32(target_vals)
+    source_transformed = sp[None] @ np.swapaxes(R, 1, 2) + t[:, None, :]                    # :629
+    b = R.shape[0]
+    idx = knn_points(source_transformed, np.broadcast_to(tp[None], (b,) + tp.shape), K=k).idx   # :623
+    dist_mat = np.linalg.norm(source_transformed[:, :, None, :] - tp[idx], axis=-1)         # :593
+    weight_mat = cauchy_kernel(dist_mat, np.float32(sigma)).astype(np.float32)              # :596
+    val_product_mat = (vp[None, :, None, :] * vq[idx]).sum(axis=-1, dtype=np.float32)       # :603
+    val_out = (weight_mat * val_product_mat).sum(axis=(1, 2), dtype=np.float32)             # :610
+    return (val_out / np.float32(vp.shape[0])).astype(np.float32)                           # :612
+
+
+def feature_corr_hypothesis_test(source_pc, target_pc, source_feat, target_feat, T_kp, sigma=0.05, corr_num_nn=20,
+                                 n_hypotheses=10, batch=64):
+    """FeatureCorrelator.feature_corr_hypothesis_test (utils/loc_utils.py:656-681).
+    source_pc [1,Ns,3], ..., T_kp [M,4,4] -> (best_T [4,4], scores [M])."""
+    source_pc = _f32(source_pc); target_pc = _f32(target_pc)
+    source_feat = _f32(source_feat); target_feat = _f32(target_feat); T_kp = _f32(T_kp)
+    m = np.concatenate((source_feat, target_feat), axis=1).mean(axis=1, dtype=np.float32)   # :661
+    src_feat_weight = feature_spatial_var(source_pc, source_feat, knn=50)                   # :662
+    tgt_feat_weight = feature_spatial_var(target_pc, target_feat, knn=50)                   # :663
+    wsf = (source_feat - m) * src_feat_weight[..., None]                                    # :664
+    wtf = (target_feat - m) * tgt_feat_weight[..., None]                                    # :665
+    scores = []
+    for i in range(0, T_kp.shape[0], batch):                                                # :666-673
+        Tb = T_kp[i:i + batch]
+        scores.append(pc_corr_cost(Tb[:, :3, :3], Tb[:, :3, 3], source_pc[0], target_pc[0], corr_num_nn, wsf[0], wtf[0],
+                                   sigma))
+    mmf_score = np.concatenate(scores)
+    order = np.argsort(-mmf_score, kind="stable")                                           # :676
+    top = order[:n_hypotheses]
+    best_T = T_kp[top][np.argmax(mmf_score[top])]                                           # :677-680
+    return best_T, mmf_score

@@ -557,3 +557,73 @@ def test_batched_pair_equals_separate_clouds(gpu):
     assert torch.equal(ref.ume_src, out.ume_src) and torch.equal(ref.ume_tgt, out.ume_tgt)
     assert torch.equal(ref.match, out.match) and torch.equal(ref.rtume_tform, out.rtume_tform)
     assert np.array_equal(ref.cond, out.cond)
+
+
+# ------------------------------------------------------------------------------------ SURVEY 8(f1)
+@pytest.mark.parametrize("n1,n2,K", [(500, 3000, 20), (64, 64, 1), (1, 200, 5), (777, 10000, 50), (300, 70, 64),
+                                     (2000, 5000, 1)])
+def test_knn_points_vs_oracle(gpu, n1, n2, K):
+    """pytorch3d.ops.knn_points: exact K nearest, squared distances ascending, ties -> lower index."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_scene
+    rng = np.random.RandomState(n1 + n2 + K)
+    p2 = synth_scene(rng, n2, 0.6).astype(np.float32) if n2 >= 1000 else (rng.standard_normal((n2, 3)) * 4).astype(np.float32)
+    p1 = (p2[rng.choice(n2, n1, replace=n1 > n2)] + rng.standard_normal((n1, 3)).astype(np.float32) * 0.7).astype(np.float32)
+    p1[: max(1, n1 // 20)] += 200.0                               # queries far outside the target bounding box
+    ref = orc.knn_points(p1[None], p2[None], K=K)
+    out = ops.knn_points(T_(p1, gpu)[None], T_(p2, gpu)[None], K=K, return_nn=True)
+    assert np.array_equal(N_(out.idx), ref.idx)
+    assert np.array_equal(N_(out.dists), ref.dists)
+    assert np.array_equal(N_(out.knn[0]), p2[ref.idx[0]])
+
+
+def test_knn_points_lattice_ties(gpu):
+    """Points on a lattice produce many exactly equal distances: ties must resolve towards the lower index."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(0)
+    g3 = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
+    p2 = (g3[rng.permutation(len(g3))] * 0.5).astype(np.float32)
+    p1 = p2[:100].copy()
+    ref = orc.knn_points(p1[None], p2[None], K=27)
+    out = ops.knn_points(T_(p1, gpu)[None], T_(p2, gpu)[None], K=27)
+    assert np.array_equal(N_(out.idx), ref.idx) and np.array_equal(N_(out.dists), ref.dists)
+
+
+def test_feature_correlator_golden(gpu):
+    """Golden G7: the reference's own feature_spatial_var / pc_corr scores / selected hypothesis."""
+    from umeregrobust_amd.utils.loc_utils import FeatureCorrelator, feature_spatial_var
+    g = load_golden("g7_feature_corr.npz")
+    t = lambda a: T_(a, gpu)[None]
+    fsv = N_(feature_spatial_var(t(g["src_pts"]), t(g["src_feat"]), knn=50)[0])
+    assert np.abs(fsv - g["fsv_src"]).max() < 2e-6
+    fc = FeatureCorrelator(sigma=1.5, batch=3, n_hypotheses=10)
+    best = fc.feature_corr_hypothesis_test(t(g["src_pts"]), t(g["tgt_pts"]), t(g["src_feat"]), t(g["tgt_feat"]),
+                                           T_(g["T_hyp"], gpu))
+    assert np.allclose(N_(fc.last_scores), g["score"], rtol=5e-5, atol=1e-6)
+    assert np.array_equal(N_(best), g["best_T"])
+
+
+def test_corr_scores_kitti_shape_vs_oracle(gpu):
+    """10 000-point clouds, 24 hypotheses (ground truth, perturbed, and garbage transforms that throw the
+    source far outside the target): scores vs the oracle, and the ground-truth transform wins."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_pair
+    p = synth_pair(91, N=10000, n_kp=100, kind="test", voxel=0.6)
+    rng = np.random.RandomState(1)
+    Ts = [p.gt_tform.astype(np.float64)]
+    for i in range(23):
+        dT = np.eye(4)
+        a = rng.standard_normal(3); a /= np.linalg.norm(a)
+        ang = np.deg2rad(rng.uniform(0.2, 5.0) if i < 15 else rng.uniform(20, 180))
+        Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        dT[:3, :3] = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        dT[:3, 3] = rng.standard_normal(3) * (0.3 if i < 15 else 40.0)
+        Ts.append(dT @ p.gt_tform.astype(np.float64))
+    Ts = np.stack(Ts).astype(np.float32)
+    wsf, wtf = p.src_feat * 0.5, p.tgt_feat * 0.5
+    ref = orc.pc_corr_cost(Ts[:, :3, :3], Ts[:, :3, 3], p.src_pts, p.tgt_pts, 20, wsf, wtf, 1.5)
+    out = N_(ops.corr_scores(T_(p.src_pts, gpu), T_(p.tgt_pts, gpu), T_(wsf, gpu), T_(wtf, gpu), T_(Ts, gpu), K=20, sigma=1.5))
+    assert np.allclose(out, ref, rtol=1e-4, atol=1e-6)
+    assert int(np.argmax(out)) == 0
+    out2 = N_(ops.corr_scores(T_(p.src_pts, gpu), T_(p.tgt_pts, gpu), T_(wsf, gpu), T_(wtf, gpu), T_(Ts, gpu), K=20, sigma=1.5))
+    assert np.array_equal(out, out2)                                # deterministic reduction order

@@ -135,3 +135,16 @@ def test_knn_points_matches_bruteforce():
     ref = np.argsort(d2, axis=1, kind="stable")[:, :7]
     assert np.array_equal(r.idx[0], ref)
     assert np.all(np.diff(r.dists[0], axis=1) >= 0)
+
+
+def test_feature_correlator_vs_reference():
+    """utils/loc_utils.py:579-681 -- golden G7 produced by the reference's own FeatureCorrelator."""
+    g = load_golden("g7_feature_corr.npz")
+    fsv = orc.feature_spatial_var(g["src_pts"][None], g["src_feat"][None], knn=50)[0]
+    assert np.abs(fsv - g["fsv_src"]).max() < 2e-6
+    best, scores = orc.feature_corr_hypothesis_test(g["src_pts"][None], g["tgt_pts"][None], g["src_feat"][None],
+                                                    g["tgt_feat"][None], g["T_hyp"], sigma=1.5, corr_num_nn=20,
+                                                    n_hypotheses=10, batch=3)
+    assert np.allclose(scores, g["score"], rtol=2e-5, atol=1e-6)
+    assert np.array_equal(best, g["best_T"])
+    assert int(np.argmax(scores)) == int(g["gt_index"])          # the ground-truth transform wins

@@ -51,6 +51,16 @@ SIGNATURES = {
     "umereg_rtume_solve_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p]),
     "umereg_hypothesis_gates_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "umereg_knn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_knn_points_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "umereg_feature_spatial_var_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                               c_size_t, c_void_p]),
+    "umereg_corr_weighted_features_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                                  c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_corr_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "umereg_corr_scores_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_rre_deg_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
 }
 

@@ -27,89 +27,9 @@
 //   a1      the ball-query entry point sorts the K kept indices (bitonic, in LDS) to emit
 //           pytorch3d's ascending order, then recomputes dists / nn from them.
 // The reference's [n_kp,K,32] gathered intermediate (960 MB at KITTI size) never exists.
-#include "common.h"
+#include "grid.h"
 
 namespace umereg {
-
-constexpr float kFar = 1.0e18f;     // padding coordinate: d2 ~ 3e36, never < r2
-constexpr int kPadPts = 256;        // packed tables are padded to a multiple of this
-constexpr int kMaxCells = 4096;     // grid cells: <= 32 x 32 x 4
-constexpr int kCapX = 32, kCapY = 32, kCapZ = 4;
-constexpr int kSortWG = 1024;       // points per workgroup in the counting sort
-constexpr int kScanUnroll = 4;      // 64-point chunks in flight per wave in the grid search
-
-// ---- workspace carve-up (per batch element) ---------------------------------------------------
-struct GridWs {
-    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_bbox, off_kperm, total;
-    int Npad, n_wg;
-};
-
-__host__ __device__ inline GridWs grid_ws(int N)
-{
-    GridWs w;
-    w.Npad = (int)((N + kPadPts - 1) / kPadPts * kPadPts);
-    w.n_wg = (N + kSortWG - 1) / kSortWG;
-    size_t o = 0;
-    w.off_p4o = o;    o += (size_t)w.Npad * 16;
-    w.off_p4s = o;    o += ((size_t)w.Npad + 64) * 16;
-    w.off_cell = o;   o += (size_t)w.Npad * 4;
-    w.off_counts = o; o += (size_t)w.n_wg * kMaxCells * 4;
-    w.off_bases = o;  o += (size_t)w.n_wg * kMaxCells * 4;
-    w.off_start = o;  o += (size_t)(kMaxCells + 64) * 4;
-    w.off_bbox = o;   o += 64;
-    w.off_kperm = o;  o += (size_t)w.Npad * 4;   // keypoint processing order (n_kp <= Npad)
-    w.total = (o + 255) / 256 * 256;
-    return w;
-}
-
-// ---- grid geometry, recomputed from the bounding box by every kernel that needs it ------------
-struct Grid {
-    float minx, miny, minz, invx, invy, invz;
-    int nx, ny, nz;
-};
-
-__device__ __forceinline__ unsigned int enc_ord(float f)
-{
-    const unsigned int b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float dec_ord(unsigned int e)
-{
-    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
-}
-
-// bbox words: [0..2] = max of ~enc(coord) (i.e. the minimum), [3..5] = max of enc(coord)
-__device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox, float radius)
-{
-    Grid g;
-    const float mn[3] = {dec_ord(~bbox[0]), dec_ord(~bbox[1]), dec_ord(~bbox[2])};
-    const float mx[3] = {dec_ord(bbox[3]), dec_ord(bbox[4]), dec_ord(bbox[5])};
-    const int cap[3] = {kCapX, kCapY, kCapZ};
-    float inv[3];
-    int n[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float ext = fmaxf(mx[a] - mn[a], 0.f);
-        // cell edge: >= 1.0001 r (so |p-q| < r spans at most one cell boundary even after
-        // rounding) and large enough that the axis fits its cap
-        const float cs = fmaxf(radius * 1.0001f, ext / (float)cap[a] * 1.0001f) + 1e-30f;
-        inv[a] = 1.0f / cs;
-        int na = (int)floorf(ext * inv[a]) + 1;
-        n[a] = na < 1 ? 1 : (na > cap[a] ? cap[a] : na);
-    }
-    g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
-    g.invx = inv[0]; g.invy = inv[1]; g.invz = inv[2];
-    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
-    return g;
-}
-
-__device__ __forceinline__ int cell_axis(float p, float mn, float inv, int n)
-{
-    const float t = (p - mn) * inv;
-    int c = (int)floorf(t);
-    c = c < 0 ? 0 : c;           // also catches NaN -> 0
-    return c > n - 1 ? n - 1 : c;
-}
 
 // ---- K0: pack [N,3] -> [Npad] float4, and the bounding box -------------------------------------
 // Few fat workgroups (grid-stride) so the bounding box costs ~6 atomics per workgroup: thousands of
@@ -167,7 +87,7 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     int* cell_of = reinterpret_cast<int*>(wb + w.off_cell);
     int* counts = reinterpret_cast<int*>(wb + w.off_counts) + (size_t)blockIdx.x * kMaxCells;
-    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) hist[c] = 0;
     __syncthreads();
     const int j = blockIdx.x * kSortWG + threadIdx.x;
@@ -194,7 +114,7 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, 
     const int* __restrict__ counts = reinterpret_cast<const int*>(wb + w.off_counts);
     int* __restrict__ bases = reinterpret_cast<int*>(wb + w.off_bases);
     int* __restrict__ start = reinterpret_cast<int*>(wb + w.off_start);
-    const Grid gg = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const Grid gg = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     const int n_cells = gg.nx * gg.ny * gg.nz;   // cells beyond this are never populated
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) {
         int run = 0;
@@ -425,7 +345,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
-    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, n2);
     const int len1 = lengths1 ? (int)lengths1[b] : n1;
     int len2 = lengths2 ? (int)lengths2[b] : n2;
     len2 = len2 < n2 ? len2 : n2;
@@ -479,7 +399,7 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
     const int b = blockIdx.y;
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     int* perm = reinterpret_cast<int*>(wb + w.off_kperm);
-    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     const int* cell_of = reinterpret_cast<const int*>(wb + w.off_cell);
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) cnt[c] = 0;
     __syncthreads();
@@ -558,7 +478,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const float4* Pb = reinterpret_cast<const float4*>(wb + w.off_p4o);
     const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
-    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     const float4* fb = feat4 + (size_t)b * N * 8;
     float qx, qy, qz;
     if (kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
@@ -632,7 +552,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st)
+int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st)
 {
     const GridWs w = grid_ws(N);
     for (int b = 0; b < B; ++b) {
@@ -653,6 +573,14 @@ static int launch_prep(const float* pts, char* ws, int B, int N, float radius, h
     UMEREG_CHECK_LAUNCH("grid_scan_kernel");
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N);
     UMEREG_CHECK_LAUNCH("grid_scatter_kernel");
+    return UMEREG_OK;
+}
+
+int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(kp_order_kernel, dim3(1, B), dim3(1024), 0, st, ws, grid_ws(N).total, kpts, kp_index, N, n_q, radius);
+    UMEREG_CHECK_LAUNCH("kp_order_kernel");
     return UMEREG_OK;
 }
 

@@ -1,0 +1,554 @@
+// corr.hip -- SURVEY 8(f1): hypothesis selection by feature correlation, for gfx950.
+// Replaces pytorch3d.ops.knn_points as used at reference utils/loc_utils.py:580,623 and
+// evaluate.py:272,274, feature_spatial_var (utils/loc_utils.py:579-585) and the per-hypothesis
+// score of pc_corr / pc_corr_cost_pytorch3d (utils/loc_utils.py:592-637) that
+// FeatureCorrelator.feature_corr_hypothesis_test (utils/loc_utils.py:656-681) maximises.
+//
+// The reference runs a brute-force kNN (every query against every target point) for each of the
+// M = 2 500 hypotheses: 2.5e11 distance tests and a [64,10000,20,32] gathered tensor (1.6 GB) per
+// batch of 64 hypotheses.  Here:
+//
+//   * exact kNN on the uniform grid of grid.h (cell edge from the point density, 5x5x5 cell
+//     neighbourhood, grown ring by ring until every query provably holds its K nearest);
+//   * one LANE per query, one wavefront per 64 spatially adjacent queries (queries are processed in
+//     cell-sorted order, and a rigid transform keeps neighbours adjacent), so the candidate set --
+//     the union box of the wave's query cells -- is streamed ONCE for 64 queries: candidates are
+//     loaded coalesced, parked in LDS and read back as broadcasts;
+//   * "K smallest by (d2, index)" without per-candidate sorted insertion: pass 1 histograms d2 per
+//     lane (32 bins, LDS, lane-private counters) to find the bin that holds the K-th neighbour;
+//     pass 2 appends only candidates up to that bin (K + ~2 of them) to a lane-private LDS list,
+//     then trims the few extras by repeated arg-max.  Overflowing lists are trimmed on the fly and
+//     the admission key tightened, so any density is handled exactly;
+//   * the score  sum_k cauchy(d_k) <vp_n, vq_jk> / Ns  is accumulated straight from the K kept
+//     (d2, index) keys; the gathered [.,.,20,32] tensor never exists.  Per-(hypothesis, 64-query
+//     chunk) partial sums are written and reduced in a fixed order => deterministic scores.
+// Squared distances use the reference's arithmetic: sum_d (p1-p2)^2 left to right in fp32, no FMA
+// contraction (-ffp-contract=off), ties resolved towards the lower index.
+#include "grid.h"
+
+namespace umereg {
+
+constexpr int kBins = 32;
+
+struct KnnCtx {
+    const float4* P4s;   // cell-sorted {x,y,z,orig index}
+    const int* start;    // cell -> first sorted slot
+    Grid g;
+    float cs_min;        // smallest cell edge: a ring of r cells covers distance r * cs_min
+};
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(v, m, kWave); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(v, m, kWave); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, kWave);   // fixed butterfly: deterministic
+    return v;
+}
+
+// remove the largest key of this lane's list (lanes with `act`); list is lane-private: list[e * 64 + lane]
+__device__ __forceinline__ void drop_max(unsigned long long* list, int& cnt, bool act, int cnt_bound, int lane)
+{
+    unsigned long long mk = 0ull;
+    int mp = 0;
+    for (int e = 0; e < cnt_bound; ++e) {
+        if (act && e < cnt) {
+            const unsigned long long k = list[e * kWave + lane];
+            if (k >= mk) { mk = k; mp = e; }
+        }
+    }
+    if (act) {
+        list[mp * kWave + lane] = list[(cnt - 1) * kWave + lane];
+        --cnt;
+    }
+}
+
+// Exact K nearest target points of one query per lane.  On return, valid lanes hold min(K, n2) keys
+// ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).  stage: 64 float4 of LDS scratch.
+__device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool valid, int K, int cap,
+                        unsigned int* hist, unsigned long long* list, float4* stage, int lane)
+{
+    const Grid& g = c.g;
+    const int cx = cell_axis(qx, g.minx, g.invx, g.nx);
+    const int cy = cell_axis(qy, g.miny, g.invy, g.ny);
+    const int cz = cell_axis(qz, g.minz, g.invz, g.nz);
+    const int lox = wave_min_i(valid ? cx : 0x7fffffff), hix = wave_max_i(valid ? cx : -1);
+    const int loy = wave_min_i(valid ? cy : 0x7fffffff), hiy = wave_max_i(valid ? cy : -1);
+    const int loz = wave_min_i(valid ? cz : 0x7fffffff), hiz = wave_max_i(valid ? cz : -1);
+    if (hix < 0) return 0;   // no valid lane in this wave
+
+    int ring = 2;
+    bool take_all = false;
+    int x0, x1, y0, y1, z0, z1, bstar;
+    float R2, scale;
+
+    // candidate stream over the box [x0..x1] x [y0..y1] x [z0..z1]: rows are contiguous runs of the
+    // sorted table; 64 candidates at a time are loaded coalesced, parked in LDS and broadcast.
+    auto for_each_candidate = [&](auto&& body) {
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int cb = (z * g.ny + y) * g.nx;
+                const int beg = __builtin_amdgcn_readfirstlane(c.start[cb + x0]);
+                const int end = __builtin_amdgcn_readfirstlane(c.start[cb + x1 + 1]);
+                for (int base = beg; base < end; base += kWave) {
+                    const int n = end - base < kWave ? end - base : kWave;
+                    __builtin_amdgcn_wave_barrier();
+                    stage[lane] = c.P4s[base + (lane < n ? lane : 0)];
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < n; ++i) {
+                        const float4 p = stage[i];   // same address for all lanes: LDS broadcast
+                        const float dx = qx - p.x;
+                        const float dy = qy - p.y;
+                        const float dz = qz - p.z;
+                        float d2 = dx * dx;
+                        d2 = d2 + dy * dy;
+                        d2 = d2 + dz * dz;
+                        body(d2, __float_as_int(p.w));
+                    }
+                }
+            }
+    };
+
+    for (;;) {
+        x0 = lox - ring > 0 ? lox - ring : 0;  x1 = hix + ring < g.nx - 1 ? hix + ring : g.nx - 1;
+        y0 = loy - ring > 0 ? loy - ring : 0;  y1 = hiy + ring < g.ny - 1 ? hiy + ring : g.ny - 1;
+        z0 = loz - ring > 0 ? loz - ring : 0;  z1 = hiz + ring < g.nz - 1 ? hiz + ring : g.nz - 1;
+        const bool full = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1;
+        // every query lies in a core cell, so everything within ring * cs_min of it is inside the box
+        const float R = (float)ring * c.cs_min;
+        R2 = take_all ? 3.0e38f : R * R;
+        scale = take_all ? 0.0f : (float)kBins / R2;
+#pragma unroll
+        for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
+        for_each_candidate([&](float d2, int) {
+            if (valid && d2 < R2) {
+                int b = (int)(d2 * scale);
+                b = b > kBins - 1 ? kBins - 1 : b;
+                atomicAdd(&hist[b * kWave + lane], 1u);   // lane-private counter; ds_add_u32, no return value
+            }
+        });
+        int cum = 0;
+        bstar = -1;
+#pragma unroll
+        for (int b = 0; b < kBins; ++b) {
+            cum += (int)hist[b * kWave + lane];
+            if (bstar < 0 && cum >= K) bstar = b;
+        }
+        const bool incomplete = valid && bstar < 0;
+        if (!__any(incomplete)) break;
+        if (full) {
+            if (take_all) { if (incomplete) bstar = kBins - 1; break; }   // fewer than K points exist
+            take_all = true;   // the whole grid is in the box: distance no longer bounds anything
+            continue;
+        }
+        ring *= 2;   // geometric growth: far-away queries reach the whole grid in a few passes
+    }
+
+    int cnt = 0;
+    unsigned long long ukey = ~0ull;   // admission bound (tightened if a list ever overflows)
+    for_each_candidate([&](float d2, int oi) {
+        int b = (int)(d2 * scale);
+        b = b > kBins - 1 ? kBins - 1 : b;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
+        const bool ok = valid && d2 < R2 && b <= bstar && key < ukey;
+        if (__any(ok)) {
+            if (ok) { list[cnt * kWave + lane] = key; ++cnt; }
+            if (__any(cnt >= cap)) {
+                // trim overflowing lanes back to K and admit only better keys from now on
+                const bool over = cnt >= cap;
+                while (__any(over && cnt > K)) drop_max(list, cnt, over && cnt > K, cap, lane);
+                if (over) {
+                    unsigned long long mk = 0ull;
+                    for (int e = 0; e < K; ++e) { const unsigned long long k = list[e * kWave + lane]; mk = k > mk ? k : mk; }
+                    ukey = mk;
+                }
+            }
+        }
+    });
+    while (__any(cnt > K)) drop_max(list, cnt, cnt > K, cap, lane);
+    return cnt;
+}
+
+// sort this lane's keys ascending (selection sort in LDS; K is small)
+__device__ __forceinline__ void sort_keys(unsigned long long* list, int cnt, int cnt_bound, int lane)
+{
+    for (int r = 0; r < cnt_bound - 1; ++r) {
+        unsigned long long mk = ~0ull;
+        int mp = r;
+        for (int e = r; e < cnt_bound; ++e) {
+            if (e < cnt) {
+                const unsigned long long k = list[e * kWave + lane];
+                if (k < mk) { mk = k; mp = e; }
+            }
+        }
+        if (r < cnt) {
+            const unsigned long long t = list[r * kWave + lane];
+            list[r * kWave + lane] = mk;
+            list[mp * kWave + lane] = t;
+        }
+    }
+}
+
+struct KnnLds {
+    unsigned int* hist;
+    unsigned long long* list;
+    float4* stage;
+};
+
+__device__ __forceinline__ KnnLds carve_lds(char* lds, int wave, int cap)
+{
+    const size_t per_wave = (size_t)kBins * kWave * 4 + (size_t)cap * kWave * 8 + kWave * 16;
+    char* base = lds + wave * per_wave;
+    KnnLds l;
+    l.list = reinterpret_cast<unsigned long long*>(base);
+    l.stage = reinterpret_cast<float4*>(base + (size_t)cap * kWave * 8);
+    l.hist = reinterpret_cast<unsigned int*>(base + (size_t)cap * kWave * 8 + kWave * 16);
+    return l;
+}
+
+__device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int K, int N)
+{
+    KnnCtx c;
+    c.P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    c.start = reinterpret_cast<const int*>(wb + w.off_start);
+    c.g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), -(float)K, N);
+    c.cs_min = fminf(1.0f / c.g.invx, fminf(1.0f / c.g.invy, 1.0f / c.g.invz));
+    return c;
+}
+
+// ---- pytorch3d.ops.knn_points ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict__ ws, size_t ws_stride,
+                                                         const float* __restrict__ p1, int n1, int n2, int K, int cap,
+                                                         int ordered, float* __restrict__ dists, int64_t* __restrict__ idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int b = blockIdx.y;
+    const GridWs w = grid_ws(n2);
+    const char* wb = ws + b * ws_stride;
+    const KnnLds L = carve_lds(lds, wave, cap);
+    const KnnCtx c = make_ctx(wb, w, K, n2);
+    const int slot = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;
+    const bool valid = slot < n1;
+    int q = valid ? slot : 0;
+    if (ordered && valid) q = reinterpret_cast<const int*>(wb + w.off_kperm)[slot];   // cell-sorted order
+    const float* pq = p1 + ((size_t)b * n1 + q) * 3;
+    const float qx = valid ? pq[0] : 0.f, qy = valid ? pq[1] : 0.f, qz = valid ? pq[2] : 0.f;
+    const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, L.stage, lane);
+    sort_keys(L.list, cnt, K, lane);
+    if (valid) {
+        float* od = dists + ((size_t)b * n1 + q) * K;
+        int64_t* oi = idx + ((size_t)b * n1 + q) * K;
+        for (int e = 0; e < K; ++e) {
+            const unsigned long long k = e < cnt ? L.list[e * kWave + lane] : 0ull;
+            od[e] = e < cnt ? __uint_as_float((unsigned int)(k >> 32)) : 0.f;
+            oi[e] = e < cnt ? (int64_t)(unsigned int)(k & 0xffffffffull) : (int64_t)-1;
+        }
+    }
+}
+
+// ---- feature_spatial_var (utils/loc_utils.py:579-585) ---------------------------------------------
+// mean over the knn-1 nearest OTHER points (idx[:, :, 1:]) of |feat_i - feat_j|_2
+__global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict__ ws, size_t ws_stride,
+                                                          const float4* __restrict__ feat4, int N, int K, int cap,
+                                                          float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int b = blockIdx.y;
+    const GridWs w = grid_ws(N);
+    const char* wb = ws + b * ws_stride;
+    const KnnLds L = carve_lds(lds, wave, cap);
+    const KnnCtx c = make_ctx(wb, w, K, N);
+    const int slot = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;   // position in the cell-sorted table
+    const bool valid = slot < N;
+    const float4 p = c.P4s[valid ? slot : 0];
+    const int me = __float_as_int(p.w);
+    const int cnt = knn_wave(c, p.x, p.y, p.z, valid, K, cap, L.hist, L.list, L.stage, lane);
+    // rank 0 = the smallest key (the point itself unless an exact duplicate has a lower index)
+    unsigned long long k0 = ~0ull;
+    for (int e = 0; e < K; ++e)
+        if (e < cnt) { const unsigned long long k = L.list[e * kWave + lane]; k0 = k < k0 ? k : k0; }
+    const float4* fb = feat4 + (size_t)b * N * 8;
+    float4 f[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) f[v] = fb[(size_t)(valid ? me : 0) * 8 + v];
+    float acc = 0.f;
+    for (int e = 0; e < K; ++e) {
+        if (e < cnt) {
+            const unsigned long long k = L.list[e * kWave + lane];
+            if (k != k0) {
+                const int j = (int)(unsigned int)(k & 0xffffffffull);
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const float4 o = fb[(size_t)j * 8 + v];
+                    const float a0 = f[v].x - o.x, a1 = f[v].y - o.y, a2 = f[v].z - o.z, a3 = f[v].w - o.w;
+                    s = fmaf(a0, a0, s); s = fmaf(a1, a1, s); s = fmaf(a2, a2, s); s = fmaf(a3, a3, s);
+                }
+                acc += sqrtf(s);
+            }
+        }
+    }
+    if (valid) out[(size_t)b * N + me] = acc / (float)(K - 1);
+}
+
+// ---- weighted features: (feat - m) * w,  m = mean over BOTH clouds' points (utils/loc_utils.py:661,664-665)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, int na, const float* __restrict__ b,
+                                                             int nb, double* __restrict__ part)
+{
+    // block `blockIdx.x` sums rows [r0, r1) of the virtual concatenation cat(a, b): 256 threads = 8 row lanes x 32 channels
+    __shared__ double red[8][32];
+    const int ch = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n = na + nb;
+    const int rows_per = (n + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per, r1 = min(r0 + rows_per, n);
+    double s = 0.0;
+    for (int r = r0 + rl; r < r1; r += 8) s += (double)(r < na ? a[(size_t)r * 32 + ch] : b[(size_t)(r - na) * 32 + ch]);
+    red[rl][ch] = s;
+    __syncthreads();
+    if (rl == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += red[k][ch];
+        part[(size_t)blockIdx.x * 32 + ch] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void feature_weight_kernel(const float* __restrict__ feat, const float* __restrict__ wgt,
+                                                             const double* __restrict__ part, int n_part, int n_total,
+                                                             int n, float* __restrict__ out)
+{
+    __shared__ float mean[32];
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < n_part; ++k) t += part[(size_t)k * 32 + threadIdx.x];   // fixed order: deterministic
+        mean[threadIdx.x] = (float)(t / (double)n_total);
+    }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)n * 32) out[i] = (feat[i] - mean[i & 31]) * wgt[i >> 5];
+}
+
+// ---- per-hypothesis correlation score (utils/loc_utils.py:592-637) ---------------------------------
+// score[h] = (1/Ns) sum_n sum_{k<K} cauchy(|R_h p_n + t_h - q_jk|, sigma) <vp_n, vq_jk>
+__global__ __launch_bounds__(128) void corr_score_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+                                                         const float4* __restrict__ vp4, const float4* __restrict__ vq4,
+                                                         const float* __restrict__ T, int Ns, int Nt, int M, int K, int cap,
+                                                         float sigma, int hyp_per_wave, int n_chunks,
+                                                         float* __restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const KnnLds L = carve_lds(lds, wave, cap);
+    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int chunk = wid % n_chunks;
+    const int hg = wid / n_chunks;
+    const int h0 = hg * hyp_per_wave;
+    if (h0 >= M) return;
+    const int h1 = min(h0 + hyp_per_wave, M);
+    // source points in THEIR cell-sorted order: 64 consecutive slots are spatial neighbours
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const int slot = chunk * kWave + lane;
+    const bool valid = slot < Ns;
+    const float4 sp = S4s[valid ? slot : 0];
+    const int sidx = __float_as_int(sp.w);
+    float4 vp[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) vp[v] = valid ? vp4[(size_t)sidx * 8 + v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = h0; h < h1; ++h) {
+        const float* Th = T + (size_t)h * 16;
+        // source_transformed = p R^T + t  (utils/loc_utils.py:629)
+        const float qx = fmaf(Th[2], sp.z, fmaf(Th[1], sp.y, Th[0] * sp.x)) + Th[3];
+        const float qy = fmaf(Th[6], sp.z, fmaf(Th[5], sp.y, Th[4] * sp.x)) + Th[7];
+        const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
+        const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, L.stage, lane);
+        float acc = 0.f;
+        for (int e = 0; e < K; ++e) {
+            if (e < cnt) {
+                const unsigned long long k = L.list[e * kWave + lane];
+                const int j = (int)(unsigned int)(k & 0xffffffffull);
+                const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));   // torch.linalg.norm (:593)
+                const float r = dist / sigma;
+                const float wgt = 1.0f / (1.0f + r * r);                               // cauchy_kernel (:588-589)
+                float dot = 0.f;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const float4 o = vq4[(size_t)j * 8 + v];
+                    dot = fmaf(vp[v].x, o.x, dot); dot = fmaf(vp[v].y, o.y, dot);
+                    dot = fmaf(vp[v].z, o.z, dot); dot = fmaf(vp[v].w, o.w, dot);
+                }
+                acc = fmaf(wgt, dot, acc);
+            }
+        }
+        acc = wave_sum_f(valid ? acc : 0.f);
+        if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restrict__ partial, int M, int n_chunks, int Ns,
+                                                          float* __restrict__ scores)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
+    scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
+}
+
+static void knn_lds_plan(int K, int* cap, int* waves, size_t* bytes, int max_waves)
+{
+    *cap = K + 16;
+    const size_t per_wave = (size_t)kBins * kWave * 4 + (size_t)(*cap) * kWave * 8 + kWave * 16;
+    int w = max_waves;
+    while (w > 1 && per_wave * w > 64 * 1024) w >>= 1;
+    *waves = w;
+    *bytes = per_wave * w;
+}
+
+}  // namespace umereg
+
+using namespace umereg;
+
+UMEREG_API size_t umereg_knn_workspace_bytes(int B, int n2)
+{
+    if (B <= 0 || n2 <= 0) return 0;
+    return (size_t)B * grid_ws(n2).total;
+}
+
+UMEREG_API int umereg_knn_points_f32(const float* p1, const float* p2, int B, int n1, int n2, int K, float* dists,
+                                     int64_t* idx, void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(p1 && p2 && dists && idx, "knn_points: null pointer");
+    UMEREG_REQUIRE(B > 0 && n1 > 0 && n2 > 0, "knn_points: B, n1, n2 must be positive (got %d, %d, %d)", B, n1, n2);
+    UMEREG_REQUIRE(K > 0 && K <= 64 && K <= n2, "knn_points: K must be in [1, min(64, n2)] (got K=%d, n2=%d)", K, n2);
+    if (int rc = check_device()) return rc;
+    if (!workspace || workspace_bytes < umereg_knn_workspace_bytes(B, n2) || ((uintptr_t)workspace & 15)) {
+        set_error("knn_points: workspace too small or misaligned (%zu < %zu)", workspace_bytes, umereg_knn_workspace_bytes(B, n2));
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = launch_prep(p2, (char*)workspace, B, n2, -(float)K, st)) return rc;
+    const int ordered = n1 <= grid_ws(n2).Npad;
+    if (ordered)
+        if (int rc = launch_query_order((char*)workspace, p1, nullptr, B, n2, n1, -(float)K, st)) return rc;
+    int cap, waves;
+    size_t lds;
+    knn_lds_plan(K, &cap, &waves, &lds, 4);
+    const int qpb = waves * kWave;
+    hipLaunchKernelGGL(knn_points_kernel, dim3((n1 + qpb - 1) / qpb, B), dim3(qpb), lds, st, (const char*)workspace,
+                       grid_ws(n2).total, p1, n1, n2, K, cap, ordered, dists, idx);
+    UMEREG_CHECK_LAUNCH("knn_points_kernel");
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* feat, int B, int N, int feat_dim, int knn,
+                                              float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(pts && feat && out, "feature_spatial_var: null pointer");
+    UMEREG_REQUIRE(feat_dim == UMEREG_FEAT_DIM, "feature_spatial_var: feature dim must be 32 (got %d)", feat_dim);
+    UMEREG_REQUIRE(B > 0 && N > 1, "feature_spatial_var: B > 0 and N > 1 required");
+    UMEREG_REQUIRE(knn > 1 && knn <= 64 && knn <= N, "feature_spatial_var: knn must be in [2, min(64, N)] (got %d)", knn);
+    UMEREG_REQUIRE(((uintptr_t)feat & 15) == 0, "feature_spatial_var: feat must be 16-byte aligned");
+    if (int rc = check_device()) return rc;
+    if (!workspace || workspace_bytes < umereg_knn_workspace_bytes(B, N) || ((uintptr_t)workspace & 15)) {
+        set_error("feature_spatial_var: workspace too small or misaligned");
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = launch_prep(pts, (char*)workspace, B, N, -(float)knn, st)) return rc;
+    int cap, waves;
+    size_t lds;
+    knn_lds_plan(knn, &cap, &waves, &lds, 4);
+    const int qpb = waves * kWave;
+    hipLaunchKernelGGL(spatial_var_kernel, dim3((N + qpb - 1) / qpb, B), dim3(qpb), lds, st, (const char*)workspace,
+                       grid_ws(N).total, (const float4*)feat, N, knn, cap, out);
+    UMEREG_CHECK_LAUNCH("spatial_var_kernel");
+    return UMEREG_OK;
+}
+
+static const int kColsumBlocks = 64;
+
+UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M)
+{
+    if (Ns <= 0 || Nt <= 0 || M <= 0) return 0;
+    const size_t n_chunks = (Ns + kWave - 1) / kWave;
+    return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
+           align_up((size_t)kColsumBlocks * 32 * 8, 256);
+}
+
+UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
+                                                 const float* tgt_w, int Ns, int Nt, float* src_out, float* tgt_out,
+                                                 void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(src_feat && tgt_feat && src_w && tgt_w && src_out && tgt_out, "corr_weighted_features: null pointer");
+    UMEREG_REQUIRE(Ns > 0 && Nt > 0, "corr_weighted_features: Ns, Nt must be positive");
+    if (int rc = check_device()) return rc;
+    const size_t need = (size_t)kColsumBlocks * 32 * 8;
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 7)) {
+        set_error("corr_weighted_features: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(kColsumBlocks), dim3(256), 0, st, src_feat, Ns, tgt_feat, Nt, part);
+    UMEREG_CHECK_LAUNCH("colsum_partial_kernel");
+    hipLaunchKernelGGL(feature_weight_kernel, dim3((Ns * 32 + 255) / 256), dim3(256), 0, st, src_feat, src_w, part,
+                       kColsumBlocks, Ns + Nt, Ns, src_out);
+    hipLaunchKernelGGL(feature_weight_kernel, dim3((Nt * 32 + 255) / 256), dim3(256), 0, st, tgt_feat, tgt_w, part,
+                       kColsumBlocks, Ns + Nt, Nt, tgt_out);
+    UMEREG_CHECK_LAUNCH("feature_weight_kernel");
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
+                                      const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
+                                      float* scores, void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(src_pts && tgt_pts && src_wfeat && tgt_wfeat && T && scores, "corr_scores: null pointer");
+    UMEREG_REQUIRE(Ns > 0 && Nt > 0 && M > 0, "corr_scores: Ns, Nt, M must be positive");
+    UMEREG_REQUIRE(K > 0 && K <= 64 && K <= Nt, "corr_scores: K must be in [1, min(64, Nt)] (got %d)", K);
+    UMEREG_REQUIRE(sigma > 0.f, "corr_scores: sigma must be positive");
+    UMEREG_REQUIRE(((uintptr_t)src_wfeat & 15) == 0 && ((uintptr_t)tgt_wfeat & 15) == 0, "corr_scores: features must be 16-byte aligned");
+    if (int rc = check_device()) return rc;
+    if (!workspace || workspace_bytes < umereg_corr_workspace_bytes(Ns, Nt, M) || ((uintptr_t)workspace & 15)) {
+        set_error("corr_scores: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
+                  umereg_corr_workspace_bytes(Ns, Nt, M));
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws_src = (char*)workspace;
+    char* ws_tgt = ws_src + grid_ws(Ns).total;
+    float* partial = (float*)(ws_tgt + grid_ws(Nt).total);
+    // target: the search structure; source: only its cell-sorted order (spatially coherent wavefronts)
+    if (int rc = launch_prep(tgt_pts, ws_tgt, 1, Nt, -(float)K, st)) return rc;
+    if (int rc = launch_prep(src_pts, ws_src, 1, Ns, -(float)K, st)) return rc;
+    int cap, waves;
+    size_t lds;
+    knn_lds_plan(K, &cap, &waves, &lds, 2);
+    const int n_chunks = (Ns + kWave - 1) / kWave;
+    const int hyp_per_wave = 8;
+    const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
+    const long n_waves = (long)n_chunks * n_hg;
+    hipLaunchKernelGGL(corr_score_kernel, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave), lds, st,
+                       (const char*)ws_tgt, (const char*)ws_src, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt,
+                       M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
+    UMEREG_CHECK_LAUNCH("corr_score_kernel");
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, scores);
+    UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
+    return UMEREG_OK;
+}

@@ -1,0 +1,105 @@
+// grid.h -- uniform-grid search structure shared by the ball search (ball_moment.hip) and the exact
+// kNN / correlation kernels (corr.hip): workspace carve-up, grid geometry from the bounding box, and
+// the host launchers of the (deterministic) build kernels that live in ball_moment.hip.
+#pragma once
+#include "common.h"
+
+namespace umereg {
+
+constexpr float kFar = 1.0e18f;     // padding coordinate: d2 ~ 3e36, never < r2
+constexpr int kPadPts = 256;        // packed tables are padded to a multiple of this
+constexpr int kMaxCells = 4096;     // grid cells: <= 32 x 32 x 4
+constexpr int kCapX = 32, kCapY = 32, kCapZ = 4;
+constexpr int kSortWG = 1024;       // points per workgroup in the counting sort
+constexpr int kScanUnroll = 4;      // 64-point chunks in flight per wave in the grid search
+
+// ---- workspace carve-up (per batch element) ---------------------------------------------------
+struct GridWs {
+    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_bbox, off_kperm, total;
+    int Npad, n_wg;
+};
+
+__host__ __device__ inline GridWs grid_ws(int N)
+{
+    GridWs w;
+    w.Npad = (int)((N + kPadPts - 1) / kPadPts * kPadPts);
+    w.n_wg = (N + kSortWG - 1) / kSortWG;
+    size_t o = 0;
+    w.off_p4o = o;    o += (size_t)w.Npad * 16;
+    w.off_p4s = o;    o += ((size_t)w.Npad + 64) * 16;
+    w.off_cell = o;   o += (size_t)w.Npad * 4;
+    w.off_counts = o; o += (size_t)w.n_wg * kMaxCells * 4;
+    w.off_bases = o;  o += (size_t)w.n_wg * kMaxCells * 4;
+    w.off_start = o;  o += (size_t)(kMaxCells + 64) * 4;
+    w.off_bbox = o;   o += 64;
+    w.off_kperm = o;  o += (size_t)w.Npad * 4;   // keypoint processing order (n_kp <= Npad)
+    w.total = (o + 255) / 256 * 256;
+    return w;
+}
+
+// ---- grid geometry, recomputed from the bounding box by every kernel that needs it ------------
+struct Grid {
+    float minx, miny, minz, invx, invy, invz;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ unsigned int enc_ord(float f)
+{
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ord(unsigned int e)
+{
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+// bbox words: [0..2] = max of ~enc(coord) (i.e. the minimum), [3..5] = max of enc(coord)
+// radius > 0: ball-search mode, cell edge >= 1.0001 * radius.
+// radius < 0: kNN mode for K = -radius neighbours: the cell edge c is derived from the point density
+//   (surface-like clouds: rho = N / (product of the two largest extents)) such that a disc of radius
+//   2c holds ~1.5 K points, i.e. a 5x5(x5) cell neighbourhood covers the K nearest of most queries.
+__device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox, float radius, int N)
+{
+    Grid g;
+    const float mn[3] = {dec_ord(~bbox[0]), dec_ord(~bbox[1]), dec_ord(~bbox[2])};
+    const float mx[3] = {dec_ord(bbox[3]), dec_ord(bbox[4]), dec_ord(bbox[5])};
+    if (radius < 0.f) {
+        const float e0 = fmaxf(mx[0] - mn[0], 1e-3f), e1 = fmaxf(mx[1] - mn[1], 1e-3f), e2 = fmaxf(mx[2] - mn[2], 1e-3f);
+        const float area = e0 * e1 * e2 / fminf(e0, fminf(e1, e2));
+        const float R = sqrtf(1.5f * (-radius) * area / (3.14159265f * (float)(N > 0 ? N : 1)));
+        radius = 0.5f * R;
+    }
+    const int cap[3] = {kCapX, kCapY, kCapZ};
+    float inv[3];
+    int n[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = fmaxf(mx[a] - mn[a], 0.f);
+        // cell edge: >= 1.0001 r (so |p-q| < r spans at most one cell boundary even after
+        // rounding) and large enough that the axis fits its cap
+        const float cs = fmaxf(radius * 1.0001f, ext / (float)cap[a] * 1.0001f) + 1e-30f;
+        inv[a] = 1.0f / cs;
+        int na = (int)floorf(ext * inv[a]) + 1;
+        n[a] = na < 1 ? 1 : (na > cap[a] ? cap[a] : na);
+    }
+    g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
+    g.invx = inv[0]; g.invy = inv[1]; g.invz = inv[2];
+    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    return g;
+}
+
+__device__ __forceinline__ int cell_axis(float p, float mn, float inv, int n)
+{
+    const float t = (p - mn) * inv;
+    int c = (int)floorf(t);
+    c = c < 0 ? 0 : c;           // also catches NaN -> 0
+    return c > n - 1 ? n - 1 : c;
+}
+
+// build the structure for `pts` [B,N,3] with cell edge >= 1.0001 * radius (pack, bbox, stable counting sort)
+int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st);
+// cell-sorted processing order of n_q query points (kpts [B,n_q,3] or indices into pts) -> ws.off_kperm
+int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,
+                       hipStream_t st);
+
+}  // namespace umereg

@@ -12,13 +12,34 @@ import torch
 from . import ops
 from .host_rng import choice_noreplace
 from .utils.eval_utils import relative_rotation_error  # noqa: F401
-from .utils.loc_utils import batch_estimate_transform_ume_old, ume_cdist, ume_kp_layer  # noqa: F401
+from .utils.loc_utils import (FeatureCorrelator, batch_estimate_transform_ume_old, ume_cdist,  # noqa: F401
+                               ume_kp_layer)
 
 
 def _index_tensor(idx, dev):
     if isinstance(idx, torch.Tensor):
         return idx.to(device=dev, dtype=torch.int64)
     return torch.as_tensor(np.asarray(idx), dtype=torch.int64, device=dev)
+
+
+def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, corr_sigma, args, timing=None):
+    """reference evaluate.py:20-47: pick the hypothesis with the highest feature correlation and report
+    its error.  Returns (R_err [bs], t_err [bs], R_hat [bs,3,3], t_hat [bs,3]); errors stay on the device."""
+    hypotisis_matcher = FeatureCorrelator(sigma=corr_sigma, batch=args.corr_batch_size, n_hypotheses=10)
+    tform_hat = []
+    for b_idx in range(args.batch_size):
+        tt = hypotisis_matcher.feature_corr_hypothesis_test(
+            source_pc=pc1_pts[b_idx][None], target_pc=pc2_pts[b_idx][None], source_feat=pc1_feat[b_idx][None],
+            target_feat=pc2_feat[b_idx][None], T_kp=rtume_hypotises[b_idx], src_norm=None, tgt_norm=None, timing=timing)
+        tform_hat.append(tt[None])
+    tform_hat = torch.cat(tform_hat, dim=0)
+    R_hat = tform_hat[:, :3, :3]
+    t_hat = tform_hat[:, :3, 3]
+    R_gt = gt_tform[:, :3, :3]
+    t_gt = gt_tform[:, :3, 3]
+    R_err = relative_rotation_error(R_hat.contiguous(), R_gt.contiguous())
+    t_err = (t_hat - t_gt).norm(dim=-1)
+    return R_err, t_err, R_hat, t_hat
 
 
 def my_ume_generation(pts, kpts, feat, args):

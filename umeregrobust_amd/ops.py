@@ -344,3 +344,94 @@ def hypothesis_gates(T, gt_tform, counts, return_errors=False):
             rc = lib.umereg_hypothesis_gates_f32(_ptr(T), _ptr(gt), n, _ptr(counts), _ptr(rre), _ptr(rte), _stream_ptr(dev))
         _lib.check(rc, "umereg_hypothesis_gates_f32")
     return (rre, rte) if return_errors else None
+
+
+# ---------------------------------------------------------------------------------------------------
+# hypothesis selection
+# ---------------------------------------------------------------------------------------------------
+KNN = namedtuple("KNN", "dists idx knn")   # pytorch3d's _KNN
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **_ignored):
+    """pytorch3d.ops.knn_points drop-in (reference utils/loc_utils.py:580,623; evaluate.py:272,274).
+    p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] squared, ascending; idx [B,n1,K] i64; knn [B,n1,K,3] | None)."""
+    if lengths1 is not None or lengths2 is not None:
+        raise NotImplementedError("knn_points: lengths1/lengths2 are not used on the reference's hot path")
+    lib = _lib.load()
+    p1 = _dev(p1, "p1"); p2 = _dev(p2, "p2")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3 or p1.shape[0] != p2.shape[0]:
+        raise ValueError(f"knn_points: expected p1 [B,n1,3], p2 [B,n2,3]; got {tuple(p1.shape)}, {tuple(p2.shape)}")
+    B, n1, _ = p1.shape
+    n2 = p2.shape[1]
+    dev = p1.device
+    dists = torch.empty((B, n1, K), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, n1, K), dtype=torch.int64, device=dev)
+    if n1 > 0:
+        ws = _workspace(dev, lib.umereg_knn_workspace_bytes(B, n2), "knn")
+        with torch.cuda.device(dev):
+            rc = lib.umereg_knn_points_f32(_ptr(p1), _ptr(p2), B, n1, n2, int(K), _ptr(dists), _ptr(idx), _ptr(ws),
+                                           ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "umereg_knn_points_f32")
+    nn = None
+    if return_nn:
+        nn = torch.gather(p2.unsqueeze(1).expand(-1, n1, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, 3))
+    return KNN(dists, idx, nn)
+
+
+def feature_spatial_var(pts, feat, knn=10):
+    """reference utils/loc_utils.py:579-585, fused.  pts [B,N,3], feat [B,N,32] -> [B,N]."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts"); feat = _dev(feat, "feat")
+    if pts.dim() != 3 or feat.dim() != 3 or feat.shape[:2] != pts.shape[:2]:
+        raise ValueError(f"feature_spatial_var: expected pts [B,N,3], feat [B,N,32]; got {tuple(pts.shape)}, {tuple(feat.shape)}")
+    B, N, _ = pts.shape
+    dev = pts.device
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.umereg_knn_workspace_bytes(B, N), "knn")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_feature_spatial_var_f32(_ptr(pts), _ptr(feat), B, N, feat.shape[2], int(knn), _ptr(out), _ptr(ws),
+                                                ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_feature_spatial_var_f32")
+    return out
+
+
+def corr_weighted_features(src_feat, tgt_feat, src_w, tgt_w):
+    """(feat - mean over both clouds) * weight  (reference utils/loc_utils.py:661,664-665).
+    src_feat [Ns,32], tgt_feat [Nt,32], src_w [Ns], tgt_w [Nt] -> (src_wfeat, tgt_wfeat)."""
+    lib = _lib.load()
+    sf = _dev(src_feat, "src_feat"); tf = _dev(tgt_feat, "tgt_feat")
+    sw = _dev(src_w, "src_w").view(-1); tw = _dev(tgt_w, "tgt_w").view(-1)
+    if sf.dim() != 2 or tf.dim() != 2 or sf.shape[1] != 32 or tf.shape[1] != 32 or sw.numel() != sf.shape[0] \
+            or tw.numel() != tf.shape[0]:
+        raise ValueError("corr_weighted_features: expected [N,32] features and [N] weights")
+    dev = sf.device
+    so, to = torch.empty_like(sf), torch.empty_like(tf)
+    ws = _workspace(dev, 64 * 32 * 8 + 256, "corrw")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_corr_weighted_features_f32(_ptr(sf), _ptr(tf), _ptr(sw), _ptr(tw), sf.shape[0], tf.shape[0],
+                                                   _ptr(so), _ptr(to), _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_corr_weighted_features_f32")
+    return so, to
+
+
+def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None):
+    """Correlation score of every hypothesis (reference utils/loc_utils.py:592-637).
+    src_pts [Ns,3], tgt_pts [Nt,3], *_wfeat [N,32], T [M,4,4] -> scores [M]."""
+    lib = _lib.load()
+    sp = _dev(src_pts, "src_pts"); tp = _dev(tgt_pts, "tgt_pts")
+    sf = _dev(src_wfeat, "src_wfeat"); tf = _dev(tgt_wfeat, "tgt_wfeat"); T = _dev(T, "T")
+    if sp.dim() != 2 or tp.dim() != 2 or sf.shape != (sp.shape[0], 32) or tf.shape != (tp.shape[0], 32) \
+            or T.dim() != 3 or T.shape[1:] != (4, 4):
+        raise ValueError("corr_scores: expected src_pts [Ns,3], tgt_pts [Nt,3], features [N,32], T [M,4,4]")
+    Ns, Nt, M = sp.shape[0], tp.shape[0], T.shape[0]
+    dev = sp.device
+    scores = torch.empty((M,), dtype=torch.float32, device=dev)
+    if M > 0:
+        ws = _workspace(dev, lib.umereg_corr_workspace_bytes(Ns, Nt, M), "corr")
+        with torch.cuda.device(dev):
+            ev = _timed(timing, dev)
+            rc = lib.umereg_corr_scores_f32(_ptr(sp), _ptr(tp), _ptr(sf), _ptr(tf), _ptr(T), Ns, Nt, M, int(K),
+                                            float(sigma), _ptr(scores), _ptr(ws), ws.numel(), _stream_ptr(dev))
+            _lib.check(rc, "umereg_corr_scores_f32")
+            _timed_end(timing, ev, dev)
+    return scores

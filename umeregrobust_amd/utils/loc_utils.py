@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ball_query  # noqa: F401  (re-export: `from utils.loc_utils import ball_query` style use)
+from ..ops import ball_query, knn_points  # noqa: F401  (re-exports of the pytorch3d replacements)
 
 
 def ume_cdist(ume1, ume2):
@@ -89,3 +89,59 @@ class ume_kp_layer(nn.Module):
                 T = T.view(bs, n_kp, 4, 4)
                 D = D.view(bs, n_kp)
         return T, D, G_all.unsqueeze(2).squeeze(), H_all.unsqueeze(1).squeeze()
+
+
+# ---------------------------------------------------------------------------------------------------
+# hypothesis selection -- reference utils/loc_utils.py:579-681
+# ---------------------------------------------------------------------------------------------------
+def feature_spatial_var(pts, feat, knn=10):
+    """reference utils/loc_utils.py:579-585: mean feature distance to the knn-1 nearest other points."""
+    return ops.feature_spatial_var(pts, feat, knn)
+
+
+def cauchy_kernel(e, k=0.1):
+    """reference utils/loc_utils.py:588-589."""
+    return 1 / (1 + (e / k) ** 2)
+
+
+def pc_corr_cost_pytorch3d(x1, x2, source_points, target_points, k, source_vals, target_vals, sigma, P=None,
+                           use_norm=False, src_norm=None, tgt_norm=None, dev="cpu"):
+    """reference utils/loc_utils.py:622-637 (+ pc_corr :592-614): correlation score of the hypotheses
+    (R = x1 [b,3,3], t = x2 [b,3]).  The P / use_norm variants are unused by every reference caller."""
+    if P is not None or use_norm:
+        raise NotImplementedError("pc_corr: P / use_norm are off on every reference call path (loc_utils.py:667-671)")
+    b = x1.shape[0]
+    T = torch.zeros((b, 4, 4), dtype=torch.float32, device=source_points.device)
+    T[:, :3, :3] = x1
+    T[:, :3, 3] = x2
+    T[:, 3, 3] = 1
+    return ops.corr_scores(source_points, target_points, source_vals, target_vals, T, K=k, sigma=sigma)
+
+
+class FeatureCorrelator:
+    """reference utils/loc_utils.py:640-681.  Same constructor and method; the hypotheses are scored in one
+    fused launch instead of `batch`-sized slices (the `batch` argument is accepted and ignored)."""
+
+    def __init__(self, n_clusters=8, batch=1, n_hypotheses=1, sigma=0.05, P=None, corr_num_nn=20):
+        self.n_clusters = n_clusters
+        self.batch = batch
+        self.sigma = sigma
+        self.n_hypotheses = n_hypotheses
+        self.P = P
+        self.corr_num_nn = corr_num_nn
+        self.last_scores = None
+
+    def feature_corr_hypothesis_test(self, source_pc, target_pc, source_feat, target_feat, T_kp, src_norm=None,
+                                     tgt_norm=None, timing=None):
+        if self.P is not None:
+            raise NotImplementedError("FeatureCorrelator: P is None on every reference call path")
+        src_feat_weight = feature_spatial_var(source_pc, source_feat, knn=50)           # :662
+        tgt_feat_weight = feature_spatial_var(target_pc, target_feat, knn=50)           # :663
+        wsf, wtf = ops.corr_weighted_features(source_feat[0], target_feat[0], src_feat_weight[0], tgt_feat_weight[0])
+        mmf_score = ops.corr_scores(source_pc[0], target_pc[0], wsf, wtf, T_kp, K=self.corr_num_nn, sigma=self.sigma,
+                                    timing=timing)                                          # :666-673
+        self.last_scores = mmf_score
+        best_T_list_order = torch.argsort(mmf_score, descending=True)                      # :676
+        return_T_list = T_kp[best_T_list_order[:self.n_hypotheses]]                        # :677
+        return_mmf_score = mmf_score[best_T_list_order[:self.n_hypotheses]]                # :679
+        return return_T_list[torch.argmax(return_mmf_score)]                               # :680
