@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from types import SimpleNamespace
 from umeregrobust_amd import ops, evaluate
 from umeregrobust_amd.synth import synth_pair

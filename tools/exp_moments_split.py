@@ -1,5 +1,5 @@
 import torch, numpy as np, time, sys
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from umeregrobust_amd import ops
 from umeregrobust_amd.synth import synth_pair
 dev=torch.device('cuda')

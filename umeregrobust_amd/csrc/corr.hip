@@ -30,6 +30,13 @@ namespace umereg {
 
 constexpr int kBins = 32;
 
+#ifdef UMEREG_KNN_DEBUG
+__device__ unsigned long long g_knn_dbg[16];
+#define KNN_DBG(i, v) do { if (lane == 0) atomicAdd(&g_knn_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define KNN_DBG(i, v) do {} while (0)
+#endif
+
 struct KnnCtx {
     const float4* P4s;   // cell-sorted {x,y,z,orig index}
     const int* start;    // cell -> first sorted slot
@@ -73,8 +80,39 @@ __device__ __forceinline__ void drop_max(unsigned long long* list, int& cnt, boo
     }
 }
 
+// Per-lane selection threshold: a tuple of histogram bins over nested d2 ranges.  Level 0 covers
+// [0, hi0); level l+1 subdivides bin bs[l] of level l into 32.  A candidate is admitted when its bin
+// tuple is lexicographically <= (bs[0], .., bs[nlev-1]).  Membership of a nested range is DEFINED by
+// the parent's bin formula, so the counts seen by the histogram passes and by the final append pass
+// agree exactly whatever the floating-point rounding at the bin edges.
+constexpr int kLevels = 3;
+struct LaneSel {
+    float hi0;
+    float lo[kLevels], sc[kLevels];
+    int bs[kLevels];
+    int nlev;
+};
+
+__device__ __forceinline__ int sel_bin(float d2, float lo, float sc)
+{
+    int b = (int)((d2 - lo) * sc);
+    b = b < 0 ? 0 : b;
+    return b > kBins - 1 ? kBins - 1 : b;
+}
+
 // Exact K nearest target points of one query per lane.  On return, valid lanes hold min(K, n2) keys
 // ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).  stage: 64 float4 of LDS scratch.
+//
+// The candidate stream (the union box of the wave's query cells, grown until it provably contains
+// every lane's K nearest) is shared by the 64 lanes; everything else is per lane:
+//   histogram pass(es)  each unfinished lane histograms the d2 of the candidates inside its current
+//                       range (32 lane-private LDS counters) and either fixes its threshold -- the
+//                       bin holding its K-th neighbour, if everything up to that bin fits the list --
+//                       or zooms into that bin (x32 resolution) for the next pass.  Typical lanes
+//                       finish in one pass; lanes of a scattered wave (huge union box) or queries far
+//                       outside the cloud need two or three.
+//   append pass         candidates up to the threshold go to the lane's LDS list (K .. K+16 of them);
+//                       the few extras are trimmed by repeated arg-max on (d2, index).
 __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool valid, int K, int cap,
                         unsigned int* hist, unsigned long long* list, float4* stage, int lane)
 {
@@ -82,15 +120,25 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
     const int cx = cell_axis(qx, g.minx, g.invx, g.nx);
     const int cy = cell_axis(qy, g.miny, g.invy, g.ny);
     const int cz = cell_axis(qz, g.minz, g.invz, g.nz);
-    const int lox = wave_min_i(valid ? cx : 0x7fffffff), hix = wave_max_i(valid ? cx : -1);
-    const int loy = wave_min_i(valid ? cy : 0x7fffffff), hiy = wave_max_i(valid ? cy : -1);
-    const int loz = wave_min_i(valid ? cz : 0x7fffffff), hiz = wave_max_i(valid ? cz : -1);
-    if (hix < 0) return 0;   // no valid lane in this wave
+    if (!__any(valid)) return 0;   // no valid lane in this wave
+    KNN_DBG(0, 1);
+
+    // an upper bound on the distance from this query to any point of the cloud (bbox corners)
+    float dmax2;
+    {
+        const float ex = fmaxf(fabsf(qx - g.minx), fabsf(qx - (g.minx + (float)g.nx / g.invx)));
+        const float ey = fmaxf(fabsf(qy - g.miny), fabsf(qy - (g.miny + (float)g.ny / g.invy)));
+        const float ez = fmaxf(fabsf(qz - g.minz), fabsf(qz - (g.minz + (float)g.nz / g.invz)));
+        dmax2 = (ex * ex + ey * ey + ez * ez) * 1.001f + 1e-12f;
+    }
 
     int ring = 2;
-    bool take_all = false;
-    int x0, x1, y0, y1, z0, z1, bstar;
-    float R2, scale;
+    int x0, x1, y0, y1, z0, z1;
+    LaneSel S;
+    S.nlev = 1; S.hi0 = 0.f;
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
+    bool done = !valid;
 
     // candidate stream over the box [x0..x1] x [y0..y1] x [z0..z1]: rows are contiguous runs of the
     // sorted table; 64 candidates at a time are loaded coalesced, parked in LDS and broadcast.
@@ -105,68 +153,136 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
                     __builtin_amdgcn_wave_barrier();
                     stage[lane] = c.P4s[base + (lane < n ? lane : 0)];
                     __builtin_amdgcn_wave_barrier();
-                    for (int i = 0; i < n; ++i) {
-                        const float4 p = stage[i];   // same address for all lanes: LDS broadcast
-                        const float dx = qx - p.x;
-                        const float dy = qy - p.y;
-                        const float dz = qz - p.z;
-                        float d2 = dx * dx;
-                        d2 = d2 + dy * dy;
-                        d2 = d2 + dz * dz;
-                        body(d2, __float_as_int(p.w));
+                    KNN_DBG(7, n);
+                    // 4 candidates per trip: four independent load -> distance chains in flight (a lone
+                    // wave per SIMD cannot hide the latency of one dependent chain per candidate)
+                    for (int i = 0; i < n; i += 4) {
+                        float d2[4];
+                        int oi[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 p = stage[(i + u) & (kWave - 1)];   // same address for all lanes: LDS broadcast
+                            const float dx = qx - p.x;
+                            const float dy = qy - p.y;
+                            const float dz = qz - p.z;
+                            float t = dx * dx;
+                            t = t + dy * dy;
+                            t = t + dz * dz;
+                            d2[u] = i + u < n ? t : 3.0e38f;   // beyond the chunk: never admitted
+                            oi[u] = __float_as_int(p.w);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) body(d2[u], oi[u]);
                     }
                 }
             }
     };
 
-    for (;;) {
+    int ax0 = 0x7fffffff, ax1 = -1, ay0 = 0x7fffffff, ay1 = -1, az0 = 0x7fffffff, az1 = -1;   // union of all boxes
+    for (;;) {   // coverage loop: grow the box until no lane can be missing a neighbour
+        KNN_DBG(1, 1);
+        // the box only has to serve the lanes that are still unfinished (after the first trip: the one or
+        // two starved lanes of the wave, not the whole 64-query strip)
+        const int lox = wave_min_i(!done ? cx : 0x7fffffff), hix = wave_max_i(!done ? cx : -1);
+        const int loy = wave_min_i(!done ? cy : 0x7fffffff), hiy = wave_max_i(!done ? cy : -1);
+        const int loz = wave_min_i(!done ? cz : 0x7fffffff), hiz = wave_max_i(!done ? cz : -1);
         x0 = lox - ring > 0 ? lox - ring : 0;  x1 = hix + ring < g.nx - 1 ? hix + ring : g.nx - 1;
         y0 = loy - ring > 0 ? loy - ring : 0;  y1 = hiy + ring < g.ny - 1 ? hiy + ring : g.ny - 1;
         z0 = loz - ring > 0 ? loz - ring : 0;  z1 = hiz + ring < g.nz - 1 ? hiz + ring : g.nz - 1;
+        ax0 = x0 < ax0 ? x0 : ax0;  ax1 = x1 > ax1 ? x1 : ax1;
+        ay0 = y0 < ay0 ? y0 : ay0;  ay1 = y1 > ay1 ? y1 : ay1;
+        az0 = z0 < az0 ? z0 : az0;  az1 = z1 > az1 ? z1 : az1;
         const bool full = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1;
-        // every query lies in a core cell, so everything within ring * cs_min of it is inside the box
+        // every query lies in a core cell, so everything within ring * cs_min of it is inside the box;
+        // once the box is the whole grid, everything is inside it
         const float R = (float)ring * c.cs_min;
-        R2 = take_all ? 3.0e38f : R * R;
-        scale = take_all ? 0.0f : (float)kBins / R2;
+        if (!done) {
+            S.nlev = 1;
+            S.hi0 = full ? dmax2 : R * R;
+            S.lo[0] = 0.f;
+            S.sc[0] = (float)kBins / S.hi0;
+        }
+        int c_lo = 0;          // candidates strictly below the current (deepest) range
+        bool starved = false;  // fewer than K candidates within hi0: needs a bigger box
+        for (;;) {             // refinement loop on this box
+            KNN_DBG(2, 1);
 #pragma unroll
-        for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
-        for_each_candidate([&](float d2, int) {
-            if (valid && d2 < R2) {
-                int b = (int)(d2 * scale);
-                b = b > kBins - 1 ? kBins - 1 : b;
-                atomicAdd(&hist[b * kWave + lane], 1u);   // lane-private counter; ds_add_u32, no return value
+            for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
+            const bool active = !done && !starved;
+            for_each_candidate([&](float d2, int) {
+                if (active && d2 < S.hi0) {
+                    int b = sel_bin(d2, S.lo[0], S.sc[0]);
+                    bool in = true;
+                    if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
+                    if (S.nlev > 2) { in = in && b == S.bs[1]; b = sel_bin(d2, S.lo[2], S.sc[2]); }
+                    if (in) atomicAdd(&hist[b * kWave + lane], 1u);   // lane-private counter (ds_add_u32)
+                }
+            });
+            if (active) {
+                int cum = c_lo, bstar = -1, before = c_lo, inbin = 0;
+#pragma unroll
+                for (int b = 0; b < kBins; ++b) {
+                    const int h = (int)hist[b * kWave + lane];
+                    if (bstar < 0 && cum + h >= K) { bstar = b; before = cum; inbin = h; }
+                    cum += h;
+                }
+                // (explicit per-level statements: runtime-indexed arrays would live in scratch memory)
+                if (bstar < 0) {
+                    if (full) {   // fewer than K points exist: keep them all
+                        if (S.nlev == 1) S.bs[0] = kBins - 1; else if (S.nlev == 2) S.bs[1] = kBins - 1; else S.bs[2] = kBins - 1;
+                        done = true;
+                    } else {
+                        starved = true;
+                    }
+                } else {
+                    if (S.nlev == 1) S.bs[0] = bstar; else if (S.nlev == 2) S.bs[1] = bstar; else S.bs[2] = bstar;
+                    if (before + inbin <= cap || S.nlev == kLevels) {
+                        done = true;
+                    } else {   // too many candidates up to this bin for the list: zoom into the bin
+                        c_lo = before;
+                        if (S.nlev == 1) {
+                            S.lo[1] = S.lo[0] + (float)bstar / S.sc[0];
+                            S.sc[1] = S.sc[0] * (float)kBins;
+                        } else {
+                            S.lo[2] = S.lo[1] + (float)bstar / S.sc[1];
+                            S.sc[2] = S.sc[1] * (float)kBins;
+                        }
+                        S.nlev += 1;
+                    }
+                }
             }
-        });
-        int cum = 0;
-        bstar = -1;
-#pragma unroll
-        for (int b = 0; b < kBins; ++b) {
-            cum += (int)hist[b * kWave + lane];
-            if (bstar < 0 && cum >= K) bstar = b;
+            if (!__any(!done && !starved)) break;
         }
-        const bool incomplete = valid && bstar < 0;
-        if (!__any(incomplete)) break;
-        if (full) {
-            if (take_all) { if (incomplete) bstar = kBins - 1; break; }   // fewer than K points exist
-            take_all = true;   // the whole grid is in the box: distance no longer bounds anything
-            continue;
-        }
-        ring *= 2;   // geometric growth: far-away queries reach the whole grid in a few passes
+        if (!__any(!done)) break;
+        ring *= 2;   // some lane is starved: geometric growth reaches the whole grid in a few steps
     }
+    KNN_DBG(6, ring);
 
+    // append pass over the union of the boxes: a finished lane's admitted candidates all lie inside the
+    // box it finished in (they are within its hi0 <= coverage radius of that box)
+    x0 = ax0; x1 = ax1; y0 = ay0; y1 = ay1; z0 = az0; z1 = az1;
     int cnt = 0;
-    unsigned long long ukey = ~0ull;   // admission bound (tightened if a list ever overflows)
+    unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
     for_each_candidate([&](float d2, int oi) {
-        int b = (int)(d2 * scale);
-        b = b > kBins - 1 ? kBins - 1 : b;
+        bool ok = valid && d2 < S.hi0;
+        if (ok) {
+            const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
+            ok = b0 <= S.bs[0];
+            if (S.nlev > 1 && b0 == S.bs[0]) {
+                const int b1 = sel_bin(d2, S.lo[1], S.sc[1]);
+                ok = b1 <= S.bs[1];
+                if (S.nlev > 2 && b1 == S.bs[1]) ok = sel_bin(d2, S.lo[2], S.sc[2]) <= S.bs[2];
+            }
+        }
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
-        const bool ok = valid && d2 < R2 && b <= bstar && key < ukey;
+        ok = ok && key < ukey;
         if (__any(ok)) {
             if (ok) { list[cnt * kWave + lane] = key; ++cnt; }
             if (__any(cnt >= cap)) {
-                // trim overflowing lanes back to K and admit only better keys from now on
+                // a list overflowed (exact ties beyond the finest bins): trim it to K, admit only better keys
                 const bool over = cnt >= cap;
-                while (__any(over && cnt > K)) drop_max(list, cnt, over && cnt > K, cap, lane);
+                KNN_DBG(3, 1);
+                while (__any(over && cnt > K)) { KNN_DBG(4, 1); drop_max(list, cnt, over && cnt > K, cap, lane); }
                 if (over) {
                     unsigned long long mk = 0ull;
                     for (int e = 0; e < K; ++e) { const unsigned long long k = list[e * kWave + lane]; mk = k > mk ? k : mk; }
@@ -175,7 +291,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             }
         }
     });
-    while (__any(cnt > K)) drop_max(list, cnt, cnt > K, cap, lane);
+    while (__any(cnt > K)) { KNN_DBG(5, 1); drop_max(list, cnt, cnt > K, cap, lane); }
     return cnt;
 }
 
@@ -552,3 +668,15 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
     return UMEREG_OK;
 }
+
+#ifdef UMEREG_KNN_DEBUG
+UMEREG_API int umereg_knn_debug_counters(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(umereg::g_knn_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(umereg::g_knn_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

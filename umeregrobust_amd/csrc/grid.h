@@ -63,13 +63,28 @@ __device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox,
     Grid g;
     const float mn[3] = {dec_ord(~bbox[0]), dec_ord(~bbox[1]), dec_ord(~bbox[2])};
     const float mx[3] = {dec_ord(bbox[3]), dec_ord(bbox[4]), dec_ord(bbox[5])};
+    int cap[3] = {kCapX, kCapY, kCapZ};
     if (radius < 0.f) {
-        const float e0 = fmaxf(mx[0] - mn[0], 1e-3f), e1 = fmaxf(mx[1] - mn[1], 1e-3f), e2 = fmaxf(mx[2] - mn[2], 1e-3f);
-        const float area = e0 * e1 * e2 / fminf(e0, fminf(e1, e2));
+        const float e[3] = {fmaxf(mx[0] - mn[0], 1e-3f), fmaxf(mx[1] - mn[1], 1e-3f), fmaxf(mx[2] - mn[2], 1e-3f)};
+        const float area = e[0] * e[1] * e[2] / fminf(e[0], fminf(e[1], e[2]));
         const float R = sqrtf(1.5f * (-radius) * area / (3.14159265f * (float)(N > 0 ? N : 1)));
-        radius = 0.5f * R;
+        float c = 0.5f * R;
+        // spend the kMaxCells budget where the points are: an axis thinner than 4 cells collapses to one
+        // layer (LiDAR clouds are ~6 m tall and 100 m wide), then the edge grows until the grid fits
+        for (int it = 0; it < 64; ++it) {
+            long prod = 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                int na = e[a] < 4.0f * c ? 1 : (int)(e[a] / c) + 2;
+                na = na > 64 ? 64 : na;
+                cap[a] = na;
+                prod *= na;
+            }
+            if (prod <= kMaxCells) break;
+            c *= 1.1f;
+        }
+        radius = c;
     }
-    const int cap[3] = {kCapX, kCapY, kCapZ};
     float inv[3];
     int n[3];
 #pragma unroll
