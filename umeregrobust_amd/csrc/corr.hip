@@ -132,97 +132,107 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
         dmax2 = (ex * ex + ey * ey + ez * ez) * 1.001f + 1e-12f;
     }
 
-    int ring = 2;
-    int x0, x1, y0, y1, z0, z1;
+    // distance from the query to the cloud's bounding box (0 inside): nothing can be closer than that
+    float dout;
+    {
+        const float ox = fmaxf(fmaxf(g.minx - qx, qx - (g.minx + (float)g.nx / g.invx)), 0.f);
+        const float oy = fmaxf(fmaxf(g.miny - qy, qy - (g.miny + (float)g.ny / g.invy)), 0.f);
+        const float oz = fmaxf(fmaxf(g.minz - qz, qz - (g.minz + (float)g.nz / g.invz)), 0.f);
+        dout = sqrtf(ox * ox + oy * oy + oz * oz);
+    }
+
     LaneSel S;
     S.nlev = 1; S.hi0 = 0.f;
 #pragma unroll
     for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
     bool done = !valid;
+    float margin = 2.0f * c.cs_min;   // search radius = dout + margin, margin doubles while the lane is starved
 
-    // candidate stream over the box [x0..x1] x [y0..y1] x [z0..z1]: rows are contiguous runs of the
-    // sorted table; 64 candidates at a time are loaded coalesced, parked in LDS and broadcast.
-    auto for_each_candidate = [&](auto&& body) {
-        for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y) {
+    // Candidate stream of ONE LANE: the cells that intersect its search ball (squared radius S.hi0), row
+    // by row -- a row's cells are one contiguous run of the sorted table, clipped to the chord of the ball
+    // in that row.  A point with d2 < hi0 always lies in a visited cell (cell_axis is monotone and the
+    // chord is computed from the row's distance to the query, a lower bound of the point's).  Rows are
+    // walked in lock-step over the union of the active lanes' row ranges; inside a row every lane
+    // advances through its own run, 4 candidates per trip.  Adjacent lanes touch the same cache lines.
+    auto for_each_candidate = [&](bool act, auto&& body) {
+        const float rq = act ? sqrtf(S.hi0) * 1.0001f + 1e-20f : 0.f;
+        const int ylo = wave_min_i(act ? cell_axis(qy - rq, g.miny, g.invy, g.ny) : 0x7fffffff);
+        const int yhi = wave_max_i(act ? cell_axis(qy + rq, g.miny, g.invy, g.ny) : -1);
+        const int zlo = wave_min_i(act ? cell_axis(qz - rq, g.minz, g.invz, g.nz) : 0x7fffffff);
+        const int zhi = wave_max_i(act ? cell_axis(qz + rq, g.minz, g.invz, g.nz) : -1);
+        const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
+        for (int z = zlo; z <= zhi; ++z) {
+            const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
+            const float dzc = fmaxf(fmaxf(z_a - qz, qz - z_b), 0.f) * 0.9999f;
+            for (int y = ylo; y <= yhi; ++y) {
+                const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
+                const float dyc = fmaxf(fmaxf(y_a - qy, qy - y_b), 0.f) * 0.9999f;
+                const float rem = S.hi0 - dyc * dyc - dzc * dzc;
+                const bool row = act && rem > 0.f;
+                const float sx = row ? sqrtf(rem) * 1.0001f + 1e-20f : 0.f;
                 const int cb = (z * g.ny + y) * g.nx;
-                const int beg = __builtin_amdgcn_readfirstlane(c.start[cb + x0]);
-                const int end = __builtin_amdgcn_readfirstlane(c.start[cb + x1 + 1]);
-                for (int base = beg; base < end; base += kWave) {
-                    const int n = end - base < kWave ? end - base : kWave;
-                    __builtin_amdgcn_wave_barrier();
-                    stage[lane] = c.P4s[base + (lane < n ? lane : 0)];
-                    __builtin_amdgcn_wave_barrier();
-                    KNN_DBG(7, n);
-                    // 4 candidates per trip: four independent load -> distance chains in flight (a lone
-                    // wave per SIMD cannot hide the latency of one dependent chain per candidate)
-                    for (int i = 0; i < n; i += 4) {
-                        float d2[4];
-                        int oi[4];
+                int pos = row ? c.start[cb + cell_axis(qx - sx, g.minx, g.invx, g.nx)] : 0;
+                const int end = row ? c.start[cb + cell_axis(qx + sx, g.minx, g.invx, g.nx) + 1] : 0;   // empty run
+                // (staging the lanes' union run through LDS was measured: no faster, and its 4 KiB per
+                // wave cost a resident wave per SIMD)
+                while (__any(pos < end)) {
+                    KNN_DBG(7, 4);
+                    float d2[4];
+                    int oi[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float4 p = stage[(i + u) & (kWave - 1)];   // same address for all lanes: LDS broadcast
-                            const float dx = qx - p.x;
-                            const float dy = qy - p.y;
-                            const float dz = qz - p.z;
-                            float t = dx * dx;
-                            t = t + dy * dy;
-                            t = t + dz * dz;
-                            d2[u] = i + u < n ? t : 3.0e38f;   // beyond the chunk: never admitted
-                            oi[u] = __float_as_int(p.w);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) body(d2[u], oi[u]);
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = pos + u < end;
+                        const float4 p = c.P4s[ok ? pos + u : 0];
+                        const float dx = qx - p.x;
+                        const float dy = qy - p.y;
+                        const float dz = qz - p.z;
+                        float t = dx * dx;
+                        t = t + dy * dy;
+                        t = t + dz * dz;
+                        d2[u] = ok ? t : 3.0e38f;   // beyond this lane's run: never admitted
+                        oi[u] = __float_as_int(p.w);
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) body(d2[u], oi[u]);
+                    pos += 4;
                 }
             }
+        }
     };
 
-    int ax0 = 0x7fffffff, ax1 = -1, ay0 = 0x7fffffff, ay1 = -1, az0 = 0x7fffffff, az1 = -1;   // union of all boxes
-    for (;;) {   // coverage loop: grow the box until no lane can be missing a neighbour
+    for (;;) {   // coverage loop: grow a starved lane's radius until it provably holds its K nearest
         KNN_DBG(1, 1);
-        // the box only has to serve the lanes that are still unfinished (after the first trip: the one or
-        // two starved lanes of the wave, not the whole 64-query strip)
-        const int lox = wave_min_i(!done ? cx : 0x7fffffff), hix = wave_max_i(!done ? cx : -1);
-        const int loy = wave_min_i(!done ? cy : 0x7fffffff), hiy = wave_max_i(!done ? cy : -1);
-        const int loz = wave_min_i(!done ? cz : 0x7fffffff), hiz = wave_max_i(!done ? cz : -1);
-        x0 = lox - ring > 0 ? lox - ring : 0;  x1 = hix + ring < g.nx - 1 ? hix + ring : g.nx - 1;
-        y0 = loy - ring > 0 ? loy - ring : 0;  y1 = hiy + ring < g.ny - 1 ? hiy + ring : g.ny - 1;
-        z0 = loz - ring > 0 ? loz - ring : 0;  z1 = hiz + ring < g.nz - 1 ? hiz + ring : g.nz - 1;
-        ax0 = x0 < ax0 ? x0 : ax0;  ax1 = x1 > ax1 ? x1 : ax1;
-        ay0 = y0 < ay0 ? y0 : ay0;  ay1 = y1 > ay1 ? y1 : ay1;
-        az0 = z0 < az0 ? z0 : az0;  az1 = z1 > az1 ? z1 : az1;
-        const bool full = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1;
-        // every query lies in a core cell, so everything within ring * cs_min of it is inside the box;
-        // once the box is the whole grid, everything is inside it
-        const float R = (float)ring * c.cs_min;
+        bool full = false;
         if (!done) {
+            const float rq = dout + margin;
+            full = !(rq * rq < dmax2);        // the ball contains the whole cloud (also taken for NaN/inf queries: no endless growth)
             S.nlev = 1;
-            S.hi0 = full ? dmax2 : R * R;
+            S.hi0 = full ? dmax2 : rq * rq;
             S.lo[0] = 0.f;
             S.sc[0] = (float)kBins / S.hi0;
         }
         int c_lo = 0;          // candidates strictly below the current (deepest) range
-        bool starved = false;  // fewer than K candidates within hi0: needs a bigger box
-        for (;;) {             // refinement loop on this box
+        bool starved = false;  // fewer than K candidates within hi0: needs a bigger radius
+        for (;;) {             // refinement loop at this radius
             KNN_DBG(2, 1);
 #pragma unroll
-            for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
+            for (int b = 0; b < kBins / 2; ++b) hist[b * kWave + lane] = 0u;   // two 16-bit counters per word
             const bool active = !done && !starved;
-            for_each_candidate([&](float d2, int) {
+            for_each_candidate(active, [&](float d2, int) {
                 if (active && d2 < S.hi0) {
                     int b = sel_bin(d2, S.lo[0], S.sc[0]);
                     bool in = true;
                     if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
                     if (S.nlev > 2) { in = in && b == S.bs[1]; b = sel_bin(d2, S.lo[2], S.sc[2]); }
-                    if (in) atomicAdd(&hist[b * kWave + lane], 1u);   // lane-private counter (ds_add_u32)
+                    if (in) atomicAdd(&hist[(b >> 1) * kWave + lane], 1u << ((b & 1) * 16));   // lane-private 16-bit counter (ds_add_u32)
                 }
             });
             if (active) {
                 int cum = c_lo, bstar = -1, before = c_lo, inbin = 0;
 #pragma unroll
                 for (int b = 0; b < kBins; ++b) {
-                    const int h = (int)hist[b * kWave + lane];
+                    const unsigned int w2 = hist[(b >> 1) * kWave + lane];
+                    const int h = (int)((b & 1) ? (w2 >> 16) : (w2 & 0xffffu));   // a count of 65535+ would need a 64k-point bin
                     if (bstar < 0 && cum + h >= K) { bstar = b; before = cum; inbin = h; }
                     cum += h;
                 }
@@ -254,16 +264,13 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             if (!__any(!done && !starved)) break;
         }
         if (!__any(!done)) break;
-        ring *= 2;   // some lane is starved: geometric growth reaches the whole grid in a few steps
+        if (!done) margin *= 2.0f;
     }
-    KNN_DBG(6, ring);
 
-    // append pass over the union of the boxes: a finished lane's admitted candidates all lie inside the
-    // box it finished in (they are within its hi0 <= coverage radius of that box)
-    x0 = ax0; x1 = ax1; y0 = ay0; y1 = ay1; z0 = az0; z1 = az1;
+    // append pass: every lane walks the ball it finished with
     int cnt = 0;
     unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
-    for_each_candidate([&](float d2, int oi) {
+    for_each_candidate(valid, [&](float d2, int oi) {
         bool ok = valid && d2 < S.hi0;
         if (ok) {
             const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
@@ -323,12 +330,12 @@ struct KnnLds {
 
 __device__ __forceinline__ KnnLds carve_lds(char* lds, int wave, int cap)
 {
-    const size_t per_wave = (size_t)kBins * kWave * 4 + (size_t)cap * kWave * 8 + kWave * 16;
+    const size_t per_wave = (size_t)(kBins / 2) * kWave * 4 + (size_t)cap * kWave * 8;
     char* base = lds + wave * per_wave;
     KnnLds l;
     l.list = reinterpret_cast<unsigned long long*>(base);
-    l.stage = reinterpret_cast<float4*>(base + (size_t)cap * kWave * 8);
-    l.hist = reinterpret_cast<unsigned int*>(base + (size_t)cap * kWave * 8 + kWave * 16);
+    l.stage = nullptr;
+    l.hist = reinterpret_cast<unsigned int*>(base + (size_t)cap * kWave * 8);
     return l;
 }
 
@@ -528,8 +535,8 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
 
 static void knn_lds_plan(int K, int* cap, int* waves, size_t* bytes, int max_waves)
 {
-    *cap = K + 16;
-    const size_t per_wave = (size_t)kBins * kWave * 4 + (size_t)(*cap) * kWave * 8 + kWave * 16;
+    *cap = K + 12;
+    const size_t per_wave = (size_t)(kBins / 2) * kWave * 4 + (size_t)(*cap) * kWave * 8;
     int w = max_waves;
     while (w > 1 && per_wave * w > 64 * 1024) w >>= 1;
     *waves = w;

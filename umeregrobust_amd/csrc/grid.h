@@ -57,7 +57,7 @@ __device__ __forceinline__ float dec_ord(unsigned int e)
 // radius > 0: ball-search mode, cell edge >= 1.0001 * radius.
 // radius < 0: kNN mode for K = -radius neighbours: the cell edge c is derived from the point density
 //   (surface-like clouds: rho = N / (product of the two largest extents)) such that a disc of radius
-//   2c holds ~1.5 K points, i.e. a 5x5(x5) cell neighbourhood covers the K nearest of most queries.
+//   2c holds ~2 K points, i.e. a ball of radius 2c covers the K nearest of nearly every query.
 __device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox, float radius, int N)
 {
     Grid g;
@@ -67,7 +67,7 @@ __device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox,
     if (radius < 0.f) {
         const float e[3] = {fmaxf(mx[0] - mn[0], 1e-3f), fmaxf(mx[1] - mn[1], 1e-3f), fmaxf(mx[2] - mn[2], 1e-3f)};
         const float area = e[0] * e[1] * e[2] / fminf(e[0], fminf(e[1], e[2]));
-        const float R = sqrtf(1.5f * (-radius) * area / (3.14159265f * (float)(N > 0 ? N : 1)));
+        const float R = sqrtf(2.0f * (-radius) * area / (3.14159265f * (float)(N > 0 ? N : 1)));
         float c = 0.5f * R;
         // spend the kMaxCells budget where the points are: an axis thinner than 4 cells collapses to one
         // layer (LiDAR clouds are ~6 m tall and 100 m wide), then the edge grows until the grid fits
