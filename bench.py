@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--dist-backend", default=None, help="(testing) torch.distributed backend override, e.g. gloo")
     ap.add_argument("--force-device", type=int, default=None,
                     help="(testing) put every rank on this device index, to exercise the N>1 path on a 1-GPU box")
+    ap.add_argument("--with-selection", action="store_true",
+                    help="also run SURVEY 8(f1) hypothesis selection (FeatureCorrelator) per pair and report the "
+                         "registration recall of the SELECTED transform; the headline metric stays the a1-a7 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=1, help="pairs timed by the CPU baseline leg")
     return ap.parse_args()
@@ -92,6 +95,12 @@ def main():
             tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
             gt=t(p.gt_tform).contiguous()))
         e = pool[-1]
+        if a.with_selection:   # random <= pc_corr_max_size subsets with their features (evaluate.py:277-285)
+            rs = np.random.RandomState(77 + i)
+            ns = min(args.pc_corr_max_size, cfg["N"])
+            si = t(rs.choice(cfg["N"], ns, replace=False)); ti = t(rs.choice(cfg["N"], ns, replace=False))
+            e.corr = (e.src_pts[:, si].contiguous(), e.tgt_pts[:, ti].contiguous(), e.src_feat[:, si].contiguous(),
+                      e.tgt_feat[:, ti].contiguous())
         e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
             if a.batch_clouds else None
     # neighbour counts (for the algorithmic-bytes roofline), outside the timed region
@@ -121,10 +130,21 @@ def main():
             mom_bytes_log.extend(e.mom_bytes)
         return h
 
+    sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
+    sel_timing = []
+
     def finish(h):
         out = pipe.finish(h)                                    # host RNG draw + SE(3) hypotheses
         with torch.cuda.stream(pipe.stream_of(h)):              # a7 + recall gates, on the device
             ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, counts[h.slot])
+            if a.with_selection:                                # f1: evaluate.py:260-296 on <= pc_corr_max_size points
+                e = h.entry
+                _, _, R_hat, t_hat = evaluate.pc_fcht(e.corr[0], e.corr[1], e.corr[2], e.corr[3], out.rtume_tform, e.gt[None],
+                                                      args.corr_kernel_sigma, args, timing=sel_timing)
+                T_sel = torch.eye(4, device=dev)[None].repeat(1, 1, 1)
+                T_sel[:, :3, :3] = R_hat
+                T_sel[:, :3, 3] = t_hat
+                ops.hypothesis_gates(T_sel.contiguous(), e.gt, sel_counts[h.slot])
 
     def run(first, n, record):
         pending = []
@@ -143,19 +163,22 @@ def main():
 
     run(0, a.warmup, False)
     torch.cuda.synchronize()
-    for c_ in counts:
+    for c_ in counts + sel_counts:
         c_.zero_()
+    sel_timing.clear()
     fence()
     t0 = time.perf_counter()
     run(a.warmup, a.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     counts = torch.stack(counts).sum(0).double()
+    sel_counts = torch.stack(sel_counts).sum(0).double()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (32 B)
+        dist.all_reduce(sel_counts, op=dist.ReduceOp.SUM)
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     mom_ms = [s.elapsed_time(e_) for s, e_ in timing["moments"]]
@@ -208,6 +231,17 @@ def main():
                                "note": "fraction of RTUME hypotheses (not selected registrations) inside each gate"},
     }
 
+    if a.with_selection:
+        sc = sel_counts.cpu().numpy()
+        sel_ms = [s_.elapsed_time(e_) for s_, e_ in sel_timing]
+        result["metric"] = "registration_pairs_per_s_with_hypothesis_selection"
+        result["config"]["workload"] += " + f1 hypothesis selection (FeatureCorrelator, K=20, sigma=%.2f, <=%d pts)" % (
+            args.corr_kernel_sigma, args.pc_corr_max_size)
+        result["selection"] = {"pairs": int(sc[0]), "rr_1.5deg_0.6m": round(sc[1] / max(sc[0], 1), 4),
+                               "rr_1.5deg_0.3m": round(sc[2] / max(sc[0], 1), 4), "rr_1deg_0.1m": round(sc[3] / max(sc[0], 1), 4),
+                               "corr_scores_avg_ms": round(float(np.mean(sel_ms)), 3) if sel_ms else None,
+                               "note": "recall of the transform SELECTED by feature correlation among the M RTUME "
+                                       "hypotheses, on synthetic pairs (no ICP refinement)"}
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc
