@@ -33,17 +33,18 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (same guide;
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="KT", choices=["K1", "KT", "NS", "SY"])
     ap.add_argument("--kind", default="test", choices=["test", "rot"])
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
-    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "f32"],
+    ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: split-f16 MFMA (fp32-class operands, default) or exact-fp32 MFMA")
     ap.add_argument("--depth", type=int, default=2,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
     ap.add_argument("--threaded-draw", action="store_true",
-                    help="host RNG draw on a worker thread (overlaps kernel enqueues too); use --depth 3")
+                    help="host RNG draw on a worker thread (the native draw releases the GIL, so it overlaps the main "
+                         "thread's kernel enqueues); off by default: at 0.08 ms per draw the hand-off jitter costs more")
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
     ap.add_argument("--dist-backend", default=None, help="(testing) torch.distributed backend override, e.g. gloo")
@@ -118,7 +119,7 @@ def main():
     pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=rng, threaded_draw=a.threaded_draw)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
-    timing = {"moments": [], "dist": []}
+    timing = {"moments": [], "dist": ops.TimingList()}
     mom_bytes_log = []
 
     def submit(i, record):
@@ -190,7 +191,18 @@ def main():
                 "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
                 "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0)}
-    if a.precision == "f16x2":
+    if a.precision == "f16r":
+        # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
+        # region is its 40 KB limit memset + the kernel); the fp64 refine of the ~15 candidates per row is
+        # timed separately.  Algorithmic flops = 2*512 per (source, target) pair, as for the scans.
+        ref_ms = [s.elapsed_time(e_) for s, e_ in timing["dist"].refine]
+        roof_dist = {"kernel": "ume_coarse_h_kernel", "bound": "mfma", "achieved": round(dist_tfs, 2),
+                     "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dist_tfs / MFMA_F16_PEAK_TFLOPS, 4),
+                     "traffic": None, "avg_launch_ms": round(float(np.mean(dist_ms)), 4), "launches": len(dist_ms),
+                     "algorithmic_flops_per_launch": dist_flops,
+                     "refine_avg_launch_ms": round(float(np.mean(ref_ms)), 4) if ref_ms else None,
+                     "d_used": "512-equivalent (Q-form), single f16 MFMA product (hi planes) + fp64 refine of the candidates"}
+    elif a.precision == "f16x2":
         # 3 f16 MFMA products per algorithmic product (hi*hi, hi*lo, lo*hi): the flops the MFMA pipe
         # executes are 3x the algorithmic count; `achieved` stays ALGORITHMIC, `issued` is reported too
         roof_dist = {"kernel": "ume_dist_h_kernel", "bound": "mfma", "achieved": round(dist_tfs, 2),

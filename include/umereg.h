@@ -49,7 +49,7 @@ enum {
     UMEREG_QLAYOUT_COLS = 2,  /* MFMA B-fragment order: target side of the distance GEMM */
     /* split-f16 operands for the fast GEMM: every basis entry is stored as hi = f16(q) and
      * lo = f16(q - hi): |q| <= 1, so the pair carries q to an absolute error <= 2^-25 */
-    UMEREG_QLAYOUT_ROWS_F16X2 = 3, /* source side; pads n to a multiple of 64 */
+    UMEREG_QLAYOUT_ROWS_F16X2 = 3, /* source side; pads n to a multiple of 128 */
     UMEREG_QLAYOUT_COLS_F16X2 = 4  /* target side; pads n to a multiple of 32 */
 };
 
@@ -116,7 +116,7 @@ int umereg_ume_moments_f32(const float* pts, const float* kpts, const float* fea
  * Householder orthonormal basis of each 32x4 UME matrix (LAPACK geqr2/org2r conventions,
  * computed in fp64, stored fp32).  The projector QQ^T -- all the reference uses -- is
  * invariant to QR sign conventions.
- *   ume [n,32,4] -> Q in `layout`; ROWS pads n to a multiple of 16, COLS to 32, ROWS_F16X2 to 64
+ *   ume [n,32,4] -> Q in `layout`; ROWS pads n to a multiple of 16, COLS to 32, ROWS_F16X2 to 128
  *   (padding is written as zeros): size = umereg_qbasis_bytes(n, layout).
  * ------------------------------------------------------------------------------------------- */
 size_t umereg_qbasis_bytes(int n, int layout);
@@ -154,6 +154,26 @@ int umereg_ume_dist_q_f16x2(const void* Q1_rows_h, const void* Q2_cols_h, int n1
 int umereg_ume_match_f16x2(const float* ume1, const float* ume2, int B, int n1, int n2,
                            int64_t* match_idx, float* match_dist, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Filter + refine matching ("f16r"): a coarse pass with the hi planes only (ONE f16 MFMA product)
+ * collects, per source row, every target whose coarse score is within a proven error margin of the
+ * row's best; the candidates (~15 per row) are re-evaluated in fp64 from hi+lo and the arg-min taken
+ * (lowest index among candidates whose squared distances agree to fp32).  The result is the arg-min of
+ * the fp64-evaluated distance over ALL targets -- deterministic, and more accurate than either scan
+ * variant -- at a third of the MFMA work.
+ * Operands in the *_F16X2 layouts; scratch from umereg_ume_match_q_scratch_bytes(n1, n2). */
+size_t umereg_ume_match_q_scratch_bytes(int n1, int n2);
+int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                            int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
+                            void* stream);
+/* the two stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, in this order) */
+int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
+                                size_t scratch_bytes, void* stream);
+int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                const void* scratch, size_t scratch_bytes, int64_t* match_idx,
+                                float* match_dist, void* stream);
+int umereg_ume_match_f16r(const float* ume1, const float* ume2, int B, int n1, int n2,
+                          int64_t* match_idx, float* match_dist, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5  a = exp((1 - ume_d)/tau); prob = a / a.sum()                   evaluate.py:235-236
@@ -170,6 +190,15 @@ int umereg_host_choice_round(double* p_host, int n, const double* x_host, int k,
                              int n_uniq, double* cdf_scratch_host, unsigned char* seen_scratch_host);
 /* numpy's pre-draw argument checks in one pass: out[0] = Kahan sum, out[1] = #(p > 0), out[2] = any NaN/negative */
 int umereg_host_choice_check(const double* p_host, int n, double* out3_host);
+/* the whole draw in one call: numpy's legacy RandomState is MT19937, so given its state
+ * (RandomState.get_state(): key[624], pos) the uniforms are generated here exactly as random_sample()
+ * would and the advanced state is handed back (set_state) -- indices, order and the RNG stream stay
+ * bit-identical to np.random.choice.  p: f32 or f64 [n]; work: 2n + size doubles; seen: n bytes.
+ * returns 0, or 1 / 2 / 3 for numpy's argument errors (NaN or negative entries / sum != 1 / fewer
+ * non-zero entries than size), -1 for bad arguments. */
+int umereg_host_choice_mt19937(uint32_t* mt_key_host, int* mt_pos_host, const void* p_host, int p_is_f32, int n,
+                               int size, int64_t* found_host, double* work_host, unsigned char* seen_host,
+                               int* rounds_out_host);
 
 /* ---------------------------------------------------------------------------------------------
  * a6  utils.loc_utils.batch_estimate_transform_ume_old(G, H)         utils/loc_utils.py:292-350

@@ -274,6 +274,86 @@ def test_ume_dist_f16x2_vs_oracle(gpu, n1, n2):
     assert rc == 0 and torch.equal(m1, mh) and torch.equal(d1, dh)
 
 
+@pytest.mark.parametrize("n1,n2", [(1, 1), (63, 33), (64, 32), (65, 31), (250, 1000), (1000, 97), (3000, 2500), (6000, 5000)])
+def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
+    """Filter + refine matching: single-product f16 coarse pass, candidates re-evaluated in fp64.  The result
+    must be the arg-min of the fp64 truth wherever that arg-min is defined above the basis rounding (2^-22)."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(n1 * 11 + n2)
+    u1 = rng.standard_normal((n1, 32, 4)).astype(np.float32)
+    u2 = rng.standard_normal((n2, 32, 4)).astype(np.float32)
+    u1[:, :, 1:] += 30.0 * u1[:, :, :1]
+    u2[:, :, 1:] += 30.0 * u2[:, :, :1]
+    k = min(n1, n2) // 2
+    u2[:k] = u1[:k] @ (np.eye(4) + 0.1 * rng.standard_normal((4, 4))).astype(np.float32)
+    mr, dr = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+    mr, dr = N_(mr[0]), N_(dr[0])
+    D64 = orc.ume_cdist_f64(u1, u2)
+    am = D64.argmin(axis=1)
+    srt = np.sort(D64 ** 2, axis=1)
+    clear = (srt[:, 1] - srt[:, 0] > 2e-5) if n2 > 1 else np.ones(n1, bool)
+    assert np.array_equal(mr[clear], am[clear])
+    # where two targets tie within the rounding of the bases, the pick must still be one of the tied ones
+    assert (D64[np.arange(n1), mr] ** 2 - srt[:, 0]).max() <= 2e-5
+    assert np.array_equal(mr[:k], np.arange(k))
+    assert np.abs(dr - D64[np.arange(n1), mr]).max() < 2e-3
+    far = D64[np.arange(n1), mr] > 0.05
+    if far.any():
+        assert np.abs(dr - D64[np.arange(n1), mr])[far].max() < 2e-5
+    # agreement with the exact-fp32 scan, and run-to-run determinism (candidate lists are timing dependent)
+    mf, _ = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f32")
+    assert (mr == N_(mf[0])).mean() >= 0.999 or n1 < 100
+    for _ in range(3):
+        m2, d2 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+        assert np.array_equal(N_(m2[0]), mr) and np.array_equal(N_(d2[0]), dr)
+    # single-call ABI entry
+    lib = __import__("umeregrobust_amd")._lib.load()
+    m1 = torch.empty((1, n1), dtype=torch.int64, device=gpu); d1 = torch.empty((1, n1), device=gpu)
+    ws = torch.empty(lib.umereg_ume_match_workspace_bytes(1, n1, n2), dtype=torch.uint8, device=gpu)
+    a, b = T_(u1, gpu)[None].contiguous(), T_(u2, gpu)[None].contiguous()
+    rc = lib.umereg_ume_match_f16r(a.data_ptr(), b.data_ptr(), 1, n1, n2, m1.data_ptr(), d1.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and np.array_equal(N_(m1[0]), mr) and np.array_equal(N_(d1[0]), dr)
+
+
+def test_ume_match_f16r_duplicates_and_degenerate(gpu):
+    """Candidate-list overflow (hundreds of identical targets), all-zero UMEs and a one-target set: the
+    exhaustive fallback of the refine kernel must give the lowest index among exact ties."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(5)
+    n1, n2 = 300, 700
+    u1 = rng.standard_normal((n1, 32, 4)).astype(np.float32)
+    u2 = rng.standard_normal((n2, 32, 4)).astype(np.float32)
+    u2[100:500] = u1[7]                     # 400 exact copies of source 7's UME -> > kCandCap candidates for row 7
+    u2[600:650] = u1[9]
+    u1[11] = 0.0                            # zero UME: Q = I[:, :4]
+    m, d = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+    m, d = N_(m[0]), N_(d[0])
+    assert m[7] == 100 and d[7] < 2e-3
+    assert m[9] == 600 and d[9] < 2e-3
+    D64 = orc.ume_cdist_f64(u1, u2)
+    srt = np.sort(D64 ** 2, axis=1)
+    clear = srt[:, 1] - srt[:, 0] > 2e-5
+    assert np.array_equal(m[clear], D64.argmin(axis=1)[clear])
+    # all targets identical
+    u3 = np.repeat(u2[:1], 333, axis=0)
+    m3, d3 = ops.ume_match(T_(u1, gpu)[None], T_(u3, gpu)[None], precision="f16r")
+    assert (N_(m3[0]) == 0).all()
+    assert np.abs(N_(d3[0]) - orc.ume_cdist_f64(u1, u3)[:, 0]).max() < 2e-3
+    # a whole block of identical sources against thousands of copies of the same UME: every (source, target)
+    # pair ties, the candidate regions overflow and the refine kernel's exhaustive re-scan must take over
+    u4 = u1[:40].copy(); u4[:16] = u1[0]
+    u5 = np.repeat(u1[:1], 3000, axis=0); u5[2900:] = u2[:100]
+    m5, d5 = ops.ume_match(T_(u4, gpu)[None], T_(u5, gpu)[None], precision="f16r")
+    m5, d5 = N_(m5[0]), N_(d5[0])
+    assert (m5[:16] == 0).all() and (d5[:16] < 2e-3).all()
+    D5 = orc.ume_cdist_f64(u4, u5)
+    s5 = np.sort(D5 ** 2, axis=1)
+    ok5 = s5[:, 1] - s5[:, 0] > 2e-5
+    assert np.array_equal(m5[ok5], D5.argmin(axis=1)[ok5])
+    assert (D5[np.arange(40), m5] ** 2 - s5[:, 0]).max() <= 2e-5
+
+
 def test_ume_cdist_batch(gpu):
     from umeregrobust_amd import ops
     rng = np.random.RandomState(2)

@@ -11,7 +11,11 @@ LIB_PATH = os.path.join(CSRC, "libumereg.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the ball-query distance must round once per operation (bit-exact indices);
 # kernels that want FMAs call fma()/fmaf() explicitly.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+# -ffp-contract=off: the reference's arithmetic has no fused multiply-adds where bit-exactness matters;
+# -fno-slp-vectorize: packed-f32 VALU (v_pk_fma_f32) issued beside MFMAs is slower than the scalar pair
+# on gfx950, so adjacent scalar f32 ops must not be re-packed behind our back (device side only: the
+# host-side sampler in api.hip relies on the SLP vectoriser for its lock-step binary searches).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Xarch_device", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-fvisibility=hidden", "-I", INCLUDE]
 
 

@@ -38,6 +38,14 @@ SIGNATURES = {
                                         c_void_p]),
     "umereg_ume_match_f16x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_size_t, c_void_p]),
+    "umereg_ume_match_q_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_ume_match_q_f16r": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_void_p]),
+    "umereg_ume_match_coarse_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umereg_ume_match_refine_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p,
+                                            c_void_p]),
+    "umereg_ume_match_f16r": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
     "umereg_qbasis_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ume_orthobasis_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "umereg_ume_cdist_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -48,6 +56,8 @@ SIGNATURES = {
     "umereg_match_prob_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "umereg_host_choice_round": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "umereg_host_choice_check": (c_int, [c_void_p, c_int, c_void_p]),
+    "umereg_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "umereg_rtume_solve_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p]),
     "umereg_hypothesis_gates_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,4 +1,5 @@
 // api.hip -- ABI version, thread-local error string, device probe.
+#include <math.h>
 #include <stdarg.h>
 
 #include "common.h"
@@ -80,28 +81,28 @@ UMEREG_API int umereg_host_choice_round(double* p, int n, const double* x, int k
     // v*last and settling the boundary with the EXACT predicate (cdf[i] / last > v) numpy evaluates:
     // 2-3 divisions per draw instead of n per round.
     // Pass 1: searchsorted for every draw, candidates parked in found[n_uniq + d].  The searches are
-    // latency-bound (dependent loads over an 80 KB array), so 8 of them advance in lock-step --
-    // every search has the same length sequence -- to keep 8 loads in flight.
+    // latency-bound (dependent loads over an 80 KB array) and their comparisons are coin flips, so 16 of
+    // them advance in lock-step -- every search has the same length sequence -- on index arithmetic
+    // with no data-dependent branch (a mispredicted branch per level costs 4x the whole search).
     int64_t* cand = found + n_uniq;
-    constexpr int W = 8;
+    constexpr int W = 16;
     for (int d0 = 0; d0 < k; d0 += W) {
         const int w = k - d0 < W ? k - d0 : W;
-        const double* base[W];
+        int idx[W];
         double t[W];
         for (int u = 0; u < W; ++u) {
-            const double v = x[d0 + (u < w ? u : 0)];
-            t[u] = v * last;
-            base[u] = cdf;
+            t[u] = x[d0 + (u < w ? u : 0)] * last;
+            idx[u] = 0;
         }
         int len = n;
         while (len > 1) {
             const int half = len >> 1;
-            for (int u = 0; u < W; ++u) base[u] = (base[u][half - 1] <= t[u]) ? base[u] + half : base[u];
+            for (int u = 0; u < W; ++u) idx[u] += half & -(int)(cdf[idx[u] + half - 1] <= t[u]);
             len -= half;
         }
         for (int u = 0; u < w; ++u) {
             const double v = x[d0 + u];
-            int lo = (int)(base[u] - cdf) + (base[u][0] <= t[u] ? 1 : 0);
+            int lo = idx[u] + (cdf[idx[u]] <= t[u] ? 1 : 0);
             // settle with numpy's exact predicate: first index with cdf[i] / last > v
             while (lo > 0 && cdf[lo - 1] / last > v) --lo;
             while (lo < n && !(cdf[lo] / last > v)) ++lo;
@@ -109,14 +110,14 @@ UMEREG_API int umereg_host_choice_round(double* p, int n, const double* x, int k
             cand[d0 + u] = lo;
         }
     }
-    // Pass 2: keep first occurrences in draw order (np.unique(return_index) + sort + take)
+    // Pass 2: keep first occurrences in draw order (np.unique(return_index) + sort + take), branch-free
     int n_new = 0;
     for (int d = 0; d < k; ++d) {
         const int64_t lo = cand[d];
-        if (!seen[lo]) {
-            seen[lo] = 1;
-            cand[n_new++] = lo;   // n_new <= d: in-place forward compaction
-        }
+        const int fresh = !seen[lo];
+        seen[lo] = 1;
+        cand[n_new] = lo;   // n_new <= d: in-place forward compaction
+        n_new += fresh;
     }
     for (int i = 0; i < n_new; ++i) seen[found[n_uniq + i]] = 0;
     return n_new;
@@ -142,5 +143,90 @@ UMEREG_API int umereg_host_choice_check(const double* p, int n, double* out)
         }
     }
     out[0] = sum; out[1] = (double)npos; out[2] = (double)bad;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The whole draw in one call.  numpy's legacy RandomState is MT19937; random_sample() is
+//   a = next32() >> 5, b = next32() >> 6, (a * 2^26 + b) / 2^53     (numpy/random/src/mt19937/mt19937.h)
+// so given the generator state (RandomState.get_state(): key[624], pos) the uniforms of every round
+// can be produced here, and the state handed back (set_state) is exactly where numpy would have left
+// it.  One ctypes call instead of 2 + 2 per round; the caller's stream stays in lock-step with the
+// reference's.
+namespace {
+
+constexpr int kMtN = 624, kMtM = 397;
+
+inline void mt19937_gen(uint32_t* key)
+{
+    constexpr uint32_t kA = 0x9908b0dfu, kUp = 0x80000000u, kLo = 0x7fffffffu;
+    int i = 0;
+    for (; i < kMtN - kMtM; ++i) {
+        const uint32_t y = (key[i] & kUp) | (key[i + 1] & kLo);
+        key[i] = key[i + kMtM] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+    }
+    for (; i < kMtN - 1; ++i) {
+        const uint32_t y = (key[i] & kUp) | (key[i + 1] & kLo);
+        key[i] = key[i + (kMtM - kMtN)] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+    }
+    const uint32_t y = (key[kMtN - 1] & kUp) | (key[0] & kLo);
+    key[kMtN - 1] = key[kMtM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+}
+
+inline uint32_t mt19937_next(uint32_t* key, int* pos)
+{
+    if (*pos >= kMtN) {
+        mt19937_gen(key);
+        *pos = 0;
+    }
+    uint32_t y = key[(*pos)++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+inline double mt19937_double(uint32_t* key, int* pos)
+{
+    const int32_t a = (int32_t)(mt19937_next(key, pos) >> 5), b = (int32_t)(mt19937_next(key, pos) >> 6);
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+}  // namespace
+
+// p: f32 (p_is_f32 != 0) or f64 probabilities [n] (not modified); work: 2n + size doubles; seen: n bytes.
+// returns 0, or numpy's argument errors: 1 = NaN / negative entries, 2 = probabilities do not sum to 1,
+// 3 = fewer non-zero entries than size; -1 = bad arguments.  *rounds (optional) = rounds taken.
+UMEREG_API int umereg_host_choice_mt19937(uint32_t* mt_key, int* mt_pos, const void* p, int p_is_f32, int n, int size,
+                                          int64_t* found, double* work, unsigned char* seen, int* rounds)
+{
+    if (!mt_key || !mt_pos || !p || !found || !work || !seen || n <= 0 || size <= 0 || size > n || *mt_pos < 0 || *mt_pos > kMtN)
+        return -1;
+    double* p64 = work;
+    double* cdf = work + n;
+    double* x = work + 2 * (size_t)n;
+    if (p_is_f32)
+        for (int i = 0; i < n; ++i) p64[i] = (double)((const float*)p)[i];
+    else
+        memcpy(p64, p, (size_t)n * sizeof(double));
+    double chk[3];
+    umereg_host_choice_check(p64, n, chk);
+    if (chk[2] != 0.0) return 1;
+    double atol = 1.4901161193847656e-08;                  // sqrt(eps64)
+    if (p_is_f32) atol = 0.000345266983001244;             // numpy: max(atol, sqrt(eps32))
+    if (!(fabs(chk[0] - 1.0) <= atol)) return 2;
+    if (chk[1] < (double)size) return 3;
+    memset(seen, 0, (size_t)n);
+    int n_uniq = 0, r = 0;
+    while (n_uniq < size) {
+        const int k = size - n_uniq;
+        for (int i = 0; i < k; ++i) x[i] = mt19937_double(mt_key, mt_pos);
+        const int n_new = umereg_host_choice_round(p64, n, x, k, found, n_uniq, cdf, seen);
+        if (n_new < 0) return -1;
+        n_uniq += n_new;
+        ++r;
+    }
+    if (rounds) *rounds = r;
     return 0;
 }

@@ -19,7 +19,10 @@
 // tiles; operands arrive in fragment order (ortho.hip), i.e. as coalesced 1 KiB dwordx4 loads,
 // with no LDS staging (K = 32 is a single MFMA k-sweep, nothing to re-use across waves that
 // the L1/L2 do not already serve).
+#include <stdlib.h>
+
 #include "common.h"
+#include "qlayout.h"
 
 namespace umereg {
 
@@ -284,6 +287,350 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_dist_h_kernel(
     }
 }
 
+// ---- filter + refine matching (precision "f16r") ---------------------------------------------------
+// The arg-min only needs the exact distance of the few targets that can win.  A COARSE pass runs the
+// contraction with the hi planes alone (one f16 MFMA product instead of three) and appends, per source
+// row, every target whose coarse score s~ = |Qi^T Qj|_F^2 comes within a margin of the best coarse score
+// seen so far; a REFINE pass re-evaluates just those candidates in fp64 from hi+lo and takes the arg-min
+// (lowest index on ties).  The result is the arg-min of the fp64 distance over ALL targets because:
+//   * |lo| <= 2^-11 |q| and the basis columns have unit norm, so each of the 16 entries of Qi^T Qj
+//     changes by at most 2 * 2^-11 when the lo planes are dropped; with sum|c| <= 4 |C|_F <= 8 this
+//     moves s by at most delta = 2 * 2^-10 * 8 = 2^-6 (+ fp32 accumulation noise ~1e-5);
+//   * every per-lane / per-row / global limit is (some coarse score of that row) - margin, hence
+//     <= (coarse row maximum) - margin, and the exact winner's coarse score is >= coarse row maximum -
+//     2 delta; margin >= 2 delta therefore keeps the exact winner (and everything tied with it) in the list.
+// Limits are shared between lanes, waves and workgroups only to keep the lists short (~20 entries per
+// row): sharing is timing dependent, the RESULT is not.  Every (wave of the coarse kernel, target split)
+// owns a private region of the candidate buffer, so candidates are appended with plain stores -- no
+// atomics, nothing the tile loop has to wait for.  A region that overflows (hundreds of exact duplicates
+// among the targets) makes the refine kernel re-scan that block of rows exhaustively.
+constexpr float kCoarseMargin = 0.03125f + 0.0009765625f;   // 2 delta + slack
+constexpr int kRegionCap = 512;    // candidates per (block of rows, split)
+constexpr int kMaxSplits = 64;
+constexpr unsigned int kShareMask = 0x8000808bu;   // after tiles 1, 2, 4, 8, 16 of a split, then every 32nd
+
+struct MatchScratch {
+    unsigned int* rowlim;   // [n1] bits of the best (coarse score - margin) published so far, >= 0
+    unsigned int* cnt;      // [n_blocks][splits] candidates appended to the region (> kRegionCap: overflowed)
+    unsigned int* cand;     // [n_blocks][splits][kRegionCap]  (local row << 27) | target
+    int splits;
+    unsigned int share_mask;   // bit k: share the limits after tile k of a split (k >= 31: every 32nd tile)
+};
+
+// all-reduce (max) over aligned groups of 32 lanes: DPP inside rows of 16, one swizzle across the two rows
+__device__ __forceinline__ float group32_max(float v)
+{
+    int x = __float_as_int(v);
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true))));    // quad_perm [1,0,3,2]
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true))));    // quad_perm [2,3,0,1]
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true))));   // row_half_mirror
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true))));   // row_mirror
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x401F))));             // lane ^ 16
+    return __int_as_float(x);
+}
+
+// Workgroup = 4 waves x 32 source keypoints (four stationary A tiles per wave, hi planes only); every
+// 32-target tile (8 KiB of hi fragments) is staged once per workgroup through a double-buffered LDS
+// stage.  The tile body is software-pipelined by hand in units of "groups" (one basis column b x two A
+// tiles = 4 MFMAs): the squares of group k run in the shadow of the MFMAs of group k+1.
+#ifndef UMEREG_COARSE_PROBE
+#define UMEREG_COARSE_PROBE 4   // timing probes (tools/exp_probe.py): 0 = MFMA stream only, 3 = no candidate queue
+#endif
+#ifndef UMEREG_COARSE_TA
+#define UMEREG_COARSE_TA 2
+#endif
+#ifndef UMEREG_COARSE_SCALAR
+#define UMEREG_COARSE_SCALAR 1
+#endif
+constexpr int kProbe = UMEREG_COARSE_PROBE;
+constexpr bool kScalarSq = UMEREG_COARSE_SCALAR != 0;
+constexpr int kCoarseTA = UMEREG_COARSE_TA;          // A tiles (8 source keypoints each) per wave
+constexpr int kCoarseRows = kCoarseTA * 8;           // source keypoints per wave
+constexpr int kCoarseWG = kCoarseRows * kDistWaves;  // source keypoints per workgroup (<= ROWS_F16X2 padding)
+struct Pairs8 { f32x2 p[8]; };
+
+// Workgroup = 4 waves x kCoarseRows source keypoints (stationary A tiles, hi planes only); every 32-target
+// tile (8 KiB of hi fragments) is staged once per workgroup through a double-buffered LDS stage, two
+// further tiles are in flight in registers.
+__global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
+    const half8* __restrict__ Afrag, const half8* __restrict__ Bfrag, int n1, int n2, int n_ablk, int n_btiles,
+    int tiles_per_split, MatchScratch ms)
+{
+    __shared__ half8 ldsB[2][512];                          // 2 x 8 KiB: hi planes of one 32-target tile
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int ablk = blockIdx.x % n_ablk;
+    const int sp = blockIdx.x / n_ablk;
+    const int jt0 = sp * tiles_per_split;
+    const int jt1 = min(jt0 + tiles_per_split, n_btiles);
+    const int h = lane >> 5;
+    const int i_base = ablk * kCoarseWG + wave * kCoarseRows;
+
+    half8 a[kCoarseTA][2];   // [A tile][k step], hi plane
+#pragma unroll
+    for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            a[t][s] = Afrag[((((size_t)(ablk * (kCoarseWG / 8) + wave * kCoarseTA + t)) * 2 + s) * 2 + 0) * 64 + lane];
+
+    // Limits, kept as the bit patterns of non-negative floats (integer max == float max, one instruction).
+    // `seen` holds what other workgroups have published for this lane's rows; it is re-read
+    // asynchronously (issued at one sharing point, consumed at the next) so that the tile loop never
+    // waits for a global round trip.  Rows beyond n1 (zero bases, score 0) never reach 3e38.
+    int lim[kCoarseTA][4];
+    unsigned int seen[kCoarseTA][4];
+#pragma unroll
+    for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = i_base + t * 8 + 2 * g + h;
+            seen[t][g] = __hip_atomic_load(ms.rowlim + min(i, n1 - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lim[t][g] = __float_as_int(i < n1 ? 1.0e-30f : 3.0e38f);
+        }
+#pragma unroll
+    for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" ::"v"(a[t][s]));
+
+    // this wave's private candidate region
+    const int blk = ablk * kDistWaves + wave;
+    unsigned int* const region = ms.cand + ((size_t)blk * ms.splits + sp) * kRegionCap;
+    int qn = 0;   // wave-uniform number of candidates appended so far
+    auto share = [&](bool reload) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v = group32_max(__int_as_float(lim[t][g]));
+                const int i = i_base + t * 8 + 2 * g + h;
+                if ((lane & 31) == 0 && i < n1 && __float_as_uint(v) > seen[t][g]) atomicMax(ms.rowlim + i, __float_as_uint(v));
+                lim[t][g] = max(__float_as_int(v), (int)seen[t][g]);
+            }
+        if (reload) {
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int i = min(i_base + t * 8 + 2 * g + h, n1 - 1);
+                    seen[t][g] = __hip_atomic_load(ms.rowlim + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+    };
+
+    // Staging: chunk c = r*256 + tid of the tile's 512 hi chunks; hi chunk (q = c>>6, l = c&63) sits at
+    // fragment index (q*2 + 0)*64 + l.  A tile's loads are issued two tile-times before its LDS store.
+    half8 stA[2], stB[2];
+    const int c0 = threadIdx.x, c1 = 256 + threadIdx.x;
+    const int src0 = ((c0 >> 6) * 2) * 64 + (c0 & 63), src1 = ((c1 >> 6) * 2) * 64 + (c1 & 63);
+    auto gload = [&](half8 (&st)[2], int jt) __attribute__((always_inline)) {
+        st[0] = Bfrag[(size_t)jt * 1024 + src0];
+        st[1] = Bfrag[(size_t)jt * 1024 + src1];
+    };
+    if (jt0 < jt1) {
+        gload(stA, jt0);
+        ldsB[0][c0] = stA[0];
+        ldsB[0][c1] = stA[1];
+    }
+    if (jt0 + 1 < jt1) gload(stB, jt0 + 1);
+    __syncthreads();
+    int cur = 0;
+    auto tile = [&](const int jt, half8 (&stLoad)[2], half8 (&stWrite)[2]) __attribute__((always_inline)) {
+        if (jt + 2 < jt1) gload(stLoad, jt + 2);
+        float sc[kCoarseTA][4];    // coarse scores of this lane's 4*TA (source, target) pairs
+        f32x2 sacc2[kCoarseTA][4];
+        f32x16 cc[kCoarseTA];
+        if (kProbe == 0) {
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t) cc[t] = f32x16{0};
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const half8 b0 = ldsB[cur][(b * 2 + 0) * 64 + lane];
+            const half8 b1 = ldsB[cur][(b * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+                cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, kProbe == 0 ? cc[t] : f32x16{0}, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
+            if (kProbe == 0) continue;
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (kScalarSq) {
+                        float acc = b == 0 ? cc[t][4 * g] * cc[t][4 * g] : fmaf(cc[t][4 * g], cc[t][4 * g], sc[t][g]);
+                        acc = fmaf(cc[t][4 * g + 1], cc[t][4 * g + 1], acc);
+                        acc = fmaf(cc[t][4 * g + 2], cc[t][4 * g + 2], acc);
+                        sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
+                    } else {
+                        const Pairs8 pp = __builtin_bit_cast(Pairs8, cc[t]);   // natural register pairs of the accumulator
+                        f32x2& acc = sacc2[t][g];
+                        acc = b == 0 ? pp.p[2 * g] * pp.p[2 * g] : __builtin_elementwise_fma(pp.p[2 * g], pp.p[2 * g], acc);
+                        acc = __builtin_elementwise_fma(pp.p[2 * g + 1], pp.p[2 * g + 1], acc);
+                    }
+                }
+        }
+        if (kProbe == 0) {
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t) lim[t][0] = max(lim[t][0], __float_as_int(cc[t][0]));
+        } else {
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (!kScalarSq) sc[t][g] = sacc2[t][g].x + sacc2[t][g].y;
+                    lim[t][g] = max(lim[t][g], __float_as_int(sc[t][g] - kCoarseMargin));
+                }
+            const int kt = jt - jt0;
+            if ((ms.share_mask >> (kt < 31 ? kt : 31)) & 1u) {
+                if (kt < 31 || (kt & 31) == 31) share(true);
+            }
+            unsigned long long hit[kCoarseTA][4], any = 0;
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    hit[t][g] = __builtin_amdgcn_ballot_w64(sc[t][g] >= __int_as_float(lim[t][g]));
+                    any |= hit[t][g];
+                }
+            if (kProbe < 4) {
+                if (any) lim[0][0] = max(lim[0][0], 1);
+            } else if (any) {
+                const unsigned int j = (unsigned int)(jt * 32 + (lane & 31));
+#pragma unroll
+                for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned long long mask = hit[t][g];
+                        if (mask) {
+                            const int pos = qn + mbcnt(mask);
+                            if (((mask >> lane) & 1ull) && pos < kRegionCap)
+                                region[pos] = ((unsigned int)(t * 8 + 2 * g + h) << 27) | j;
+                            qn += __builtin_popcountll(mask);
+                        }
+                    }
+            }
+        }
+        if (jt + 1 < jt1) {
+            ldsB[cur ^ 1][c0] = stWrite[0];
+            ldsB[cur ^ 1][c1] = stWrite[1];
+        }
+        __syncthreads();
+        cur ^= 1;
+    };
+    for (int jt = jt0; jt < jt1; jt += 2) {
+        tile(jt, stA, stB);
+        if (jt + 1 < jt1) tile(jt + 1, stB, stA);
+    }
+    // publish what this split learned for the workgroups that start later
+    share(false);
+    if (lane == 0) ms.cnt[(size_t)blk * ms.splits + sp] = (unsigned int)qn;
+}
+
+// refine: one workgroup per block of kCoarseRows source rows (= one wave of the coarse kernel), one
+// thread per candidate.  d2 = 4 - sum_ab (Qi[:,a] . Qj[:,b])^2 in fp64 from hi+lo; per-row arg-min through
+// an LDS atomicMin on (bits(float(d2)) << 32 | j): lowest index among candidates whose d2 agree to fp32.
+constexpr int kQiStride = 130;   // doubles per row in LDS: 128 + 2 (rows land on different banks)
+
+__global__ __launch_bounds__(256, 4) void match_refine_kernel(const _Float16* __restrict__ Ah,
+                                                           const _Float16* __restrict__ Bh, int n1, int n2,
+                                                           MatchScratch ms, int64_t* __restrict__ idx,
+                                                           float* __restrict__ dist)
+{
+    __shared__ double qi[kCoarseRows * kQiStride];
+    __shared__ unsigned long long best[kCoarseRows];
+    __shared__ unsigned int offs[kWave + 1];
+    __shared__ int overflow;
+    const int blk = blockIdx.x;
+    const int i0 = blk * kCoarseRows;
+    const int tid = threadIdx.x;
+    if (tid < kWave) {   // wave 0: exclusive prefix sum of the region fills (splits <= kMaxSplits = 64)
+        const unsigned int c = tid < ms.splits ? ms.cnt[(size_t)blk * ms.splits + tid] : 0u;
+        const bool ovf = c > (unsigned int)kRegionCap;
+        unsigned int incl = min(c, (unsigned int)kRegionCap);
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned int up = (unsigned int)__shfl_up((int)incl, d, kWave);
+            if (tid >= d) incl += up;
+        }
+        offs[tid + 1] = incl;
+        if (tid == 0) {
+            offs[0] = 0;
+            overflow = __builtin_amdgcn_ballot_w64(ovf) != 0ull;
+        }
+    }
+    if (tid < kCoarseRows) best[tid] = ~0ull;
+    // stationary rows: 16 (a, k8) groups of 8 channels per row
+    for (int e = tid; e < kCoarseRows * 16; e += blockDim.x) {
+        const int r = e >> 4, a = (e >> 2) & 3, k8 = e & 3;
+        const int i = min(i0 + r, n1 - 1);
+        const half8 vh = *reinterpret_cast<const half8*>(Ah + hoff_rows(i, a, k8 * 8, 0));
+        const half8 vl = *reinterpret_cast<const half8*>(Ah + hoff_rows(i, a, k8 * 8, 1));
+#pragma unroll
+        for (int x = 0; x < 8; ++x) qi[r * kQiStride + (k8 * 8 + x) * 4 + a] = (double)vh[x] + (double)vl[x];
+    }
+    __syncthreads();
+    const bool exhaustive = overflow != 0;
+    const unsigned int total = exhaustive ? (unsigned int)kCoarseRows * (unsigned int)n2 : offs[ms.splits];
+    const unsigned int* const regions = ms.cand + (size_t)blk * ms.splits * kRegionCap;
+    int sp = 0;
+    for (unsigned int e = tid; e < total; e += blockDim.x) {
+        unsigned int r, j;
+        if (exhaustive) {
+            r = e % kCoarseRows;
+            j = e / kCoarseRows;
+        } else {
+            while (e >= offs[sp + 1]) ++sp;   // e grows monotonically per thread
+            const unsigned int ent = regions[(size_t)sp * kRegionCap + (e - offs[sp])];
+            r = ent >> 27;
+            j = ent & 0x07ffffffu;
+        }
+        const double* const q = qi + r * kQiStride;
+        double dot[4][4];   // [a][b]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dot[a][b] = 0.0;
+#pragma unroll 2
+        for (int k8 = 0; k8 < 4; ++k8) {
+            half8 vh[4], vl[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                vh[b] = *reinterpret_cast<const half8*>(Bh + hoff_cols((int)j, b, k8 * 8, 0));
+                vl[b] = *reinterpret_cast<const half8*>(Bh + hoff_cols((int)j, b, k8 * 8, 1));
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int k = k8 * 8 + x;
+                const double q0 = q[k * 4 + 0], q1 = q[k * 4 + 1], q2 = q[k * 4 + 2], q3 = q[k * 4 + 3];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double v = (double)((float)vh[b][x] + (float)vl[b][x]);   // fp32 sum: error <= 2^-24 |q|
+                    dot[0][b] = fma(q0, v, dot[0][b]);
+                    dot[1][b] = fma(q1, v, dot[1][b]);
+                    dot[2][b] = fma(q2, v, dot[2][b]);
+                    dot[3][b] = fma(q3, v, dot[3][b]);
+                }
+            }
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s = fma(dot[a][b], dot[a][b], s);
+        const float d2 = (float)fmax(4.0 - s, 0.0);
+        if (d2 == d2 && (int)(i0 + r) < n1)   // NaN scores never win
+            atomicMin(&best[r], ((unsigned long long)__float_as_uint(d2) << 32) | j);
+    }
+    __syncthreads();
+    if (tid < kCoarseRows && i0 + tid < n1) {
+        const unsigned long long k = best[tid];
+        const bool ok = k != ~0ull;   // all-NaN rows: report target 0 at the maximum distance
+        idx[i0 + tid] = ok ? (int64_t)(unsigned int)(k & 0xffffffffull) : 0;
+        if (dist) dist[i0 + tid] = ok ? sqrtf(__uint_as_float((unsigned int)(k >> 32))) : 2.0f;
+    }
+}
+
 __global__ void match_finalize_kernel(const unsigned long long* __restrict__ best, int n,
                                       int64_t* __restrict__ idx, float* __restrict__ dist)
 {
@@ -339,8 +686,31 @@ static DistPlan make_plan(int n1, int n2)
     return p;
 }
 
-static size_t qa_bytes(int n1) { return align_up((size_t)n1, 64) * 128 * sizeof(float); }   // covers ROWS and ROWS_F16X2
+static size_t qa_bytes(int n1) { return align_up((size_t)n1, 128) * 128 * sizeof(float); }   // covers ROWS and ROWS_F16X2
 static size_t qb_bytes(int n2) { return align_up((size_t)n2, 32) * 128 * sizeof(float); }
+struct CoarsePlan {
+    int n_ablk, n_blocks, n_btiles, splits, tiles_per_split;
+};
+static CoarsePlan coarse_plan(int n1, int n2)
+{
+    CoarsePlan p;
+    p.n_ablk = (n1 + kCoarseWG - 1) / kCoarseWG;
+    p.n_blocks = p.n_ablk * kDistWaves;
+    p.n_btiles = (n2 + 31) / 32;
+    int splits = (2560 + p.n_ablk - 1) / p.n_ablk;   // ~10 workgroups per CU
+    if (const char* e = getenv("UMEREG_SPLITS")) splits = atoi(e);   // tuning probe
+    if (splits > kMaxSplits) splits = kMaxSplits;
+    if (splits > p.n_btiles) splits = p.n_btiles;
+    if (splits < 1) splits = 1;
+    p.tiles_per_split = (p.n_btiles + splits - 1) / splits;
+    p.splits = (p.n_btiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    return p;
+}
+static size_t match_scratch_bytes(int n1, int n2)
+{
+    const CoarsePlan p = coarse_plan(n1, n2);
+    return align_up(((size_t)n1 + (size_t)p.n_blocks * p.splits * (1 + kRegionCap)) * sizeof(unsigned int), 256);
+}
 
 }  // namespace umereg
 
@@ -355,7 +725,77 @@ UMEREG_API size_t umereg_ume_cdist_workspace_bytes(int B, int n1, int n2)
 UMEREG_API size_t umereg_ume_match_workspace_bytes(int B, int n1, int n2)
 {
     if (B <= 0 || n1 <= 0 || n2 <= 0) return 0;
-    return qa_bytes(n1) + qb_bytes(n2) + align_up((size_t)n1 * sizeof(unsigned long long), 256);
+    return qa_bytes(n1) + qb_bytes(n2) + match_scratch_bytes(n1, n2) + 8 * (size_t)n1;   // covers the n1 x 8 B keys of the scan variants
+}
+
+UMEREG_API size_t umereg_ume_match_q_scratch_bytes(int n1, int n2) { return n1 > 0 && n2 > 0 ? match_scratch_bytes(n1, n2) : 0; }
+
+static int match_args(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch, size_t scratch_bytes,
+                      const char* who)
+{
+    UMEREG_REQUIRE(Q1_rows_h && Q2_cols_h, "%s: null basis pointer", who);
+    UMEREG_REQUIRE(n1 > 0 && n2 > 0, "%s: n1, n2 must be positive (got %d, %d)", who, n1, n2);
+    UMEREG_REQUIRE(n2 < (1 << 27), "%s: n2 must be below 2^27 (got %d)", who, n2);
+    UMEREG_REQUIRE(((uintptr_t)Q1_rows_h & 15) == 0 && ((uintptr_t)Q2_cols_h & 15) == 0, "%s: misaligned basis pointer", who);
+    if (int rc = check_device()) return rc;
+    if (!scratch || scratch_bytes < match_scratch_bytes(n1, n2) || ((uintptr_t)scratch & 15)) {
+        set_error("%s: scratch too small or misaligned (%zu < %zu)", who, scratch_bytes, match_scratch_bytes(n1, n2));
+        return UMEREG_EWORKSPACE;
+    }
+    return UMEREG_OK;
+}
+
+static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
+{
+    MatchScratch ms;
+    ms.rowlim = (unsigned int*)scratch;
+    ms.cnt = ms.rowlim + n1;
+    ms.cand = ms.cnt + (size_t)p.n_blocks * p.splits;
+    ms.splits = p.splits;
+    ms.share_mask = kShareMask;
+    if (const char* e = getenv("UMEREG_SHARE_MASK")) ms.share_mask = (unsigned int)strtoul(e, nullptr, 0);   // tuning probe
+    return ms;
+}
+
+UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
+                                           size_t scratch_bytes, void* stream)
+{
+    if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, "ume_match_coarse_f16")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const CoarsePlan p = coarse_plan(n1, n2);
+    const MatchScratch ms = carve_scratch(scratch, n1, p);
+    if (hipMemsetAsync(ms.rowlim, 0, (size_t)n1 * sizeof(unsigned int), st) != hipSuccess) {
+        set_error("ume_match_coarse_f16: hipMemsetAsync failed");
+        return UMEREG_ELAUNCH;
+    }
+    hipLaunchKernelGGL(ume_coarse_h_kernel, dim3(p.n_ablk * p.splits), dim3(kWave * kDistWaves), 0, st,
+                       (const half8*)Q1_rows_h, (const half8*)Q2_cols_h, n1, n2, p.n_ablk, p.n_btiles, p.tiles_per_split, ms);
+    UMEREG_CHECK_LAUNCH("ume_coarse_h_kernel");
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                           const void* scratch, size_t scratch_bytes, int64_t* match_idx,
+                                           float* match_dist, void* stream)
+{
+    UMEREG_REQUIRE(match_idx, "ume_match_refine_f16: null match_idx");
+    if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, (void*)scratch, scratch_bytes, "ume_match_refine_f16")) return rc;
+    const CoarsePlan p = coarse_plan(n1, n2);
+    const MatchScratch ms = carve_scratch((void*)scratch, n1, p);
+    hipLaunchKernelGGL(match_refine_kernel, dim3(p.n_blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)Q1_rows_h,
+                       (const _Float16*)Q2_cols_h, n1, n2, ms, match_idx, match_dist);
+    UMEREG_CHECK_LAUNCH("match_refine_kernel");
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                       int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
+                                       void* stream)
+{
+    UMEREG_REQUIRE(match_idx, "ume_match_q_f16r: null match_idx");
+    if (int rc = umereg_ume_match_coarse_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, stream)) return rc;
+    if (kProbe < 4) return UMEREG_OK;
+    return umereg_ume_match_refine_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, match_idx, match_dist, stream);
 }
 
 UMEREG_API int umereg_ume_dist_q_f32(const float* Q1_rows, const float* Q2_cols, int n1, int n2, float* D,
@@ -448,7 +888,7 @@ UMEREG_API int umereg_ume_dist_q_f16x2(const void* Q1_rows_h, const void* Q2_col
 
 static int dist_common(const float* ume1, const float* ume2, int B, int n1, int n2, float* D,
                        int64_t* match_idx, float* match_dist, void* workspace, size_t workspace_bytes,
-                       size_t need, void* stream, const char* who, bool f16x2 = false)
+                       size_t need, void* stream, const char* who, bool f16x2 = false, bool refine = false)
 {
     UMEREG_REQUIRE(ume1 && ume2, "%s: null UME pointer", who);
     UMEREG_REQUIRE(B > 0 && n1 > 0 && n2 > 0, "%s: B, n1, n2 must be positive (got %d, %d, %d)", who, B, n1, n2);
@@ -470,8 +910,9 @@ static int dist_common(const float* ume1, const float* ume2, int B, int n1, int 
         float* Db = D ? D + (size_t)b * n1 * n2 : nullptr;
         int64_t* mi = match_idx ? match_idx + (size_t)b * n1 : nullptr;
         float* md = match_dist ? match_dist + (size_t)b * n1 : nullptr;
-        const int rc = f16x2 ? umereg_ume_dist_q_f16x2(QA, QB, n1, n2, Db, mi, md, match_idx ? keys : nullptr, stream)
-                             : umereg_ume_dist_q_f32(QA, QB, n1, n2, Db, mi, md, match_idx ? keys : nullptr, stream);
+        const int rc = refine  ? umereg_ume_match_q_f16r(QA, QB, n1, n2, mi, md, keys, match_scratch_bytes(n1, n2), stream)
+                       : f16x2 ? umereg_ume_dist_q_f16x2(QA, QB, n1, n2, Db, mi, md, match_idx ? keys : nullptr, stream)
+                               : umereg_ume_dist_q_f32(QA, QB, n1, n2, Db, mi, md, match_idx ? keys : nullptr, stream);
         if (rc) return rc;
     }
     return UMEREG_OK;
@@ -511,4 +952,13 @@ UMEREG_API int umereg_ume_match_f16x2(const float* ume1, const float* ume2, int 
     UMEREG_REQUIRE(match_idx, "ume_match_f16x2: null match_idx");
     return dist_common(ume1, ume2, B, n1, n2, nullptr, match_idx, match_dist, workspace, workspace_bytes,
                        umereg_ume_match_workspace_bytes(B, n1, n2), stream, "ume_match_f16x2", true);
+}
+
+UMEREG_API int umereg_ume_match_f16r(const float* ume1, const float* ume2, int B, int n1, int n2,
+                                     int64_t* match_idx, float* match_dist, void* workspace,
+                                     size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(match_idx, "ume_match_f16r: null match_idx");
+    return dist_common(ume1, ume2, B, n1, n2, nullptr, match_idx, match_dist, workspace, workspace_bytes,
+                       umereg_ume_match_workspace_bytes(B, n1, n2), stream, "ume_match_f16r", true, true);
 }

@@ -54,7 +54,7 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
     dev = src_pts.device
     # UME matrices (:206-212); the keypoint gathers src_pts[0, src_inds] (:201-202) are fused into the kernel
     t_mom = None if timing is None else timing.setdefault("moments", [])
-    t_dist = None if timing is None else timing.setdefault("dist", [])
+    t_dist = None if timing is None else timing.setdefault("dist", ops.TimingList())
     if pair is not None:
         # both clouds of the pair as ONE batch of 2 through every kernel (same arithmetic per cloud; half
         # the launches, twice the parallelism for the small grid-building kernels)

@@ -15,38 +15,80 @@ def _is_legacy(rng):
     return rng is np.random or isinstance(rng, np.random.RandomState)
 
 
+_addr_cache = {}
+
+
+def _mt19937_of(rng):
+    """The MT19937 BitGenerator behind a legacy RandomState / the np.random module, or None."""
+    if rng is np.random:
+        rng = getattr(np.random.mtrand, "_rand", None)
+    bitgen = getattr(rng, "_bit_generator", None)
+    if isinstance(bitgen, np.random.MT19937) and hasattr(bitgen, "ctypes") and hasattr(bitgen, "lock"):
+        return bitgen
+    return None
+
+
+def _state_address(bitgen):
+    k = id(bitgen)
+    ent = _addr_cache.get(k)
+    if ent is None or ent[0] is not bitgen:
+        if len(_addr_cache) > 64:
+            _addr_cache.clear()
+        ent = _addr_cache[k] = (bitgen, int(bitgen.ctypes.state_address))
+    return ent[1]
+
+
+_ERRORS = {1: "probabilities contain NaN or are not non-negative", 2: "probabilities do not sum to 1",
+           3: "Fewer non-zero entries in p than size"}
+_scratch = {}
+
+
 def choice_noreplace(rng, n, size, p):
-    """Bit-identical replacement for rng.choice(n, size, replace=False, p=p) (legacy numpy RNGs).
-    Any other generator type is forwarded to its own .choice()."""
+    """Bit-identical replacement for rng.choice(n, size, replace=False, p=p) (legacy numpy RNGs: same
+    indices, same order, same generator state afterwards).  Any other generator type is forwarded to its
+    own .choice().  One native call (umereg_host_choice_mt19937) on the generator's MT19937 state."""
     if not _is_legacy(rng):
         return rng.choice(n, size, replace=False, p=p)
     lib = _lib.load()
-    p64 = np.array(p, dtype=np.float64, copy=True, order="C").ravel()
-    if p64.shape[0] != n:
+    p = np.asarray(p)
+    if p.dtype != np.float32:
+        p = p.astype(np.float64, copy=False)
+    p = np.ascontiguousarray(p).ravel()
+    if p.shape[0] != n:
         raise ValueError("'a' and 'p' must have same size")
     if size > n:
         raise ValueError("Cannot take a larger sample than population when 'replace=False'")
-    chk = np.empty(3, dtype=np.float64)
-    lib.umereg_host_choice_check(p64.ctypes.data, n, chk.ctypes.data)
-    if chk[2] != 0.0:
-        raise ValueError("probabilities contain NaN or are not non-negative")
-    pd = np.asarray(p).dtype
-    atol = np.sqrt(np.finfo(np.float64).eps)
-    if np.issubdtype(pd, np.floating):
-        atol = max(atol, np.sqrt(np.finfo(pd).eps))          # numpy relaxes the tolerance for float32 input
-    if abs(chk[0] - 1.0) > atol:
-        raise ValueError("probabilities do not sum to 1")
-    if chk[1] < size:
-        raise ValueError("Fewer non-zero entries in p than size")
+    if size <= 0:
+        return rng.choice(n, size, replace=False, p=p)
+    sc = _scratch.get((n, size))
+    if sc is None:
+        work = np.empty(2 * n + size, dtype=np.float64)
+        seen = np.empty(n, dtype=np.uint8)
+        pos = np.zeros(1, dtype=np.int32)
+        sc = _scratch[(n, size)] = (work, seen, pos, work.ctypes.data, seen.ctypes.data, pos.ctypes.data)
+        if len(_scratch) > 16:
+            _scratch.pop(next(iter(_scratch)))
+    work, seen, pos, work_p, seen_p, pos_p = sc
     found = np.empty(size, dtype=np.int64)
-    cdf = np.empty(n, dtype=np.float64)
-    seen = np.zeros(n, dtype=np.uint8)
-    n_uniq = 0
-    while n_uniq < size:
-        x = rng.rand(size - n_uniq)
-        n_new = lib.umereg_host_choice_round(p64.ctypes.data, n, x.ctypes.data, x.shape[0], found.ctypes.data, n_uniq,
-                                             cdf.ctypes.data, seen.ctypes.data)
-        if n_new < 0:
-            raise RuntimeError("umereg_host_choice_round failed")
-        n_uniq += n_new
+    is_f32 = int(p.dtype == np.float32)
+    # numpy's legacy RandomState wraps an MT19937 bit generator whose state struct {uint32 key[624]; int pos;}
+    # is exposed through the documented BitGenerator.ctypes interface: advance it in place, under its lock
+    bitgen = _mt19937_of(rng)
+    if bitgen is not None:
+        addr = _state_address(bitgen)
+        with bitgen.lock:
+            rc = lib.umereg_host_choice_mt19937(addr, addr + 624 * 4, p.ctypes.data, is_f32, n, size,
+                                                found.ctypes.data, work_p, seen_p, None)
+    else:
+        st = rng.get_state()
+        if st[0] != "MT19937":
+            return rng.choice(n, size, replace=False, p=p)
+        key = st[1]
+        pos[0] = st[2]
+        rc = lib.umereg_host_choice_mt19937(key.ctypes.data, pos_p, p.ctypes.data, is_f32, n, size,
+                                            found.ctypes.data, work_p, seen_p, None)
+        if rc == 0:
+            rng.set_state((st[0], key, int(pos[0]), st[3], st[4]))
+    if rc != 0:
+        raise ValueError(_ERRORS.get(rc, "umereg_host_choice_mt19937 failed"))
     return found

@@ -15,7 +15,9 @@ BallQuery = namedtuple("BallQuery", "dists idx knn")   # pytorch3d's _KNN field 
 
 QLAYOUT_PLAIN, QLAYOUT_ROWS, QLAYOUT_COLS, QLAYOUT_ROWS_F16X2, QLAYOUT_COLS_F16X2 = 0, 1, 2, 3, 4
 ORDER_KEYPOINTS = True   # process keypoints in cell-sorted, XCD-sliced order (cache locality only)
-DEFAULT_MATCH_PRECISION = "f16x2"   # "f32": exact-fp32 MFMA; "f16x2": split-f16 MFMA (fp32-class, ~5x faster)
+# arg-min engines: "f32" exact-fp32 MFMA scan; "f16x2" split-f16 MFMA scan (fp32-class, ~4x faster);
+# "f16r" single-product f16 filter + fp64 refine of the candidates (exact arg-min of the fp64 distance)
+DEFAULT_MATCH_PRECISION = "f16r"
 
 _workspaces = {}
 
@@ -76,6 +78,14 @@ def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_n
                                        _ptr(idx), _ptr(dists), _ptr(nn), _ptr(ws), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "umereg_ball_query_f32")
     return BallQuery(dists, idx, nn)
+
+
+class TimingList(list):
+    """List of (start, stop) event pairs of a dominant kernel; `.refine` collects the follow-up stage of
+    the filter + refine matcher separately."""
+    def __init__(self):
+        super().__init__()
+        self.refine = []
 
 
 def _timed(timing, dev):
@@ -182,15 +192,17 @@ def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
         if want_match:
             raise ValueError("ume_match: empty UME set")
         return D, m, d
-    if precision not in ("f32", "f16x2"):
-        raise ValueError(f"precision must be 'f32' or 'f16x2', got {precision!r}")
-    half = precision == "f16x2"
+    if precision not in ("f32", "f16x2", "f16r") or (precision == "f16r" and want_D):
+        raise ValueError(f"precision must be 'f32' or 'f16x2' (or 'f16r' for ume_match), got {precision!r}")
+    refine = precision == "f16r"
+    half = precision != "f32"
     lay_a = QLAYOUT_ROWS_F16X2 if half else QLAYOUT_ROWS
     lay_b = QLAYOUT_COLS_F16X2 if half else QLAYOUT_COLS
     dist_fn = lib.umereg_ume_dist_q_f16x2 if half else lib.umereg_ume_dist_q_f32
     qa = lib.umereg_qbasis_bytes(n1, lay_a)
     qb = lib.umereg_qbasis_bytes(n2, lay_b)
-    ws = _workspace(dev, qa + qb + 8 * n1 + 256, "dist")
+    scratch = lib.umereg_ume_match_q_scratch_bytes(n1, n2) if refine else 8 * n1 + 256
+    ws = _workspace(dev, qa + qb + scratch, "dist")
     base = ws.data_ptr()
     st = _stream_ptr(dev)
     with torch.cuda.device(dev):
@@ -198,10 +210,19 @@ def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
             _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume1[b]), n1, lay_a, base, st), "umereg_ume_orthobasis_f32")
             _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume2[b]), n2, lay_b, base + qa, st), "umereg_ume_orthobasis_f32")
             ev = _timed(timing, dev)
-            rc = dist_fn(base, base + qa, n1, n2, _ptr(D[b]) if want_D else None,
-                                           _ptr(m[b]) if want_match else None, _ptr(d[b]) if want_match else None,
-                                           base + qa + qb if want_match else None, st)
-            _lib.check(rc, "umereg_ume_dist_q_f32")
+            if refine:
+                # the two stages of umereg_ume_match_q_f16r; `timing` brackets the coarse (dominant) stage
+                rc = lib.umereg_ume_match_coarse_f16(base, base + qa, n1, n2, base + qa + qb, scratch, st)
+                _lib.check(rc, "umereg_ume_match_coarse_f16")
+                _timed_end(timing, ev, dev)
+                timing = getattr(timing, "refine", None)
+                ev = _timed(timing, dev)
+                rc = lib.umereg_ume_match_refine_f16(base, base + qa, n1, n2, base + qa + qb, scratch, _ptr(m[b]), _ptr(d[b]), st)
+            else:
+                rc = dist_fn(base, base + qa, n1, n2, _ptr(D[b]) if want_D else None,
+                             _ptr(m[b]) if want_match else None, _ptr(d[b]) if want_match else None,
+                             base + qa + qb if want_match else None, st)
+            _lib.check(rc, "umereg_ume_dist_q")
             _timed_end(timing, ev, dev)
     return D, m, d
 
