@@ -271,6 +271,24 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
                            const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
                            float* scores, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f2  o3d.pipelines.registration.registration_icp(src, tgt, max_dist, T_init,
+ *         TransformationEstimationPointToPoint(), ICPConvergenceCriteria(max_iteration=...))
+ *                                                                     evaluate.py:93-96
+ * Point-to-point ICP: per iteration every source point (transformed in fp64) takes its exact nearest
+ * target point (ties -> lower index) if closer than max_correspondence_distance; update = Umeyama
+ * without scaling on the correspondences; stops like open3d (|d fitness| < relative_fitness and
+ * |d inlier_rmse| < relative_rmse, or max_iteration updates).  open3d's defaults: 1e-6, 1e-6, 30.
+ *   src f32 [n_src,3], tgt f32 [n_tgt,3] on the device; T_init / T_out: HOST double[16], row major;
+ *   fitness, inlier_rmse, iterations: HOST outputs (NULL to skip).  Synchronous w.r.t. `stream`.
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_icp_workspace_bytes(int n_src, int n_tgt);
+int umereg_icp_point_to_point_f32(const float* src, const float* tgt, int n_src, int n_tgt,
+                                  const double* T_init_host, float max_correspondence_distance,
+                                  int max_iteration, double relative_fitness, double relative_rmse,
+                                  double* T_out_host, double* fitness_host, double* inlier_rmse_host,
+                                  int* iterations_host, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,3 +356,69 @@ def feature_corr_hypothesis_test(source_pc, target_pc, source_feat, target_feat,
     top = order[:n_hypotheses]
     best_T = T_kp[top][np.argmax(mmf_score[top])]                                           # :677-680
     return best_T, mmf_score
+
+
+# ---------------------------------------------------------------------------------------------------
+# f2: point-to-point ICP.  reference evaluate.py:93-96 calls open3d==0.18 (requirements.txt), which is not
+# installable here: PARITY UNPINNED.  This restates open3d's RegistrationICP
+# (cpp/open3d/pipelines/registration/Registration.cpp: GetRegistrationResultAndCorrespondences,
+# RegistrationICP) and TransformationEstimationPointToPoint::ComputeTransformation (Eigen::umeyama,
+# with_scaling=false).  One deliberate choice, shared with the HIP kernel: the nearest-neighbour search runs
+# on the fp32 rounding of the fp64-transformed source point with fp32 squared distances accumulated left to
+# right and ties -> lower index; residuals and all sums are fp64 like open3d's.
+def icp_evaluate(src, tgt, T, max_dist, chunk=512):
+    """-> (corr_idx int64 [n] (-1 = none), fitness, inlier_rmse, q_f64 [n,3])."""
+    src64 = np.asarray(src, np.float64)
+    T = np.asarray(T, np.float64)
+    q = np.stack([T[a, 0] * src64[:, 0] + T[a, 1] * src64[:, 1] + T[a, 2] * src64[:, 2] + T[a, 3] for a in range(3)], axis=1)
+    qf = q.astype(np.float32)
+    tgt32 = np.asarray(tgt, np.float32)
+    n = qf.shape[0]
+    idx = np.full(n, -1, np.int64)
+    d2min = np.full(n, np.inf, np.float32)
+    for s in range(0, n, chunk):
+        d = qf[s:s + chunk, None, :] - tgt32[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        j = d2.argmin(axis=1)                               # first minimum = lowest index
+        idx[s:s + chunk] = j
+        d2min[s:s + chunk] = d2[np.arange(d2.shape[0]), j]
+    r2 = np.float32(max_dist) * np.float32(max_dist)
+    ok = d2min < r2
+    idx[~ok] = -1
+    cnt = int(ok.sum())
+    e = q[ok] - tgt32[idx[ok]].astype(np.float64)
+    rmse = float(np.sqrt((e * e).sum() / cnt)) if cnt else 0.0
+    return idx, cnt / float(n), rmse, q
+
+
+def umeyama_no_scaling(p, q):
+    """Eigen::umeyama(src=p, dst=q, with_scaling=false): R, t with q ~ R p + t."""
+    mp, mq = p.mean(axis=0), q.mean(axis=0)
+    cov = (q - mq).T @ (p - mp) / p.shape[0]
+    U, _, Vt = np.linalg.svd(cov)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    return R, mq - R @ mp
+
+
+def icp_point_to_point(src, tgt, T_init, max_dist=0.2, max_iteration=30, relative_fitness=1e-6, relative_rmse=1e-6):
+    """-> (T float64 [4,4], fitness, inlier_rmse, iterations)."""
+    T = np.asarray(T_init, np.float64).copy()
+    tgt64 = np.asarray(tgt, np.float32).astype(np.float64)
+    idx, fit, rmse, q = icp_evaluate(src, tgt, T, max_dist)
+    it = 0
+    for _ in range(max_iteration):
+        ok = idx >= 0
+        upd = np.eye(4)
+        if ok.any():
+            R, t = umeyama_no_scaling(q[ok], tgt64[idx[ok]])
+            upd[:3, :3], upd[:3, 3] = R, t
+        T = upd @ T
+        it += 1
+        pf, pr = fit, rmse
+        idx, fit, rmse, q = icp_evaluate(src, tgt, T, max_dist)
+        if abs(pf - fit) < relative_fitness and abs(pr - rmse) < relative_rmse:
+            break
+    return T, fit, rmse, it

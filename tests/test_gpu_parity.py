@@ -707,3 +707,70 @@ def test_corr_scores_kitti_shape_vs_oracle(gpu):
     assert int(np.argmax(out)) == 0
     out2 = N_(ops.corr_scores(T_(p.src_pts, gpu), T_(p.tgt_pts, gpu), T_(wsf, gpu), T_(wtf, gpu), T_(Ts, gpu), K=20, sigma=1.5))
     assert np.array_equal(out, out2)                                # deterministic reduction order
+
+
+# ------------------------------------------------------------------------------------------- f2: ICP
+def _icp_case(seed, n_tgt=6000, n_src=4000, noise=0.01, ang_deg=0.6, shift=0.08):
+    rng = np.random.RandomState(seed)
+    tgt = np.round(rng.uniform([-20, -20, -2], [20, 20, 2], (n_tgt, 3)) / 0.05) * 0.05   # lattice -> distance ties
+    tgt = tgt.astype(np.float32)
+    ang = np.deg2rad(rng.uniform(-8, 8)); c, s_ = np.cos(ang), np.sin(ang)
+    R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]); t = rng.uniform(-3, 3, 3) * [1, 1, 0.1]
+    gt = np.eye(4); gt[:3, :3] = R; gt[:3, 3] = t                                       # src -> tgt
+    pick = rng.choice(n_tgt, n_src, replace=False)
+    src = ((tgt[pick].astype(np.float64) - t) @ R + rng.normal(0, noise, (n_src, 3))).astype(np.float32)
+    da = np.deg2rad(ang_deg); ca, sa = np.cos(da), np.sin(da)
+    P = np.eye(4); P[:3, :3] = [[ca, -sa, 0], [sa, ca, 0], [0, 0, 1]]; P[:3, 3] = [shift, -shift, shift / 4]
+    return src, tgt, gt, P @ gt
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_icp_point_to_point_vs_oracle(gpu, seed):
+    """open3d-style point-to-point ICP: same correspondences, fitness, rmse, iteration count and transform
+    as the CPU restatement (fp64 sums in a different order: 1e-9), and it converges onto the ground truth."""
+    from umeregrobust_amd import ops
+    src, tgt, gt, T0 = _icp_case(seed)
+    for max_it in (0, 1, 5, 30):
+        ref = orc.icp_point_to_point(src, tgt, T0, 0.2, max_it)
+        out = ops.icp_point_to_point(T_(src, gpu), T_(tgt, gpu), T0, 0.2, max_it)
+        assert out.iterations == ref[3]
+        assert abs(out.fitness - ref[1]) < 1e-12 and abs(out.inlier_rmse - ref[2]) < 1e-9
+        assert np.abs(out.transformation - ref[0]).max() < 1e-9
+    assert out.fitness > 0.95
+    Rerr = np.rad2deg(np.arccos(np.clip((np.trace(out.transformation[:3, :3] @ gt[:3, :3].T) - 1) / 2, -1, 1)))
+    assert Rerr < 0.02 and np.linalg.norm(out.transformation[:3, 3] - gt[:3, 3]) < 5e-3
+    # deterministic (fixed-order fp64 reductions)
+    out2 = ops.icp_point_to_point(T_(src, gpu), T_(tgt, gpu), T0, 0.2, 30)
+    assert np.array_equal(out2.transformation, out.transformation) and out2.inlier_rmse == out.inlier_rmse
+
+
+def test_icp_edge_cases(gpu):
+    from umeregrobust_amd import ops
+    src, tgt, gt, T0 = _icp_case(7, n_tgt=900, n_src=333)
+    far = np.eye(4); far[:3, 3] = [500.0, 0, 0]                       # nothing within 0.2 m: identity updates, stop after 1
+    out = ops.icp_point_to_point(T_(src, gpu), T_(tgt, gpu), far, 0.2, 30)
+    ref = orc.icp_point_to_point(src, tgt, far, 0.2, 30)
+    assert out.fitness == 0.0 and out.inlier_rmse == 0.0 and out.iterations == ref[3] == 1
+    assert np.array_equal(out.transformation, far)
+    one = ops.icp_point_to_point(T_(src[:1], gpu), T_(tgt[:1], gpu), np.eye(4), 1e3, 30)   # single point each
+    r1 = orc.icp_point_to_point(src[:1], tgt[:1], np.eye(4), 1e3, 30)
+    assert one.iterations == r1[3] and np.abs(one.transformation - r1[0]).max() < 1e-9
+    with pytest.raises(ValueError):
+        ops.icp_point_to_point(T_(src, gpu), T_(tgt, gpu), np.eye(3))
+    # wide correspondence radius (several cells per query) and a large cloud
+    src, tgt, gt, T0 = _icp_case(11, n_tgt=50000, n_src=20000, noise=0.02, ang_deg=1.0, shift=0.3)
+    out = ops.icp_point_to_point(T_(src, gpu), T_(tgt, gpu), T0, 1.0, 3)
+    ref = orc.icp_point_to_point(src, tgt, T0, 1.0, 3)
+    assert out.iterations == ref[3] and abs(out.fitness - ref[1]) < 1e-12 and np.abs(out.transformation - ref[0]).max() < 1e-9
+
+
+def test_refine_registration_mirror(gpu):
+    """evaluate.refine_registration (reference evaluate.py:63-109): ICP from the selected transform + RRE / RTE."""
+    from umeregrobust_amd.evaluate import refine_registration
+    from types import SimpleNamespace
+    cases = [_icp_case(s) for s in (3, 4)]
+    R_hat = [c[3][:3, :3] for c in cases]; t_hat = [c[3][:3, 3] for c in cases]
+    pairs = [(T_(c[0], gpu), T_(c[1], gpu), torch.from_numpy(c[2]).float()) for c in cases]
+    T_est, rre, rte = refine_registration(R_hat, t_hat, SimpleNamespace(), pairs)
+    assert T_est.shape == (2, 4, 4) and rre.shape == (2,) and rte.shape == (2,)
+    assert float(rre.max()) < 0.05 and float(rte.max()) < 0.01

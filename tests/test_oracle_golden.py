@@ -148,3 +148,21 @@ def test_feature_correlator_vs_reference():
     assert np.allclose(scores, g["score"], rtol=2e-5, atol=1e-6)
     assert np.array_equal(best, g["best_T"])
     assert int(np.argmax(scores)) == int(g["gt_index"])          # the ground-truth transform wins
+
+
+def test_icp_oracle_recovers_ground_truth():
+    """f2 (parity unpinned, open3d not installable): the restated ICP loop must at least converge onto the
+    transform that generated the data, stop by its own criterion and leave a perfect alignment untouched."""
+    rng = np.random.RandomState(0)
+    tgt = rng.uniform([-10, -10, -1], [10, 10, 1], (1500, 3)).astype(np.float32)
+    ang = 0.1; R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]]); t = np.array([1.0, -2.0, 0.1])
+    src = ((tgt[:900].astype(np.float64) - t) @ R).astype(np.float32)
+    gt = np.eye(4); gt[:3, :3] = R; gt[:3, 3] = t
+    T0 = gt.copy(); T0[:3, 3] += [0.05, -0.04, 0.01]
+    T, fit, rmse, it = orc.icp_point_to_point(src, tgt, T0, 0.2, 30)
+    assert fit == 1.0 and rmse < 1e-5 and it < 30
+    assert np.abs(T - gt).max() < 1e-5
+    T2, fit2, _, it2 = orc.icp_point_to_point(src, tgt, gt, 0.2, 30)
+    assert it2 == 1 and fit2 == 1.0 and np.abs(T2 - gt).max() < 1e-6
+    Rr, tr = orc.umeyama_no_scaling(src[:50].astype(np.float64), tgt[:50].astype(np.float64))
+    assert np.abs(Rr - R).max() < 1e-6 and np.abs(tr - t).max() < 1e-5 and abs(np.linalg.det(Rr) - 1) < 1e-12

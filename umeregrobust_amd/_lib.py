@@ -16,6 +16,7 @@ import torch  # noqa: F401
 from ._build import LIB_PATH
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/umereg.h one to one
 SIGNATURES = {
@@ -54,6 +55,9 @@ SIGNATURES = {
     "umereg_ume_match_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
     "umereg_match_prob_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "umereg_icp_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_icp_point_to_point_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_double, c_double,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_host_choice_round": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "umereg_host_choice_check": (c_int, [c_void_p, c_int, c_void_p]),
     "umereg_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

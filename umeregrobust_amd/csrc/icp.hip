@@ -1,0 +1,254 @@
+// icp.hip -- SURVEY 8(f2): point-to-point ICP refinement of the selected transform.
+// Replaces the open3d call in refine_registration (reference evaluate.py:93-96):
+//     o3d.pipelines.registration.registration_icp(src, tgt, 0.2, T_init,
+//         TransformationEstimationPointToPoint(), ICPConvergenceCriteria(max_iteration=200))
+// open3d is not installable here (parity unpinned); the loop
+// restates open3d's RegistrationICP:
+//     result = evaluate(T)                                   // correspondences, fitness, inlier_rmse
+//     repeat max_iteration times:
+//         update = umeyama(src'[corr], tgt[corr])            // no scaling, det fix
+//         T = update * T;  backup = result;  result = evaluate(T)
+//         stop if |backup.fitness - result.fitness| < relative_fitness
+//                 and |backup.inlier_rmse - result.inlier_rmse| < relative_rmse
+// evaluate(T): every source point, transformed in fp64, looks up its nearest target point (exact, on the
+// uniform grid of grid.h; ties -> lower index) and keeps it if the squared distance is < max_dist^2.
+// Two kernels per iteration, no host round trip inside a batch of iterations:
+//   icp_eval_kernel  one lane per source point: grid NN + fp64 partial sums {n, sum p', sum q, sum q p'^T,
+//                    sum |p'-q|^2} per workgroup (fixed reduction order => deterministic);
+//   icp_step_kernel  one workgroup: totals, convergence test, 3x3 polar rotation, T <- update * T.
+// Once `done` is set the remaining queued launches return immediately.
+#include "grid.h"
+#include "polar.h"
+
+namespace umereg {
+
+constexpr int kIcpSums = 17;   // n, p'(3), q(3), q p'^T (9), e2
+constexpr int kIcpWG = 256;
+
+struct IcpState {
+    double T[16];        // current source -> target transform (row major)
+    double fitness, rmse;
+    double prev_fitness, prev_rmse;
+    int iters;           // updates applied so far
+    int done;
+    int have_prev;
+    int pad;
+};
+
+__global__ __launch_bounds__(kIcpWG) void icp_eval_kernel(const float* __restrict__ src, int n_src,
+                                                           const char* __restrict__ ws, int n_tgt, float max_dist,
+                                                           const IcpState* __restrict__ state, double* __restrict__ partial)
+{
+    __shared__ double red[kIcpWG / kWave][kIcpSums];
+    if (state->done) return;
+    const GridWs w = grid_ws(n_tgt);
+    const float4* __restrict__ P4s = reinterpret_cast<const float4*>(ws + w.off_p4s);
+    const int* __restrict__ start = reinterpret_cast<const int*>(ws + w.off_start);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(ws + w.off_bbox), -1.0f, n_tgt);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s[kIcpSums];
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) s[k] = 0.0;
+    if (i < n_src) {
+        const double px = src[3 * i + 0], py = src[3 * i + 1], pz = src[3 * i + 2];
+        const double* T = state->T;
+        const double qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        const double qy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        const double qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+        const float fx = (float)qx, fy = (float)qy, fz = (float)qz;
+        // cells that can hold a point within max_dist (slack covers the rounding of the cell map)
+        const float r = max_dist * 1.001f + 1e-6f;
+        const int x0 = cell_axis(fx - r, g.minx, g.invx, g.nx), x1 = cell_axis(fx + r, g.minx, g.invx, g.nx);
+        const int y0 = cell_axis(fy - r, g.miny, g.invy, g.ny), y1 = cell_axis(fy + r, g.miny, g.invy, g.ny);
+        const int z0 = cell_axis(fz - r, g.minz, g.invz, g.nz), z1 = cell_axis(fz + r, g.minz, g.invz, g.nz);
+        float best = 3.0e38f;
+        int bidx = 0x7fffffff;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int cbase = (z * g.ny + y) * g.nx;
+                const int beg = start[cbase + x0], end = start[cbase + x1 + 1];   // cells of one x-row are contiguous
+                for (int k = beg; k < end; ++k) {
+                    const float4 t = P4s[k];
+                    const float dx = fx - t.x, dy = fy - t.y, dz = fz - t.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;   // left to right, no contraction
+                    const int oi = __float_as_int(t.w);
+                    if (d2 < best || (d2 == best && oi < bidx)) { best = d2; bidx = oi; bx = t.x; by = t.y; bz = t.z; }
+                }
+            }
+        if (best < max_dist * max_dist) {
+            const double tx = bx, ty = by, tz = bz;
+            const double ex = qx - tx, ey = qy - ty, ez = qz - tz;
+            s[0] = 1.0;
+            s[1] = qx; s[2] = qy; s[3] = qz;
+            s[4] = tx; s[5] = ty; s[6] = tz;
+            s[7] = tx * qx;  s[8] = tx * qy;  s[9] = tx * qz;
+            s[10] = ty * qx; s[11] = ty * qy; s[12] = ty * qz;
+            s[13] = tz * qx; s[14] = tz * qy; s[15] = tz * qz;
+            s[16] = ex * ex + ey * ey + ez * ez;
+        }
+    }
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) {
+        double v = s[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kIcpSums) {
+        double v = 0.0;
+        for (int q = 0; q < kIcpWG / kWave; ++q) v += red[q][threadIdx.x];
+        partial[(size_t)blockIdx.x * kIcpSums + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(kIcpWG) void icp_step_kernel(const double* __restrict__ partial, int n_blocks, int n_src,
+                                                           int max_iter, double rel_fitness, double rel_rmse,
+                                                           IcpState* __restrict__ state)
+{
+    __shared__ double tot[kIcpSums];
+    __shared__ double red[kIcpWG / kWave][kIcpSums];
+    if (state->done) return;
+    // fixed-order totals: thread t sums blocks t, t+256, ...; then a fixed tree
+    double s[kIcpSums];
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) s[k] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += kIcpWG)
+#pragma unroll
+        for (int k = 0; k < kIcpSums; ++k) s[k] += partial[(size_t)b * kIcpSums + k];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) {
+        double v = s[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kIcpSums) {
+        double v = 0.0;
+        for (int q = 0; q < kIcpWG / kWave; ++q) v += red[q][threadIdx.x];
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double n = tot[0];
+    const double fitness = n / (double)n_src;
+    const double rmse = n > 0.0 ? sqrt(tot[16] / n) : 0.0;
+    state->fitness = fitness;
+    state->rmse = rmse;
+    if (state->have_prev && fabs(state->prev_fitness - fitness) < rel_fitness && fabs(state->prev_rmse - rmse) < rel_rmse) {
+        state->done = 1;
+        return;
+    }
+    if (state->iters >= max_iter) {
+        state->done = 1;
+        return;
+    }
+    // update = umeyama(p' -> q) without scaling; no correspondences: identity (open3d returns I)
+    if (n > 0.0) {
+        const double mp[3] = {tot[1] / n, tot[2] / n, tot[3] / n};
+        const double mq[3] = {tot[4] / n, tot[5] / n, tot[6] / n};
+        double A[3][3], R[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) A[a][b] = tot[7 + 3 * a + b] / n - mq[a] * mp[b];
+        polar_rotation(A, R);
+        const double t[3] = {mq[0] - (R[0][0] * mp[0] + R[0][1] * mp[1] + R[0][2] * mp[2]),
+                             mq[1] - (R[1][0] * mp[0] + R[1][1] * mp[1] + R[1][2] * mp[2]),
+                             mq[2] - (R[2][0] * mp[0] + R[2][1] * mp[1] + R[2][2] * mp[2])};
+        double Tn[16];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                Tn[4 * a + c] = R[a][0] * state->T[c] + R[a][1] * state->T[4 + c] + R[a][2] * state->T[8 + c] + (c == 3 ? t[a] : 0.0);
+        }
+        Tn[12] = 0.0; Tn[13] = 0.0; Tn[14] = 0.0; Tn[15] = 1.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) state->T[k] = Tn[k];
+    }
+    state->prev_fitness = fitness;
+    state->prev_rmse = rmse;
+    state->have_prev = 1;
+    state->iters += 1;
+}
+
+static size_t icp_extra_bytes(int n_src)
+{
+    const size_t n_blocks = ((size_t)n_src + kIcpWG - 1) / kIcpWG;
+    return align_up(sizeof(IcpState), 256) + align_up(n_blocks * kIcpSums * sizeof(double), 256);
+}
+
+}  // namespace umereg
+
+using namespace umereg;
+
+UMEREG_API size_t umereg_icp_workspace_bytes(int n_src, int n_tgt)
+{
+    if (n_src <= 0 || n_tgt <= 0) return 0;
+    return grid_ws(n_tgt).total + icp_extra_bytes(n_src);
+}
+
+// src f32 [n_src,3], tgt f32 [n_tgt,3] (device); T_init / T_out: HOST double [16] row major; fitness,
+// inlier_rmse, iterations: HOST outputs (may be NULL).  Synchronous with respect to `stream`: the loop's stop
+// test lives on the device, the host polls it once per batch of 8 iterations.
+UMEREG_API int umereg_icp_point_to_point_f32(const float* src, const float* tgt, int n_src, int n_tgt,
+                                             const double* T_init_host, float max_correspondence_distance,
+                                             int max_iteration, double relative_fitness, double relative_rmse,
+                                             double* T_out_host, double* fitness_host, double* inlier_rmse_host,
+                                             int* iterations_host, void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(src && tgt && T_init_host && T_out_host, "icp_point_to_point: null pointer");
+    UMEREG_REQUIRE(n_src > 0 && n_tgt > 0, "icp_point_to_point: empty cloud (n_src %d, n_tgt %d)", n_src, n_tgt);
+    UMEREG_REQUIRE(max_correspondence_distance > 0.f && max_iteration >= 0, "icp_point_to_point: bad distance / iteration limit");
+    if (int rc = check_device()) return rc;
+    const size_t need = umereg_icp_workspace_bytes(n_src, n_tgt);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+        set_error("icp_point_to_point: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const GridWs w = grid_ws(n_tgt);
+    IcpState* state = (IcpState*)(ws + w.total);
+    double* partial = (double*)(ws + w.total + align_up(sizeof(IcpState), 256));
+    if (int rc = launch_prep(tgt, ws, 1, n_tgt, -1.0f, st)) return rc;   // kNN-mode grid for K = 1
+    IcpState h;
+    memset(&h, 0, sizeof(h));
+    for (int k = 0; k < 16; ++k) h.T[k] = T_init_host[k];
+    if (hipMemcpyAsync(state, &h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) {
+        set_error("icp_point_to_point: state upload failed");
+        return UMEREG_ELAUNCH;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) {   // `h` is a stack object
+        set_error("icp_point_to_point: stream synchronize failed");
+        return UMEREG_ELAUNCH;
+    }
+    const int n_blocks = (n_src + kIcpWG - 1) / kIcpWG;
+    int launched = 0;
+    while (true) {
+        for (int b = 0; b < 8; ++b) {
+            hipLaunchKernelGGL(icp_eval_kernel, dim3(n_blocks), dim3(kIcpWG), 0, st, src, n_src, ws, n_tgt,
+                               max_correspondence_distance, state, partial);
+            hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(kIcpWG), 0, st, partial, n_blocks, n_src, max_iteration,
+                               relative_fitness, relative_rmse, state);
+        }
+        UMEREG_CHECK_LAUNCH("icp kernels");
+        launched += 8;
+        if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            set_error("icp_point_to_point: state download failed");
+            return UMEREG_ELAUNCH;
+        }
+        if (h.done || launched > max_iteration + 1) break;
+    }
+    for (int k = 0; k < 16; ++k) T_out_host[k] = h.T[k];
+    if (fitness_host) *fitness_host = h.fitness;
+    if (inlier_rmse_host) *inlier_rmse_host = h.rmse;
+    if (iterations_host) *iterations_host = h.iters;
+    return UMEREG_OK;
+}

@@ -42,6 +42,32 @@ def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, cor
     return R_err, t_err, R_hat, t_hat
 
 
+def refine_registration(R_hat, t_hat, args, pairs):
+    """reference evaluate.py:63-109 (`refine_registration`): point-to-point ICP from every selected (R_hat, t_hat),
+    max correspondence distance 0.2 m, max_iteration=200, then RRE / RTE against the ground truth.
+    The reference re-opens its dataset here; this takes the raw clouds instead:
+    pairs = iterable of (src_pts_raw [n,3], tgt_pts_raw [m,3], gt_tform [4,4]).
+    -> (T_est [P,4,4] f32, rre [P] deg, rte [P] m), like the reference."""
+    T_est_arr, rre_arr, rte_arr = [], [], []
+    max_corr = float(getattr(args, "icp_max_correspondence_distance", 0.2))
+    max_it = int(getattr(args, "icp_max_iteration", 200))
+    for itr, (src_pts_raw, tgt_pts_raw, gt_tform) in enumerate(pairs):
+        tform_hat = np.zeros((4, 4))
+        tform_hat[:3, :3] = np.asarray(R_hat[itr].detach().cpu() if isinstance(R_hat[itr], torch.Tensor) else R_hat[itr])
+        tform_hat[:3, 3] = np.asarray(t_hat[itr].detach().cpu() if isinstance(t_hat[itr], torch.Tensor) else t_hat[itr])
+        tform_hat[3, 3] = 1
+        reg = ops.icp_point_to_point(src_pts_raw, tgt_pts_raw, tform_hat, max_corr, max_it)
+        new_tform = torch.from_numpy(reg.transformation).float()
+        T_est_arr.append(new_tform)
+        gt = gt_tform.detach().cpu().float() if isinstance(gt_tform, torch.Tensor) else torch.as_tensor(gt_tform).float()
+        dev = src_pts_raw.device
+        rre = relative_rotation_error(new_tform[:3, :3][None].to(dev).contiguous(), gt[:3, :3][None].to(dev).contiguous()).cpu()
+        rte = (new_tform[:3, 3] - gt[:3, 3]).norm(dim=-1)
+        rre_arr.append(rre)
+        rte_arr.append(rte)
+    return torch.stack(T_est_arr), torch.cat(rre_arr), torch.stack(rte_arr)
+
+
 def my_ume_generation(pts, kpts, feat, args):
     """reference evaluate.py:50-60.  pts [bs,N,3], kpts [bs,n,3], feat [bs,N,32] -> F [bs,n,32,4];
     args.ume_max_nn / args.ume_r_nn as in the benchmark YAMLs."""

@@ -456,3 +456,34 @@ def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, tim
             _lib.check(rc, "umereg_corr_scores_f32")
             _timed_end(timing, ev, dev)
     return scores
+
+
+def icp_point_to_point(src_pts, tgt_pts, T_init, max_correspondence_distance=0.2, max_iteration=30,
+                       relative_fitness=1e-6, relative_rmse=1e-6):
+    """Point-to-point ICP with open3d's registration_icp semantics (reference evaluate.py:93-96).
+    src_pts [n,3], tgt_pts [m,3] (device f32), T_init [4,4] (any float tensor / array) ->
+    SimpleNamespace(transformation float64 [4,4] numpy, fitness, inlier_rmse, iterations)."""
+    import numpy as np
+    from types import SimpleNamespace
+    lib = _lib.load()
+    sp = _dev(src_pts, "src_pts"); tp = _dev(tgt_pts, "tgt_pts")
+    if sp.dim() != 2 or tp.dim() != 2 or sp.shape[1] != 3 or tp.shape[1] != 3:
+        raise ValueError(f"icp_point_to_point: expected [n,3] clouds, got {tuple(sp.shape)}, {tuple(tp.shape)}")
+    T0 = np.ascontiguousarray(np.asarray(T_init.detach().cpu() if isinstance(T_init, torch.Tensor) else T_init, dtype=np.float64))
+    if T0.shape != (4, 4):
+        raise ValueError("icp_point_to_point: T_init must be 4x4")
+    n, m = sp.shape[0], tp.shape[0]
+    if n == 0 or m == 0:
+        raise ValueError("icp_point_to_point: empty cloud")
+    dev = sp.device
+    T = np.empty((4, 4), dtype=np.float64)
+    out = np.zeros(2, dtype=np.float64)
+    iters = np.zeros(1, dtype=np.int32)
+    ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_icp_point_to_point_f32(_ptr(sp), _ptr(tp), n, m, T0.ctypes.data, float(max_correspondence_distance),
+                                               int(max_iteration), float(relative_fitness), float(relative_rmse),
+                                               T.ctypes.data, out.ctypes.data, out.ctypes.data + 8, iters.ctypes.data,
+                                               _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_icp_point_to_point_f32")
+    return SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
