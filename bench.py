@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--with-selection", action="store_true",
                     help="also run SURVEY 8(f1) hypothesis selection (FeatureCorrelator) per pair and report the "
                          "registration recall of the SELECTED transform; the headline metric stays the a1-a7 path")
+    ap.add_argument("--with-refinement", action="store_true",
+                    help="with --with-selection: also refine the selected transform by SURVEY 8(f2) point-to-point ICP "
+                         "(0.2 m, <= 200 iterations, reference evaluate.py:93-96) and report its recall / mean errors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="max pairs timed by the CPU baseline leg (stops after ~10 s)")
     return ap.parse_args()
@@ -132,7 +135,9 @@ def main():
         return h
 
     sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
+    ref_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     sel_timing = []
+    icp_log = []
 
     def finish(h):
         out = pipe.finish(h)                                    # host RNG draw + SE(3) hypotheses
@@ -146,6 +151,12 @@ def main():
                 T_sel[:, :3, :3] = R_hat
                 T_sel[:, :3, 3] = t_hat
                 ops.hypothesis_gates(T_sel.contiguous(), e.gt, sel_counts[h.slot])
+                if a.with_refinement:                           # f2: evaluate.py:63-109 (synchronous: host-side stop test)
+                    t_icp = time.perf_counter()
+                    reg = ops.icp_point_to_point(e.src_pts[0], e.tgt_pts[0], T_sel[0].double().cpu().numpy(), 0.2, 200)
+                    icp_log.append((time.perf_counter() - t_icp, reg.iterations, reg.fitness))
+                    T_ref = torch.from_numpy(reg.transformation).float().to(dev)[None].contiguous()
+                    ops.hypothesis_gates(T_ref, e.gt, ref_counts[h.slot])
 
     def run(first, n, record):
         pending = []
@@ -164,8 +175,9 @@ def main():
 
     run(0, a.warmup, False)
     torch.cuda.synchronize()
-    for c_ in counts + sel_counts:
+    for c_ in counts + sel_counts + ref_counts:
         c_.zero_()
+    icp_log.clear()
     sel_timing.clear()
     fence()
     t0 = time.perf_counter()
@@ -174,12 +186,14 @@ def main():
     elapsed = time.perf_counter() - t0
     counts = torch.stack(counts).sum(0).double()
     sel_counts = torch.stack(sel_counts).sum(0).double()
+    ref_counts = torch.stack(ref_counts).sum(0).double()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (32 B)
         dist.all_reduce(sel_counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(ref_counts, op=dist.ReduceOp.SUM)
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     mom_ms = [s.elapsed_time(e_) for s, e_ in timing["moments"]]
@@ -254,6 +268,17 @@ def main():
                                "corr_scores_avg_ms": round(float(np.mean(sel_ms)), 3) if sel_ms else None,
                                "note": "recall of the transform SELECTED by feature correlation among the M RTUME "
                                        "hypotheses, on synthetic pairs (no ICP refinement)"}
+    if a.with_selection and a.with_refinement:
+        rc = ref_counts.cpu().numpy()
+        result["metric"] = "registration_pairs_per_s_with_selection_and_icp"
+        result["config"]["workload"] += " + f2 point-to-point ICP (0.2 m, <= 200 iterations)"
+        result["refinement"] = {"pairs": int(rc[0]), "rr_1.5deg_0.6m": round(rc[1] / max(rc[0], 1), 4),
+                                "rr_1.5deg_0.3m": round(rc[2] / max(rc[0], 1), 4), "rr_1deg_0.1m": round(rc[3] / max(rc[0], 1), 4),
+                                "icp_avg_ms": round(1e3 * float(np.mean([x[0] for x in icp_log])), 3) if icp_log else None,
+                                "icp_avg_iterations": round(float(np.mean([x[1] for x in icp_log])), 1) if icp_log else None,
+                                "icp_avg_fitness": round(float(np.mean([x[2] for x in icp_log])), 4) if icp_log else None,
+                                "note": "recall after ICP refinement of the selected transform (reference evaluate.py:301-309), "
+                                        "synthetic pairs; rank 0's ICP timings"}
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc
