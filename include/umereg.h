@@ -97,11 +97,15 @@ int umereg_pack_points_f32(const float* pts, int B, int N, float radius, void* p
                            size_t packed_bytes, void* stream);
 int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
                                   const float* feat, int B, int N, int n_kp, int feat_dim, int K,
-                                  float radius, int ordered, float* F, int32_t* nn_count,
+                                  float radius, int flags, float* F, int32_t* nn_count,
                                   int64_t* nn_idx, void* stream);
-/*   ordered != 0: process keypoints in the cell-sorted, XCD-sliced order that
+/*   flags & UMEREG_MOMENTS_ORDERED: process keypoints in the cell-sorted, XCD-sliced order that
  *   umereg_ume_keypoint_order wrote into `packed` for these same keypoints (results are unchanged;
- *   only cache locality differs).  Requires n_kp <= N rounded up to 256. */
+ *   only cache locality differs).  Requires n_kp <= N rounded up to 256.
+ *   flags & UMEREG_MOMENTS_RAW: F = [sum f, sum f p^T] without the normaliser -- the matrix of
+ *   generate_ume_from_keypoints2(normalized_ume=False), utils/loc_utils.py:160-162. */
+#define UMEREG_MOMENTS_ORDERED 1
+#define UMEREG_MOMENTS_RAW 2
 int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
                               int n_kp, float radius, void* stream);
 /*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers
@@ -270,6 +274,13 @@ size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M);
 int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
                            const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
                            float* scores, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3  torch.linalg.svdvals(ume)                                       utils/eval_utils.py:31-32
+ * Singular values (descending) of each 32x4 UME matrix, one-sided Jacobi in fp64.
+ *   ume f32 [n,32,4] -> sv f32 [n,4]
+ * ------------------------------------------------------------------------------------------- */
+int umereg_ume_svdvals_f32(const float* ume, int n, float* sv, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f2  o3d.pipelines.registration.registration_icp(src, tgt, max_dist, T_init,

@@ -106,10 +106,49 @@ def unit_feat(rng, pts, d=32):
     return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
 
 
+def gen_g8(loc_utils, eval_utils):
+    """G8: generate_ume_from_keypoints2 (utils/loc_utils.py:86-188) + calc_inliear_ratio (utils/eval_utils.py:8-57)."""
+    p = synth_pair(21, N=3000, n_kp=64)
+    rng = np.random.RandomState(8)
+    seg = rng.choice([1, 2, 9, 9, 11], size=(1, 3000, 1)).astype(np.int64)      # label 9 = "flat", ignored
+    # a target that only partly overlaps the source: drop a slab of it
+    keep = p.tgt_pts[:, 0] < np.percentile(p.tgt_pts[:, 0], 80)
+    tgt_pts, tgt_feat = p.tgt_pts[keep], p.tgt_feat[keep]
+    tgt_feat = tgt_feat + 1.0 * rng.standard_normal(tgt_feat.shape).astype(np.float32)   # imperfect descriptors
+    tgt_feat = (tgt_feat / np.linalg.norm(tgt_feat, axis=1, keepdims=True)).astype(np.float32)
+    out = dict(src_pts=p.src_pts, src_seg=seg[0], src_feat=p.src_feat, tgt_pts=tgt_pts, tgt_feat=tgt_feat,
+               gt_tform=p.gt_tform)
+    cfgs = dict(a=dict(nn_r=5.0, max_nn=64, min_nn=10, num_samples=48, normalized_ume=False),
+                b=dict(nn_r=4.0, max_nn=32, min_nn=12, num_samples=4000, normalized_ume=True))
+    for tag, c in cfgs.items():
+        with torch.no_grad():
+            r = loc_utils.generate_ume_from_keypoints2(_t(p.src_pts[None]), _t(seg), _t(p.src_feat[None]), _t(tgt_pts[None]),
+                                                       _t(tgt_feat[None]), _t(p.gt_tform[None]), flat_labels=[9],
+                                                       nn_intersection_r=0.6, **c)
+        for k, v in zip(("F_velo", "F_ref", "velo_kp", "ref_kp", "ratio", "with_kpts"), r):
+            out[f"{k}_{tag}"] = v.numpy()
+        for k, v in c.items():
+            out[f"cfg_{k}_{tag}"] = np.float64(v)
+        print("G8", tag, {k: tuple(v.shape) for k, v in zip(("F_velo", "F_ref", "velo_kp", "ref_kp", "ratio"), r)})
+    with torch.no_grad():
+        src_in = dict(pts=_t(p.src_pts[None]), seg=_t(seg), feat=_t(p.src_feat[None]))
+        tgt_in = dict(pts=_t(tgt_pts[None]), seg=_t(seg[:, :tgt_pts.shape[0]]), feat=_t(tgt_feat[None]))
+        for tag, kw in dict(a=dict(ume_r_nn=5.0, ume_max_nn=64, ume_min_nn=10, eval_num_kpts=48),
+                            b=dict(ume_r_nn=4.0, ume_max_nn=32, ume_min_nn=12, eval_num_kpts=30)).items():
+            ir = eval_utils.calc_inliear_ratio(src_in, tgt_in, None, _t(p.gt_tform[None]), keypoints_ignore_segments=[9],
+                                               inlear_thr=0.6, nn_inter_thr=0.6, svd_thr=1e-5, **kw)
+            out[f"inlier_ratio_{tag}"] = ir.numpy()
+            print("G8 inlier ratio", tag, ir.numpy())
+    np.savez_compressed(os.path.join(OUT, "g8_gt_ume_inlier.npz"), **out)
+
+
 def main():
     loc_utils, eval_utils, evaluate = import_reference()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        gen_g8(loc_utils, eval_utils)
+        return
 
     # ---- G1 ball_query (oracle restatement; parity unpinned) + G2 my_ume_generation -------------
     rng = np.random.RandomState(1)
@@ -258,6 +297,7 @@ def main():
                         score=score.numpy(), best_T=best.numpy(), gt_index=np.int64(np.where(order == 0)[0][0]))
     print("G7 scores", score.numpy(), "best is gt:", bool(torch.allclose(best, _t(Ts[np.where(order == 0)[0][0]]))))
 
+    gen_g8(loc_utils, eval_utils)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -422,3 +422,102 @@ def icp_point_to_point(src, tgt, T_init, max_dist=0.2, max_iteration=30, relativ
         if abs(pf - fit) < relative_fitness and abs(pr - rmse) < relative_rmse:
             break
     return T, fit, rmse, it
+
+
+# ---------------------------------------------------------------------------------------------------
+# f3: ground-truth-driven UME generator + inlier ratio (numpy restatement, statement by statement, of
+# reference utils/loc_utils.py:86-188 and utils/eval_utils.py:8-57; fp32 tensors like the reference).
+def generate_ume_from_keypoints2(velo_pts, velo_seg, velo_feat, ref_pts, ref_feat, gt_tform, nn_r=10, max_nn=5000,
+                                 min_nn=1000, num_samples=1024, flat_labels=(9,), normalized_ume=False,
+                                 nn_intersection_r=0.6):
+    velo_pts, velo_feat, ref_pts, ref_feat, gt_tform = (np.asarray(a, np.float32) for a in (velo_pts, velo_feat, ref_pts, ref_feat, gt_tform))
+    bs, velo_pc_size, dim_size = velo_feat.shape
+    ref_pc_size = ref_pts.shape[1]
+    non_floor_mask = (np.asarray(velo_seg) != np.asarray(flat_labels)).all(axis=-1).reshape(bs, -1)              # :93
+    R_gt, t_gt = gt_tform[:, :3, :3], gt_tform[:, :3, 3]
+    velo_pts_tform = (velo_pts @ R_gt.transpose(0, 2, 1) + t_gt[:, None]).astype(np.float32)                     # :98
+    tt = ball_query(velo_pts_tform, ref_pts, K=1, radius=nn_intersection_r, return_nn=False).idx                 # :99
+    filter_cond = (tt[..., 0] > -1) & non_floor_mask                                                             # :100-101
+    mask_idxs_tensor = -np.ones((bs, velo_pc_size), np.int64)                                                    # :103-108
+    for b in range(bs):
+        w = np.where(filter_cond[b])[0]
+        mask_idxs_tensor[b, w] = w
+    mask_idxs_tensor = -np.sort(-mask_idxs_tensor, axis=1)
+    lengths = (mask_idxs_tensor > -1).sum(-1)
+    mask_idxs_tensor[mask_idxs_tensor == -1] = 0
+    keypoints_velo_pts = np.take_along_axis(velo_pts, mask_idxs_tensor[..., None].repeat(3, -1), 1)
+    min_length = int(lengths.min())                                                                              # :111
+    bq = ball_query(keypoints_velo_pts, velo_pts, lengths1=lengths, K=max_nn, radius=nn_r, return_nn=True)       # :112
+    bq_idxs, bq_nn = bq.idx[:, :min_length], bq.knn[:, :min_length]
+    dense_cond = (bq_idxs > -1).sum(-1) >= min_nn                                                                # :119
+    mit = -np.ones((bs, min_length), np.int64)
+    for b in range(bs):
+        w = np.where(dense_cond[b])[0]
+        mit[b, w] = w
+    mit = -np.sort(-mit, axis=1)
+    lengths2 = (mit > -1).sum(-1)
+    mit[mit == -1] = 0
+    min_length2 = int(lengths2.min())
+    with_kpts = lengths2 > 0                                                                                     # :128
+    if min_length2 == 0:                                                                                         # :129-141
+        mit, keypoints_velo_pts, bq_idxs, bq_nn = mit[with_kpts], keypoints_velo_pts[with_kpts], bq_idxs[with_kpts], bq_nn[with_kpts]
+        velo_feat, ref_feat, ref_pts, gt_tform = velo_feat[with_kpts], ref_feat[with_kpts], ref_pts[with_kpts], gt_tform[with_kpts]
+        min_length2 = int(lengths2[with_kpts].min())
+        R_gt, t_gt = gt_tform[:, :3, :3], gt_tform[:, :3, 3]
+        bs = R_gt.shape[0]
+    num_samples = min(min_length2, num_samples)                                                                  # :143
+    mit = mit[:, :num_samples]
+    velo_keypoint_pts = np.take_along_axis(keypoints_velo_pts, mit[..., None].repeat(3, -1), 1)
+    nn_idx = np.take_along_axis(bq_idxs, mit[..., None].repeat(max_nn, -1), 1).copy()
+    nn_idx[nn_idx == -1] = velo_pc_size
+    nn_pts = np.take_along_axis(bq_nn, mit[..., None, None].repeat(max_nn, -2).repeat(3, -1), 1)
+    feat_pad = np.concatenate([velo_feat, np.zeros_like(velo_feat[:, :1])], 1)
+
+    def ume(feat_pad_, idx_, pts_):
+        out = np.empty(idx_.shape[:2] + (dim_size, 4), np.float32)
+        for b in range(idx_.shape[0]):
+            f = feat_pad_[b][idx_[b]]                                    # [ns, max_nn, D]
+            F1 = np.einsum("nkd,nkc->ndc", f, pts_[b], dtype=np.float32)   # :160  (fp32 matmul, order-free check in tests)
+            F0 = f.sum(axis=1)[..., None]
+            F = np.concatenate([F0, F1], -1)
+            if normalized_ume:
+                F = F / (F0.sum(axis=-2, keepdims=True) + np.float32(1e-6))
+            out[b] = F
+        return out
+
+    F_velo = ume(feat_pad, nn_idx, nn_pts)
+    hom = np.concatenate([velo_keypoint_pts, np.ones_like(velo_keypoint_pts[..., :1])], -1) @ gt_tform.transpose(0, 2, 1)   # :165-167
+    ref_keypoint_pts = (hom[..., :3] / hom[..., 3:4]).astype(np.float32)
+    bq2 = ball_query(ref_keypoint_pts, ref_pts, K=max_nn, radius=nn_r, return_nn=True)                           # :168
+    ref_nn = bq2.knn
+    ridx = bq2.idx.copy()
+    ridx[ridx == -1] = ref_pc_size
+    F_ref = ume(np.concatenate([ref_feat, np.zeros_like(ref_feat[:, :1])], 1), ridx, ref_nn)
+    nn_tform = (nn_pts @ R_gt[:, None].transpose(0, 1, 3, 2) + t_gt[:, None, None]).astype(np.float32)           # :184
+    idx = ball_query(nn_tform.reshape(-1, max_nn, 3), ref_nn.reshape(-1, max_nn, 3), K=1, radius=nn_intersection_r,
+                     return_nn=False).idx
+    ratio = (idx > -1).reshape(bs, num_samples, -1).astype(np.float32).mean(-1)
+    return F_velo, F_ref, velo_keypoint_pts, ref_keypoint_pts, ratio, with_kpts
+
+
+def calc_inliear_ratio(src_inputs, tgt_inputs, gt_tform, ume_r_nn, ume_max_nn, ume_min_nn, eval_num_kpts,
+                       keypoints_ignore_segments=(), inlear_thr=0.6, nn_inter_thr=0.6, svd_thr=1e-5):
+    from scipy.optimize import linear_sum_assignment
+    gt_tform = np.asarray(gt_tform, np.float32)
+    ume_src, ume_tgt, src_kp, tgt_kp, _, _ = generate_ume_from_keypoints2(
+        src_inputs["pts"], src_inputs["seg"], src_inputs["feat"], tgt_inputs["pts"], tgt_inputs["feat"], gt_tform,
+        nn_r=ume_r_nn, max_nn=ume_max_nn, min_nn=ume_min_nn, num_samples=eval_num_kpts,
+        flat_labels=keypoints_ignore_segments, nn_intersection_r=nn_inter_thr)
+    ok = ((np.linalg.svd(ume_src, compute_uv=False) > svd_thr).sum(-1) == 4) & \
+         ((np.linalg.svd(ume_tgt, compute_uv=False) > svd_thr).sum(-1) == 4)                                    # :30-33
+    invalid = np.zeros(ume_src.shape[1], bool)
+    invalid[np.where(~ok)[1]] = True
+    ume_src, ume_tgt = ume_src[:, ~invalid], ume_tgt[:, ~invalid]
+    out = []
+    for b in range(ume_src.shape[0]):
+        D = ume_cdist(ume_src[b:b + 1], ume_tgt[b:b + 1])[0]                                                     # :40
+        si, ti = linear_sum_assignment(D)
+        R, t = gt_tform[b, :3, :3], gt_tform[b, :3, 3]
+        re = np.linalg.norm(tgt_kp[b][ti] - (src_kp[b][si] @ R.T + t), axis=-1)
+        out.append(np.float32((re <= inlear_thr).mean()))
+    return np.array(out, np.float32)

@@ -774,3 +774,82 @@ def test_refine_registration_mirror(gpu):
     T_est, rre, rte = refine_registration(R_hat, t_hat, SimpleNamespace(), pairs)
     assert T_est.shape == (2, 4, 4) and rre.shape == (2,) and rte.shape == (2,)
     assert float(rre.max()) < 0.05 and float(rte.max()) < 0.01
+
+
+# ------------------------------------------------------------- f3: GT-driven UME generator + inlier ratio
+def test_ume_moments_raw_and_svdvals(gpu):
+    """un-normalised moments (generate_ume_from_keypoints2, normalized_ume=False) and 32x4 singular values."""
+    from umeregrobust_amd import ops
+    g = load_golden("g12_ballquery_moments.npz")
+    pts, kpts, feat = g["pts"], g["kpts"], g["feat"]
+    Fn, cnt, idx = ops.ume_moments(T_(pts, gpu)[None], T_(kpts, gpu)[None], T_(feat, gpu)[None], 16, 5.0, return_count=True, return_idx=True)
+    Fr = N_(ops.ume_moments(T_(pts, gpu)[None], T_(kpts, gpu)[None], T_(feat, gpu)[None], 16, 5.0, normalize=False)[0])
+    idx = N_(idx[0])
+    fpad = np.concatenate([feat, np.zeros((1, 32), np.float32)]).astype(np.float64)
+    ppad = np.concatenate([pts, np.zeros((1, 3), np.float32)]).astype(np.float64)
+    f = fpad[idx]; p = ppad[idx]
+    F64 = np.concatenate([f.sum(1)[..., None], np.einsum("nkd,nkc->ndc", f, p)], -1)
+    scale = np.abs(F64).max(axis=(1, 2), keepdims=True) + 1e-30
+    assert (np.abs(Fr - F64) / scale).max() < 3e-7
+    sv = N_(ops.ume_svdvals(T_(Fr, gpu)))
+    sv64 = np.linalg.svd(Fr.astype(np.float64), compute_uv=False)
+    assert sv.shape == (kpts.shape[0], 4) and (np.diff(sv, axis=1) <= 0).all()
+    assert np.abs(sv - sv64).max() <= 2e-6 * sv64.max() and (np.abs(sv - sv64) <= 1e-6 * sv64[:, :1] + 1e-30).all()
+    rng = np.random.RandomState(0)
+    A = rng.standard_normal((100, 32, 4)).astype(np.float32)
+    A[:, :, 3] = A[:, :, 0] * np.float32(2.0)                        # rank 3: smallest singular value ~ 0
+    A[50:, :, 2] *= np.float32(1e-6)                                 # tiny but non-zero third singular value
+    sv = N_(ops.ume_svdvals(T_(A, gpu)))
+    sv64 = np.linalg.svd(A.astype(np.float64), compute_uv=False)
+    assert (sv[:, 3] < 1e-6).all() and np.abs(sv[:, :3] - sv64[:, :3]).max() < 1e-5
+    assert np.abs(sv[50:, 2] / sv64[50:, 2] - 1).max() < 1e-4        # relative accuracy of a 1e-6-sized value
+    assert N_(ops.ume_svdvals(torch.zeros(2, 3, 32, 4, device=gpu))).shape == (2, 3, 4)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_generate_ume_from_keypoints2_golden_gpu(gpu, tag):
+    """f3 against the reference's own outputs (G8): same keypoints in the same order, same ratio, UMEs within
+    the reference's fp32 summation noise."""
+    from umeregrobust_amd.utils.loc_utils import generate_ume_from_keypoints2
+    from tests.test_oracle_golden import _g8_call, check_g8_outputs
+    g = load_golden("g8_gt_ume_inlier.npz")
+    fn = lambda *a, **k: tuple(N_(o) for o in generate_ume_from_keypoints2(*(T_(x, gpu) for x in a), **k))
+    check_g8_outputs(_g8_call(fn, g, tag), g, tag, 2e-5)
+
+
+def test_generate_ume_from_keypoints2_batch_vs_oracle(gpu):
+    """bs = 2 with different candidate counts (the reference truncates to the batch minimum) and one element
+    whose keypoints all fail the density test (dropped, with_kpts False)."""
+    from umeregrobust_amd.utils.loc_utils import generate_ume_from_keypoints2
+    from umeregrobust_amd.synth import synth_pair
+    rng = np.random.RandomState(4)
+    ps = [synth_pair(31 + i, N=2500, n_kp=16) for i in range(3)]
+    src = np.stack([p.src_pts for p in ps]); tgt = np.stack([p.tgt_pts for p in ps])
+    sf = np.stack([p.src_feat for p in ps]); tf = np.stack([p.tgt_feat for p in ps]); gt = np.stack([p.gt_tform for p in ps])
+    seg = rng.choice([1, 9], size=(3, 2500, 1), p=[0.7, 0.3]).astype(np.int64)
+    src[2] = src[2] * np.float32(6.0); tgt[2] = (src[2] @ gt[2, :3, :3].T + gt[2, :3, 3]).astype(np.float32)   # sparse: nothing dense
+    kw = dict(nn_r=5.0, max_nn=48, min_nn=12, num_samples=40, flat_labels=[9], normalized_ume=False, nn_intersection_r=0.6)
+    ref = orc.generate_ume_from_keypoints2(src, seg, sf, tgt, tf, gt, **kw)
+    out = tuple(N_(o) for o in generate_ume_from_keypoints2(T_(src, gpu), T_(seg, gpu), T_(sf, gpu), T_(tgt, gpu), T_(tf, gpu), T_(gt, gpu), **kw))
+    assert np.array_equal(out[5], ref[5]) and list(out[5]) == [True, True, False]
+    assert np.array_equal(out[2], ref[2]) and np.abs(out[3] - ref[3]).max() < 1e-5 and np.abs(out[4] - ref[4]).max() < 1e-6
+    for a, b in ((out[0], ref[0]), (out[1], ref[1])):
+        scale = np.abs(b).max(axis=(2, 3), keepdims=True) + 1e-30
+        assert (np.abs(a - b) / scale).max() < 2e-4 and np.median(np.abs(a - b) / scale) < 1e-6
+
+
+def test_calc_inliear_ratio_golden_gpu(gpu):
+    from umeregrobust_amd.utils.eval_utils import calc_inliear_ratio
+    g = load_golden("g8_gt_ume_inlier.npz")
+    src = dict(pts=T_(g["src_pts"], gpu)[None], seg=T_(g["src_seg"], gpu)[None], feat=T_(g["src_feat"], gpu)[None])
+    tgt = dict(pts=T_(g["tgt_pts"], gpu)[None], seg=None, feat=T_(g["tgt_feat"], gpu)[None])
+    gt = T_(g["gt_tform"], gpu)[None]
+    for tag, kw in dict(a=dict(ume_r_nn=5.0, ume_max_nn=64, ume_min_nn=10, eval_num_kpts=48),
+                        b=dict(ume_r_nn=4.0, ume_max_nn=32, ume_min_nn=12, eval_num_kpts=30)).items():
+        ir = calc_inliear_ratio(src, tgt, None, gt, keypoints_ignore_segments=[9], inlear_thr=0.6, nn_inter_thr=0.6, **kw)
+        assert ir.shape == (1,)
+        assert abs(float(ir[0]) - float(g[f"inlier_ratio_{tag}"][0])) <= 2.5 / kw["eval_num_kpts"]
+    # clean descriptors: every match is an inlier
+    tgt2 = dict(pts=src["pts"] @ gt[0, :3, :3].T + gt[0, :3, 3], seg=None, feat=src["feat"])
+    ir = calc_inliear_ratio(src, tgt2, None, gt, 5.0, 64, 10, 48, keypoints_ignore_segments=[9])
+    assert float(ir[0]) == 1.0

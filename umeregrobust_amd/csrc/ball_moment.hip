@@ -452,9 +452,10 @@ constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 me
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
-    float radius, int ordered, float* __restrict__ F, int32_t* __restrict__ nn_count,
+    float radius, int flags, float* __restrict__ F, int32_t* __restrict__ nn_count,
     int64_t* __restrict__ nn_idx)
 {
+    const bool ordered = flags & UMEREG_MOMENTS_ORDERED;
     extern __shared__ int lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -541,7 +542,8 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     double s = (a0[0] + a0[1]) + (a0[2] + a0[3]);
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) s += shfl_xor_f64(s, m);
-    const double den = s + 1e-6;
+    // UMEREG_MOMENTS_RAW: the un-normalised matrix of generate_ume_from_keypoints2 (utils/loc_utils.py:160-162)
+    const double den = (flags & UMEREG_MOMENTS_RAW) ? 1.0 : s + 1e-6;
     if (slot == 0) {
         float4* o = reinterpret_cast<float4*>(F + (((size_t)b * n_kp + kp) * 32 + 4 * qd) * 4);
 #pragma unroll
@@ -664,7 +666,7 @@ UMEREG_API int umereg_ume_keypoint_order(void* packed, const float* kpts, const 
 
 UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
                                              const float* feat, int B, int N, int n_kp, int feat_dim, int K,
-                                             float radius, int ordered, float* F, int32_t* nn_count, int64_t* nn_idx,
+                                             float radius, int flags, float* F, int32_t* nn_count, int64_t* nn_idx,
                                              void* stream)
 {
     UMEREG_REQUIRE(packed && (kpts || kp_index) && feat && F, "ume_moments: null pointer (packed/kpts|kp_index/feat/F)");
@@ -681,7 +683,7 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     dim3 grid((n_kp + waves - 1) / waves, B);
     hipLaunchKernelGGL(ume_moments_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
                        (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                       n_kp, K, cap, radius, ordered, F, nn_count, nn_idx);
+                       n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
     return UMEREG_OK;
 }

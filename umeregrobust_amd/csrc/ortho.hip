@@ -48,6 +48,47 @@ __global__ __launch_bounds__(256) void orthobasis_kernel(const float* __restrict
     }
 }
 
+// singular values of each 32x4 UME (torch.linalg.svdvals at reference utils/eval_utils.py:31-32): one-sided
+// Jacobi (Hestenes) on the four columns in fp64, 32 lanes per matrix -- small singular values keep their
+// relative accuracy (the Gram-matrix route would lose everything below 1e-8 * sigma_max).
+__global__ __launch_bounds__(256) void svdvals_kernel(const float* __restrict__ ume, int n, float* __restrict__ sv)
+{
+    const int row = threadIdx.x & 31;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (i >= n) return;  // uniform per 32-lane group
+    const float4 f = reinterpret_cast<const float4*>(ume)[(size_t)i * 32 + row];
+    double a[4] = {f.x, f.y, f.z, f.w};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                const double alpha = group32_sum(a[p] * a[p]);
+                const double beta = group32_sum(a[q] * a[q]);
+                const double gamma = group32_sum(a[p] * a[q]);
+                if (fabs(gamma) > 1e-15 * sqrt(alpha * beta) && gamma != 0.0) {
+                    const double zeta = (beta - alpha) / (2.0 * gamma);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                    const double ap = c * a[p] - s * a[q], aq = s * a[p] + c * a[q];
+                    a[p] = ap;
+                    a[q] = aq;
+                    rotated = true;
+                }
+            }
+        if (!rotated) break;   // uniform: the sums are group-wide
+    }
+    double s4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s4[c] = sqrt(group32_sum(a[c] * a[c]));
+    // descending order (4-element sorting network)
+#define UMEREG_CSWAP(x, y) { const double lo = fmin(s4[x], s4[y]), hi = fmax(s4[x], s4[y]); s4[x] = hi; s4[y] = lo; }
+    UMEREG_CSWAP(0, 1) UMEREG_CSWAP(2, 3) UMEREG_CSWAP(0, 2) UMEREG_CSWAP(1, 3) UMEREG_CSWAP(1, 2)
+#undef UMEREG_CSWAP
+    if (row == 0) reinterpret_cast<float4*>(sv)[i] = make_float4((float)s4[0], (float)s4[1], (float)s4[2], (float)s4[3]);
+}
+
 int qlayout_pad(int layout)
 {
     switch (layout) {
@@ -88,4 +129,15 @@ UMEREG_API int umereg_ume_orthobasis_f32(const float* ume, int n, int layout, fl
     UMEREG_REQUIRE(((uintptr_t)ume & 15) == 0 && ((uintptr_t)Q & 15) == 0, "ume_orthobasis: pointers must be 16-byte aligned");
     if (int rc = check_device()) return rc;
     return launch_orthobasis(ume, n, layout, Q, (hipStream_t)stream);
+}
+
+UMEREG_API int umereg_ume_svdvals_f32(const float* ume, int n, float* sv, void* stream)
+{
+    UMEREG_REQUIRE(ume && sv, "ume_svdvals: null pointer");
+    UMEREG_REQUIRE(n > 0, "ume_svdvals: n must be positive (got %d)", n);
+    UMEREG_REQUIRE(((uintptr_t)ume & 15) == 0 && ((uintptr_t)sv & 15) == 0, "ume_svdvals: pointers must be 16-byte aligned");
+    if (int rc = check_device()) return rc;
+    hipLaunchKernelGGL(svdvals_kernel, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, ume, n, sv);
+    UMEREG_CHECK_LAUNCH("svdvals_kernel");
+    return UMEREG_OK;
 }

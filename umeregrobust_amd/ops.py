@@ -103,12 +103,14 @@ def _timed_end(timing, ev, dev):
         timing.append(ev)
 
 
-def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None, kp_index=None):
+def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None, kp_index=None,
+                normalize=True):
     """Fused ball query + gather + UME moment matrix (reference evaluate.py:50-60).
     pts [B,N,3], kpts [B,n,3], feat [B,N,32] -> F [B,n,32,4] (+ nn_count i32 [B,n], nn_idx i64 [B,n,K]).
     timing: optional list; receives a (start, end) event pair bracketing the moment kernel alone.
     kp_index: optional int64 [B,n] -- keypoints as indices into pts (kpts may then be None): the gather
-    `pts[0, inds]` of reference evaluate.py:201-202 fused into the kernel."""
+    `pts[0, inds]` of reference evaluate.py:201-202 fused into the kernel.
+    normalize=False: the un-normalised matrix of generate_ume_from_keypoints2 (utils/loc_utils.py:160-162)."""
     lib = _lib.load()
     pts = _dev(pts, "pts"); feat = _dev(feat, "feat")
     if kp_index is not None:
@@ -144,7 +146,7 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
                 _lib.check(rc, "umereg_ume_keypoint_order")
             ev = _timed(timing, dev)
             rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(kp_index), _ptr(feat), B, N, n, d, int(K),
-                                                   float(radius), ordered, _ptr(F), _ptr(cnt), _ptr(nidx),
+                                                   float(radius), ordered | (0 if normalize else 2), _ptr(F), _ptr(cnt), _ptr(nidx),
                                                    _stream_ptr(dev))
             _lib.check(rc, "umereg_ume_moments_packed_f32")
             _timed_end(timing, ev, dev)
@@ -487,3 +489,18 @@ def icp_point_to_point(src_pts, tgt_pts, T_init, max_correspondence_distance=0.2
                                                _ptr(ws), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "umereg_icp_point_to_point_f32")
     return SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
+
+
+def ume_svdvals(ume):
+    """torch.linalg.svdvals of 32x4 UME matrices (reference utils/eval_utils.py:31-32): ume [...,32,4] -> [...,4]."""
+    lib = _lib.load()
+    ume = _dev(ume, "ume")
+    if ume.dim() < 2 or ume.shape[-2:] != (32, 4):
+        raise ValueError(f"ume_svdvals: expected [...,32,4], got {tuple(ume.shape)}")
+    n = ume.numel() // 128
+    sv = torch.empty(ume.shape[:-2] + (4,), dtype=torch.float32, device=ume.device)
+    if n > 0:
+        with torch.cuda.device(ume.device):
+            rc = lib.umereg_ume_svdvals_f32(_ptr(ume), n, _ptr(sv), _stream_ptr(ume.device))
+        _lib.check(rc, "umereg_ume_svdvals_f32")
+    return sv

@@ -30,6 +30,75 @@ def batch_estimate_transform_ume_old(G, H):
     return T, D
 
 
+def generate_ume_from_keypoints2(velo_pts, velo_seg, velo_feat, ref_pts, ref_feat, gt_tform,
+                                 nn_r=10, max_nn=5000, min_nn=1000, num_samples=1024, flat_labels=[9],
+                                 normalized_ume=False, nn_intersection_r=0.6):
+    """reference utils/loc_utils.py:86-188.  Ground-truth-driven keypoints: source points that are not of a
+    flat class (:93), overlap the target under gt_tform (:96-101) and have >= min_nn neighbours within nn_r
+    (:111-126) -- the first `num_samples` of them in the reference's (descending-index) order -- with the
+    UME matrices of their neighbourhoods in both clouds and the matched-neighbourhood intersection ratio.
+    -> F_velo, F_ref [bs',ns,D,4], velo_keypoint_pts, ref_keypoint_pts [bs',ns,3], ratio [bs',ns], with_kpts [bs].
+
+    Same outputs as the reference; the [bs,N,max_nn,3] neighbour tensor it builds for EVERY candidate (:113-116)
+    is replaced by the fused count + moment kernel, neighbour lists are only formed for the selected keypoints."""
+    bs, velo_pc_size, dim_size = velo_feat.shape
+    dev = velo_pts.device
+    non_floor_mask = (velo_seg != torch.tensor(flat_labels, device=velo_seg.device)).all(dim=-1).flatten(1)     # :93
+    R_gt = gt_tform[:, :3, :3]
+    t_gt = gt_tform[:, :3, 3]
+    velo_pts_tform = velo_pts @ R_gt.transpose(-1, -2) + t_gt[:, None]                                          # :98
+    tt = ball_query(velo_pts_tform.contiguous(), ref_pts, K=1, radius=nn_intersection_r, return_nn=False).idx   # :99
+    filter_cond = (tt[..., 0] > -1) & non_floor_mask                                                             # :100-101
+    # candidates in DESCENDING index order, zero padded (:103-108)
+    ar = torch.arange(velo_pc_size, device=dev).expand(bs, -1)
+    mask_idxs_tensor = torch.where(filter_cond, ar, torch.full_like(ar, -1)).sort(dim=1, descending=True)[0]
+    lengths = (mask_idxs_tensor > -1).sum(dim=-1)
+    min_length = int(lengths.min())
+    if min_length == 0:
+        # the reference fails inside torch.gather / min() on an empty selection; say why instead
+        raise RuntimeError("generate_ume_from_keypoints2: a batch element has no candidate keypoint "
+                           "(no non-flat source point overlaps the target)")
+    cand = mask_idxs_tensor[:, :min_length].clamp_min(0)                                                        # :115-116
+    keypoints_velo_pts = torch.gather(velo_pts, 1, cand[..., None].expand(-1, -1, 3))
+    # neighbour counts (:119) and UME matrices (:146-162) of every candidate in one fused pass
+    F_all, cnt = ops.ume_moments(velo_pts, None, velo_feat, max_nn, nn_r, return_count=True, kp_index=cand,
+                                 normalize=bool(normalized_ume))
+    dense_cond = cnt >= min_nn
+    pos = torch.arange(min_length, device=dev).expand(bs, -1)
+    pos_sorted = torch.where(dense_cond, pos, torch.full_like(pos, -1)).sort(dim=1, descending=True)[0]         # :120-123
+    lengths2 = (pos_sorted > -1).sum(dim=-1)
+    pos_sorted = pos_sorted.clamp_min(0)
+    with_kpts_batch_cond = lengths2 > 0                                                                          # :128
+    if not bool(with_kpts_batch_cond.any()):
+        raise RuntimeError("generate_ume_from_keypoints2: no keypoint with >= min_nn neighbours in any batch element")
+    if int(lengths2.min()) == 0:                                                                                 # :129-141
+        keep = with_kpts_batch_cond
+        pos_sorted, keypoints_velo_pts, F_all = pos_sorted[keep], keypoints_velo_pts[keep], F_all[keep]
+        velo_pts, velo_feat, ref_feat, ref_pts, gt_tform = velo_pts[keep], velo_feat[keep], ref_feat[keep], ref_pts[keep], gt_tform[keep]
+        lengths2 = lengths2[keep]
+        R_gt = gt_tform[:, :3, :3]
+        t_gt = gt_tform[:, :3, 3]
+        bs = R_gt.shape[0]
+    num_samples = min(int(lengths2.min()), num_samples)                                                          # :143
+    sel = pos_sorted[:, :num_samples]
+    velo_keypoint_pts = torch.gather(keypoints_velo_pts, 1, sel[..., None].expand(-1, -1, 3))                    # :145
+    F_velo = torch.gather(F_all, 1, sel[..., None, None].expand(-1, -1, dim_size, 4)).contiguous()
+    # matched keypoints in the target (:165-168) and their UME matrices (:169-181)
+    ref_keypoint_pts = torch.cat([velo_keypoint_pts, torch.ones_like(velo_keypoint_pts[..., :1])], dim=-1)
+    ref_keypoint_pts = ref_keypoint_pts @ gt_tform.transpose(-1, -2)
+    ref_keypoint_pts = (ref_keypoint_pts[..., :3] / ref_keypoint_pts[..., 3].unsqueeze(-1)).contiguous()
+    F_ref = ops.ume_moments(ref_pts.contiguous(), ref_keypoint_pts, ref_feat.contiguous(), max_nn, nn_r,
+                            normalize=bool(normalized_ume))
+    # matched-neighbourhood intersection ratio (:183-190): padded slots count like the reference's zeros
+    velo_nn = ball_query(velo_keypoint_pts.contiguous(), velo_pts.contiguous(), K=max_nn, radius=nn_r, return_nn=True).knn
+    ref_nn = ball_query(ref_keypoint_pts, ref_pts.contiguous(), K=max_nn, radius=nn_r, return_nn=True).knn
+    velo_nn_tform = velo_nn @ R_gt[:, None].transpose(-1, -2) + t_gt[:, None, None]
+    idx = ball_query(velo_nn_tform.flatten(0, 1).contiguous(), ref_nn.flatten(0, 1).contiguous(), K=1,
+                     radius=nn_intersection_r, return_nn=False).idx
+    matched_nn_intersection_ratio = (idx > -1).view(bs, num_samples, -1).float().mean(dim=-1)
+    return F_velo, F_ref, velo_keypoint_pts, ref_keypoint_pts, matched_nn_intersection_ratio, with_kpts_batch_cond
+
+
 def knn_gather(x, idx, lengths=None):
     """pytorch3d.ops.knn_gather: x [N,M,U], idx [N,L,K] -> [N,L,K,U] (plain device indexing)."""
     N, L, K = idx.shape
