@@ -17,17 +17,23 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_distributed(backend=None):
-    """One process per GPU; rendezvous through MASTER_ADDR/MASTER_PORT (torch.distributed.run)."""
+def init_distributed(backend=None, device_index=None):
+    """One process per GPU; rendezvous through MASTER_ADDR/MASTER_PORT (torch.distributed.run).
+    device_index: GPU of this rank (default LOCAL_RANK); bound to the process group so RCCL does not have to guess."""
     rank, local_rank, world = env_world()
+    if device_index is None:
+        device_index = local_rank
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            torch.cuda.set_device(device_index)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
