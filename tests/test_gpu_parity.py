@@ -853,3 +853,27 @@ def test_calc_inliear_ratio_golden_gpu(gpu):
     tgt2 = dict(pts=src["pts"] @ gt[0, :3, :3].T + gt[0, :3, 3], seg=None, feat=src["feat"])
     ir = calc_inliear_ratio(src, tgt2, None, gt, 5.0, 64, 10, 48, keypoints_ignore_segments=[9])
     assert float(ir[0]) == 1.0
+
+
+def test_sparse_quantize_and_select_hypothesis(gpu):
+    """reference evaluate.py:258-296: voxel thinning (first point per voxel, in order of appearance), K=1 feature
+    transfer, host-RNG sub-sampling and hypothesis selection; the selected transform must be the planted one."""
+    from umeregrobust_amd import evaluate
+    from types import SimpleNamespace
+    rng = np.random.RandomState(0)
+    pts = rng.uniform(-10, 10, (5000, 3)).astype(np.float32)
+    pts[100] = pts[7] + np.float32(0.01)                       # same voxel as an earlier point: dropped
+    coords, inds = evaluate.sparse_quantize(T_(pts, gpu), return_index=True, quantization_size=0.6)
+    q = np.floor(pts / np.float32(0.6)).astype(np.int64)
+    _, first = np.unique(q, axis=0, return_index=True)
+    assert np.array_equal(N_(inds), np.sort(first)) and np.array_equal(N_(coords), q[np.sort(first)])
+    assert 100 not in N_(inds) or not np.array_equal(q[100], q[7])
+    g = load_golden("g7_feature_corr.npz")
+    args = SimpleNamespace(corr_ds=0.6, pc_corr_max_size=10000, corr_kernel_sigma=1.5, corr_batch_size=3, batch_size=1)
+    gt = g["T_hyp"][int(g["gt_index"])]
+    R_err, t_err, R_hat, t_hat = evaluate.select_hypothesis(
+        T_(g["src_pts"], gpu), T_(g["tgt_pts"], gpu), T_(g["src_pts"], gpu)[None], T_(g["tgt_pts"], gpu)[None],
+        T_(g["src_feat"], gpu)[None], T_(g["tgt_feat"], gpu)[None], T_(g["T_hyp"], gpu)[None], T_(gt, gpu), args,
+        rng=np.random.RandomState(1))
+    assert np.allclose(N_(R_hat[0]), gt[:3, :3], atol=1e-6) and np.allclose(N_(t_hat[0]), gt[:3, 3], atol=1e-6)
+    assert float(R_err[0]) < 1e-2 and float(t_err[0]) < 1e-4

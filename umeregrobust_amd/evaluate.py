@@ -42,6 +42,55 @@ def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, cor
     return R_err, t_err, R_hat, t_hat
 
 
+def sparse_quantize(coordinates, return_index=True, quantization_size=1.0):
+    """MinkowskiEngine.utils.sparse_quantize as used at reference evaluate.py:261-264: one representative per
+    occupied voxel of edge `quantization_size`.  -> (voxel coords int32 [m,3], index int64 [m]).
+    MinkowskiEngine is not installable here (parity unpinned): this restates its documented behaviour --
+    floor(coordinates / quantization_size), the FIRST point of every voxel, in order of first appearance.
+    Device-side (stable sort of the voxel keys); coordinates [n,3] float tensor."""
+    q = torch.floor(coordinates / quantization_size).to(torch.int64)
+    qmin = q.min(dim=0).values
+    span = (q.max(dim=0).values - qmin + 1)
+    rel = q - qmin
+    key = (rel[:, 0] * span[1] + rel[:, 1]) * span[2] + rel[:, 2]
+    skey, perm = torch.sort(key, stable=True)
+    first = torch.ones_like(skey, dtype=torch.bool)
+    first[1:] = skey[1:] != skey[:-1]
+    inds = torch.sort(perm[first]).values
+    coords = q[inds].to(torch.int32)
+    return (coords, inds) if return_index else coords
+
+
+def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_feat, rtume_tform, gt_tform, args,
+                      rng=np.random, timing=None):
+    """reference evaluate.py:258-296 (one loop iteration): voxel-thin the RAW clouds (corr_ds / 0.3 m), give every
+    kept point the feature of its nearest network point (K=1), random-subsample to pc_corr_max_size with the host
+    RNG and let the FeatureCorrelator pick one RTUME hypothesis.
+    src_pts_raw [n,3], tgt_pts_raw [m,3]; src_pts/tgt_pts [1,N,3] with src_feat/tgt_feat [1,N,32];
+    rtume_tform [1,M,4,4]; gt_tform [4,4].  -> (R_err, t_err, R_hat_corr [1,3,3], t_hat_corr [1,3])."""
+    dev = src_pts.device
+    _, src_inds = sparse_quantize(src_pts_raw, return_index=True, quantization_size=args.corr_ds)       # :261-262
+    _, tgt_inds = sparse_quantize(tgt_pts_raw, return_index=True, quantization_size=0.3)                # :263-264
+    src_pts_raw = src_pts_raw[src_inds][None].to(dev)
+    tgt_pts_raw = tgt_pts_raw[tgt_inds][None].to(dev)
+    gt_tform = gt_tform[None].to(dev)
+    ind = ops.knn_points(src_pts_raw.contiguous(), src_pts, K=1)                                        # :272
+    src_feat_corr = torch.gather(src_feat, 1, ind[1][:, :, 0:1].expand(-1, -1, src_feat.shape[2]))     # knn_gather(...)[:, :, 0, :]
+    ind = ops.knn_points(tgt_pts_raw.contiguous(), tgt_pts, K=1)                                        # :274
+    tgt_feat_corr = torch.gather(tgt_feat, 1, ind[1][:, :, 0:1].expand(-1, -1, tgt_feat.shape[2]))
+    num_pts = min(args.pc_corr_max_size, src_pts_raw.shape[1])                                          # :278-285
+    rand_idxs = _index_tensor(rng.choice(src_pts_raw.shape[1], num_pts, replace=False), dev)
+    src_pts_raw = src_pts_raw[:, rand_idxs]
+    src_feat_corr = src_feat_corr[:, rand_idxs]
+    num_pts = min(args.pc_corr_max_size, tgt_pts_raw.shape[1])
+    rand_idxs = _index_tensor(rng.choice(tgt_pts_raw.shape[1], num_pts, replace=False), dev)
+    tgt_pts_raw = tgt_pts_raw[:, rand_idxs]
+    tgt_feat_corr = tgt_feat_corr[:, rand_idxs]
+    return pc_fcht(pc1_pts=src_pts_raw.contiguous(), pc2_pts=tgt_pts_raw.contiguous(), pc1_feat=src_feat_corr.contiguous(),
+                   pc2_feat=tgt_feat_corr.contiguous(), rtume_hypotises=rtume_tform, gt_tform=gt_tform,
+                   corr_sigma=args.corr_kernel_sigma, args=args, timing=timing)
+
+
 def refine_registration(R_hat, t_hat, args, pairs):
     """reference evaluate.py:63-109 (`refine_registration`): point-to-point ICP from every selected (R_hat, t_hat),
     max correspondence distance 0.2 m, max_iteration=200, then RRE / RTE against the ground truth.
