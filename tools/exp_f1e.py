@@ -2,7 +2,7 @@ import sys, ctypes, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch, time
 import umeregrobust_amd._build as b
-b.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libumereg_dbg.so')
+b.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('DBGLIB', 'libumereg_dbg.so'))
 import umeregrobust_amd._lib as L
 L.LIB_PATH = b.LIB_PATH
 L.SIGNATURES["umereg_knn_debug_counters"] = (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int])
@@ -25,10 +25,17 @@ def hyps(n, sigma_t, ang):
     return t(np.stack(Ts).astype(np.float32))
 names = ['knn calls', 'box iters', 'hist passes', 'overflow events', 'overflow drops', 'final drops', 'sum ring', 'cand steps(lane0 chunks)']
 cnt = (ctypes.c_ulonglong * 16)()
-for label, T in (('near-gt', hyps(64, 0.05, 0.5)), ('garbage 30m', hyps(64, 30.0, 180.0))):
+for label, T in (('near-gt', hyps(64, 0.05, 0.5)), ('3deg/1m', hyps(64, 1.0, 3.0)), ('garbage 30m', hyps(64, 30.0, 180.0))):
     lib.umereg_knn_debug_counters(cnt, 1)
     ops.corr_scores(sp, tp, sf, tf, T, K=20, sigma=1.5); torch.cuda.synchronize()
     lib.umereg_knn_debug_counters(cnt, 1)
     n = cnt[0]
     print(label, ' '.join(f'{nm}={cnt[i]}' for i, nm in enumerate(names)))
+    print('   anchored calls %d, fast overflow events %d, waves with slow lanes %d, lanes without fast ball %d, fast lanes short of K %d' % (cnt[8], cnt[10], cnt[11], cnt[12], cnt[13]))
     print('   per knn call: box iters %.2f hist passes %.2f final drops %.2f candidates/scan %.0f' % (cnt[1]/n, cnt[2]/n, cnt[5]/n, cnt[7]/(cnt[2]+n)))
+
+T = hyps(1024, 0.3, 1.0)
+for _ in range(2): ops.corr_scores(sp, tp, sf, tf, T, K=20, sigma=1.5)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): ops.corr_scores(sp, tp, sf, tf, T, K=20, sigma=1.5)
+torch.cuda.synchronize(); print('us per hypothesis (1deg/0.3m):', (time.perf_counter() - t0) / 3 / 1024 * 1e6)

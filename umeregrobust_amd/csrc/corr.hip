@@ -29,6 +29,8 @@
 namespace umereg {
 
 constexpr int kBins = 32;
+constexpr float kKnnMaxCells = 6.0f;   // upper bound of the first search radius, in cells
+constexpr float kKnnTarget = 2.0f;     // expected points in the first search ball, in units of K
 
 #ifdef UMEREG_KNN_DEBUG
 __device__ unsigned long long g_knn_dbg[16];
@@ -100,6 +102,63 @@ __device__ __forceinline__ int sel_bin(float d2, float lo, float sc)
     return b > kBins - 1 ? kBins - 1 : b;
 }
 
+// Candidate stream of ONE LANE: the cells that intersect its search ball (squared radius r2), row by row -- a
+// row's cells are one contiguous run of the sorted table, clipped to the chord of the ball in that row.  A
+// point with d2 < r2 always lies in a visited cell (cell_axis is monotone and the chord is computed from the
+// row's distance to the query, a lower bound of the point's).  Rows are walked in lock-step over the union of
+// the active lanes' row ranges; inside a row every lane advances through its own run, 4 candidates per trip.
+// Adjacent lanes touch the same cache lines.  body(d2, original index) is called for every candidate slot;
+// slots beyond a lane's run arrive with d2 = 3e38.
+template <class Body>
+__device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, float qz, bool act, float r2, int lane,
+                                          Body&& body)
+{
+    const Grid& g = c.g;
+    const float rq = act ? sqrtf(r2) * 1.0001f + 1e-20f : 0.f;
+    const int ylo = wave_min_i(act ? cell_axis(qy - rq, g.miny, g.invy, g.ny) : 0x7fffffff);
+    const int yhi = wave_max_i(act ? cell_axis(qy + rq, g.miny, g.invy, g.ny) : -1);
+    const int zlo = wave_min_i(act ? cell_axis(qz - rq, g.minz, g.invz, g.nz) : 0x7fffffff);
+    const int zhi = wave_max_i(act ? cell_axis(qz + rq, g.minz, g.invz, g.nz) : -1);
+    const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
+    for (int z = zlo; z <= zhi; ++z) {
+        const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
+        const float dzc = fmaxf(fmaxf(z_a - qz, qz - z_b), 0.f) * 0.9999f;
+        for (int y = ylo; y <= yhi; ++y) {
+            const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
+            const float dyc = fmaxf(fmaxf(y_a - qy, qy - y_b), 0.f) * 0.9999f;
+            const float rem = r2 - dyc * dyc - dzc * dzc;
+            const bool row = act && rem > 0.f;
+            const float sx = row ? sqrtf(rem) * 1.0001f + 1e-20f : 0.f;
+            const int cb = (z * g.ny + y) * g.nx;
+            int pos = row ? c.start[cb + cell_axis(qx - sx, g.minx, g.invx, g.nx)] : 0;
+            const int end = row ? c.start[cb + cell_axis(qx + sx, g.minx, g.invx, g.nx) + 1] : 0;   // empty run
+            // (staging the lanes' union run through LDS was measured: no faster, and its 4 KiB per
+            // wave cost a resident wave per SIMD)
+            while (__any(pos < end)) {
+                KNN_DBG(7, 4);
+                float d2[4];
+                int oi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = pos + u < end;
+                    const float4 p = c.P4s[ok ? pos + u : 0];
+                    const float dx = qx - p.x;
+                    const float dy = qy - p.y;
+                    const float dz = qz - p.z;
+                    float t = dx * dx;
+                    t = t + dy * dy;
+                    t = t + dz * dz;
+                    d2[u] = ok ? t : 3.0e38f;   // beyond this lane's run: never admitted
+                    oi[u] = __float_as_int(p.w);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(d2[u], oi[u]);
+                pos += 4;
+            }
+        }
+    }
+}
+
 // Exact K nearest target points of one query per lane.  On return, valid lanes hold min(K, n2) keys
 // ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).  stage: 64 float4 of LDS scratch.
 //
@@ -146,59 +205,27 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
 #pragma unroll
     for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
     bool done = !valid;
-    float margin = 2.0f * c.cs_min;   // search radius = dout + margin, margin doubles while the lane is starved
-
-    // Candidate stream of ONE LANE: the cells that intersect its search ball (squared radius S.hi0), row
-    // by row -- a row's cells are one contiguous run of the sorted table, clipped to the chord of the ball
-    // in that row.  A point with d2 < hi0 always lies in a visited cell (cell_axis is monotone and the
-    // chord is computed from the row's distance to the query, a lower bound of the point's).  Rows are
-    // walked in lock-step over the union of the active lanes' row ranges; inside a row every lane
-    // advances through its own run, 4 candidates per trip.  Adjacent lanes touch the same cache lines.
-    auto for_each_candidate = [&](bool act, auto&& body) {
-        const float rq = act ? sqrtf(S.hi0) * 1.0001f + 1e-20f : 0.f;
-        const int ylo = wave_min_i(act ? cell_axis(qy - rq, g.miny, g.invy, g.ny) : 0x7fffffff);
-        const int yhi = wave_max_i(act ? cell_axis(qy + rq, g.miny, g.invy, g.ny) : -1);
-        const int zlo = wave_min_i(act ? cell_axis(qz - rq, g.minz, g.invz, g.nz) : 0x7fffffff);
-        const int zhi = wave_max_i(act ? cell_axis(qz + rq, g.minz, g.invz, g.nz) : -1);
-        const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
-        for (int z = zlo; z <= zhi; ++z) {
-            const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
-            const float dzc = fmaxf(fmaxf(z_a - qz, qz - z_b), 0.f) * 0.9999f;
-            for (int y = ylo; y <= yhi; ++y) {
-                const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
-                const float dyc = fmaxf(fmaxf(y_a - qy, qy - y_b), 0.f) * 0.9999f;
-                const float rem = S.hi0 - dyc * dyc - dzc * dzc;
-                const bool row = act && rem > 0.f;
-                const float sx = row ? sqrtf(rem) * 1.0001f + 1e-20f : 0.f;
+    // Search radius = dout + margin; the margin doubles while the lane is starved, so its first value only
+    // matters for speed.  The grid's cell edge makes 2 cells right for the MEAN density; LiDAR clouds are far
+    // from uniform (walls, the dense ring near the sensor), so start from the LOCAL density instead: the
+    // count of the 3x3(x3) cell block around the query, aiming at ~3K points inside the ball, at most 2 cells.
+    float margin = 2.0f * c.cs_min;
+    if (valid) {
+        const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+        int n_loc = 0;
+        for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z)
+            for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
                 const int cb = (z * g.ny + y) * g.nx;
-                int pos = row ? c.start[cb + cell_axis(qx - sx, g.minx, g.invx, g.nx)] : 0;
-                const int end = row ? c.start[cb + cell_axis(qx + sx, g.minx, g.invx, g.nx) + 1] : 0;   // empty run
-                // (staging the lanes' union run through LDS was measured: no faster, and its 4 KiB per
-                // wave cost a resident wave per SIMD)
-                while (__any(pos < end)) {
-                    KNN_DBG(7, 4);
-                    float d2[4];
-                    int oi[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool ok = pos + u < end;
-                        const float4 p = c.P4s[ok ? pos + u : 0];
-                        const float dx = qx - p.x;
-                        const float dy = qy - p.y;
-                        const float dz = qz - p.z;
-                        float t = dx * dx;
-                        t = t + dy * dy;
-                        t = t + dz * dz;
-                        d2[u] = ok ? t : 3.0e38f;   // beyond this lane's run: never admitted
-                        oi[u] = __float_as_int(p.w);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) body(d2[u], oi[u]);
-                    pos += 4;
-                }
+                n_loc += c.start[cb + xb + 1] - c.start[cb + xa];
             }
-        }
-    };
+        const float ex = 3.0f / g.invx, ey = 3.0f / g.invy, ez = 3.0f / g.invz;
+        float r;
+        if (g.nz == 1)        // surface-like cloud, collapsed axis: pi r^2 * n_loc / (ex ey) = 3K
+            r = sqrtf(kKnnTarget * (float)K * ex * ey / (3.14159265f * (float)(n_loc + 1)));
+        else                  // 4/3 pi r^3 * n_loc / (ex ey ez) = 3K
+            r = cbrtf(kKnnTarget * (float)K * ex * ey * ez / (4.18879f * (float)(n_loc + 1)));
+        margin = fminf(kKnnMaxCells * c.cs_min, fmaxf(r, 0.25f * c.cs_min));
+    }
 
     for (;;) {   // coverage loop: grow a starved lane's radius until it provably holds its K nearest
         KNN_DBG(1, 1);
@@ -211,6 +238,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             S.lo[0] = 0.f;
             S.sc[0] = (float)kBins / S.hi0;
         }
+        int found = 0;         // candidates inside the ball when the lane turned out to be starved
         int c_lo = 0;          // candidates strictly below the current (deepest) range
         bool starved = false;  // fewer than K candidates within hi0: needs a bigger radius
         for (;;) {             // refinement loop at this radius
@@ -218,7 +246,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
 #pragma unroll
             for (int b = 0; b < kBins / 2; ++b) hist[b * kWave + lane] = 0u;   // two 16-bit counters per word
             const bool active = !done && !starved;
-            for_each_candidate(active, [&](float d2, int) {
+            walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
                 if (active && d2 < S.hi0) {
                     int b = sel_bin(d2, S.lo[0], S.sc[0]);
                     bool in = true;
@@ -238,6 +266,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
                 }
                 // (explicit per-level statements: runtime-indexed arrays would live in scratch memory)
                 if (bstar < 0) {
+                    found = cum;
                     if (full) {   // fewer than K points exist: keep them all
                         if (S.nlev == 1) S.bs[0] = kBins - 1; else if (S.nlev == 2) S.bs[1] = kBins - 1; else S.bs[2] = kBins - 1;
                         done = true;
@@ -264,13 +293,18 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             if (!__any(!done && !starved)) break;
         }
         if (!__any(!done)) break;
-        if (!done) margin *= 2.0f;
+        // a starved lane found `found` < K points inside its ball: LiDAR neighbourhoods are surface-like, so
+        // the count grows ~ r^2 -- jump to the radius expected to hold 1.5 K (at least x1.25, at most x4)
+        if (!done) margin = (dout + margin) * fminf(4.0f, fmaxf(1.25f, sqrtf(1.5f * (float)K / ((float)found + 0.5f)))) - dout;
     }
 
-    // append pass: every lane walks the ball it finished with
+    // append pass: every lane walks the ball that holds everything up to its threshold bin -- at level 0 a
+    // candidate is admitted only if int(d2 * sc0) <= bs0, i.e. d2 < (bs0 + 1) / sc0 (the last bin also takes the
+    // clamped overflow, so it keeps the full radius)
     int cnt = 0;
     unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
-    for_each_candidate(valid, [&](float d2, int oi) {
+    const float r2_app = S.bs[0] >= kBins - 1 ? S.hi0 : fminf(S.hi0, ((float)(S.bs[0] + 1) / S.sc[0]) * 1.0001f + 1e-30f);
+    walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi) {
         bool ok = valid && d2 < S.hi0;
         if (ok) {
             const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
