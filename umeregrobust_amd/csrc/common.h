@@ -60,11 +60,34 @@ __device__ __forceinline__ double shfl_f64(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// Butterfly partner of step S (0..4) inside an aligned group of 32 lanes, for all-reduces whose operands are
+// already uniform over the 2^S lanes combined so far: pairs and quads by quad_perm, 8s and 16s by the DPP row
+// mirrors (lane i <-> 7-i / 15-i: the same partner GROUP as i^4 / i^8), the two rows by one ds_swizzle.  Same
+// summation tree as the xor butterfly, i.e. bit-identical results, without the LDS-pipe round trips of
+// ds_bpermute (4 of the 5 steps are plain VALU moves).
+template <int S>
+__device__ __forceinline__ int partner32_i32(int x)
+{
+    if (S == 0) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    if (S == 1) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    if (S == 2) return __builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    if (S == 3) return __builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true);   // row_mirror
+    return __builtin_amdgcn_ds_swizzle(x, 0x401F);                           // lane ^ 16
+}
+template <int S>
+__device__ __forceinline__ double partner32_f64(double v)
+{
+    return __hiloint2double(partner32_i32<S>(__double2hiint(v)), partner32_i32<S>(__double2loint(v)));
+}
+
 // all-reduce (sum) over aligned groups of 32 lanes
 __device__ __forceinline__ double group32_sum(double v)
 {
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += shfl_xor_f64(v, m);
+    v += partner32_f64<0>(v);
+    v += partner32_f64<1>(v);
+    v += partner32_f64<2>(v);
+    v += partner32_f64<3>(v);
+    v += partner32_f64<4>(v);
     return v;
 }
 

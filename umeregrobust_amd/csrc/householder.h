@@ -45,10 +45,7 @@ __device__ __forceinline__ void householder_q_32x4(const double a_in[4], double 
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c] = v * q[c];
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) w[c] += shfl_xor_f64(w[c], m);
-        }
+        for (int c = 0; c < 4; ++c) w[c] = group32_sum(w[c]);   // four independent butterflies, interleaved by the scheduler
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] -= tau[k] * w[c] * v;
     }

@@ -50,6 +50,11 @@ __device__ inline void polar_rotation(const double A[3][3], double R[3][3])
         jacobi_rotate<0, 1>(B, V);
         jacobi_rotate<0, 2>(B, V);
         jacobi_rotate<1, 2>(B, V);
+        // converged: the off-diagonal mass is below the rounding of the diagonal (cyclic Jacobi converges
+        // quadratically; 3x3 problems need 3-5 sweeps)
+        const double off = B[0][1] * B[0][1] + B[0][2] * B[0][2] + B[1][2] * B[1][2];
+        const double dia = B[0][0] * B[0][0] + B[1][1] * B[1][1] + B[2][2] * B[2][2];
+        if (off <= 1e-34 * dia) break;
     }
     // pick the two largest eigenvalues (branch-free selects keep everything in registers)
     const double l0 = B[0][0], l1 = B[1][1], l2 = B[2][2];
