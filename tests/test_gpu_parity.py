@@ -352,6 +352,14 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     ok5 = s5[:, 1] - s5[:, 0] > 2e-5
     assert np.array_equal(m5[ok5], D5.argmin(axis=1)[ok5])
     assert (D5[np.arange(40), m5] ** 2 - s5[:, 0]).max() <= 2e-5
+    # overflow in a LATER target split only (regression: the overflow vote must count every split, not just the first):
+    # the copies sit at the end of a long target list
+    u6 = rng.standard_normal((6000, 32, 4)).astype(np.float32); u6[4000:] = u1[0]
+    m6, d6 = ops.ume_match(T_(u4, gpu)[None], T_(u6, gpu)[None], precision="f16r")
+    m6, d6 = N_(m6[0]), N_(d6[0])
+    assert (m6[:16] == 4000).all() and (d6[:16] < 2e-3).all()
+    mf6, _ = ops.ume_match(T_(u4, gpu)[None], T_(u6, gpu)[None], precision="f32")
+    assert np.array_equal(m6[16:], N_(mf6[0])[16:])
 
 
 def test_ume_cdist_batch(gpu):

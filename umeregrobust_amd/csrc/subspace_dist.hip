@@ -315,6 +315,7 @@ struct MatchScratch {
     unsigned int* cand;     // [n_blocks][splits][kRegionCap]  (local row << 27) | target
     int splits;
     unsigned int share_mask;   // bit k: share the limits after tile k of a split (k >= 31: every 32nd tile)
+    int force_exhaustive;      // testing probe: UMEREG_FORCE_EXHAUSTIVE
 };
 
 // all-reduce (max) over aligned groups of 32 lanes: DPP inside rows of 16, one swizzle across the two rows
@@ -333,21 +334,9 @@ __device__ __forceinline__ float group32_max(float v)
 // 32-target tile (8 KiB of hi fragments) is staged once per workgroup through a double-buffered LDS
 // stage.  The tile body is software-pipelined by hand in units of "groups" (one basis column b x two A
 // tiles = 4 MFMAs): the squares of group k run in the shadow of the MFMAs of group k+1.
-#ifndef UMEREG_COARSE_PROBE
-#define UMEREG_COARSE_PROBE 4   // timing probes (tools/exp_probe.py): 0 = MFMA stream only, 3 = no candidate queue
-#endif
-#ifndef UMEREG_COARSE_TA
-#define UMEREG_COARSE_TA 2
-#endif
-#ifndef UMEREG_COARSE_SCALAR
-#define UMEREG_COARSE_SCALAR 1
-#endif
-constexpr int kProbe = UMEREG_COARSE_PROBE;
-constexpr bool kScalarSq = UMEREG_COARSE_SCALAR != 0;
-constexpr int kCoarseTA = UMEREG_COARSE_TA;          // A tiles (8 source keypoints each) per wave
+constexpr int kCoarseTA = 2;                         // A tiles (8 source keypoints each) per wave
 constexpr int kCoarseRows = kCoarseTA * 8;           // source keypoints per wave
 constexpr int kCoarseWG = kCoarseRows * kDistWaves;  // source keypoints per workgroup (<= ROWS_F16X2 padding)
-struct Pairs8 { f32x2 p[8]; };
 
 // Workgroup = 4 waves x kCoarseRows source keypoints (stationary A tiles, hi planes only); every 32-target
 // tile (8 KiB of hi fragments) is staged once per workgroup through a double-buffered LDS stage, two
@@ -437,55 +426,51 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
     auto tile = [&](const int jt, half8 (&stLoad)[2], half8 (&stWrite)[2]) __attribute__((always_inline)) {
         if (jt + 2 < jt1) gload(stLoad, jt + 2);
         float sc[kCoarseTA][4];    // coarse scores of this lane's 4*TA (source, target) pairs
-        f32x2 sacc2[kCoarseTA][4];
-        f32x16 cc[kCoarseTA];
-        if (kProbe == 0) {
-#pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t) cc[t] = f32x16{0};
-        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const half8 b0 = ldsB[cur][(b * 2 + 0) * 64 + lane];
             const half8 b1 = ldsB[cur][(b * 2 + 1) * 64 + lane];
+            f32x16 cc[kCoarseTA];
 #pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t)
-                cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, kProbe == 0 ? cc[t] : f32x16{0}, 0, 0, 0);
+            for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, f32x16{0}, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
-            if (kProbe == 0) continue;
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (kScalarSq) {
-                        float acc = b == 0 ? cc[t][4 * g] * cc[t][4 * g] : fmaf(cc[t][4 * g], cc[t][4 * g], sc[t][g]);
-                        acc = fmaf(cc[t][4 * g + 1], cc[t][4 * g + 1], acc);
-                        acc = fmaf(cc[t][4 * g + 2], cc[t][4 * g + 2], acc);
-                        sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
-                    } else {
-                        const Pairs8 pp = __builtin_bit_cast(Pairs8, cc[t]);   // natural register pairs of the accumulator
-                        f32x2& acc = sacc2[t][g];
-                        acc = b == 0 ? pp.p[2 * g] * pp.p[2 * g] : __builtin_elementwise_fma(pp.p[2 * g], pp.p[2 * g], acc);
-                        acc = __builtin_elementwise_fma(pp.p[2 * g + 1], pp.p[2 * g + 1], acc);
-                    }
+                    // scalar FMAs on purpose: packed f32 VALU beside MFMAs is slower on gfx950
+                    float acc = b == 0 ? cc[t][4 * g] * cc[t][4 * g] : fmaf(cc[t][4 * g], cc[t][4 * g], sc[t][g]);
+                    acc = fmaf(cc[t][4 * g + 1], cc[t][4 * g + 1], acc);
+                    acc = fmaf(cc[t][4 * g + 2], cc[t][4 * g + 2], acc);
+                    sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
                 }
         }
-        if (kProbe == 0) {
 #pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t) lim[t][0] = max(lim[t][0], __float_as_int(cc[t][0]));
-        } else {
+        for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lim[t][g] = max(lim[t][g], __float_as_int(sc[t][g] - kCoarseMargin));
+        const int kt = jt - jt0;
+        if ((ms.share_mask >> (kt < 31 ? kt : 31)) & 1u) {
+            if (kt < 31 || (kt & 31) == 31) share(true);
+        }
+        unsigned long long hit[kCoarseTA][4], any = 0;
+#pragma unroll
+        for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                hit[t][g] = __builtin_amdgcn_ballot_w64(sc[t][g] >= __int_as_float(lim[t][g]));
+                any |= hit[t][g];
+            }
+        if (__builtin_popcountll(any) > 8) {
+            // a crowd of lanes hits at once: neighbouring targets are similar (spatially ordered keypoints) and
+            // each lane only knows its own column's history.  Pool the limits of the 32 columns first, so that
+            // only scores within the margin of this tile's row maximum remain.
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (!kScalarSq) sc[t][g] = sacc2[t][g].x + sacc2[t][g].y;
-                    lim[t][g] = max(lim[t][g], __float_as_int(sc[t][g] - kCoarseMargin));
-                }
-            const int kt = jt - jt0;
-            if ((ms.share_mask >> (kt < 31 ? kt : 31)) & 1u) {
-                if (kt < 31 || (kt & 31) == 31) share(true);
-            }
-            unsigned long long hit[kCoarseTA][4], any = 0;
+                for (int g = 0; g < 4; ++g) lim[t][g] = __float_as_int(group32_max(__int_as_float(lim[t][g])));
+            any = 0;
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
@@ -493,23 +478,21 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
                     hit[t][g] = __builtin_amdgcn_ballot_w64(sc[t][g] >= __int_as_float(lim[t][g]));
                     any |= hit[t][g];
                 }
-            if (kProbe < 4) {
-                if (any) lim[0][0] = max(lim[0][0], 1);
-            } else if (any) {
-                const unsigned int j = (unsigned int)(jt * 32 + (lane & 31));
+        }
+        if (any) {
+            const unsigned int j = (unsigned int)(jt * 32 + (lane & 31));
 #pragma unroll
-                for (int t = 0; t < kCoarseTA; ++t)
+            for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const unsigned long long mask = hit[t][g];
-                        if (mask) {
-                            const int pos = qn + mbcnt(mask);
-                            if (((mask >> lane) & 1ull) && pos < kRegionCap)
-                                region[pos] = ((unsigned int)(t * 8 + 2 * g + h) << 27) | j;
-                            qn += __builtin_popcountll(mask);
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned long long mask = hit[t][g];
+                    if (mask) {
+                        const int pos = qn + mbcnt(mask);
+                        if (((mask >> lane) & 1ull) && pos < kRegionCap)
+                            region[pos] = ((unsigned int)(t * 8 + 2 * g + h) << 27) | j;
+                        qn += __builtin_popcountll(mask);
                     }
-            }
+                }
         }
         if (jt + 1 < jt1) {
             ldsB[cur ^ 1][c0] = stWrite[0];
@@ -554,9 +537,10 @@ __global__ __launch_bounds__(256, 4) void match_refine_kernel(const _Float16* __
             if (tid >= d) incl += up;
         }
         offs[tid + 1] = incl;
+        const bool any_ovf = __builtin_amdgcn_ballot_w64(ovf) != 0ull;   // all 64 lanes vote (NOT inside the tid == 0 branch)
         if (tid == 0) {
             offs[0] = 0;
-            overflow = __builtin_amdgcn_ballot_w64(ovf) != 0ull;
+            overflow = any_ovf || ms.force_exhaustive;
         }
     }
     if (tid < kCoarseRows) best[tid] = ~0ull;
@@ -753,6 +737,7 @@ static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
     ms.cand = ms.cnt + (size_t)p.n_blocks * p.splits;
     ms.splits = p.splits;
     ms.share_mask = kShareMask;
+    ms.force_exhaustive = getenv("UMEREG_FORCE_EXHAUSTIVE") ? 1 : 0;
     if (const char* e = getenv("UMEREG_SHARE_MASK")) ms.share_mask = (unsigned int)strtoul(e, nullptr, 0);   // tuning probe
     return ms;
 }
@@ -794,7 +779,6 @@ UMEREG_API int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_col
 {
     UMEREG_REQUIRE(match_idx, "ume_match_q_f16r: null match_idx");
     if (int rc = umereg_ume_match_coarse_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, stream)) return rc;
-    if (kProbe < 4) return UMEREG_OK;
     return umereg_ume_match_refine_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, match_idx, match_dist, stream);
 }
 
