@@ -362,6 +362,39 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     assert np.array_equal(m6[16:], N_(mf6[0])[16:])
 
 
+def test_ume_match_f16r_spatially_ordered_keypoints(gpu):
+    """Keypoints in spatial (scan) order make neighbouring rows AND columns similar -- crowds of candidates per
+    tile, candidate regions filling up in a few target splits.  The matcher must return the same matches as for
+    any other order (here: vs the exact-fp32 scan and vs its own result on the shuffled inputs)."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_pair
+    p = synth_pair(5, N=30000, n_kp=6000)
+    def spatial(pts):
+        c = np.floor((pts[:, :2] + 100.0) / 5.0).astype(np.int64)
+        return np.lexsort((c[:, 0], c[:, 1]))
+    ks = p.src_inds[spatial(p.src_pts[p.src_inds])]; kt = p.tgt_inds[spatial(p.tgt_pts[p.tgt_inds])]
+    F1 = ops.ume_moments(T_(p.src_pts, gpu)[None], None, T_(p.src_feat, gpu)[None], 750, 5.0, kp_index=T_(ks, gpu)[None])
+    F2 = ops.ume_moments(T_(p.tgt_pts, gpu)[None], None, T_(p.tgt_feat, gpu)[None], 750, 5.0, kp_index=T_(kt, gpu)[None])
+    mr, dr = ops.ume_match(F1, F2, precision="f16r")
+    mf, df = ops.ume_match(F1, F2, precision="f32")
+    same = N_(mr[0]) == N_(mf[0])
+    assert same.mean() >= 0.999
+    assert np.abs(N_(dr[0]) - N_(df[0]))[same].max() < 2e-3 and np.abs(N_(dr[0]) - N_(df[0]))[~same].max(initial=0.0) < 2e-3
+    rng = np.random.RandomState(0)
+    s1, s2 = rng.permutation(6000), rng.permutation(6000)
+    ms, ds = ops.ume_match(F1[:, T_(s1, gpu)].contiguous(), F2[:, T_(s2, gpu)].contiguous(), precision="f16r")
+    back = np.empty(6000, np.int64); back[s1] = s2[N_(ms[0])]
+    dback = np.empty(6000, np.float32); dback[s1] = N_(ds[0])
+    # identical distances; a different target only where two targets tie exactly (lowest index in the GIVEN order wins)
+    assert np.array_equal(dback, N_(dr[0]))
+    diff = back != N_(mr[0])
+    assert diff.mean() < 0.01
+    if diff.any():
+        D = N_(ops.ume_cdist(F1[:, T_(np.where(diff)[0], gpu)].contiguous(), F2, precision="f32")[0])
+        rows = np.arange(int(diff.sum()))
+        assert np.abs(D[rows, back[diff]] - D[rows, N_(mr[0])[diff]]).max() < 1e-3
+
+
 def test_ume_cdist_batch(gpu):
     from umeregrobust_amd import ops
     rng = np.random.RandomState(2)
