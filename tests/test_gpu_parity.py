@@ -568,6 +568,28 @@ def test_errors_are_loud(gpu):
     lib = _lib.load()
     assert lib.umereg_ume_dist_q_f32(None, None, 1, 1, None, None, None, None, None) == -1
     assert b"null" in lib.umereg_last_error()
+    # the newer entry points: argument errors (-1) and undersized scratch (-3), each with a message
+    q = torch.zeros(4096, device=gpu); out_i = torch.zeros(8, dtype=torch.int64, device=gpu); out_f = torch.zeros(8, device=gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.umereg_ume_match_q_f16r(None, q.data_ptr(), 4, 4, out_i.data_ptr(), out_f.data_ptr(), q.data_ptr(), 16384, st) == -1
+    assert lib.umereg_ume_match_coarse_f16(q.data_ptr(), q.data_ptr(), 4, 4, q.data_ptr(), 8, st) == -3
+    assert b"scratch" in lib.umereg_last_error()
+    assert lib.umereg_ume_match_refine_f16(q.data_ptr(), q.data_ptr(), 4, 4, q.data_ptr(), 16384, None, out_f.data_ptr(), st) == -1
+    assert lib.umereg_ume_svdvals_f32(None, 4, out_f.data_ptr(), st) == -1
+    assert lib.umereg_ume_svdvals_f32(q.data_ptr(), 0, out_f.data_ptr(), st) == -1
+    T0 = np.eye(4)
+    assert lib.umereg_icp_point_to_point_f32(q.data_ptr(), q.data_ptr(), 10, 10, T0.ctypes.data, 0.2, 5, 1e-6, 1e-6, T0.ctypes.data,
+                                             None, None, None, q.data_ptr(), 64, st) == -3
+    assert lib.umereg_icp_point_to_point_f32(q.data_ptr(), q.data_ptr(), 0, 10, T0.ctypes.data, 0.2, 5, 1e-6, 1e-6, T0.ctypes.data,
+                                             None, None, None, q.data_ptr(), 1 << 20, st) == -1
+    assert lib.umereg_icp_point_to_point_f32(q.data_ptr(), q.data_ptr(), 10, 10, T0.ctypes.data, -1.0, 5, 1e-6, 1e-6, T0.ctypes.data,
+                                             None, None, None, q.data_ptr(), 1 << 20, st) == -1
+    with pytest.raises(ValueError):
+        ops.ume_match(torch.zeros((1, 4, 32, 4), device=gpu), torch.zeros((1, 4, 32, 4), device=gpu), precision="f8")
+    with pytest.raises(ValueError):
+        ops.ume_cdist(torch.zeros((1, 4, 32, 4), device=gpu), torch.zeros((1, 4, 32, 4), device=gpu), precision="f16r")
+    with pytest.raises(ValueError):
+        ops.ume_svdvals(torch.zeros((4, 32, 3), device=gpu))
 
 
 def test_ume_kp_layer_runs(gpu):
