@@ -207,7 +207,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0)}
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
-        # region is its 40 KB limit memset + the kernel); the fp64 refine of the ~15 candidates per row is
+        # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
         # timed separately.  Algorithmic flops = 2*512 per (source, target) pair, as for the scans.
         ref_ms = [s.elapsed_time(e_) for s, e_ in timing["dist"].refine]
         roof_dist = {"kernel": "ume_coarse_h_kernel", "bound": "mfma", "achieved": round(dist_tfs, 2),

@@ -169,7 +169,9 @@ size_t umereg_ume_match_q_scratch_bytes(int n1, int n2);
 int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
                             int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
                             void* stream);
-/* the two stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, in this order) */
+/* the stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, in this order): reset zeroes the
+ * per-row limits (a 4 n1 byte memset), coarse is the MFMA filter, refine the fp64 arg-min over the candidates */
+int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, int n1, int n2, void* stream);
 int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
                                 size_t scratch_bytes, void* stream);
 int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,

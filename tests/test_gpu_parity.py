@@ -573,6 +573,7 @@ def test_errors_are_loud(gpu):
     st = torch.cuda.current_stream().cuda_stream
     assert lib.umereg_ume_match_q_f16r(None, q.data_ptr(), 4, 4, out_i.data_ptr(), out_f.data_ptr(), q.data_ptr(), 16384, st) == -1
     assert lib.umereg_ume_match_coarse_f16(q.data_ptr(), q.data_ptr(), 4, 4, q.data_ptr(), 8, st) == -3
+    assert lib.umereg_ume_match_reset_f16(q.data_ptr(), 8, 4, 4, st) == -3
     assert b"scratch" in lib.umereg_last_error()
     assert lib.umereg_ume_match_refine_f16(q.data_ptr(), q.data_ptr(), 4, 4, q.data_ptr(), 16384, None, out_f.data_ptr(), st) == -1
     assert lib.umereg_ume_svdvals_f32(None, 4, out_f.data_ptr(), st) == -1

@@ -42,6 +42,7 @@ SIGNATURES = {
     "umereg_ume_match_q_scratch_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ume_match_q_f16r": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                         c_void_p]),
+    "umereg_ume_match_reset_f16": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "umereg_ume_match_coarse_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "umereg_ume_match_refine_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p,
                                             c_void_p]),

@@ -742,6 +742,22 @@ static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
     return ms;
 }
 
+UMEREG_API int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, int n1, int n2, void* stream)
+{
+    UMEREG_REQUIRE(n1 > 0 && n2 > 0, "ume_match_reset_f16: n1, n2 must be positive (got %d, %d)", n1, n2);
+    if (int rc = check_device()) return rc;
+    if (!scratch || scratch_bytes < match_scratch_bytes(n1, n2) || ((uintptr_t)scratch & 15)) {
+        set_error("ume_match_reset_f16: scratch too small or misaligned (%zu < %zu)", scratch_bytes, match_scratch_bytes(n1, n2));
+        return UMEREG_EWORKSPACE;
+    }
+    // the per-row limits start at 0; everything else in the scratch is written before it is read
+    if (hipMemsetAsync(scratch, 0, (size_t)n1 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) {
+        set_error("ume_match_reset_f16: hipMemsetAsync failed");
+        return UMEREG_ELAUNCH;
+    }
+    return UMEREG_OK;
+}
+
 UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
                                            size_t scratch_bytes, void* stream)
 {
@@ -749,10 +765,6 @@ UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2
     hipStream_t st = (hipStream_t)stream;
     const CoarsePlan p = coarse_plan(n1, n2);
     const MatchScratch ms = carve_scratch(scratch, n1, p);
-    if (hipMemsetAsync(ms.rowlim, 0, (size_t)n1 * sizeof(unsigned int), st) != hipSuccess) {
-        set_error("ume_match_coarse_f16: hipMemsetAsync failed");
-        return UMEREG_ELAUNCH;
-    }
     hipLaunchKernelGGL(ume_coarse_h_kernel, dim3(p.n_ablk * p.splits), dim3(kWave * kDistWaves), 0, st,
                        (const half8*)Q1_rows_h, (const half8*)Q2_cols_h, n1, n2, p.n_ablk, p.n_btiles, p.tiles_per_split, ms);
     UMEREG_CHECK_LAUNCH("ume_coarse_h_kernel");
@@ -778,6 +790,7 @@ UMEREG_API int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_col
                                        void* stream)
 {
     UMEREG_REQUIRE(match_idx, "ume_match_q_f16r: null match_idx");
+    if (int rc = umereg_ume_match_reset_f16(scratch, scratch_bytes, n1, n2, stream)) return rc;
     if (int rc = umereg_ume_match_coarse_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, stream)) return rc;
     return umereg_ume_match_refine_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, match_idx, match_dist, stream);
 }

@@ -211,6 +211,8 @@ def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
         for b in range(B):
             _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume1[b]), n1, lay_a, base, st), "umereg_ume_orthobasis_f32")
             _lib.check(lib.umereg_ume_orthobasis_f32(_ptr(ume2[b]), n2, lay_b, base + qa, st), "umereg_ume_orthobasis_f32")
+            if refine:
+                _lib.check(lib.umereg_ume_match_reset_f16(base + qa + qb, scratch, n1, n2, st), "umereg_ume_match_reset_f16")
             ev = _timed(timing, dev)
             if refine:
                 # the two stages of umereg_ume_match_q_f16r; `timing` brackets the coarse (dominant) stage
