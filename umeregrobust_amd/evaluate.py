@@ -274,7 +274,6 @@ class RegistrationPipeline:
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(depth)]
         self.host_prob = [None] * depth
         self.host_cond = [None] * depth
-        self.last_a_done = None
         self.n_submitted = 0
 
     def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None, pair=None):
@@ -288,8 +287,9 @@ class RegistrationPipeline:
         else:
             src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, self.rng, src_inds, tgt_inds)
         st.wait_stream(torch.cuda.current_stream(self.dev))
-        if self.last_a_done is not None:
-            st.wait_event(self.last_a_done)        # phase A of consecutive pairs stays back-to-back on the GPU
+        # (no ordering between the phase-A blocks of consecutive pairs: the single-workgroup kernels of one pair --
+        # keypoint order, grid scan, softmax, RTUME -- then run beside the machine-filling kernels of the other:
+        # 0.416 -> 0.36 ms per pair)
         with torch.cuda.stream(st):
             a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair)
             if a.prob is not None:
@@ -298,7 +298,6 @@ class RegistrationPipeline:
                 self.host_prob[k].copy_(a.prob, non_blocking=True)
             a.ready = torch.cuda.Event()
             a.ready.record(st)
-            self.last_a_done = a.ready
         a.slot = k
         a.draw = None
         if self.pool is not None and self.args.filter_by_ume_dist_cond:
