@@ -182,6 +182,20 @@ int umereg_ume_match_f16r(const float* ume1, const float* ume2, int B, int n1, i
                           size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a1..a5 of one registration pair in one call                          evaluate.py:206-236
+ * (my_ume_generation x2, ume_cdist + arg-min + match distances, match probabilities: everything up
+ * to the host RNG draw).  Pure composition of the entry points above -- same kernels, same results.
+ *   pts f32 [2,N,3], feat f32 [2,N,32] (row 0 = source cloud, row 1 = target cloud),
+ *   kp_index int64 [2,n_kp] keypoints as indices into their cloud (evaluate.py:199-202)
+ *   -> F f32 [2,n_kp,32,4], match_idx int64 [n_kp], match_dist f32 [n_kp],
+ *      prob f32 [n_kp] (NULL to skip: configs without filter_by_ume_dist_cond)
+ * ------------------------------------------------------------------------------------------- */
+size_t umereg_pair_match_workspace_bytes(int N, int n_kp);
+int umereg_pair_match_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
+                          float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
+                          float* prob, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a5  a = exp((1 - ume_d)/tau); prob = a / a.sum()                   evaluate.py:235-236
  *   ume_d f32 [n] -> prob f32 [n].  (The draw itself, np.random.choice(..., p=prob) at
  *   evaluate.py:238, consumes the HOST numpy RNG and stays on the host.)

@@ -55,6 +55,9 @@ SIGNATURES = {
     "umereg_ume_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "umereg_ume_match_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    "umereg_pair_match_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_pair_match_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_match_prob_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "umereg_ume_svdvals_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "umereg_icp_workspace_bytes": (c_size_t, [c_int, c_int]),

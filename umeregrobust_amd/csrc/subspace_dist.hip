@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "grid.h"
 #include "qlayout.h"
 
 namespace umereg {
@@ -958,4 +959,45 @@ UMEREG_API int umereg_ume_match_f16r(const float* ume1, const float* ume2, int B
     UMEREG_REQUIRE(match_idx, "ume_match_f16r: null match_idx");
     return dist_common(ume1, ume2, B, n1, n2, nullptr, match_idx, match_dist, workspace, workspace_bytes,
                        umereg_ume_match_workspace_bytes(B, n1, n2), stream, "ume_match_f16r", true, true);
+}
+
+// ---- a1..a5 of one registration pair in ONE call -----------------------------------------------------------------
+// reference evaluate.py:206-236: UME matrices of both clouds, matching, match probabilities -- everything up to the
+// host RNG draw.  Pure composition of the entry points above (same kernels, same results); exists because a pair
+// is ~12 launches and a Python caller pays ~10 us per ctypes call.
+UMEREG_API size_t umereg_pair_match_workspace_bytes(int N, int n_kp)
+{
+    if (N <= 0 || n_kp <= 0) return 0;
+    return align_up(umereg_ume_moments_workspace_bytes(2, N), 256) + umereg_ume_match_workspace_bytes(1, n_kp, n_kp);
+}
+
+UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
+                                     float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
+                                     float* prob, void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(pts && feat && kp_index && F && match_idx && match_dist, "pair_match: null pointer");
+    UMEREG_REQUIRE(N > 0 && n_kp > 0, "pair_match: N, n_kp must be positive (got %d, %d)", N, n_kp);
+    UMEREG_REQUIRE(!prob || tau > 0.f, "pair_match: tau must be positive when prob is requested");
+    if (int rc = check_device()) return rc;
+    const size_t need = umereg_pair_match_workspace_bytes(N, n_kp);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+        set_error("pair_match: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+        return UMEREG_EWORKSPACE;
+    }
+    char* ws_mom = (char*)workspace;
+    const size_t mom_bytes = align_up(umereg_ume_moments_workspace_bytes(2, N), 256);
+    char* ws_match = ws_mom + mom_bytes;
+    if (int rc = umereg_pack_points_f32(pts, 2, N, radius, ws_mom, mom_bytes, stream)) return rc;
+    const int ordered = n_kp <= grid_ws(N).Npad && n_kp >= 64;
+    if (ordered)
+        if (int rc = umereg_ume_keypoint_order(ws_mom, nullptr, kp_index, 2, N, n_kp, radius, stream)) return rc;
+    if (int rc = umereg_ume_moments_packed_f32(ws_mom, nullptr, kp_index, feat, 2, N, n_kp, UMEREG_FEAT_DIM, K, radius,
+                                               ordered ? UMEREG_MOMENTS_ORDERED : 0, F, nullptr, nullptr, stream))
+        return rc;
+    if (int rc = umereg_ume_match_f16r(F, F + (size_t)n_kp * 128, 1, n_kp, n_kp, match_idx, match_dist, ws_match,
+                                       workspace_bytes - mom_bytes, stream))
+        return rc;
+    if (prob)
+        if (int rc = umereg_match_prob_f32(match_dist, n_kp, tau, prob, stream)) return rc;
+    return UMEREG_OK;
 }

@@ -130,6 +130,14 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
     # UME matrices (:206-212); the keypoint gathers src_pts[0, src_inds] (:201-202) are fused into the kernel
     t_mom = None if timing is None else timing.setdefault("moments", [])
     t_dist = None if timing is None else timing.setdefault("dist", ops.TimingList())
+    if pair is not None and timing is None and not materialize_D and ops.DEFAULT_MATCH_PRECISION == "f16r" \
+            and not getattr(args, "hungarian_matching_flag", False):
+        # the whole of a1..a5 in one native call (same kernels as the layered path below)
+        F, m_tgt, ume_d, prob = ops.pair_match(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn,
+                                               args.tau if args.filter_by_ume_dist_cond else None)
+        return SimpleNamespace(ume_src=F[0:1], ume_tgt=F[1:2], match=m_tgt, match_d=ume_d, prob=prob, D=None,
+                               src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=F.shape[1], dev=dev,
+                               src_pts=src_pts, tgt_pts=tgt_pts)
     if pair is not None:
         # both clouds of the pair as ONE batch of 2 through every kernel (same arithmetic per cloud; half
         # the launches, twice the parallelism for the small grid-building kernels)

@@ -506,3 +506,30 @@ def ume_svdvals(ume):
             rc = lib.umereg_ume_svdvals_f32(_ptr(ume), n, _ptr(sv), _stream_ptr(ume.device))
         _lib.check(rc, "umereg_ume_svdvals_f32")
     return sv
+
+
+def pair_match(pts, feat, kp_index, K, radius, tau=None):
+    """a1..a5 of one registration pair in one native call (reference evaluate.py:206-236).
+    pts [2,N,3], feat [2,N,32], kp_index int64 [2,n_kp] (row 0 = source, row 1 = target) ->
+    (F [2,n_kp,32,4], match [1,n_kp] i64, match_d [1,n_kp] f32, prob [n_kp] f32 | None).  Same kernels and results
+    as ume_moments + ume_match(precision="f16r") + match_prob."""
+    lib = _lib.load()
+    pts = _dev(pts, "pts"); feat = _dev(feat, "feat"); kp_index = _dev(kp_index, "kp_index", torch.int64)
+    if pts.dim() != 3 or pts.shape[0] != 2 or feat.shape[:2] != pts.shape[:2] or feat.shape[2] != 32 or kp_index.dim() != 2 \
+            or kp_index.shape[0] != 2:
+        raise ValueError("pair_match: expected pts [2,N,3], feat [2,N,32], kp_index [2,n_kp]")
+    N, n = pts.shape[1], kp_index.shape[1]
+    if n == 0:
+        raise ValueError("pair_match: no keypoints")
+    dev = pts.device
+    F = torch.empty((2, n, 32, 4), dtype=torch.float32, device=dev)
+    m = torch.empty((1, n), dtype=torch.int64, device=dev)
+    d = torch.empty((1, n), dtype=torch.float32, device=dev)
+    prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
+    ws = _workspace(dev, lib.umereg_pair_match_workspace_bytes(N, n), "pair")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_pair_match_f32(_ptr(pts), _ptr(feat), _ptr(kp_index), N, n, int(K), float(radius),
+                                       float(tau) if tau is not None else 0.0, _ptr(F), _ptr(m), _ptr(d), _ptr(prob),
+                                       _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_pair_match_f32")
+    return F, m, d, prob
