@@ -362,6 +362,25 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     assert np.array_equal(m6[16:], N_(mf6[0])[16:])
 
 
+def test_ume_match_f16r_forced_exhaustive_refine(gpu):
+    """The refine kernel's exhaustive fallback on every block of rows (testing probe UMEREG_FORCE_EXHAUSTIVE): it must
+    reproduce the exact-fp32 scan at sizes where several target splits and many row blocks exist."""
+    import os
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(3)
+    u1 = T_(rng.standard_normal((1, 1500, 32, 4)).astype(np.float32), gpu)
+    u2 = T_(rng.standard_normal((1, 7000, 32, 4)).astype(np.float32), gpu)
+    mx, dx = ops.ume_match(u1, u2, precision="f32")
+    os.environ["UMEREG_FORCE_EXHAUSTIVE"] = "1"
+    try:
+        mr, dr = ops.ume_match(u1, u2, precision="f16r")
+    finally:
+        del os.environ["UMEREG_FORCE_EXHAUSTIVE"]
+    assert torch.equal(mr, mx) and float((dr - dx).abs().max()) < 1e-5
+    mr2, dr2 = ops.ume_match(u1, u2, precision="f16r")          # and the normal path agrees with it bit for bit
+    assert torch.equal(mr2, mr) and torch.equal(dr2, dr)
+
+
 def test_ume_match_f16r_spatially_ordered_keypoints(gpu):
     """Keypoints in spatial (scan) order make neighbouring rows AND columns similar -- crowds of candidates per
     tile, candidate regions filling up in a few target splits.  The matcher must return the same matches as for
