@@ -2,6 +2,8 @@ import sys, ctypes, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch, time
 import umeregrobust_amd._build as b
+# build first:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Xarch_device -fno-slp-vectorize -fPIC -shared \
+#   -fvisibility=hidden -DUMEREG_KNN_DEBUG -I include umeregrobust_amd/csrc/*.hip -o tools/libumereg_dbg.so
 b.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('DBGLIB', 'libumereg_dbg.so'))
 import umeregrobust_amd._lib as L
 L.LIB_PATH = b.LIB_PATH
@@ -31,7 +33,6 @@ for label, T in (('near-gt', hyps(64, 0.05, 0.5)), ('3deg/1m', hyps(64, 1.0, 3.0
     lib.umereg_knn_debug_counters(cnt, 1)
     n = cnt[0]
     print(label, ' '.join(f'{nm}={cnt[i]}' for i, nm in enumerate(names)))
-    print('   anchored calls %d, fast overflow events %d, waves with slow lanes %d, lanes without fast ball %d, fast lanes short of K %d' % (cnt[8], cnt[10], cnt[11], cnt[12], cnt[13]))
     print('   per knn call: box iters %.2f hist passes %.2f final drops %.2f candidates/scan %.0f' % (cnt[1]/n, cnt[2]/n, cnt[5]/n, cnt[7]/(cnt[2]+n)))
 
 T = hyps(1024, 0.3, 1.0)
