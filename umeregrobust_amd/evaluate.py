@@ -336,3 +336,43 @@ class RegistrationPipeline:
 
     def stream_of(self, a):
         return self.streams[a.slot]
+
+
+def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False):
+    """The reference's evaluation loop (evaluate.py:175-309) over an iterable of registration pairs, with the
+    reference's RNG consumption order per pair (keypoint draws, weighted match draw, correlation sub-sampling):
+
+        pair = dict(src_pts [1,N,3], tgt_pts [1,N,3], src_feat [1,N,32], tgt_feat [1,N,32]  (network points + features),
+                    src_pts_raw [n,3], tgt_pts_raw [m,3]  (raw clouds; default: the network points), gt_tform [4,4])
+
+    -> dict(R_sel, t_sel [P,...] (selected hypotheses), T_est [P,4,4], rre [P], rte [P], rr_np, rr_sp, mrre, mrte)
+    where the last four are the numbers the reference prints (:304-309).  Datasets and the feature network are the
+    caller's business (out of scope); everything between them and the printed metrics is here."""
+    R_sel, t_sel, raw = [], [], []
+    for pair in pairs:
+        out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng)   # :195-254
+        src_raw = pair.get("src_pts_raw", pair["src_pts"][0])
+        tgt_raw = pair.get("tgt_pts_raw", pair["tgt_pts"][0])
+        _, _, R_hat, t_hat = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
+                                               pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng)  # :258-296
+        R_sel.append(R_hat.cpu())
+        t_sel.append(t_hat.cpu())
+        raw.append((src_raw, tgt_raw, pair["gt_tform"]))
+    R_sel, t_sel = torch.cat(R_sel, dim=0), torch.cat(t_sel, dim=0)
+    if refine:
+        T_est, rre, rte = refine_registration(R_sel, t_sel, args, raw)                                             # :301
+    else:
+        T_est = torch.eye(4)[None].repeat(R_sel.shape[0], 1, 1)
+        T_est[:, :3, :3], T_est[:, :3, 3] = R_sel, t_sel
+        gts = torch.stack([g.detach().cpu().float() if isinstance(g, torch.Tensor) else torch.as_tensor(g).float() for _, _, g in raw])
+        dev = raw[0][0].device
+        rre = relative_rotation_error(T_est[:, :3, :3].to(dev).contiguous(), gts[:, :3, :3].to(dev).contiguous()).cpu()
+        rte = (T_est[:, :3, 3] - gts[:, :3, 3]).norm(dim=-1)
+    rr_np = float(((rre <= 1.5) & (rte <= 0.6)).float().mean())                                                   # :304-305
+    rr_sp = float(((rre <= 1) & (rte <= 0.1)).float().mean())
+    res = dict(R_sel=R_sel, t_sel=t_sel, T_est=T_est, rre=rre, rte=rte, rr_np=rr_np, rr_sp=rr_sp,
+               mrre=float(rre.mean()), mrte=float(rte.mean()))
+    if verbose:
+        print(f"N.P: {100 * rr_np:.03f} | S.P: {100 * rr_sp:.03f}")
+        print(f"mRRE: {res['mrre']:.03f} | mRTE: {res['mrte']:.03f}")
+    return res
