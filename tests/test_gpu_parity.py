@@ -574,6 +574,53 @@ def test_kitti_full_size_properties(gpu):
     assert (np.abs(F - F64) / scale).max() < 3e-7
 
 
+@pytest.mark.parametrize("config", ["NS", "SY"])
+def test_other_configs_full_size_properties(gpu, config):
+    """BASELINE.json configs[2] (nuScenes shape: N = 35 000, 5 000 keypoints, no tau filter, M = 5 000) and configs[3]
+    (N = 200 000 at a 0.15 m lattice: saturated balls, streaming first-K selection) at full size, through the pipelined
+    one-call path: determinism, twin matches, valid outputs, oracle spot check of the moment matrices."""
+    from types import SimpleNamespace
+    from umeregrobust_amd import evaluate, ops
+    from umeregrobust_amd.synth import CONFIGS, synth_pair_cfg
+    cfg = CONFIGS[config]
+    p = synth_pair_cfg(41, config)
+    n_kp = cfg["n_kp"]
+    tgt_inds = np.concatenate([p.tgt_twin_of_src[p.src_inds[:n_kp // 2]], p.tgt_inds[:n_kp - n_kp // 2]])
+    args = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0, filter_by_ume_dist_cond=cfg["filter_by_ume_dist_cond"],
+                           ume_n_samples=cfg["M"], tau=0.05)
+    t = lambda a: T_(a, gpu)[None]
+    clouds = (t(p.src_pts), t(p.tgt_pts), t(p.src_feat), t(p.tgt_feat))
+    pair = evaluate.PairBatch.from_clouds(*clouds, T_(p.src_inds, gpu), T_(tgt_inds, gpu))
+    pipe = evaluate.RegistrationPipeline(args, gpu, depth=2, rng=np.random.RandomState(0))
+    hs = [pipe.submit(*clouds, src_inds=T_(p.src_inds, gpu), tgt_inds=T_(tgt_inds, gpu), pair=pair) for _ in range(2)]
+    outs = [pipe.finish(h) for h in hs]
+    torch.cuda.synchronize()
+    a, b = outs
+    assert torch.equal(a.ume_src, b.ume_src) and torch.equal(a.match, b.match) and torch.equal(a.match_d, b.match_d)
+    m, d = N_(a.match[0]), N_(a.match_d[0])
+    half = n_kp // 2
+    assert m.min() >= 0 and m.max() < n_kp and np.isfinite(d).all() and d.min() >= 0 and d.max() <= 2.0
+    # (saturated balls keep the first K points BY INDEX, which is not invariant to the target's permutation: twins of
+    # the SY shape see different neighbourhoods and sit at a larger distance than those of unsaturated shapes)
+    assert (m[:half] == np.arange(half)).mean() > 0.9 and np.median(d[:half]) < (0.15 if config == "SY" else 0.05)
+    M = cfg["M"] if cfg["filter_by_ume_dist_cond"] else n_kp
+    assert a.rtume_tform.shape == (1, min(M, n_kp), 4, 4) and torch.isfinite(a.rtume_tform).all()
+    R = a.rtume_tform[0, :, :3, :3]
+    assert float((R @ R.transpose(1, 2) - torch.eye(3, device=gpu)).abs().max()) < 1e-4
+    # the one-call path equals the layered one
+    F = ops.ume_moments(pair.pts, None, pair.feat, 750, 5.0, kp_index=pair.inds)
+    m2, d2 = ops.ume_match(F[0:1], F[1:2], precision="f16r")
+    assert torch.equal(F[0:1], a.ume_src) and torch.equal(m2, a.match) and torch.equal(d2, a.match_d)
+    # moment matrices against the oracle on a sample (saturated balls included for SY)
+    sel = np.arange(0, n_kp, max(n_kp // 24, 1))[:24]
+    F64, c64 = orc.ume_moments(p.src_pts, p.src_pts[p.src_inds[sel]], p.src_feat, 750, 5.0, accum="f64", return_count=True)
+    if config == "SY":
+        assert c64.max() == 750
+    Fs = N_(a.ume_src[0])[sel]
+    scale = np.abs(F64).max(axis=(1, 2), keepdims=True) + 1e-30
+    assert (np.abs(Fs - F64) / scale).max() < 3e-7
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_errors_are_loud(gpu):
     from umeregrobust_amd import ops, _lib
