@@ -287,21 +287,34 @@ def main():
         orc.lib()
         t_cpu = 0.0
         n_cpu = 0
+        gates = lambda rre, rte: np.array([rre.size, ((rre <= 1.5) & (rte <= 0.6)).sum(), ((rre <= 1.5) & (rte <= 0.3)).sum(),
+                                           ((rre <= 1.0) & (rte <= 0.1)).sum()], np.float64)
+        q_cpu, q_gpu = np.zeros(4), np.zeros(4)
         for i in range(a.cpu_pairs):
             if t_cpu > 10.0:
                 break
             n_cpu += 1
-            p = pool[i % len(pool)].host
-            rs = np.random.RandomState(7 + i)
+            e = pool[i % len(pool)]
             tc = time.perf_counter()
-            o = cpu_pair(orc, p, args, rs)
+            rre, rte = cpu_pair(orc, e.host, args, np.random.RandomState(7 + i))
             t_cpu += time.perf_counter() - tc
-            del o
+            q_cpu += gates(rre, rte)
+            # the same pair with the same RNG seed through the HIP path (outside any timed region)
+            og = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=np.random.RandomState(7 + i),
+                                        src_inds=e.src_inds, tgt_inds=e.tgt_inds)
+            cg = torch.zeros(4, dtype=torch.int64, device=dev)
+            ops.hypothesis_gates(og.rtume_tform[0], e.gt, cg)
+            q_gpu += cg.cpu().numpy()
         result["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 4), "unit": "pairs/s", "cores": os.cpu_count(),
                                   "kind": "port",
                                   "sample": f"{n_cpu} full {a.config} pair(s) through the oracle's named path "
                                             f"(C/OpenMP scan+moments, numpy LAPACK/BLAS for QR/cdist/SVD), "
-                                            f"{t_cpu:.1f} s wall"}
+                                            f"{t_cpu:.1f} s wall",
+                                  "quality_check": {
+                                      "note": "fraction of RTUME hypotheses inside the gates (1.5deg,0.6m) / (1.5deg,0.3m) / (1deg,0.1m) on "
+                                              "the SAME pairs and RNG seeds: CPU restatement of the reference vs this library",
+                                      "cpu": [round(float(v), 4) for v in q_cpu[1:] / max(q_cpu[0], 1)],
+                                      "gpu": [round(float(v), 4) for v in q_gpu[1:] / max(q_gpu[0], 1)]}}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -325,7 +338,9 @@ def cpu_pair(orc, p, args, rs):
         cond = np.arange(D.shape[0])
     T, _ = orc.batch_estimate_transform_ume_old(ume_src[cond], ume_tgt[m[cond]], with_dist=False)
     R_gt = np.broadcast_to(p.gt_tform[:3, :3], T[:, :3, :3].shape)
-    return orc.relative_rotation_error(T[:, :3, :3], R_gt)
+    rre = orc.relative_rotation_error(T[:, :3, :3], R_gt)
+    rte = np.linalg.norm(T[:, :3, 3] - p.gt_tform[:3, 3], axis=-1)
+    return rre, rte
 
 
 if __name__ == "__main__":
