@@ -206,7 +206,10 @@ def main():
     roof_mom = {"kernel": "ume_moments_kernel", "bound": "hbm", "achieved": round(mom_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
-                "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0)}
+                "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0),
+                "note": "algorithmic bytes = SURVEY 8(d) per-keypoint figure (140 n_i + 524) summed over both clouds of a pair; "
+                        "they are neighbour gathers from 8 MB tables, served mostly by L2 / Infinity Cache, so the rate can exceed "
+                        "the HBM peak while `traffic` (fabric bytes from PMC) stays far below the algorithmic bytes"}
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
