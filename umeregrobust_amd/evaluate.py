@@ -262,10 +262,12 @@ class RegistrationPipeline:
     """Same computation as register_pair, software-pipelined over consecutive pairs.
 
     The reference draws the match sub-sample on the host (np.random.choice with p from the device,
-    evaluate.py:238), which costs ~0.6 ms of host time per KITTI-sized pair with the GPU idle.  Here
-    phase A of pair i+1 (moments, distance GEMM, probabilities) is enqueued on a second HIP stream
-    before the host draws for pair i, so the draw overlaps GPU work.  Results are identical to
-    register_pair given the same RNG stream; `submit` and `finish` must be called in order.
+    evaluate.py:238): a device -> host -> device round trip in the middle of every pair.  Here phase A of
+    pair i+1 (moments, matching, probabilities: one native call) is enqueued on another HIP stream before
+    the host draws for pair i, so the draw overlaps GPU work, and the streams are not ordered against
+    each other, so the single-workgroup kernels of one pair run beside the machine-filling kernels of the
+    other.  Results are identical to register_pair given the same RNG stream; `submit` and `finish` must
+    be called in order.
     """
 
     def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False):
