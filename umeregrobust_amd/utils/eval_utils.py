@@ -16,31 +16,28 @@ def calc_inliear_ratio(src_inputs, tgt_inputs, src_pts_tform, gt_tform, ume_r_nn
     """reference utils/eval_utils.py:8-57: inlier ratio of the UME descriptor matching (Hungarian on the host, like
     the reference) between ground-truth-driven keypoints.  src_inputs / tgt_inputs: dicts with 'pts', 'seg', 'feat'."""
     from .loc_utils import generate_ume_from_keypoints2, ume_cdist
-    device = gt_tform.device
-    ume_src, ume_tgt, src_keypoint_pts, tgt_keypoint_pts, _, _ = generate_ume_from_keypoints2(
+    opts = dict(nn_r=ume_r_nn, max_nn=ume_max_nn, min_nn=ume_min_nn, num_samples=eval_num_kpts,
+                flat_labels=keypoints_ignore_segments, nn_intersection_r=nn_inter_thr)
+    F_src, F_tgt, kp_src, kp_tgt, _, _ = generate_ume_from_keypoints2(
         src_inputs['pts'], src_inputs['seg'], src_inputs['feat'], tgt_inputs['pts'], tgt_inputs['feat'], gt_tform,
-        nn_r=ume_r_nn, max_nn=ume_max_nn, min_nn=ume_min_nn, num_samples=eval_num_kpts,
-        flat_labels=keypoints_ignore_segments, nn_intersection_r=nn_inter_thr)
-    # filter invalid (rank-deficient) UME matrices (:30-38)
-    src_valid_ume_mask = (ops.ume_svdvals(ume_src) > svd_thr).sum(dim=-1) == 4
-    tgt_valid_ume_mask = (ops.ume_svdvals(ume_tgt) > svd_thr).sum(dim=-1) == 4
-    src_valid_ume_mask = src_valid_ume_mask & tgt_valid_ume_mask
-    invalid_keypoints_src = torch.zeros_like(ume_src[0, :, 0, 0]).bool()
-    invalid_keypoints_src[torch.where(~src_valid_ume_mask)[1]] = True
-    ume_src = ume_src[:, ~invalid_keypoints_src].contiguous()
-    ume_tgt = ume_tgt[:, ~invalid_keypoints_src].contiguous()
-    D = ume_cdist(ume_src, ume_tgt).cpu().numpy()                                                     # :40
-    bs = D.shape[0]
-    m = np.zeros((bs, min(D.shape[1], D.shape[2]), 2))
-    for b_idx in range(bs):                                                                           # :43-46
-        src_m_idxs, tgt_m_idxs = linear_sum_assignment(D[b_idx])
-        m[b_idx, :, 0] = src_m_idxs
-        m[b_idx, :, 1] = tgt_m_idxs
-    m = torch.from_numpy(m).long().to(device)
-    tgt_matches_keypoint_pts = torch.gather(tgt_keypoint_pts, 1, m[..., 1].unsqueeze(-1).expand(-1, -1, 3))
-    src_matches_keypoint_pts = torch.gather(src_keypoint_pts, 1, m[..., 0].unsqueeze(-1).expand(-1, -1, 3))
-    R_gt = gt_tform[:, :3, :3]
-    t_gt = gt_tform[:, :3, 3]
-    src_matches_keypoint_pts_tform = (src_matches_keypoint_pts @ R_gt.transpose(-1, -2) + t_gt[:, None])
-    my_re_proj = (tgt_matches_keypoint_pts - src_matches_keypoint_pts_tform).norm(dim=-1)
-    return (my_re_proj <= inlear_thr).float().mean(dim=-1)                                            # :55-57
+        **opts)
+
+    # :30-38 - a keypoint column survives only if both of its moment matrices have rank 4 in every batch entry
+    # (the reference indexes the keep-mask by column only, so one bad entry removes the column everywhere).
+    def full_rank(F):
+        return (ops.ume_svdvals(F) > svd_thr).all(dim=-1)
+    keep = (full_rank(F_src) & full_rank(F_tgt)).all(dim=0)
+    F_src, F_tgt = F_src[:, keep].contiguous(), F_tgt[:, keep].contiguous()
+
+    # :40-46 - optimal one-to-one assignment on the subspace distances (host, scipy - as the reference does)
+    cost = ume_cdist(F_src, F_tgt).cpu().numpy()
+    assign = np.stack([np.stack(linear_sum_assignment(c), axis=-1) for c in cost])           # [b, m, (src, tgt)]
+    assign = torch.from_numpy(assign).to(device=gt_tform.device, dtype=torch.long)
+
+    # :47-57 - re-projection error of the matched keypoints under the ground truth.  The assignment indexes the
+    # filtered columns but the reference gathers from the unfiltered keypoint lists; kept as is.
+    def pick(kp, col):
+        return torch.gather(kp, 1, assign[..., col, None].expand(-1, -1, 3))
+    moved = pick(kp_src, 0) @ gt_tform[:, :3, :3].mT + gt_tform[:, None, :3, 3]
+    err = torch.linalg.vector_norm(pick(kp_tgt, 1) - moved, dim=-1)
+    return (err <= inlear_thr).float().mean(dim=-1)
