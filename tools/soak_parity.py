@@ -1,0 +1,189 @@
+"""Randomised parity soak on the GPU: the HIP path against the CPU checker on many random shapes and input
+structures (ragged sizes, clustered / duplicated / spatially coherent inputs), for a wall-clock budget.
+
+    python tools/soak_parity.py [--seconds 240] [--seed 0]
+
+Test infrastructure (uses oracle/); prints one line per failure with the seed that reproduces it and a summary."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402
+from umeregrobust_amd import ops  # noqa: E402
+from umeregrobust_amd.synth import synth_scene  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def T_(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+BIG = False
+
+
+def rand_size(rng, hi):
+    """log-uniform in [1, hi] with extra weight on tile edges; --big: uniform in [hi/4, hi]"""
+    if BIG:
+        return int(rng.randint(max(1, hi // 4), hi + 1))
+    if rng.rand() < 0.25:
+        return int(np.clip(rng.choice([1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 511, 512, 513]), 1, hi))
+    return int(np.exp(rng.uniform(0, np.log(hi))))
+
+
+def umes(rng, n, kind, protos=None):
+    u = rng.standard_normal((n, 32, 4)).astype(np.float32)
+    if kind == "corr":
+        u[:, :, 1:] += 30.0 * u[:, :, :1]
+    elif kind == "clustered":
+        k = max(1, n // 50)
+        p = protos if protos is not None else rng.standard_normal((k, 32, 4)).astype(np.float32)
+        u = p[rng.randint(0, len(p), n)] + np.float32(rng.choice([1e-4, 1e-2, 0.2])) * u
+    elif kind == "coherent":       # a slow random walk: neighbours in index are near-identical subspaces
+        u = np.cumsum(u * np.float32(0.05), axis=0).astype(np.float32) + rng.standard_normal((1, 32, 4)).astype(np.float32)
+    return u
+
+
+def soak_match(rng):
+    n1, n2 = rand_size(rng, 3000), rand_size(rng, 8000)
+    kind = rng.choice(["plain", "corr", "clustered", "coherent"])
+    protos = rng.standard_normal((max(1, n2 // 50), 32, 4)).astype(np.float32) if kind == "clustered" else None
+    u1, u2 = umes(rng, n1, kind, protos), umes(rng, n2, kind, protos)
+    if rng.rand() < 0.5 and min(n1, n2) > 1:       # planted matches / exact duplicates at random places
+        k = rng.randint(1, min(n1, n2))
+        src = rng.randint(0, n1, k)
+        dst = rng.randint(0, n2, k)
+        A = (np.eye(4) + 0.1 * rng.standard_normal((k, 4, 4))).astype(np.float32) if rng.rand() < 0.5 else np.eye(4, dtype=np.float32)[None]
+        u2[dst] = u1[src] @ A
+    if rng.rand() < 0.15 and n1 > 2:
+        u1[rng.randint(0, n1)] = 0.0
+    m, d = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f16r")
+    m, d = N_(m[0]), N_(d[0])
+    D64 = orc.ume_cdist_f64(u1, u2)
+    best = D64.min(axis=1) ** 2
+    got = D64[np.arange(n1), m] ** 2
+    assert (got - best).max() <= 2e-5, f"match not minimal: excess {(got - best).max():.3g} ({kind}, {n1}x{n2})"
+    if n2 > 1:
+        srt = np.partition(D64 ** 2, 1, axis=1)[:, :2]
+        srt.sort(axis=1)
+        clear = srt[:, 1] - srt[:, 0] > 2e-5
+        assert np.array_equal(m[clear], D64.argmin(axis=1)[clear]), f"clear arg-min differs ({kind}, {n1}x{n2})"
+    assert np.abs(d - np.sqrt(got)).max() < 2e-3, f"distance off ({kind}, {n1}x{n2})"
+    m2, d2 = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f16r")
+    assert np.array_equal(N_(m2[0]), m) and np.array_equal(N_(d2[0]), d), "not deterministic"
+    mf, _ = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f32")
+    gf = D64[np.arange(n1), N_(mf[0])] ** 2
+    assert (gf - best).max() <= 2e-5, f"f32 match not minimal ({kind}, {n1}x{n2})"
+    return f"match {kind} {n1}x{n2}"
+
+
+def cloud(rng, N):
+    kind = rng.choice(["scene", "gauss", "plane", "lattice"])
+    if kind == "scene" and N >= 256:
+        return synth_scene(rng, N, float(rng.choice([0.1, 0.3, 0.6]))).astype(np.float32)
+    if kind == "plane":
+        p = rng.uniform(-40, 40, (N, 3)).astype(np.float32)
+        p[:, 2] = np.float32(0.01) * rng.standard_normal(N).astype(np.float32)
+        return p
+    if kind == "lattice":          # many exactly equal distances
+        return rng.randint(-6, 7, (N, 3)).astype(np.float32)
+    return (rng.standard_normal((N, 3)) * rng.choice([1.0, 5.0, 30.0])).astype(np.float32)
+
+
+def soak_ball(rng):
+    N, n1 = rand_size(rng, 30000), rand_size(rng, 400)
+    K = int(rng.choice([1, 5, 64, 750, rand_size(rng, 2000)]))
+    r = float(rng.choice([0.5, 2.0, 5.0, 20.0]))
+    pts = cloud(rng, N)
+    q = (pts[rng.randint(0, N, n1)] + rng.standard_normal((n1, 3)).astype(np.float32) * np.float32(rng.choice([0.0, 0.05, 3.0]))).astype(np.float32)
+    if rng.rand() < 0.3:
+        q[rng.randint(0, n1)] = [900.0, 0.0, 0.0]
+    ref = orc.ball_query(q[None], pts[None], K=K, radius=r, return_nn=True)
+    out = ops.ball_query(T_(q)[None], T_(pts)[None], K=K, radius=r, return_nn=True)
+    assert np.array_equal(N_(out.idx), ref.idx), f"ball idx differs (N={N}, n1={n1}, K={K}, r={r})"
+    assert np.array_equal(N_(out.dists), ref.dists), "ball dists differ"
+    if K <= 750:
+        feat = rng.standard_normal((N, 32)).astype(np.float32)
+        Fr = orc.ume_moments(pts, q, feat, K=K, radius=r)
+        Fg = N_(ops.ume_moments(T_(pts)[None], T_(q)[None], T_(feat)[None], K, r)[0])
+        scale = np.abs(Fr).max(axis=(1, 2), keepdims=True) + 1e-30
+        assert (np.abs(Fg - Fr) / scale).max() < 3e-6, f"moments differ {(np.abs(Fg - Fr) / scale).max():.3g} (N={N}, n1={n1}, K={K}, r={r})"
+    return f"ball N={N} n1={n1} K={K} r={r}"
+
+
+def soak_knn(rng):
+    n2, n1 = rand_size(rng, 12000), rand_size(rng, 3000)
+    K = int(min(n2, rng.choice([1, 5, 20, 50, 64])))
+    p2 = cloud(rng, n2)
+    p1 = (p2[rng.randint(0, n2, n1)] + rng.standard_normal((n1, 3)).astype(np.float32) * np.float32(rng.choice([0.0, 0.7, 10.0]))).astype(np.float32)
+    if rng.rand() < 0.3:
+        p1[: max(1, n1 // 20)] += np.float32(200.0)
+    ref = orc.knn_points(p1[None], p2[None], K=K)
+    out = ops.knn_points(T_(p1)[None], T_(p2)[None], K=K, return_nn=False)
+    assert np.array_equal(N_(out.dists), ref.dists), f"knn dists differ (n1={n1}, n2={n2}, K={K})"
+    assert np.array_equal(N_(out.idx), ref.idx), f"knn idx differs (n1={n1}, n2={n2}, K={K})"
+    return f"knn {n1}x{n2} K={K}"
+
+
+def soak_rtume(rng):
+    n = rand_size(rng, 3000)
+    G = rng.standard_normal((n, 32, 4)).astype(np.float32)
+    Rq, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(Rq) < 0:
+        Rq[:, 0] = -Rq[:, 0]
+    A = np.eye(4); A[1:, 1:] = Rq; A[1:, 0] = rng.standard_normal(3) * 3
+    H = (G @ A.T.astype(np.float32) + np.float32(1e-3) * rng.standard_normal(G.shape).astype(np.float32)).astype(np.float32)
+    from umeregrobust_amd.utils.loc_utils import batch_estimate_transform_ume_old
+    Tr = orc.batch_estimate_transform_ume_old(G, H)[0]
+    Tg = N_(batch_estimate_transform_ume_old(T_(G), T_(H))[0])
+    assert np.abs(Tg[:, :3, :3] - Tr[:, :3, :3]).max() < 1e-4, f"rtume R differs {np.abs(Tg[:, :3, :3] - Tr[:, :3, :3]).max():.3g}"
+    assert np.abs(Tg[:, :3, 3] - Tr[:, :3, 3]).max() < 1e-3, f"rtume t differs {np.abs(Tg[:, :3, 3] - Tr[:, :3, 3]).max():.3g}"
+    assert np.abs(Tg[:, :3, :3] - Rq).max() < 1e-2
+    return f"rtume {n}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--big", action="store_true", help="sizes uniform in [hi/4, hi] instead of log-uniform")
+    a = ap.parse_args()
+    global BIG
+    BIG = a.big
+    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume}
+    if a.only:
+        kinds = {k: v for k, v in kinds.items() if k in a.only.split(",")}
+    t0 = time.time()
+    done, fails, trial = {k: 0 for k in kinds}, [], 0
+    names = list(kinds)
+    while time.time() - t0 < a.seconds:
+        k = names[trial % len(names)]
+        seed = a.seed * 1000003 + trial
+        try:
+            kinds[k](np.random.RandomState(seed))
+            done[k] += 1
+        except Exception as e:  # noqa: BLE001
+            fails.append((k, seed, str(e).splitlines()[0] if str(e) else repr(e)))
+            print(f"FAIL {k} seed={seed}: {e}", flush=True)
+            if not isinstance(e, AssertionError):
+                traceback.print_exc()
+        trial += 1
+    print(f"soak: {sum(done.values())} trials passed {done}, {len(fails)} failed, {time.time() - t0:.0f} s")
+    for f in fails:
+        print("  ", f)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
