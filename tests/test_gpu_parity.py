@@ -1028,3 +1028,23 @@ def test_evaluate_pairs_end_to_end(gpu):
     assert res["rr_np"] == 1.0 and res["rr_sp"] == 1.0 and res["mrre"] < 0.05 and res["mrte"] < 0.02
     res2 = evaluate_pairs(pairs, args, rng=np.random.RandomState(0), refine=False)
     assert res2["rr_np"] == 1.0 and torch.equal(res2["R_sel"], res["R_sel"])          # same RNG stream -> same selection
+
+
+def test_evaluate_command_line(gpu, tmp_path, capsys):
+    """reference evaluate.py:113-124, 304-309: `--benchmark` selects the YAML, the run prints the reference's header and
+    result lines.  Pairs from .npz files in the loader contract, and the synthetic default at the benchmark's shape."""
+    from umeregrobust_amd.evaluate import main
+    from umeregrobust_amd.synth import synth_pair
+    for seed in (4, 5):
+        p = synth_pair(seed, N=12000, n_kp=64)
+        np.savez(tmp_path / f"pair{seed}.npz", src_pts=p.src_pts, tgt_pts=p.tgt_pts, src_feat=p.src_feat, tgt_feat=p.tgt_feat,
+                 gt_tform=p.gt_tform, src_pts_raw=p.src_pts, tgt_pts_raw=p.tgt_pts)
+    s = main(["--benchmark", "kitti_test", "--pairs", str(tmp_path)])
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("Evaluate kitti Benchmark: kitti_test config file: ")
+    assert out[-2] == "N.P: 100.000 | S.P: 100.000" and out[-1].startswith("mRRE: 0.0")
+    assert s["n_pairs"] == 2 and s["rr_sp"] == 100.0
+    s2 = main(["--benchmark", "kitti_test", "--pairs", str(tmp_path / "pair4.npz"), str(tmp_path / "pair5.npz"), "--no-refine"])
+    assert s2["n_pairs"] == 2 and s2["rr_np_06"] == 100.0
+    s3 = main(["--benchmark", "rotnuscenes", "--synthetic", "1"])
+    assert s3["n_pairs"] == 1 and s3["rr_np_06"] == 100.0

@@ -378,3 +378,82 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False):
         print(f"N.P: {100 * rr_np:.03f} | S.P: {100 * rr_sp:.03f}")
         print(f"mRRE: {res['mrre']:.03f} | mRTE: {res['mrte']:.03f}")
     return res
+
+
+def load_pair_file(path, device):
+    """One registration pair from an .npz in the loader output contract of SURVEY 8(f4): `src_pts`/`tgt_pts` [N,3] (network
+    points), `src_feat`/`tgt_feat` [N,32] (their features), `gt_tform` [4,4], optionally `src_pts_raw`/`tgt_pts_raw`."""
+    with np.load(path) as z:
+        dev = lambda k: torch.from_numpy(np.ascontiguousarray(z[k], dtype=np.float32)).to(device)   # noqa: E731
+        pair = dict(src_pts=dev("src_pts")[None], tgt_pts=dev("tgt_pts")[None], src_feat=dev("src_feat")[None],
+                    tgt_feat=dev("tgt_feat")[None], gt_tform=dev("gt_tform"))
+        for k in ("src_pts_raw", "tgt_pts_raw"):
+            if k in z.files:
+                pair[k] = dev(k)
+    return pair
+
+
+def synthetic_pairs(benchmark, indices, device):
+    """Synthetic stand-ins of the benchmark's shape: KITTI-shaped or nuScenes-shaped clouds; the rot*
+    benchmarks draw the large-yaw distribution.  Generated lazily, one pair resident at a time."""
+    from .synth import synth_pair_cfg
+    config = "NS" if "nuscenes" in benchmark else "KT"
+    kind = "rot" if benchmark.startswith("rot") else "test"
+    for i in indices:
+        p = synth_pair_cfg(i, config, kind)
+        t = lambda a: torch.from_numpy(a).to(device)   # noqa: E731
+        yield dict(src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
+                   tgt_feat=t(p.tgt_feat)[None], gt_tform=t(p.gt_tform))
+
+
+def main(argv=None):
+    """`python -m umeregrobust_amd.evaluate --benchmark kitti_test` - the reference's command line (evaluate.py:113-124)
+    and result lines (:304-309).  Datasets and the feature network are not part of this library: pairs come
+    from --pairs files (points + features as the loader/network would hand them over) or, by default, from the synthetic
+    generator at the benchmark's shape.  Under torch.distributed.run every rank takes pairs[rank::world] and the metric
+    counts are summed with one all-reduce; each rank then seeds its host RNG with seed + rank."""
+    import argparse
+    import glob
+    import os
+    from .dist import RegistrationMetrics, init_distributed, shard_indices
+    from .utils.general_utils import BENCHMARK_CONFIGS, benchmark_config_path, update_namespace_from_yaml
+    parser = argparse.ArgumentParser(description=main.__doc__)
+    parser.add_argument("--benchmark", type=str, choices=list(BENCHMARK_CONFIGS), default="kitti_test")
+    parser.add_argument("--pairs", nargs="*", default=None, help=".npz pair files or directories of them (see load_pair_file)")
+    parser.add_argument("--synthetic", type=int, default=8, help="number of synthetic pairs when no --pairs are given")
+    parser.add_argument("--no-refine", action="store_true", help="skip the ICP refinement (evaluate.py:301)")
+    cli = parser.parse_args(argv)
+    config_path = benchmark_config_path(cli.benchmark)
+    args = update_namespace_from_yaml(argparse.Namespace(benchmark=cli.benchmark), config_path)
+    rank, local_rank, world = init_distributed()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    args.device = str(device)
+    torch.manual_seed(args.seed)
+    rng = np.random.RandomState(args.seed + rank) if world > 1 else np.random
+    if world == 1:
+        np.random.seed(args.seed)                                                                     # :127
+    if rank == 0:
+        print(f"Evaluate {args.dataset} Benchmark: {args.benchmark} config file: {config_path}")
+    if cli.pairs:
+        files = []
+        for p in cli.pairs:
+            files += sorted(glob.glob(os.path.join(p, "*.npz"))) if os.path.isdir(p) else [p]
+        mine = [files[i] for i in shard_indices(len(files), rank, world)]
+        pairs = (load_pair_file(f, device) for f in mine)
+    else:
+        pairs = synthetic_pairs(cli.benchmark, shard_indices(cli.synthetic, rank, world), device)
+    metrics = RegistrationMetrics()
+    with torch.no_grad():
+        for pair in pairs:
+            res = evaluate_pairs([pair], args, rng=rng, refine=not cli.no_refine)
+            metrics.update(res["rre"].numpy(), res["rte"].numpy())
+    s = metrics.all_reduce(device).summary()
+    if rank == 0:
+        print(f"N.P: {s['rr_np_06']:.03f} | S.P: {s['rr_sp']:.03f}")
+        print(f"mRRE: {s['mrre']:.03f} | mRTE: {s['mrte']:.03f}")
+    return s
+
+
+if __name__ == "__main__":
+    main()
