@@ -8,17 +8,19 @@
 // M = 2 500 hypotheses: 2.5e11 distance tests and a [64,10000,20,32] gathered tensor (1.6 GB) per
 // batch of 64 hypotheses.  Here:
 //
-//   * exact kNN on the uniform grid of grid.h (cell edge from the point density, 5x5x5 cell
-//     neighbourhood, grown ring by ring until every query provably holds its K nearest);
+//   * exact kNN on the uniform grid of grid.h (kNN mode: cell edge from the point density, thin axes
+//     collapsed);
 //   * one LANE per query, one wavefront per 64 spatially adjacent queries (queries are processed in
-//     cell-sorted order, and a rigid transform keeps neighbours adjacent), so the candidate set --
-//     the union box of the wave's query cells -- is streamed ONCE for 64 queries: candidates are
-//     loaded coalesced, parked in LDS and read back as broadcasts;
+//     cell-sorted order, and a rigid transform keeps neighbours adjacent, so adjacent lanes touch the
+//     same cache lines); each lane walks only the cell rows that intersect ITS search ball, clipped to
+//     the ball's chord (walk_ball).  The first radius comes from the local point density and grows
+//     while the lane is starved, until the ball provably holds the K nearest;
 //   * "K smallest by (d2, index)" without per-candidate sorted insertion: pass 1 histograms d2 per
-//     lane (32 bins, LDS, lane-private counters) to find the bin that holds the K-th neighbour;
-//     pass 2 appends only candidates up to that bin (K + ~2 of them) to a lane-private LDS list,
-//     then trims the few extras by repeated arg-max.  Overflowing lists are trimmed on the fly and
-//     the admission key tightened, so any density is handled exactly;
+//     lane (32 bins, LDS, lane-private counters) to find the bin that holds the K-th neighbour,
+//     zooming x32 into that bin when too many candidates share it; pass 2 walks the (smaller) ball of
+//     that bin and appends only candidates up to it (K + a few) to a lane-private LDS list, then
+//     trims the extras by repeated arg-max.  Overflowing lists are trimmed on the fly and the
+//     admission key tightened, so any density is handled exactly;
 //   * the score  sum_k cauchy(d_k) <vp_n, vq_jk> / Ns  is accumulated straight from the K kept
 //     (d2, index) keys; the gathered [.,.,20,32] tensor never exists.  Per-(hypothesis, 64-query
 //     chunk) partial sums are written and reduced in a fixed order => deterministic scores.
@@ -162,8 +164,8 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
 // Exact K nearest target points of one query per lane.  On return, valid lanes hold min(K, n2) keys
 // ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).  stage: 64 float4 of LDS scratch.
 //
-// The candidate stream (the union box of the wave's query cells, grown until it provably contains
-// every lane's K nearest) is shared by the 64 lanes; everything else is per lane:
+// Every lane streams its own candidates (walk_ball); the walks run in lock-step over the union of the
+// lanes' row ranges:
 //   histogram pass(es)  each unfinished lane histograms the d2 of the candidates inside its current
 //                       range (32 lane-private LDS counters) and either fixes its threshold -- the
 //                       bin holding its K-th neighbour, if everything up to that bin fits the list --
