@@ -67,19 +67,38 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
-// remove the largest key of this lane's list (lanes with `act`); list is lane-private: list[e * 64 + lane]
-__device__ __forceinline__ void drop_max(unsigned long long* list, int& cnt, bool act, int cnt_bound, int lane)
+// A lane's candidate list lives in LDS as two planes, d2 bits [cap][64] and the target's original index
+// [cap][64]; the index plane is 16 bits wide whenever the target cloud has <= 65 536 points (6 bytes per entry
+// instead of 8: what lets a fourth wave per SIMD fit at K = 20).  Keys compare as (d2 bits << 32) | index.
+template <class IdxT>
+struct KeyList {
+    unsigned int* d2;
+    IdxT* ix;
+    __device__ __forceinline__ unsigned long long get(int e, int lane) const
+    {
+        return ((unsigned long long)d2[e * kWave + lane] << 32) | (unsigned int)ix[e * kWave + lane];
+    }
+    __device__ __forceinline__ void set(int e, int lane, unsigned long long k) const
+    {
+        d2[e * kWave + lane] = (unsigned int)(k >> 32);
+        ix[e * kWave + lane] = (IdxT)(k & 0xffffffffull);
+    }
+};
+
+// remove the largest key of this lane's list (lanes with `act`)
+template <class IdxT>
+__device__ __forceinline__ void drop_max(const KeyList<IdxT>& list, int& cnt, bool act, int cnt_bound, int lane)
 {
     unsigned long long mk = 0ull;
     int mp = 0;
     for (int e = 0; e < cnt_bound; ++e) {
         if (act && e < cnt) {
-            const unsigned long long k = list[e * kWave + lane];
+            const unsigned long long k = list.get(e, lane);
             if (k >= mk) { mk = k; mp = e; }
         }
     }
     if (act) {
-        list[mp * kWave + lane] = list[(cnt - 1) * kWave + lane];
+        list.set(mp, lane, list.get(cnt - 1, lane));
         --cnt;
     }
 }
@@ -174,8 +193,9 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
 //                       outside the cloud need two or three.
 //   append pass         candidates up to the threshold go to the lane's LDS list (K .. K+16 of them);
 //                       the few extras are trimmed by repeated arg-max on (d2, index).
+template <class IdxT>
 __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool valid, int K, int cap,
-                        unsigned int* hist, unsigned long long* list, float4* stage, int lane)
+                        unsigned int* hist, const KeyList<IdxT>& list, int lane)
 {
     const Grid& g = c.g;
     const int cx = cell_axis(qx, g.minx, g.invx, g.nx);
@@ -320,7 +340,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
         ok = ok && key < ukey;
         if (__any(ok)) {
-            if (ok) { list[cnt * kWave + lane] = key; ++cnt; }
+            if (ok) { list.set(cnt, lane, key); ++cnt; }
             if (__any(cnt >= cap)) {
                 // a list overflowed (exact ties beyond the finest bins): trim it to K, admit only better keys
                 const bool over = cnt >= cap;
@@ -328,7 +348,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
                 while (__any(over && cnt > K)) { KNN_DBG(4, 1); drop_max(list, cnt, over && cnt > K, cap, lane); }
                 if (over) {
                     unsigned long long mk = 0ull;
-                    for (int e = 0; e < K; ++e) { const unsigned long long k = list[e * kWave + lane]; mk = k > mk ? k : mk; }
+                    for (int e = 0; e < K; ++e) { const unsigned long long k = list.get(e, lane); mk = k > mk ? k : mk; }
                     ukey = mk;
                 }
             }
@@ -339,39 +359,46 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
 }
 
 // sort this lane's keys ascending (selection sort in LDS; K is small)
-__device__ __forceinline__ void sort_keys(unsigned long long* list, int cnt, int cnt_bound, int lane)
+template <class IdxT>
+__device__ __forceinline__ void sort_keys(const KeyList<IdxT>& list, int cnt, int cnt_bound, int lane)
 {
     for (int r = 0; r < cnt_bound - 1; ++r) {
         unsigned long long mk = ~0ull;
         int mp = r;
         for (int e = r; e < cnt_bound; ++e) {
             if (e < cnt) {
-                const unsigned long long k = list[e * kWave + lane];
+                const unsigned long long k = list.get(e, lane);
                 if (k < mk) { mk = k; mp = e; }
             }
         }
         if (r < cnt) {
-            const unsigned long long t = list[r * kWave + lane];
-            list[r * kWave + lane] = mk;
-            list[mp * kWave + lane] = t;
+            const unsigned long long t = list.get(r, lane);
+            list.set(r, lane, mk);
+            list.set(mp, lane, t);
         }
     }
 }
 
+template <class IdxT>
 struct KnnLds {
     unsigned int* hist;
-    unsigned long long* list;
-    float4* stage;
+    KeyList<IdxT> list;
 };
 
-__device__ __forceinline__ KnnLds carve_lds(char* lds, int wave, int cap)
+__host__ __device__ constexpr size_t knn_lds_per_wave(int cap, size_t idx_bytes)
 {
     // the histogram is only live during the threshold search, the list only afterwards: they share the region
-    const size_t per_wave = (size_t)cap * kWave * 8;
-    char* base = lds + wave * per_wave;
-    KnnLds l;
-    l.list = reinterpret_cast<unsigned long long*>(base);
-    l.stage = nullptr;
+    const size_t list_bytes = (size_t)cap * kWave * (4 + idx_bytes), hist_bytes = (size_t)(kBins / 2) * kWave * 4;
+    return ((list_bytes > hist_bytes ? list_bytes : hist_bytes) + 15) & ~(size_t)15;
+}
+
+template <class IdxT>
+__device__ __forceinline__ KnnLds<IdxT> carve_lds(char* lds, int wave, int cap)
+{
+    char* base = lds + wave * knn_lds_per_wave(cap, sizeof(IdxT));
+    KnnLds<IdxT> l;
+    l.list.d2 = reinterpret_cast<unsigned int*>(base);
+    l.list.ix = reinterpret_cast<IdxT*>(base + (size_t)cap * kWave * 4);
     l.hist = reinterpret_cast<unsigned int*>(base);
     return l;
 }
@@ -387,6 +414,7 @@ __device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int 
 }
 
 // ---- pytorch3d.ops.knn_points ------------------------------------------------------------------
+template <class IdxT>
 __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict__ ws, size_t ws_stride,
                                                          const float* __restrict__ p1, int n1, int n2, int K, int cap,
                                                          int ordered, float* __restrict__ dists, int64_t* __restrict__ idx)
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict_
     const int b = blockIdx.y;
     const GridWs w = grid_ws(n2);
     const char* wb = ws + b * ws_stride;
-    const KnnLds L = carve_lds(lds, wave, cap);
+    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const KnnCtx c = make_ctx(wb, w, K, n2);
     const int slot = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;
     const bool valid = slot < n1;
@@ -405,13 +433,13 @@ __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict_
     if (ordered && valid) q = reinterpret_cast<const int*>(wb + w.off_kperm)[slot];   // cell-sorted order
     const float* pq = p1 + ((size_t)b * n1 + q) * 3;
     const float qx = valid ? pq[0] : 0.f, qy = valid ? pq[1] : 0.f, qz = valid ? pq[2] : 0.f;
-    const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, L.stage, lane);
+    const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
     sort_keys(L.list, cnt, K, lane);
     if (valid) {
         float* od = dists + ((size_t)b * n1 + q) * K;
         int64_t* oi = idx + ((size_t)b * n1 + q) * K;
         for (int e = 0; e < K; ++e) {
-            const unsigned long long k = e < cnt ? L.list[e * kWave + lane] : 0ull;
+            const unsigned long long k = e < cnt ? L.list.get(e, lane) : 0ull;
             od[e] = e < cnt ? __uint_as_float((unsigned int)(k >> 32)) : 0.f;
             oi[e] = e < cnt ? (int64_t)(unsigned int)(k & 0xffffffffull) : (int64_t)-1;
         }
@@ -420,6 +448,7 @@ __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict_
 
 // ---- feature_spatial_var (utils/loc_utils.py:579-585) ---------------------------------------------
 // mean over the knn-1 nearest OTHER points (idx[:, :, 1:]) of |feat_i - feat_j|_2
+template <class IdxT>
 __global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict__ ws, size_t ws_stride,
                                                           const float4* __restrict__ feat4, int N, int K, int cap,
                                                           float* __restrict__ out)
@@ -430,17 +459,17 @@ __global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict
     const int b = blockIdx.y;
     const GridWs w = grid_ws(N);
     const char* wb = ws + b * ws_stride;
-    const KnnLds L = carve_lds(lds, wave, cap);
+    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const KnnCtx c = make_ctx(wb, w, K, N);
     const int slot = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;   // position in the cell-sorted table
     const bool valid = slot < N;
     const float4 p = c.P4s[valid ? slot : 0];
     const int me = __float_as_int(p.w);
-    const int cnt = knn_wave(c, p.x, p.y, p.z, valid, K, cap, L.hist, L.list, L.stage, lane);
+    const int cnt = knn_wave(c, p.x, p.y, p.z, valid, K, cap, L.hist, L.list, lane);
     // rank 0 = the smallest key (the point itself unless an exact duplicate has a lower index)
     unsigned long long k0 = ~0ull;
     for (int e = 0; e < K; ++e)
-        if (e < cnt) { const unsigned long long k = L.list[e * kWave + lane]; k0 = k < k0 ? k : k0; }
+        if (e < cnt) { const unsigned long long k = L.list.get(e, lane); k0 = k < k0 ? k : k0; }
     const float4* fb = feat4 + (size_t)b * N * 8;
     float4 f[8];
 #pragma unroll
@@ -448,7 +477,7 @@ __global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict
     float acc = 0.f;
     for (int e = 0; e < K; ++e) {
         if (e < cnt) {
-            const unsigned long long k = L.list[e * kWave + lane];
+            const unsigned long long k = L.list.get(e, lane);
             if (k != k0) {
                 const int j = (int)(unsigned int)(k & 0xffffffffull);
                 float s = 0.f;
@@ -503,7 +532,8 @@ __global__ __launch_bounds__(256) void feature_weight_kernel(const float* __rest
 
 // ---- per-hypothesis correlation score (utils/loc_utils.py:592-637) ---------------------------------
 // score[h] = (1/Ns) sum_n sum_{k<K} cauchy(|R_h p_n + t_h - q_jk|, sigma) <vp_n, vq_jk>
-__global__ __launch_bounds__(128) void corr_score_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+template <class IdxT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_score_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                          const float4* __restrict__ vp4, const float4* __restrict__ vq4,
                                                          const float* __restrict__ T, int Ns, int Nt, int M, int K, int cap,
                                                          float sigma, int hyp_per_wave, int n_chunks,
@@ -513,7 +543,7 @@ __global__ __launch_bounds__(128) void corr_score_kernel(const char* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
-    const KnnLds L = carve_lds(lds, wave, cap);
+    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
     const int chunk = wid % n_chunks;
@@ -527,20 +557,22 @@ __global__ __launch_bounds__(128) void corr_score_kernel(const char* __restrict_
     const bool valid = slot < Ns;
     const float4 sp = S4s[valid ? slot : 0];
     const int sidx = __float_as_int(sp.w);
-    float4 vp[8];
-#pragma unroll
-    for (int v = 0; v < 8; ++v) vp[v] = valid ? vp4[(size_t)sidx * 8 + v] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int h = h0; h < h1; ++h) {
         const float* Th = T + (size_t)h * 16;
         // source_transformed = p R^T + t  (utils/loc_utils.py:629)
         const float qx = fmaf(Th[2], sp.z, fmaf(Th[1], sp.y, Th[0] * sp.x)) + Th[3];
         const float qy = fmaf(Th[6], sp.z, fmaf(Th[5], sp.y, Th[4] * sp.x)) + Th[7];
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
-        const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, L.stage, lane);
+        const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
+        // this query's weighted feature row: re-read per hypothesis (cache hit) rather than held across the search,
+        // where its 32 registers would cost a resident wave
+        float4 vp[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) vp[v] = valid ? vp4[(size_t)sidx * 8 + v] : make_float4(0.f, 0.f, 0.f, 0.f);
         float acc = 0.f;
         for (int e = 0; e < K; ++e) {
             if (e < cnt) {
-                const unsigned long long k = L.list[e * kWave + lane];
+                const unsigned long long k = L.list.get(e, lane);
                 const int j = (int)(unsigned int)(k & 0xffffffffull);
                 const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));   // torch.linalg.norm (:593)
                 const float r = dist / sigma;
@@ -570,14 +602,13 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
     scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
 }
 
-static void knn_lds_plan(int K, int* cap, int* waves, size_t* bytes, int max_waves)
+static void knn_lds_plan(int K, int n2, int* cap, int* waves, size_t* bytes, int max_waves, bool* idx16)
 {
-    // K + 6 list entries: the threshold bin typically holds 2-3 candidates (a fuller one is zoomed into), and at
-    // K = 20 this is what lets a third wave per SIMD fit the LDS (13 KiB per wave): 13.6 -> 10.3 us per hypothesis;
-    // K + 4 and K + 12 measured slower.  The shared region must also hold the 4 KiB histogram.
-    const int extra = 6;
-    *cap = K + extra < kBins / 4 ? kBins / 4 : K + extra;
-    const size_t per_wave = (size_t)(*cap) * kWave * 8;
+    // K + 6 list entries: the threshold bin typically holds 2-3 candidates (a fuller one is zoomed into); K + 4 and
+    // K + 12 measured slower.  At K = 20 with 16-bit indices a wave needs 9.75 KiB: four waves per SIMD.
+    *cap = K + 6;
+    *idx16 = n2 <= 65536;
+    const size_t per_wave = knn_lds_per_wave(*cap, *idx16 ? 2 : 4);
     int w = max_waves;
     while (w > 1 && per_wave * w > 64 * 1024) w >>= 1;
     *waves = w;
@@ -612,10 +643,15 @@ UMEREG_API int umereg_knn_points_f32(const float* p1, const float* p2, int B, in
         if (int rc = launch_query_order((char*)workspace, p1, nullptr, B, n2, n1, -(float)K, st)) return rc;
     int cap, waves;
     size_t lds;
-    knn_lds_plan(K, &cap, &waves, &lds, 4);
+    bool idx16;
+    knn_lds_plan(K, n2, &cap, &waves, &lds, 4, &idx16);
     const int qpb = waves * kWave;
-    hipLaunchKernelGGL(knn_points_kernel, dim3((n1 + qpb - 1) / qpb, B), dim3(qpb), lds, st, (const char*)workspace,
-                       grid_ws(n2).total, p1, n1, n2, K, cap, ordered, dists, idx);
+    if (idx16)
+        hipLaunchKernelGGL(knn_points_kernel<unsigned short>, dim3((n1 + qpb - 1) / qpb, B), dim3(qpb), lds, st,
+                           (const char*)workspace, grid_ws(n2).total, p1, n1, n2, K, cap, ordered, dists, idx);
+    else
+        hipLaunchKernelGGL(knn_points_kernel<unsigned int>, dim3((n1 + qpb - 1) / qpb, B), dim3(qpb), lds, st,
+                           (const char*)workspace, grid_ws(n2).total, p1, n1, n2, K, cap, ordered, dists, idx);
     UMEREG_CHECK_LAUNCH("knn_points_kernel");
     return UMEREG_OK;
 }
@@ -637,10 +673,15 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
     if (int rc = launch_prep(pts, (char*)workspace, B, N, -(float)knn, st)) return rc;
     int cap, waves;
     size_t lds;
-    knn_lds_plan(knn, &cap, &waves, &lds, 4);
+    bool idx16;
+    knn_lds_plan(knn, N, &cap, &waves, &lds, 4, &idx16);
     const int qpb = waves * kWave;
-    hipLaunchKernelGGL(spatial_var_kernel, dim3((N + qpb - 1) / qpb, B), dim3(qpb), lds, st, (const char*)workspace,
-                       grid_ws(N).total, (const float4*)feat, N, knn, cap, out);
+    if (idx16)
+        hipLaunchKernelGGL(spatial_var_kernel<unsigned short>, dim3((N + qpb - 1) / qpb, B), dim3(qpb), lds, st,
+                           (const char*)workspace, grid_ws(N).total, (const float4*)feat, N, knn, cap, out);
+    else
+        hipLaunchKernelGGL(spatial_var_kernel<unsigned int>, dim3((N + qpb - 1) / qpb, B), dim3(qpb), lds, st,
+                           (const char*)workspace, grid_ws(N).total, (const float4*)feat, N, knn, cap, out);
     UMEREG_CHECK_LAUNCH("spatial_var_kernel");
     return UMEREG_OK;
 }
@@ -703,14 +744,20 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
     if (int rc = launch_prep(src_pts, ws_src, 1, Ns, -(float)K, st)) return rc;
     int cap, waves;
     size_t lds;
-    knn_lds_plan(K, &cap, &waves, &lds, 2);
+    bool idx16;
+    knn_lds_plan(K, Nt, &cap, &waves, &lds, 2, &idx16);
     const int n_chunks = (Ns + kWave - 1) / kWave;
     const int hyp_per_wave = 8;
     const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
     const long n_waves = (long)n_chunks * n_hg;
-    hipLaunchKernelGGL(corr_score_kernel, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave), lds, st,
-                       (const char*)ws_tgt, (const char*)ws_src, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt,
-                       M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
+    if (idx16)
+        hipLaunchKernelGGL(corr_score_kernel<unsigned short>, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
+                           lds, st, (const char*)ws_tgt, (const char*)ws_src, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
+    else
+        hipLaunchKernelGGL(corr_score_kernel<unsigned int>, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
+                           lds, st, (const char*)ws_tgt, (const char*)ws_src, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
     UMEREG_CHECK_LAUNCH("corr_score_kernel");
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
