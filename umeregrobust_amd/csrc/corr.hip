@@ -266,23 +266,32 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
         for (;;) {             // refinement loop at this radius
             KNN_DBG(2, 1);
 #pragma unroll
-            for (int b = 0; b < kBins / 2; ++b) hist[b * kWave + lane] = 0u;   // two 16-bit counters per word
+            for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
             const bool active = !done && !starved;
-            walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
-                if (active && d2 < S.hi0) {
-                    int b = sel_bin(d2, S.lo[0], S.sc[0]);
-                    bool in = true;
-                    if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
-                    if (S.nlev > 2) { in = in && b == S.bs[1]; b = sel_bin(d2, S.lo[2], S.sc[2]); }
-                    if (in) atomicAdd(&hist[(b >> 1) * kWave + lane], 1u << ((b & 1) * 16));   // lane-private 16-bit counter (ds_add_u32)
-                }
-            });
+            if (!__any(active && S.nlev > 1)) {
+                // common case, every lane still at level 0 (lo = 0): one multiply, one conversion, one LDS add
+                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
+                    if (active && d2 < S.hi0) {
+                        const int b = min((int)(d2 * S.sc[0]), kBins - 1);
+                        atomicAdd(&hist[b * kWave + lane], 1u);   // lane-private counter (ds_add_u32)
+                    }
+                });
+            } else {
+                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
+                    if (active && d2 < S.hi0) {
+                        int b = sel_bin(d2, S.lo[0], S.sc[0]);
+                        bool in = true;
+                        if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
+                        if (S.nlev > 2) { in = in && b == S.bs[1]; b = sel_bin(d2, S.lo[2], S.sc[2]); }
+                        if (in) atomicAdd(&hist[b * kWave + lane], 1u);
+                    }
+                });
+            }
             if (active) {
                 int cum = c_lo, bstar = -1, before = c_lo, inbin = 0;
 #pragma unroll
                 for (int b = 0; b < kBins; ++b) {
-                    const unsigned int w2 = hist[(b >> 1) * kWave + lane];
-                    const int h = (int)((b & 1) ? (w2 >> 16) : (w2 & 0xffffu));   // a count of 65535+ would need a 64k-point bin
+                    const int h = (int)hist[b * kWave + lane];
                     if (bstar < 0 && cum + h >= K) { bstar = b; before = cum; inbin = h; }
                     cum += h;
                 }
@@ -326,17 +335,7 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
     int cnt = 0;
     unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
     const float r2_app = S.bs[0] >= kBins - 1 ? S.hi0 : fminf(S.hi0, ((float)(S.bs[0] + 1) / S.sc[0]) * 1.0001f + 1e-30f);
-    walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi) {
-        bool ok = valid && d2 < S.hi0;
-        if (ok) {
-            const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
-            ok = b0 <= S.bs[0];
-            if (S.nlev > 1 && b0 == S.bs[0]) {
-                const int b1 = sel_bin(d2, S.lo[1], S.sc[1]);
-                ok = b1 <= S.bs[1];
-                if (S.nlev > 2 && b1 == S.bs[1]) ok = sel_bin(d2, S.lo[2], S.sc[2]) <= S.bs[2];
-            }
-        }
+    auto admit = [&](bool ok, float d2, int oi) __attribute__((always_inline)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
         ok = ok && key < ukey;
         if (__any(ok)) {
@@ -353,7 +352,28 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
                 }
             }
         }
-    });
+    };
+    if (!__any(valid && S.nlev > 1)) {
+        // common case, level 0 only: int(d2 * sc0) <= bs0  <=>  d2 * sc0 < bs0 + 1 (the last bin takes everything)
+        const float thr = S.bs[0] >= kBins - 1 ? 3.0e38f : (float)(S.bs[0] + 1);
+        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi) {
+            admit(valid && d2 < S.hi0 && (d2 * S.sc[0] < thr || S.bs[0] >= kBins - 1), d2, oi);
+        });
+    } else {
+        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi) {
+            bool ok = valid && d2 < S.hi0;
+            if (ok) {
+                const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
+                ok = b0 <= S.bs[0];
+                if (S.nlev > 1 && b0 == S.bs[0]) {
+                    const int b1 = sel_bin(d2, S.lo[1], S.sc[1]);
+                    ok = b1 <= S.bs[1];
+                    if (S.nlev > 2 && b1 == S.bs[1]) ok = sel_bin(d2, S.lo[2], S.sc[2]) <= S.bs[2];
+                }
+            }
+            admit(ok, d2, oi);
+        });
+    }
     while (__any(cnt > K)) { KNN_DBG(5, 1); drop_max(list, cnt, cnt > K, cap, lane); }
     return cnt;
 }
@@ -388,7 +408,7 @@ struct KnnLds {
 __host__ __device__ constexpr size_t knn_lds_per_wave(int cap, size_t idx_bytes)
 {
     // the histogram is only live during the threshold search, the list only afterwards: they share the region
-    const size_t list_bytes = (size_t)cap * kWave * (4 + idx_bytes), hist_bytes = (size_t)(kBins / 2) * kWave * 4;
+    const size_t list_bytes = (size_t)cap * kWave * (4 + idx_bytes), hist_bytes = (size_t)kBins * kWave * 4;
     return ((list_bytes > hist_bytes ? list_bytes : hist_bytes) + 15) & ~(size_t)15;
 }
 
