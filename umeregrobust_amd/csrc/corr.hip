@@ -162,7 +162,9 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const bool ok = pos + u < end;
-                    const float4 p = c.P4s[ok ? pos + u : 0];
+                    // 32-bit byte offset from the table base (the table is < 4 GiB): base + offset addressing, no 64-bit math
+                    const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(c.P4s) +
+                                                                      ((unsigned int)(ok ? pos + u : 0) << 4));
                     const float dx = qx - p.x;
                     const float dy = qy - p.y;
                     const float dz = qz - p.z;
@@ -270,11 +272,10 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             const bool active = !done && !starved;
             if (!__any(active && S.nlev > 1)) {
                 // common case, every lane still at level 0 (lo = 0): one multiply, one conversion, one LDS add
+                // branch-free: rejected candidates (and the 3e38 padding: inf -> saturated conversion -> last bin) add 0
                 walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
-                    if (active && d2 < S.hi0) {
-                        const int b = min((int)(d2 * S.sc[0]), kBins - 1);
-                        atomicAdd(&hist[b * kWave + lane], 1u);   // lane-private counter (ds_add_u32)
-                    }
+                    const int b = min((int)(d2 * S.sc[0]), kBins - 1);
+                    atomicAdd(&hist[b * kWave + lane], active && d2 < S.hi0 ? 1u : 0u);   // lane-private counter (ds_add_u32)
                 });
             } else {
                 walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
