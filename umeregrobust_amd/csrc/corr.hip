@@ -128,8 +128,8 @@ __device__ __forceinline__ int sel_bin(float d2, float lo, float sc)
 // point with d2 < r2 always lies in a visited cell (cell_axis is monotone and the chord is computed from the
 // row's distance to the query, a lower bound of the point's).  Rows are walked in lock-step over the union of
 // the active lanes' row ranges; inside a row every lane advances through its own run, 4 candidates per trip.
-// Adjacent lanes touch the same cache lines.  body(d2, original index) is called for every candidate slot;
-// slots beyond a lane's run arrive with d2 = 3e38.
+// Adjacent lanes touch the same cache lines.  body(d2, original index, in_run) is called for every candidate
+// slot; slots beyond a lane's run arrive with in_run = false.
 template <class Body>
 __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, float qz, bool act, float r2, int lane,
                                           Body&& body)
@@ -159,9 +159,10 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
                 KNN_DBG(7, 4);
                 float d2[4];
                 int oi[4];
+                bool in_run[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const bool ok = pos + u < end;
+                    const bool ok = in_run[u] = pos + u < end;
                     // 32-bit byte offset from the table base (the table is < 4 GiB): base + offset addressing, no 64-bit math
                     const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(c.P4s) +
                                                                       ((unsigned int)(ok ? pos + u : 0) << 4));
@@ -171,11 +172,11 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
                     float t = dx * dx;
                     t = t + dy * dy;
                     t = t + dz * dz;
-                    d2[u] = ok ? t : 3.0e38f;   // beyond this lane's run: never admitted
+                    d2[u] = t;
                     oi[u] = __float_as_int(p.w);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) body(d2[u], oi[u]);
+                for (int u = 0; u < 4; ++u) body(d2[u], oi[u], in_run[u]);   // !in_run: beyond this lane's run, d2 is of no meaning
                 pos += 4;
             }
         }
@@ -273,13 +274,13 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             if (!__any(active && S.nlev > 1)) {
                 // common case, every lane still at level 0 (lo = 0): one multiply, one conversion, one LDS add
                 // branch-free: rejected candidates (and the 3e38 padding: inf -> saturated conversion -> last bin) add 0
-                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
+                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int, bool in_run) {
                     const int b = min((int)(d2 * S.sc[0]), kBins - 1);
-                    atomicAdd(&hist[b * kWave + lane], active && d2 < S.hi0 ? 1u : 0u);   // lane-private counter (ds_add_u32)
+                    atomicAdd(&hist[b * kWave + lane], in_run && d2 < S.hi0 ? 1u : 0u);   // lane-private counter (ds_add_u32)
                 });
             } else {
-                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int) {
-                    if (active && d2 < S.hi0) {
+                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int, bool in_run) {
+                    if (in_run && d2 < S.hi0) {
                         int b = sel_bin(d2, S.lo[0], S.sc[0]);
                         bool in = true;
                         if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
@@ -357,12 +358,16 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
     if (!__any(valid && S.nlev > 1)) {
         // common case, level 0 only: int(d2 * sc0) <= bs0  <=>  d2 * sc0 < bs0 + 1 (the last bin takes everything)
         const float thr = S.bs[0] >= kBins - 1 ? 3.0e38f : (float)(S.bs[0] + 1);
-        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi) {
-            admit(valid && d2 < S.hi0 && (d2 * S.sc[0] < thr || S.bs[0] >= kBins - 1), d2, oi);
+        // At level 0 the histogram pass has already established that at most `cap` candidates pass this test
+        // (same arithmetic, same candidates), so the list cannot overflow: plain masked stores, no branches.
+        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi, bool in_run) {
+            const bool ok = in_run && d2 < S.hi0 && (d2 * S.sc[0] < thr || S.bs[0] >= kBins - 1) && cnt < cap;
+            if (ok) list.set(cnt, lane, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi);
+            cnt += ok ? 1 : 0;
         });
     } else {
-        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi) {
-            bool ok = valid && d2 < S.hi0;
+        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi, bool in_run) {
+            bool ok = in_run && d2 < S.hi0;
             if (ok) {
                 const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
                 ok = b0 <= S.bs[0];
