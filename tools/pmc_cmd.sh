@@ -17,7 +17,8 @@ for f in glob.glob("$OUT/*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in acc.items():
-    if not any(x in k for x in ("coarse", "refine", "dist_h", "moments")):
+    import os
+    if not any(x in k for x in os.environ.get("KFILTER", "coarse,refine,dist_h,moments").split(",")):
         continue
     print(k)
     for n, v in sorted(c.items()):

@@ -32,7 +32,7 @@ namespace umereg {
 
 constexpr int kBins = 32;
 constexpr float kKnnMaxCells = 6.0f;   // upper bound of the first search radius, in cells
-constexpr float kKnnTarget = 2.0f;     // expected points in the first search ball, in units of K
+constexpr float kKnnTarget = 4.0f;     // expected points in the first search ball, in units of K
 
 #ifdef UMEREG_KNN_DEBUG
 __device__ unsigned long long g_knn_dbg[16];
