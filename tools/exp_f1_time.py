@@ -9,7 +9,7 @@ if os.environ.get('ALTLIB'):
 from umeregrobust_amd import ops
 from umeregrobust_amd.synth import synth_pair
 dev = torch.device('cuda')
-p = synth_pair(0, N=50000, n_kp=100, kind='test')
+p = synth_pair(0, N=50000, n_kp=100, kind=os.environ.get('KIND', 'test'))
 t = lambda x: torch.from_numpy(x).to(dev)
 rs = np.random.RandomState(5)
 si = rs.choice(50000, 10000, replace=False); ti = rs.choice(50000, 10000, replace=False)

@@ -556,11 +556,52 @@ __global__ __launch_bounds__(256) void feature_weight_kernel(const float* __rest
     if (i < (size_t)n * 32) out[i] = (feat[i] - mean[i & 31]) * wgt[i >> 5];
 }
 
+// ---- processing order of the source points ---------------------------------------------------------
+// 64 consecutive points of the order form one wavefront of queries.  Its walks are cheapest when, AFTER the
+// hypothesis' transform, those queries lie along a row of the target grid (every lane then needs the same few
+// rows).  Most hypotheses agree on the rotation, so the order is taken from the cell-sorted order of Rbar * p,
+// Rbar = entry-wise mean of the hypotheses' rotation blocks (a scaled rotation near the consensus; its scale
+// and the translations do not matter for an order).  Speed only: scores do not depend on the order beyond
+// the summation order of the per-chunk partial sums.
+__global__ __launch_bounds__(256) void mean_rotation_kernel(const float* __restrict__ T, int M, float* __restrict__ Rbar)
+{
+    __shared__ double red[256];
+    for (int e = 0; e < 9; ++e) {
+        const int off = (e / 3) * 4 + (e % 3);
+        double s = 0.0;
+        for (int h = threadIdx.x; h < M; h += 256) s += (double)T[(size_t)h * 16 + off];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float v = (float)(red[0] / (double)M);
+            Rbar[e] = v == v ? v : (e % 4 == 0 ? 1.f : 0.f);   // NaN hypotheses: fall back to the identity's entry
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void rotate_points_kernel(const float* __restrict__ pts, int N, const float* __restrict__ Rbar,
+                                                            float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float v = fmaf(Rbar[r * 3 + 2], z, fmaf(Rbar[r * 3 + 1], y, Rbar[r * 3] * x));
+        out[(size_t)i * 3 + r] = v == v && fabsf(v) < 1e30f ? v : 0.f;
+    }
+}
+
 // ---- per-hypothesis correlation score (utils/loc_utils.py:592-637) ---------------------------------
 // score[h] = (1/Ns) sum_n sum_{k<K} cauchy(|R_h p_n + t_h - q_jk|, sigma) <vp_n, vq_jk>
 template <class IdxT>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_score_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
-                                                         const float4* __restrict__ vp4, const float4* __restrict__ vq4,
+                                                         const float* __restrict__ src_pts, const float4* __restrict__ vp4, const float4* __restrict__ vq4,
                                                          const float* __restrict__ T, int Ns, int Nt, int M, int K, int cap,
                                                          float sigma, int hyp_per_wave, int n_chunks,
                                                          float* __restrict__ partial)
@@ -577,12 +618,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int h0 = hg * hyp_per_wave;
     if (h0 >= M) return;
     const int h1 = min(h0 + hyp_per_wave, M);
-    // source points in THEIR cell-sorted order: 64 consecutive slots are spatial neighbours
+    // source points in the cell-sorted order of their consensus-rotated copies (see mean_rotation_kernel): the
+    // sorted table only supplies the order, coordinates are the caller's
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
     const int slot = chunk * kWave + lane;
     const bool valid = slot < Ns;
-    const float4 sp = S4s[valid ? slot : 0];
-    const int sidx = __float_as_int(sp.w);
+    const int sidx = __float_as_int(S4s[valid ? slot : 0].w);
+    float4 sp;
+    sp.x = src_pts[(size_t)sidx * 3]; sp.y = src_pts[(size_t)sidx * 3 + 1]; sp.z = src_pts[(size_t)sidx * 3 + 2];
     for (int h = h0; h < h1; ++h) {
         const float* Th = T + (size_t)h * 16;
         // source_transformed = p R^T + t  (utils/loc_utils.py:629)
@@ -719,7 +762,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M)
     if (Ns <= 0 || Nt <= 0 || M <= 0) return 0;
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
-           align_up((size_t)kColsumBlocks * 32 * 8, 256);
+           align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256;
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -765,9 +808,17 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
     char* ws_src = (char*)workspace;
     char* ws_tgt = ws_src + grid_ws(Ns).total;
     float* partial = (float*)(ws_tgt + grid_ws(Nt).total);
-    // target: the search structure; source: only its cell-sorted order (spatially coherent wavefronts)
+    const size_t n_chunks_sz = (size_t)((Ns + kWave - 1) / kWave);
+    float* rotated = (float*)((char*)partial + align_up((size_t)M * n_chunks_sz * 4, 256) + align_up((size_t)kColsumBlocks * 32 * 8, 256));
+    float* Rbar = (float*)((char*)rotated + align_up((size_t)Ns * 12, 256));
+    // target: the search structure; source: only a processing order (wavefronts of queries that stay row-aligned
+    // with the target grid under the consensus rotation)
     if (int rc = launch_prep(tgt_pts, ws_tgt, 1, Nt, -(float)K, st)) return rc;
-    if (int rc = launch_prep(src_pts, ws_src, 1, Ns, -(float)K, st)) return rc;
+    hipLaunchKernelGGL(mean_rotation_kernel, dim3(1), dim3(256), 0, st, T, M, Rbar);
+    UMEREG_CHECK_LAUNCH("mean_rotation_kernel");
+    hipLaunchKernelGGL(rotate_points_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, src_pts, Ns, (const float*)Rbar, rotated);
+    UMEREG_CHECK_LAUNCH("rotate_points_kernel");
+    if (int rc = launch_prep(rotated, ws_src, 1, Ns, -(float)K, st)) return rc;
     int cap, waves;
     size_t lds;
     bool idx16;
@@ -778,11 +829,11 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
     const long n_waves = (long)n_chunks * n_hg;
     if (idx16)
         hipLaunchKernelGGL(corr_score_kernel<unsigned short>, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
-                           lds, st, (const char*)ws_tgt, (const char*)ws_src, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
+                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
                            Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
     else
         hipLaunchKernelGGL(corr_score_kernel<unsigned int>, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
-                           lds, st, (const char*)ws_tgt, (const char*)ws_src, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
+                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
                            Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
     UMEREG_CHECK_LAUNCH("corr_score_kernel");
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, scores);
