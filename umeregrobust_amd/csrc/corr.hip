@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict_
 template <class IdxT>
 __global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict__ ws, size_t ws_stride,
                                                           const float4* __restrict__ feat4, int N, int K, int cap,
-                                                          float* __restrict__ out)
+                                                          int lanes_used, float* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -487,8 +487,10 @@ __global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict
     const char* wb = ws + b * ws_stride;
     const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const KnnCtx c = make_ctx(wb, w, K, N);
-    const int slot = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;   // position in the cell-sorted table
-    const bool valid = slot < N;
+    // a small cloud does not fill the chip with full wavefronts: fewer queries per wavefront spread the work over
+    // all compute units and shorten the lock-step walks (the slowest of 16 lanes instead of 64)
+    const int slot = (blockIdx.x * (blockDim.x >> 6) + wave) * lanes_used + lane;   // position in the cell-sorted table
+    const bool valid = lane < lanes_used && slot < N;
     const float4 p = c.P4s[valid ? slot : 0];
     const int me = __float_as_int(p.w);
     const int cnt = knn_wave(c, p.x, p.y, p.z, valid, K, cap, L.hist, L.list, lane);
@@ -744,13 +746,15 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
     size_t lds;
     bool idx16;
     knn_lds_plan(knn, N, &cap, &waves, &lds, 4, &idx16);
-    const int qpb = waves * kWave;
+    int lanes_used = kWave;   // queries per wavefront: halve while the launch has fewer wavefronts than the chip has SIMDs
+    while (lanes_used > 8 && (N + lanes_used - 1) / lanes_used < 1024) lanes_used >>= 1;
+    const int qpb = waves * lanes_used;
     if (idx16)
-        hipLaunchKernelGGL(spatial_var_kernel<unsigned short>, dim3((N + qpb - 1) / qpb, B), dim3(qpb), lds, st,
-                           (const char*)workspace, grid_ws(N).total, (const float4*)feat, N, knn, cap, out);
+        hipLaunchKernelGGL(spatial_var_kernel<unsigned short>, dim3((N + qpb - 1) / qpb, B), dim3(waves * kWave), lds, st,
+                           (const char*)workspace, grid_ws(N).total, (const float4*)feat, N, knn, cap, lanes_used, out);
     else
-        hipLaunchKernelGGL(spatial_var_kernel<unsigned int>, dim3((N + qpb - 1) / qpb, B), dim3(qpb), lds, st,
-                           (const char*)workspace, grid_ws(N).total, (const float4*)feat, N, knn, cap, out);
+        hipLaunchKernelGGL(spatial_var_kernel<unsigned int>, dim3((N + qpb - 1) / qpb, B), dim3(waves * kWave), lds, st,
+                           (const char*)workspace, grid_ws(N).total, (const float4*)feat, N, knn, cap, lanes_used, out);
     UMEREG_CHECK_LAUNCH("spatial_var_kernel");
     return UMEREG_OK;
 }
