@@ -33,6 +33,7 @@ json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), in
 print(json.dumps({k: v for k, v in out.items() if k not in ("_comment", "raw_kib")}, indent=1))
 if dst:
     os.makedirs(dst, exist_ok=True)
-    for f in ("bench_default.json", "kernel_stats.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv", "bench_with_selection.json"):
+    for f in ("bench_default.json", "kernel_stats.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv", "bench_with_selection.json",
+              "bench_end_to_end.json", "kernel_stats_end_to_end.csv"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
