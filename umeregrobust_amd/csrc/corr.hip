@@ -184,7 +184,7 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
 }
 
 // Exact K nearest target points of one query per lane.  On return, valid lanes hold min(K, n2) keys
-// ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).  stage: 64 float4 of LDS scratch.
+// ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).
 //
 // Every lane streams its own candidates (walk_ball); the walks run in lock-step over the union of the
 // lanes' row ranges:
@@ -194,7 +194,7 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
 //                       or zooms into that bin (x32 resolution) for the next pass.  Typical lanes
 //                       finish in one pass; lanes of a scattered wave (huge union box) or queries far
 //                       outside the cloud need two or three.
-//   append pass         candidates up to the threshold go to the lane's LDS list (K .. K+16 of them);
+//   append pass         candidates up to the threshold go to the lane's LDS list (K .. K+6 of them);
 //                       the few extras are trimmed by repeated arg-max on (d2, index).
 template <class IdxT>
 __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool valid, int K, int cap,
