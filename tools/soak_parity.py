@@ -152,6 +152,33 @@ def soak_rtume(rng):
     return f"rtume {n}"
 
 
+def soak_corr(rng):
+    """per-hypothesis correlation scores (f1) vs the brute-force oracle: random clouds, random and degenerate transforms"""
+    Ns, Nt = max(2, rand_size(rng, 3000)), max(2, rand_size(rng, 3000))
+    K = int(min(Nt, rng.choice([1, 5, 20, 20, 20])))
+    M = int(rng.randint(1, 12))
+    tgt = cloud(rng, Nt)
+    src = cloud(rng, Ns) if rng.rand() < 0.3 else (tgt[rng.randint(0, Nt, Ns)] + rng.standard_normal((Ns, 3)).astype(np.float32) * np.float32(0.3))
+    Ts = []
+    for _ in range(M):
+        a = rng.standard_normal(3); a /= np.linalg.norm(a)
+        th = np.deg2rad(rng.choice([0.0, 1.0, 30.0, 180.0])) * rng.rand()
+        Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        T = np.eye(4); T[:3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        T[:3, 3] = rng.standard_normal(3) * rng.choice([0.0, 0.5, 50.0])
+        Ts.append(T)
+    Ts = np.stack(Ts).astype(np.float32)
+    sf = rng.standard_normal((Ns, 32)).astype(np.float32); tf = rng.standard_normal((Nt, 32)).astype(np.float32)
+    sigma = float(rng.choice([0.05, 1.5]))
+    ref = orc.pc_corr_cost(Ts[:, :3, :3], Ts[:, :3, 3], src, tgt, K, sf, tf, sigma)
+    out = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma))
+    scale = np.abs(ref).max() + 1e-6
+    assert np.abs(out - ref).max() <= 2e-4 * scale + 1e-6, f"corr scores differ {np.abs(out - ref).max():.3g} of {scale:.3g} (Ns={Ns}, Nt={Nt}, K={K}, M={M})"
+    out2 = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma))
+    assert np.array_equal(out, out2), "corr scores not deterministic"
+    return f"corr {Ns}x{Nt} K={K} M={M}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
@@ -161,7 +188,7 @@ def main():
     a = ap.parse_args()
     global BIG
     BIG = a.big
-    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume}
+    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr}
     if a.only:
         kinds = {k: v for k, v in kinds.items() if k in a.only.split(",")}
     t0 = time.time()
