@@ -568,11 +568,10 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st)
 {
     const GridWs w = grid_ws(N);
-    for (int b = 0; b < B; ++b) {
-        if (hipMemsetAsync(ws + b * w.total + w.off_bbox, 0, 64, st) != hipSuccess) {
-            set_error("hipMemsetAsync(bbox) failed");
-            return UMEREG_ELAUNCH;
-        }
+    // the B bounding-box records (64 B each, one per cloud's workspace slice) in one call
+    if ((B == 1 ? hipMemsetAsync(ws + w.off_bbox, 0, 64, st) : hipMemset2DAsync(ws + w.off_bbox, w.total, 0, 64, B, st)) != hipSuccess) {
+        set_error("hipMemsetAsync(bbox) failed");
+        return UMEREG_ELAUNCH;
     }
     {
         int nb = (w.Npad + kPackWG - 1) / kPackWG;

@@ -9,8 +9,8 @@
 
 namespace umereg {
 
-__global__ __launch_bounds__(256) void orthobasis_kernel(const float* __restrict__ ume, int n, int n_pad,
-                                                         int layout, float* __restrict__ Q)
+__device__ __forceinline__ void orthobasis_body(const float* __restrict__ ume, int n, int n_pad, int layout,
+                                                float* __restrict__ Q)
 {
     const int row = threadIdx.x & 31;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -46,6 +46,21 @@ __global__ __launch_bounds__(256) void orthobasis_kernel(const float* __restrict
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void orthobasis_kernel(const float* __restrict__ ume, int n, int n_pad,
+                                                         int layout, float* __restrict__ Q)
+{
+    orthobasis_body(ume, n, n_pad, layout, Q);
+}
+
+// both sets of a matching problem in one launch (blockIdx.y: 0 = rows / source set, 1 = columns / target set)
+__global__ __launch_bounds__(256) void orthobasis_pair_kernel(const float* __restrict__ ume1, int n1, int n1_pad, int layout1,
+                                                              float* __restrict__ Q1, const float* __restrict__ ume2, int n2,
+                                                              int n2_pad, int layout2, float* __restrict__ Q2)
+{
+    if (blockIdx.y == 0) orthobasis_body(ume1, n1, n1_pad, layout1, Q1);
+    else orthobasis_body(ume2, n2, n2_pad, layout2, Q2);
 }
 
 // singular values of each 32x4 UME (torch.linalg.svdvals at reference utils/eval_utils.py:31-32): one-sided
@@ -108,6 +123,18 @@ int launch_orthobasis(const float* ume, int n, int layout, float* Q, hipStream_t
     dim3 grid((n_pad + groups_per_wg - 1) / groups_per_wg);
     hipLaunchKernelGGL(orthobasis_kernel, grid, dim3(256), 0, st, ume, n, n_pad, layout, Q);
     UMEREG_CHECK_LAUNCH("orthobasis_kernel");
+    return UMEREG_OK;
+}
+
+int launch_orthobasis_pair(const float* ume1, int n1, int layout1, float* Q1, const float* ume2, int n2, int layout2,
+                           float* Q2, hipStream_t st)
+{
+    const int n1_pad = (int)align_up((size_t)n1, qlayout_pad(layout1)), n2_pad = (int)align_up((size_t)n2, qlayout_pad(layout2));
+    const int groups_per_wg = 256 / 32;
+    const int gx = ((n1_pad > n2_pad ? n1_pad : n2_pad) + groups_per_wg - 1) / groups_per_wg;
+    hipLaunchKernelGGL(orthobasis_pair_kernel, dim3(gx, 2), dim3(256), 0, st, ume1, n1, n1_pad, layout1, Q1, ume2, n2, n2_pad,
+                       layout2, Q2);
+    UMEREG_CHECK_LAUNCH("orthobasis_pair_kernel");
     return UMEREG_OK;
 }
 

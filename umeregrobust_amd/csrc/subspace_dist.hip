@@ -28,6 +28,8 @@
 namespace umereg {
 
 int launch_orthobasis(const float* ume, int n, int layout, float* Q, hipStream_t st);  // ortho.hip
+int launch_orthobasis_pair(const float* ume1, int n1, int layout1, float* Q1, const float* ume2, int n2, int layout2,
+                           float* Q2, hipStream_t st);
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -901,10 +903,9 @@ static int dist_common(const float* ume1, const float* ume2, int B, int n1, int 
     float* QB = (float*)((char*)workspace + qa_bytes(n1));
     void* keys = (char*)workspace + qa_bytes(n1) + qb_bytes(n2);
     for (int b = 0; b < B; ++b) {
-        if (int rc = launch_orthobasis(ume1 + (size_t)b * n1 * 128, n1,
-                                       f16x2 ? UMEREG_QLAYOUT_ROWS_F16X2 : UMEREG_QLAYOUT_ROWS, QA, st)) return rc;
-        if (int rc = launch_orthobasis(ume2 + (size_t)b * n2 * 128, n2,
-                                       f16x2 ? UMEREG_QLAYOUT_COLS_F16X2 : UMEREG_QLAYOUT_COLS, QB, st)) return rc;
+        if (int rc = launch_orthobasis_pair(ume1 + (size_t)b * n1 * 128, n1, f16x2 ? UMEREG_QLAYOUT_ROWS_F16X2 : UMEREG_QLAYOUT_ROWS, QA,
+                                            ume2 + (size_t)b * n2 * 128, n2, f16x2 ? UMEREG_QLAYOUT_COLS_F16X2 : UMEREG_QLAYOUT_COLS, QB,
+                                            st)) return rc;
         float* Db = D ? D + (size_t)b * n1 * n2 : nullptr;
         int64_t* mi = match_idx ? match_idx + (size_t)b * n1 : nullptr;
         float* md = match_dist ? match_dist + (size_t)b * n1 : nullptr;
