@@ -615,10 +615,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
-    const int chunk = wid % n_chunks;
-    const int hg = wid / n_chunks;
+    // consecutive wavefronts take the SAME 64 queries under different groups of hypotheses: what is resident on the
+    // chip at any time then works in one neighbourhood of the target, and its table and feature rows are cache hits
+    const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
+    const int chunk = wid / n_hg;
+    const int hg = wid % n_hg;
     const int h0 = hg * hyp_per_wave;
-    if (h0 >= M) return;
+    if (chunk >= n_chunks) return;
     const int h1 = min(h0 + hyp_per_wave, M);
     // source points in the cell-sorted order of their consensus-rotated copies (see mean_rotation_kernel): the
     // sorted table only supplies the order, coordinates are the caller's
