@@ -638,28 +638,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qy = fmaf(Th[6], sp.z, fmaf(Th[5], sp.y, Th[4] * sp.x)) + Th[7];
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
         const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
-        // this query's weighted feature row: re-read per hypothesis (cache hit) rather than held across the search,
-        // where its 32 registers would cost a resident wave
-        float4 vp[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) vp[v] = valid ? vp4[(size_t)sidx * 8 + v] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float acc = 0.f;
+        // Score epilogue.  A feature row is 128 B: read by one lane it costs eight 16-byte gathers that each touch 64
+        // different cache lines per wavefront.  Instead 8 lanes share a row (one line per 8 lanes, one gather per
+        // neighbour): group g = lanes 8g..8g+7 serves its 8 queries one after the other, lane `sub` holding the
+        // sub-th quad of the query's and of the neighbour's row; the keys are read from the owner's LDS list.
+        // (1) owners turn the d2 of their keys into Cauchy weights in place
         for (int e = 0; e < K; ++e) {
             if (e < cnt) {
-                const unsigned long long k = L.list.get(e, lane);
-                const int j = (int)(unsigned int)(k & 0xffffffffull);
-                const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));   // torch.linalg.norm (:593)
+                const float dist = sqrtf(__uint_as_float(L.list.d2[e * kWave + lane]));   // torch.linalg.norm (:593)
                 const float r = dist / sigma;
-                const float wgt = 1.0f / (1.0f + r * r);                               // cauchy_kernel (:588-589)
-                float dot = 0.f;
-#pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    const float4 o = vq4[(size_t)j * 8 + v];
-                    dot = fmaf(vp[v].x, o.x, dot); dot = fmaf(vp[v].y, o.y, dot);
-                    dot = fmaf(vp[v].z, o.z, dot); dot = fmaf(vp[v].w, o.w, dot);
-                }
-                acc = fmaf(wgt, dot, acc);
+                L.list.d2[e * kWave + lane] = __float_as_uint(1.0f / (1.0f + r * r));       // cauchy_kernel (:588-589)
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int grp8 = lane & ~7, sub = lane & 7;
+        float acc = 0.f;
+        for (int it = 0; it < 8; ++it) {
+            const int q = grp8 + it;                       // the group's current query = that lane's id
+            const int cq = __shfl(cnt, q, kWave);
+            const int sq = __shfl(sidx, q, kWave);
+            const float4 a = vp4[(size_t)sq * 8 + sub];
+            float part = 0.f;
+#pragma unroll 4
+            for (int e = 0; e < K; ++e) {
+                if (e < cq) {
+                    const float wgt = __uint_as_float(L.list.d2[e * kWave + q]);
+                    const int j = (int)L.list.ix[e * kWave + q];
+                    const float4 o = vq4[(size_t)j * 8 + sub];
+                    float d = a.x * o.x;
+                    d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                    part = fmaf(wgt, d, part);
+                }
+            }
+            part += __shfl_xor(part, 1, kWave);
+            part += __shfl_xor(part, 2, kWave);
+            part += __shfl_xor(part, 4, kWave);
+            acc = sub == it ? part : acc;                 // lane q keeps its query's sum
         }
         acc = wave_sum_f(valid ? acc : 0.f);
         if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
