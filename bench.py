@@ -4,13 +4,21 @@
   python bench.py --gpus N --steps K --warmup W            (N = 1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-A "step" is one pass of the named hot path over one synthetic
-KITTI-shaped registration pair whose inputs are already resident in HBM: keypoint gather ->
-fused ball-query + UME moments (x2 clouds) -> orthonormal bases -> MFMA subspace-distance GEMM with
-fused row arg-min -> match probabilities -> tau-weighted sub-sampling (host numpy RNG, like the
+A "step" is one pass of the named hot path over one BATCH of
+`--pairs-per-step` synthetic KITTI-shaped registration pairs whose inputs are already resident in HBM:
+keypoint gather -> fused ball-query + UME moments (x2 clouds) -> orthonormal bases -> MFMA subspace-distance
+GEMM with fused row arg-min -> match probabilities -> tau-weighted sub-sampling (host numpy RNG, like the
 reference evaluate.py:238) -> closed-form SE(3) per match -> RRE/RTE of every hypothesis.
-Pairs are independent, so N GPUs run N disjoint pair streams (weak scaling); the only collective
-is the final all-reduce of the metric counters.  Rank 0 prints ONE JSON line.
+Pairs are independent, so N GPUs run N disjoint pair streams (weak scaling); the only collective is the
+final all-reduce of the metric counters.  Rank 0 prints ONE JSON line.  `value` = named-path pairs/s.
+
+Beside the named-path value the line carries
+  * `end_to_end`: the whole loop iteration of reference evaluate.py:195-309 on the same KT pairs, timed separately --
+    host keypoint draws + a1-a7 + raw-cloud prep (:260-285) + f1 hypothesis selection + f2 ICP -- with pairs/s,
+    per-stage ms and the numbers the reference prints (:304-309: recall at the gates, mRRE, mRTE);
+  * `end_to_end_hard`: the same on pairs that can fail (partial overlap, point noise, corrupted features);
+  * `cpu_baseline`: the oracle (CPU port of the reference path) timed on this box's host cores, and a recall
+    comparison CPU oracle vs HIP pipeline on the same hard pairs and RNG seeds.
 """
 import argparse
 import json
@@ -26,39 +34,45 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+L2_PEAK_GBS = 34500.0        # aggregate L2 -> CU rate, same guide ("L2 (per XCD)": ~34.5 TB/s)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same guide)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (same guide; 2:1-sparsity figures excluded)
+# the reduced-size recall check uses a harsher variant than the KT-size hard leg (calibrated so that recall sits near 75 %)
+RR_CHECK_HARD = dict(sector_deg=180.0, sector_shift_deg=120.0, noise_sigma=0.03, feat_corrupt=0.5)
+GATES = ((1.5, 0.6), (1.5, 0.3), (1.0, 0.1))   # (deg, m): evaluate.py:304 (code), README "Normal", evaluate.py:305 "Strict"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs-per-step", type=int, default=64, help="registration pairs per step and GPU")
     ap.add_argument("--config", default="KT", choices=["K1", "KT", "NS", "SY"])
     ap.add_argument("--kind", default="test", choices=["test", "rot"])
-    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs (cycled; pair g uses pool[g %% pool])")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
-                    help="distance GEMM: split-f16 MFMA (fp32-class operands, default) or exact-fp32 MFMA")
+                    help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=2,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
-    ap.add_argument("--threaded-draw", action="store_true",
-                    help="host RNG draw on a worker thread (the native draw releases the GIL, so it overlaps the main "
-                         "thread's kernel enqueues); off by default: at 0.08 ms per draw the hand-off jitter costs more")
+    ap.add_argument("--threaded-draw", action="store_true", help="host RNG draw on a worker thread (off: slower, see DESIGN 3.5)")
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
     ap.add_argument("--dist-backend", default=None, help="(testing) torch.distributed backend override, e.g. gloo")
     ap.add_argument("--force-device", type=int, default=None,
                     help="(testing) put every rank on this device index, to exercise the N>1 path on a 1-GPU box")
-    ap.add_argument("--with-selection", action="store_true",
-                    help="also run SURVEY 8(f1) hypothesis selection (FeatureCorrelator) per pair and report the "
-                         "registration recall of the SELECTED transform; the headline metric stays the a1-a7 path")
-    ap.add_argument("--with-refinement", action="store_true",
-                    help="with --with-selection: also refine the selected transform by SURVEY 8(f2) point-to-point ICP "
-                         "(0.2 m, <= 200 iterations, reference evaluate.py:93-96) and report its recall / mean errors")
+    ap.add_argument("--e2e-pairs", type=int, default=32, help="pairs per GPU in the end-to-end leg (0 = skip)")
+    ap.add_argument("--e2e-hard-pairs", type=int, default=16, help="hard pairs per GPU in the end-to-end leg (0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip both end-to-end legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="max pairs timed by the CPU baseline leg (stops after ~10 s)")
+    ap.add_argument("--cpu-rr-pairs", type=int, default=64, help="max hard pairs of the CPU-vs-HIP recall check (stops after ~25 s)")
     return ap.parse_args()
+
+
+def gate_counts(rre, rte):
+    rre, rte = np.asarray(rre, np.float64), np.asarray(rte, np.float64)
+    return [int(((rre <= r) & (rte <= t)).sum()) for r, t in GATES]
 
 
 def main():
@@ -68,8 +82,8 @@ def main():
 
     import umeregrobust_amd
     from umeregrobust_amd import evaluate, ops
-    from umeregrobust_amd.dist import RegistrationMetrics, init_distributed
-    from umeregrobust_amd.synth import CONFIGS, synth_pair
+    from umeregrobust_amd.dist import init_distributed
+    from umeregrobust_amd.synth import CONFIGS, synth_pair, synth_pair_hard
     from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
 
     ops.DEFAULT_MATCH_PRECISION = a.precision
@@ -88,25 +102,23 @@ def main():
     args.ume_n_samples = cfg["M"]
     args.filter_by_ume_dist_cond = cfg["filter_by_ume_dist_cond"]
     n_kp = cfg["n_kp"] if args.filter_by_ume_dist_cond else min(cfg["n_kp"], args.ume_n_samples)
+    P = max(1, a.pairs_per_step)
+    t = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
+
+    def resident(p):
+        return SimpleNamespace(host=p, src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
+                               tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
+                               gt=t(p.gt_tform).contiguous())
 
     # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------
+    # the pool and every pair's RNG seed depend on the pair's GLOBAL index g = rank + world * i only, so the integer
+    # results of an N-GPU run equal those of a 1-GPU run over the same number of pairs
     pool = []
     for i in range(max(1, a.pool)):
-        p = synth_pair(seed=1000 * rank + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"])
-        t = lambda x: torch.from_numpy(x).to(dev)
-        pool.append(SimpleNamespace(
-            host=p, src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
-            tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
-            gt=t(p.gt_tform).contiguous()))
-        e = pool[-1]
-        if a.with_selection:   # random <= pc_corr_max_size subsets with their features (evaluate.py:277-285)
-            rs = np.random.RandomState(77 + i)
-            ns = min(args.pc_corr_max_size, cfg["N"])
-            si = t(rs.choice(cfg["N"], ns, replace=False)); ti = t(rs.choice(cfg["N"], ns, replace=False))
-            e.corr = (e.src_pts[:, si].contiguous(), e.tgt_pts[:, ti].contiguous(), e.src_feat[:, si].contiguous(),
-                      e.tgt_feat[:, ti].contiguous())
+        e = resident(synth_pair(seed=i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))
         e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
             if a.batch_clouds else None
+        pool.append(e)
     # neighbour counts (for the algorithmic-bytes roofline), outside the timed region
     for e in pool:
         per_cloud = []
@@ -117,53 +129,35 @@ def main():
         e.mom_bytes = [sum(per_cloud)] if e.pair is not None else per_cloud
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
-    rng = np.random.RandomState(1234 + rank)
     depth = max(1, a.depth)
-    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=rng, threaded_draw=a.threaded_draw)
+    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     timing = {"moments": [], "dist": ops.TimingList()}
     mom_bytes_log = []
+    n_local = (a.warmup + a.steps) * P
+    rngs = [np.random.RandomState(1234 + rank + world * i) for i in range(n_local)]   # pair g draws from RandomState(1234 + g)
 
     def submit(i, record):
-        e = pool[i % len(pool)]
+        e = pool[(rank + world * i) % len(pool)]
         h = pipe.submit(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, src_inds=e.src_inds, tgt_inds=e.tgt_inds,
-                        timing=timing if record else None, pair=e.pair)
+                        timing=timing if record else None, pair=e.pair, rng=rngs[i])
         h.entry = e
         if record:
             mom_bytes_log.extend(e.mom_bytes)
         return h
 
-    sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
-    ref_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
-    sel_timing = []
-    icp_log = []
-
     def finish(h):
         out = pipe.finish(h)                                    # host RNG draw + SE(3) hypotheses
         with torch.cuda.stream(pipe.stream_of(h)):              # a7 + recall gates, on the device
             ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, counts[h.slot])
-            if a.with_selection:                                # f1: evaluate.py:260-296 on <= pc_corr_max_size points
-                e = h.entry
-                _, _, R_hat, t_hat = evaluate.pc_fcht(e.corr[0], e.corr[1], e.corr[2], e.corr[3], out.rtume_tform, e.gt[None],
-                                                      args.corr_kernel_sigma, args, timing=sel_timing)
-                T_sel = torch.eye(4, device=dev)[None].repeat(1, 1, 1)
-                T_sel[:, :3, :3] = R_hat
-                T_sel[:, :3, 3] = t_hat
-                ops.hypothesis_gates(T_sel.contiguous(), e.gt, sel_counts[h.slot])
-                if a.with_refinement:                           # f2: evaluate.py:63-109 (synchronous: host-side stop test)
-                    t_icp = time.perf_counter()
-                    reg = ops.icp_point_to_point(e.src_pts[0], e.tgt_pts[0], T_sel[0].double().cpu().numpy(), 0.2, 200)
-                    icp_log.append((time.perf_counter() - t_icp, reg.iterations, reg.fitness))
-                    T_ref = torch.from_numpy(reg.transformation).float().to(dev)[None].contiguous()
-                    ops.hypothesis_gates(T_ref, e.gt, ref_counts[h.slot])
 
     def run(first, n, record):
         pending = []
-        for i in range(n):
-            # per-kernel event pairs (the roofline leg) on every 4th timed step only: they need the layered entry points;
-            # the other steps go through the one-call a1..a5 entry
-            pending.append(submit(first + i, record and i % 4 == 0))
+        for i in range(first, first + n):
+            # per-kernel event pairs (the roofline leg) on every 4th timed pair only: they need the layered entry points;
+            # the other pairs go through the one-call a1..a5 entry
+            pending.append(submit(i, record and i % 4 == 0))
             if len(pending) >= depth:
                 finish(pending.pop(0))
         while pending:
@@ -175,27 +169,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(0, a.warmup, False)
+    run(0, a.warmup * P, False)
     torch.cuda.synchronize()
-    for c_ in counts + sel_counts + ref_counts:
+    for c_ in counts:
         c_.zero_()
-    icp_log.clear()
-    sel_timing.clear()
     fence()
     t0 = time.perf_counter()
-    run(a.warmup, a.steps, True)
+    run(a.warmup * P, a.steps * P, True)
     fence()
     elapsed = time.perf_counter() - t0
     counts = torch.stack(counts).sum(0).double()
-    sel_counts = torch.stack(sel_counts).sum(0).double()
-    ref_counts = torch.stack(ref_counts).sum(0).double()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (32 B)
-        dist.all_reduce(sel_counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(ref_counts, op=dist.ReduceOp.SUM)
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     mom_ms = [s.elapsed_time(e_) for s, e_ in timing["moments"]]
@@ -205,11 +193,13 @@ def main():
     dist_tfs = dist_flops * len(dist_ms) / (dist_total_ms * 1e-3) / 1e12
     roof_mom = {"kernel": "ume_moments_kernel", "bound": "hbm", "achieved": round(mom_gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "l2_frac": round(mom_gbs / L2_PEAK_GBS, 4),
                 "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
                 "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0),
-                "note": "algorithmic bytes = SURVEY 8(d) per-keypoint figure (140 n_i + 524) summed over both clouds of a pair; "
-                        "they are neighbour gathers from 8 MB tables, served mostly by L2 / Infinity Cache, so the rate can exceed "
-                        "the HBM peak while `traffic` (fabric bytes from PMC) stays far below the algorithmic bytes"}
+                "note": "algorithmic bytes = SURVEY 8(d) per-keypoint figure (140 n_i + 524) summed over both clouds of a pair. "
+                        "They are neighbour gathers from 8 MB tables that L2 / Infinity Cache serve (`traffic` = fabric bytes is "
+                        "~5 % of them), so `frac` against the HBM peak can exceed 1 and is NOT a utilisation; the rate that "
+                        "actually bounds the gathers is the aggregate L2 -> CU bandwidth: `l2_frac` = achieved / 34.5 TB/s"}
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
@@ -235,14 +225,29 @@ def main():
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dist_tfs / MFMA_F32_PEAK_TFLOPS, 4),
                      "traffic": None, "avg_launch_ms": round(float(np.mean(dist_ms)), 4), "launches": len(dist_ms),
                      "algorithmic_flops_per_launch": dist_flops, "d_used": "512-equivalent (Q-form), fp32 MFMA"}
-    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")      # filled from rocprofv3 --pmc passes, if present
+    # counters that only a profiler can read are taken from the tracked summaries of earlier rocprofv3 --pmc passes of
+    # this same command (tools/collect_profiles.sh), NOT measured in this run -- and labelled as such
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         tr = json.load(open(pmc))
-        roof_mom["traffic"] = tr.get("ume_moments_kernel")
-        roof_dist["traffic"] = tr.get(roof_dist["kernel"])
+        for r_ in (roof_mom, roof_dist):
+            r_["traffic"] = tr.get(r_["kernel"])
+            r_["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run " \
+                                   "of this command; fabric bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)"
+    sq = os.path.join(REPO, "profiles", "sq_summary.json")
+    if os.path.exists(sq):
+        sqs = json.load(open(sq))
+        for r_ in (roof_mom, roof_dist):
+            k_ = sqs.get(r_["kernel"])
+            if k_:
+                for key in ("mfma_busy_frac", "valu_per_mfma", "vmem_busy_frac", "wait_any_frac", "issue_frac", "l2_hit_rate",
+                            "effective_clock_ghz"):
+                    if key in k_:
+                        r_[key] = k_[key]
+                r_["counters_source"] = "profiles/sq_summary.json (rocprofv3 --pmc SQ passes of an earlier run of this command)"
     dominant = roof_mom if mom_total_ms >= dist_total_ms else roof_dist
 
-    total_pairs = a.steps * world
+    total_pairs = a.steps * P * world
     c = counts.cpu().numpy()
     result = {
         "metric": "registration_pairs_per_s", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
@@ -251,47 +256,107 @@ def main():
         "config": {"workload": f"{a.config}: named hot path a1-a7 on synthetic KITTI-shaped pairs "
                                f"(N={cfg['N']} pts/cloud, {n_kp} keypoints/cloud, K={args.ume_max_nn}, r={args.ume_r_nn} m, "
                                f"d=32, M={args.ume_n_samples} hypotheses, tau={args.tau}, kind={a.kind})",
-                   "pairs_per_step_per_gpu": 1, "sharding": f"pairs[rank::{world}] (no data-path collective)",
+                   "pairs_per_step_per_gpu": P, "ms_per_pair": round(1e3 * elapsed / (a.steps * P), 4),
+                   "sharding": f"pairs[rank::{world}] (no data-path collective)",
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
-                   "pairs_in_flight": depth, "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1},
+                   "pairs_in_flight": depth, "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
+                   "excluded_from_value": "the two keypoint draws of evaluate.py:199-200 (indices pre-drawn with the pair; they are "
+                                          "inside `end_to_end`), the feature network, hypothesis selection and ICP (see `end_to_end`)"},
         "roofline": dominant,
         "rooflines": {"ume_moments_kernel": roof_mom, roof_dist["kernel"]: roof_dist},
         "hypothesis_quality": {"hypotheses": int(c[0]), "within_1.5deg_0.6m": round(c[1] / max(c[0], 1), 4),
                                "within_1.5deg_0.3m": round(c[2] / max(c[0], 1), 4),
-                               "within_1deg_0.1m": round(c[3] / max(c[0], 1), 4),
+                               "within_1deg_0.1m": round(c[3] / max(c[0], 1), 4), "counts": [int(v) for v in c],
                                "note": "fraction of RTUME hypotheses (not selected registrations) inside each gate"},
     }
 
-    if a.with_selection:
-        sc = sel_counts.cpu().numpy()
-        sel_ms = [s_.elapsed_time(e_) for s_, e_ in sel_timing]
-        result["metric"] = "registration_pairs_per_s_with_hypothesis_selection"
-        result["config"]["workload"] += " + f1 hypothesis selection (FeatureCorrelator, K=20, sigma=%.2f, <=%d pts)" % (
-            args.corr_kernel_sigma, args.pc_corr_max_size)
-        result["selection"] = {"pairs": int(sc[0]), "rr_1.5deg_0.6m": round(sc[1] / max(sc[0], 1), 4),
-                               "rr_1.5deg_0.3m": round(sc[2] / max(sc[0], 1), 4), "rr_1deg_0.1m": round(sc[3] / max(sc[0], 1), 4),
-                               "corr_scores_avg_ms": round(float(np.mean(sel_ms)), 3) if sel_ms else None,
-                               "note": "recall of the transform SELECTED by feature correlation among the M RTUME "
-                                       "hypotheses, on synthetic pairs (no ICP refinement)"}
-    if a.with_selection and a.with_refinement:
-        rc = ref_counts.cpu().numpy()
-        result["metric"] = "registration_pairs_per_s_with_selection_and_icp"
-        result["config"]["workload"] += " + f2 point-to-point ICP (0.2 m, <= 200 iterations)"
-        result["refinement"] = {"pairs": int(rc[0]), "rr_1.5deg_0.6m": round(rc[1] / max(rc[0], 1), 4),
-                                "rr_1.5deg_0.3m": round(rc[2] / max(rc[0], 1), 4), "rr_1deg_0.1m": round(rc[3] / max(rc[0], 1), 4),
-                                "icp_avg_ms": round(1e3 * float(np.mean([x[0] for x in icp_log])), 3) if icp_log else None,
-                                "icp_avg_iterations": round(float(np.mean([x[1] for x in icp_log])), 1) if icp_log else None,
-                                "icp_avg_fitness": round(float(np.mean([x[2] for x in icp_log])), 4) if icp_log else None,
-                                "note": "recall after ICP refinement of the selected transform (reference evaluate.py:301-309), "
-                                        "synthetic pairs; rank 0's ICP timings"}
+    # ---- end-to-end legs: the whole loop iteration of evaluate.py:195-309, timed separately ----------------------------
+    def e2e_leg(entries, n_pairs, seed_base, label):
+        """host keypoint draws + a1-a7 + raw-cloud prep + f1 + f2 per pair, pair by pair like the reference's loop."""
+        sel_timing, ev, errs, icp_it = [], [], [], []
+        sel_counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        ref_counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        eye = torch.eye(4, device=dev)
+
+        def one(i, timed):
+            g = rank + world * i
+            e = entries[g % len(entries)]
+            rng = np.random.RandomState(seed_base + g)
+            stamps = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            stamps[0].record()
+            out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=rng)              # :195-254
+            stamps[1].record()
+            _, _, R_hat, t_hat = evaluate.select_hypothesis(e.src_pts[0], e.tgt_pts[0], e.src_pts, e.tgt_pts, e.src_feat,
+                                                            e.tgt_feat, out.rtume_tform, e.gt, args, rng=rng,
+                                                            timing=sel_timing if timed else None)                   # :258-296
+            stamps[2].record()
+            T_sel = eye.clone()[None]
+            T_sel[0, :3, :3] = R_hat[0]
+            T_sel[0, :3, 3] = t_hat[0]
+            reg = ops.icp_point_to_point(e.src_pts[0], e.tgt_pts[0], T_sel[0].double().cpu().numpy(), 0.2, 200)     # :63-109
+            stamps[3].record()
+            if timed:
+                ops.hypothesis_gates(T_sel.contiguous(), e.gt, sel_counts)
+                T_ref = torch.from_numpy(reg.transformation).float().to(dev)[None].contiguous()
+                errs.append(ops.hypothesis_gates(T_ref, e.gt, ref_counts, return_errors=True))
+                ev.append(stamps)
+                icp_it.append(reg.iterations)
+
+        for i in range(2):
+            one(i, False)
+        fence()
+        t_0 = time.perf_counter()
+        for i in range(n_pairs):
+            one(i, True)
+        fence()
+        el = time.perf_counter() - t_0
+        rre = torch.cat([x[0] for x in errs]).double()
+        rte = torch.cat([x[1] for x in errs]).double()
+        sums = torch.stack([rre.sum(), rte.sum()])
+        stage = torch.tensor([[s[k].elapsed_time(s[k + 1]) for k in range(3)] for s in ev], dtype=torch.float64).sum(0).to(dev)
+        f1ms = torch.tensor([sum(s_.elapsed_time(e_) for s_, e_ in sel_timing)], dtype=torch.float64, device=dev)
+        if world > 1:
+            tm = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+            for x in (sel_counts, ref_counts, sums, stage, f1ms):
+                dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        n_tot = n_pairs * world
+        sc, rc = sel_counts.cpu().numpy(), ref_counts.cpu().numpy()
+        st = stage.cpu().numpy() / n_tot
+        return {"workload": label, "pairs": n_tot, "pairs_per_s": round(n_tot / el, 2), "ms_per_pair_per_gpu": round(1e3 * el / n_pairs, 3),
+                "stage_ms": {"keypoint_draws_and_named_path_a1_a7": round(float(st[0]), 3),
+                             "raw_prep_and_f1_selection": round(float(st[1]), 3),
+                             "of_which_corr_scores_kernels": round(float(f1ms.item()) / n_tot, 3),
+                             "f2_icp": round(float(st[2]), 3)},
+                "icp_avg_iterations": round(float(np.mean(icp_it)), 2),
+                "rr_1.5deg_0.6m": round(100.0 * rc[1] / n_tot, 3), "rr_1.5deg_0.3m": round(100.0 * rc[2] / n_tot, 3),
+                "rr_1deg_0.1m": round(100.0 * rc[3] / n_tot, 3),
+                "mRRE_deg": round(float(sums[0].item()) / n_tot, 5), "mRTE_m": round(float(sums[1].item()) / n_tot, 5),
+                "selected_before_icp": {"rr_1.5deg_0.6m": round(100.0 * sc[1] / n_tot, 3), "rr_1.5deg_0.3m": round(100.0 * sc[2] / n_tot, 3),
+                                        "rr_1deg_0.1m": round(100.0 * sc[3] / n_tot, 3)},
+                "note": "reference evaluate.py:195-309 per pair, pair by pair: host keypoint draws (:199-200), a1-a7, "
+                        "sparse_quantize + K=1 feature transfer + host sub-sampling (:260-285), FeatureCorrelator (f1), "
+                        "point-to-point ICP 0.2 m / <= 200 iterations (f2); N.P / S.P / mRRE / mRTE as printed at :304-309 "
+                        "(N.P uses 0.6 m in the code, 0.3 m in the README: both given); raw clouds = the network points"}
+
+    if not a.no_e2e and a.e2e_pairs > 0:
+        result["end_to_end"] = e2e_leg(pool, a.e2e_pairs, 500000, f"{a.config} pairs of the named-path leg (exact rigid copies, kind={a.kind})")
+    hard_pool = None
+    if not a.no_e2e and a.e2e_hard_pairs > 0:
+        hard_pool = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))
+                     for i in range(min(4, a.e2e_hard_pairs))]
+        result["end_to_end_hard"] = e2e_leg(hard_pool, a.e2e_hard_pairs, 600000,
+                                            f"{a.config}-size HARD pairs: partial overlap (two 240-deg sectors 100 deg apart), "
+                                            "sigma = 2 cm point noise, 20 % corrupted features")
+        del hard_pool
+
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc
         orc.lib()
         t_cpu = 0.0
         n_cpu = 0
-        gates = lambda rre, rte: np.array([rre.size, ((rre <= 1.5) & (rte <= 0.6)).sum(), ((rre <= 1.5) & (rte <= 0.3)).sum(),
-                                           ((rre <= 1.0) & (rte <= 0.1)).sum()], np.float64)
         q_cpu, q_gpu = np.zeros(4), np.zeros(4)
         for i in range(a.cpu_pairs):
             if t_cpu > 10.0:
@@ -301,7 +366,7 @@ def main():
             tc = time.perf_counter()
             rre, rte = cpu_pair(orc, e.host, args, np.random.RandomState(7 + i))
             t_cpu += time.perf_counter() - tc
-            q_cpu += gates(rre, rte)
+            q_cpu += np.array([rre.size] + gate_counts(rre, rte), np.float64)
             # the same pair with the same RNG seed through the HIP path (outside any timed region)
             og = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=np.random.RandomState(7 + i),
                                         src_inds=e.src_inds, tgt_inds=e.tgt_inds)
@@ -310,7 +375,7 @@ def main():
             q_gpu += cg.cpu().numpy()
         result["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 4), "unit": "pairs/s", "cores": os.cpu_count(),
                                   "kind": "port",
-                                  "sample": f"{n_cpu} full {a.config} pair(s) through the oracle's named path "
+                                  "sample": f"{n_cpu} full {a.config} pair(s) through the oracle's named path a1-a7 "
                                             f"(C/OpenMP scan+moments, numpy LAPACK/BLAS for QR/cdist/SVD), "
                                             f"{t_cpu:.1f} s wall",
                                   "quality_check": {
@@ -318,6 +383,10 @@ def main():
                                               "the SAME pairs and RNG seeds: CPU restatement of the reference vs this library",
                                       "cpu": [round(float(v), 4) for v in q_cpu[1:] / max(q_cpu[0], 1)],
                                       "gpu": [round(float(v), 4) for v in q_gpu[1:] / max(q_gpu[0], 1)]}}
+        # f1 on the CPU: the oracle's pc_corr_cost (C loops, brute-force kNN like the reference) on a few hypotheses of one
+        # KT pair, scaled to the M hypotheses of a pair -- the CPU figure next to end_to_end.stage_ms
+        result["cpu_baseline"]["f1_selection"] = cpu_f1_leg(orc, pool[0], args, cfg)
+        result["cpu_baseline"]["rr_check"] = rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -344,6 +413,61 @@ def cpu_pair(orc, p, args, rs):
     rre = orc.relative_rotation_error(T[:, :3, :3], R_gt)
     rte = np.linalg.norm(T[:, :3, 3] - p.gt_tform[:3, 3], axis=-1)
     return rre, rte
+
+
+def cpu_f1_leg(orc, e, args, cfg, n_hyp=8):
+    """reference utils/loc_utils.py:592-637 on the CPU (brute-force kNN, as pytorch3d does it): n_hyp hypotheses of one KT pair
+    at pc_corr_max_size points, scaled to M hypotheses."""
+    p = e.host
+    rs = np.random.RandomState(5)
+    ns = min(args.pc_corr_max_size, p.src_pts.shape[0])
+    si, ti = rs.choice(p.src_pts.shape[0], ns, replace=False), rs.choice(p.tgt_pts.shape[0], ns, replace=False)
+    T = np.tile(p.gt_tform[None], (n_hyp, 1, 1)).astype(np.float32)
+    T[:, :3, 3] += rs.normal(0, 0.3, (n_hyp, 3)).astype(np.float32)
+    tc = time.perf_counter()
+    orc.pc_corr_cost_c(T, p.src_pts[si], p.tgt_pts[ti], 20, p.src_feat[si], p.tgt_feat[ti], float(args.corr_kernel_sigma))
+    dt = time.perf_counter() - tc
+    return {"cpu_ms_per_hypothesis": round(1e3 * dt / n_hyp, 3), "cpu_ms_per_pair_scaled": round(1e3 * dt / n_hyp * cfg["M"], 1),
+            "cores": os.cpu_count(), "sample": f"{n_hyp} hypotheses x {ns} source points, brute-force 20-NN in {ns} target points "
+                                               f"(oracle pc_corr_cost, C/OpenMP), scaled to M={cfg['M']}"}
+
+
+def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M=256, budget_s=25.0):
+    """Registration recall of the WHOLE pipeline (a1-a7 + raw prep + f1 + f2) on hard pairs at reduced size: the CPU oracle
+    (a restatement of the reference's loop iteration, evaluate.py:195-309) vs this library on the same pairs and RNG seeds."""
+    small = SimpleNamespace(**vars(args))
+    small.ume_n_samples = M
+    small.pc_corr_max_size = N
+    rows = []
+    t_cpu = 0.0
+    for i in range(a.cpu_rr_pairs):
+        if t_cpu > budget_s:
+            break
+        p = synth_pair_hard(seed=20000 + i, N=N, n_kp=N, kind=a.kind, voxel=0.3, **RR_CHECK_HARD)
+        tc = time.perf_counter()
+        rc = orc.evaluate_pair_full(p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.gt_tform, np.random.RandomState(31 + i),
+                                    ume_max_nn=small.ume_max_nn, ume_r_nn=small.ume_r_nn, ume_n_samples=M, tau=small.tau,
+                                    filter_by_ume_dist_cond=small.filter_by_ume_dist_cond, corr_ds=small.corr_ds,
+                                    pc_corr_max_size=N, sigma=small.corr_kernel_sigma)
+        t_cpu += time.perf_counter() - tc
+        t = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
+        pair = dict(src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
+                    tgt_feat=t(p.tgt_feat)[None], gt_tform=t(p.gt_tform))
+        rg = evaluate.evaluate_pairs([pair], small, rng=np.random.RandomState(31 + i), refine=True)
+        rows.append((rc["rre"], rc["rte"], float(rg["rre"][0]), float(rg["rte"][0])))
+    r = np.array(rows, np.float64)
+    n = r.shape[0]
+    cpu_ok = np.stack([(r[:, 0] <= g0) & (r[:, 1] <= g1) for g0, g1 in GATES], 1)
+    gpu_ok = np.stack([(r[:, 2] <= g0) & (r[:, 3] <= g1) for g0, g1 in GATES], 1)
+    differing = [{"pair": int(i), "cpu_rre_rte": [round(r[i, 0], 4), round(r[i, 1], 4)], "hip_rre_rte": [round(r[i, 2], 4), round(r[i, 3], 4)]}
+                 for i in np.flatnonzero((cpu_ok != gpu_ok).any(1))]
+    return {"pairs": int(n), "size": f"N={N} pts/cloud, {N} keypoints, M={M} hypotheses; hard pairs: {RR_CHECK_HARD}",
+            "gates": ["1.5deg,0.6m", "1.5deg,0.3m", "1deg,0.1m"],
+            "cpu_rr_percent": [round(100.0 * float(v), 3) for v in cpu_ok.mean(0)],
+            "hip_rr_percent": [round(100.0 * float(v), 3) for v in gpu_ok.mean(0)],
+            "cpu_mRRE_mRTE": [round(float(r[:, 0].mean()), 4), round(float(r[:, 1].mean()), 4)],
+            "hip_mRRE_mRTE": [round(float(r[:, 2].mean()), 4), round(float(r[:, 3].mean()), 4)],
+            "pairs_with_a_different_gate_outcome": differing, "cpu_s": round(t_cpu, 1), "cpu_pairs_per_s": round(n / max(t_cpu, 1e-9), 3)}
 
 
 if __name__ == "__main__":

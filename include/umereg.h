@@ -291,6 +291,19 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
                            const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
                            float* scores, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with an explicit choice of the search structure (tuning / tests; results are the same sets of K
+ * neighbours either way).  By default jobs of >= 2^17 queries (M x Ns) into <= 65 471 target points build a
+ * per-cell candidate lattice on the target once and stream every query's cell list; smaller jobs walk the grid.
+ *   UMEREG_CORR_NO_LATTICE     always walk the grid
+ *   UMEREG_CORR_FORCE_LATTICE  build the lattice whatever the job size (still needs <= 65 471 target points)
+ * The workspace size depends on the flags: query it with the same ones. */
+#define UMEREG_CORR_NO_LATTICE 1
+#define UMEREG_CORR_FORCE_LATTICE 2
+size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
+int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
+                              const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
+                              int flags, float* scores, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * f3  torch.linalg.svdvals(ume)                                       utils/eval_utils.py:31-32
  * Singular values (descending) of each 32x4 UME matrix, one-sided Jacobi in fp64.

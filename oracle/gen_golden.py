@@ -142,7 +142,52 @@ def gen_g8(loc_utils, eval_utils):
     np.savez_compressed(os.path.join(OUT, "g8_gt_ume_inlier.npz"), **out)
 
 
+def gen_g9(loc_utils, evaluate):
+    """G9: the matching block of the reference's evaluation loop with hungarian_matching_flag = True.  That block is
+    inline code of evaluate.py's `__main__` section (:214-254), not a function, so its statements are read from the
+    reference file IN PLACE at generation time, de-indented and executed on seeded inputs in a namespace that holds the
+    reference's own ume_cdist / batch_estimate_transform_ume_old.  Nothing of the text is kept: the fixture stores
+    inputs (UME matrices, keypoints, RNG seed, config) and outputs (matches, kept sub-sample, hypotheses)."""
+    import textwrap
+    from scipy.optimize import linear_sum_assignment
+    p = synth_pair(9, N=2048, n_kp=96, kind="rot")
+    tgt_inds = np.concatenate([p.tgt_twin_of_src[p.src_inds[:48]], p.tgt_inds[:48]])
+    margs = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0)
+    with torch.no_grad():
+        ume_src = evaluate.my_ume_generation(_t(p.src_pts[None]), _t(p.src_pts[p.src_inds][None]), _t(p.src_feat[None]), margs)
+        ume_tgt = evaluate.my_ume_generation(_t(p.tgt_pts[None]), _t(p.tgt_pts[tgt_inds][None]), _t(p.tgt_feat[None]), margs)
+    lines = open(os.path.join(REF, "evaluate.py")).read().split("\n")[214:254]          # evaluate.py:215-254
+    block = textwrap.dedent("\n".join(lines))
+    assert block.lstrip().startswith("D = ume_cdist(ume_src, ume_tgt)") and "batch_estimate_transform_ume_old(G, H)" in block
+    out = {}
+    for tag, filt in (("filt", True), ("all", False)):
+        ns = dict(torch=torch, np=np, linear_sum_assignment=linear_sum_assignment, ume_cdist=loc_utils.ume_cdist,
+                  batch_estimate_transform_ume_old=loc_utils.batch_estimate_transform_ume_old,
+                  args=SimpleNamespace(hungarian_matching_flag=True, batch_size=1, device="cpu", filter_by_ume_dist_cond=filt,
+                                       tau=0.05, ume_n_samples=32),
+                  ume_src=ume_src.clone(), ume_tgt=ume_tgt.clone(), src_keypoint_pts=_t(p.src_pts[p.src_inds][None]),
+                  tgt_keypoint_pts=_t(p.tgt_pts[tgt_inds][None]))
+        np.random.seed(9)
+        with torch.no_grad():
+            exec(block, ns)
+        out[f"m_{tag}"] = ns["m"][0].numpy()
+        out[f"T_{tag}"] = ns["rtume_tform"][0].numpy()
+        if filt:
+            out["cond"] = np.asarray(ns["cond"])
+            out["prob"] = ns["prob"].numpy()
+    np.savez_compressed(os.path.join(OUT, "g9_hungarian.npz"), src_pts=p.src_pts, tgt_pts=p.tgt_pts, src_feat=p.src_feat,
+                        tgt_feat=p.tgt_feat, src_inds=p.src_inds.astype(np.int64), tgt_inds=tgt_inds.astype(np.int64),
+                        ume_src=ume_src[0].numpy(), ume_tgt=ume_tgt[0].numpy(), seed=np.int64(9), tau=np.float32(0.05),
+                        ume_n_samples=np.int64(32), **out)
+    twins = float((out["m_all"][:48, 1] == np.arange(48)).mean())
+    print("G9 hungarian: twins matched", twins, "| kept", out["cond"].shape, "| T", out["T_filt"].shape, out["T_all"].shape)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
+        loc_utils, eval_utils, evaluate = import_reference()
+        gen_g9(loc_utils, evaluate)
+        return
     loc_utils, eval_utils, evaluate = import_reference()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -298,6 +343,7 @@ def main():
     print("G7 scores", score.numpy(), "best is gt:", bool(torch.allclose(best, _t(Ts[np.where(order == 0)[0][0]]))))
 
     gen_g8(loc_utils, eval_utils)
+    gen_g9(loc_utils, evaluate)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

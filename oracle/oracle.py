@@ -44,7 +44,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(_SO)
         for name in ("orc_ball_query_f32", "orc_ume_moments_f32", "orc_orthobasis_f64",
-                     "orc_ume_cdist_f64", "orc_knn_points_f32"):
+                     "orc_ume_cdist_f64", "orc_knn_points_f32", "orc_pc_corr_cost_f32"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -335,8 +335,20 @@ def pc_corr_cost(R, t, source_points, target_points, k, source_vals, target_vals
     return (val_out / np.float32(vp.shape[0])).astype(np.float32)                           # :612
 
 
+def pc_corr_cost_c(T, source_points, target_points, k, source_vals, target_vals, sigma):
+    """pc_corr_cost for all hypotheses T [M,4,4] through the C loops (orc_pc_corr_cost_f32): same arithmetic per point,
+    fp64 final sum.  Checked against pc_corr_cost (the numpy restatement pinned to golden G7) in tests/."""
+    T = _f32(T); sp = _f32(source_points); tp = _f32(target_points); vp = _f32(source_vals); vq = _f32(target_vals)
+    scores = np.empty(T.shape[0], np.float32)
+    rc = lib().orc_pc_corr_cost_f32(_p(T), ctypes.c_int64(T.shape[0]), _p(sp), ctypes.c_int64(sp.shape[0]), _p(tp),
+                                    ctypes.c_int64(tp.shape[0]), _p(vp), _p(vq), ctypes.c_int(vp.shape[1]), ctypes.c_int(k),
+                                    ctypes.c_float(sigma), _p(scores))
+    assert rc == 0
+    return scores
+
+
 def feature_corr_hypothesis_test(source_pc, target_pc, source_feat, target_feat, T_kp, sigma=0.05, corr_num_nn=20,
-                                 n_hypotheses=10, batch=64):
+                                 n_hypotheses=10, batch=64, fast=False):
     """FeatureCorrelator.feature_corr_hypothesis_test (utils/loc_utils.py:656-681).
     source_pc [1,Ns,3], ..., T_kp [M,4,4] -> (best_T [4,4], scores [M])."""
     source_pc = _f32(source_pc); target_pc = _f32(target_pc)
@@ -346,8 +358,8 @@ def feature_corr_hypothesis_test(source_pc, target_pc, source_feat, target_feat,
     tgt_feat_weight = feature_spatial_var(target_pc, target_feat, knn=50)                   # :663
     wsf = (source_feat - m) * src_feat_weight[..., None]                                    # :664
     wtf = (target_feat - m) * tgt_feat_weight[..., None]                                    # :665
-    scores = []
-    for i in range(0, T_kp.shape[0], batch):                                                # :666-673
+    scores = [pc_corr_cost_c(T_kp, source_pc[0], target_pc[0], corr_num_nn, wsf[0], wtf[0], sigma)] if fast else []
+    for i in range(0, 0 if fast else T_kp.shape[0], batch):                                 # :666-673
         Tb = T_kp[i:i + batch]
         scores.append(pc_corr_cost(Tb[:, :3, :3], Tb[:, :3, 3], source_pc[0], target_pc[0], corr_num_nn, wsf[0], wtf[0],
                                    sigma))
@@ -366,7 +378,7 @@ def feature_corr_hypothesis_test(source_pc, target_pc, source_feat, target_feat,
 # with_scaling=false).  One deliberate choice, shared with the HIP kernel: the nearest-neighbour search runs
 # on the fp32 rounding of the fp64-transformed source point with fp32 squared distances accumulated left to
 # right and ties -> lower index; residuals and all sums are fp64 like open3d's.
-def icp_evaluate(src, tgt, T, max_dist, chunk=512):
+def icp_evaluate(src, tgt, T, max_dist):
     """-> (corr_idx int64 [n] (-1 = none), fitness, inlier_rmse, q_f64 [n,3])."""
     src64 = np.asarray(src, np.float64)
     T = np.asarray(T, np.float64)
@@ -374,14 +386,11 @@ def icp_evaluate(src, tgt, T, max_dist, chunk=512):
     qf = q.astype(np.float32)
     tgt32 = np.asarray(tgt, np.float32)
     n = qf.shape[0]
-    idx = np.full(n, -1, np.int64)
-    d2min = np.full(n, np.inf, np.float32)
-    for s in range(0, n, chunk):
-        d = qf[s:s + chunk, None, :] - tgt32[None, :, :]
-        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
-        j = d2.argmin(axis=1)                               # first minimum = lowest index
-        idx[s:s + chunk] = j
-        d2min[s:s + chunk] = d2[np.arange(d2.shape[0]), j]
+    # nearest target per point: the C loop of knn_points (K = 1) -- d2 = ((dx*dx) + (dy*dy)) + (dz*dz) in fp32, first
+    # minimum = lowest index, the arithmetic the numpy form `(d0*d0 + d1*d1) + d2*d2` + argmin of this restatement had
+    nn = knn_points(qf[None], tgt32[None], K=1)
+    idx = nn.idx[0, :, 0].copy()
+    d2min = nn.dists[0, :, 0]
     r2 = np.float32(max_dist) * np.float32(max_dist)
     ok = d2min < r2
     idx[~ok] = -1
@@ -521,3 +530,64 @@ def calc_inliear_ratio(src_inputs, tgt_inputs, gt_tform, ume_r_nn, ume_max_nn, u
         re = np.linalg.norm(tgt_kp[b][ti] - (src_kp[b][si] @ R.T + t), axis=-1)
         out.append(np.float32((re <= inlear_thr).mean()))
     return np.array(out, np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# One whole loop iteration of the reference's evaluation (evaluate.py:195-309) on the CPU: used by bench.py's
+# cpu_baseline leg to compare registration recall with the HIP pipeline on the same pairs and RNG seeds.
+# ---------------------------------------------------------------------------------------------------
+def sparse_quantize(coordinates, quantization_size):
+    """MinkowskiEngine.utils.sparse_quantize(return_index=True) as used at evaluate.py:261-264 (ME is not installable:
+    PARITY UNPINNED): floor(coordinates / quantization_size), one representative per voxel = its first point, returned
+    in order of first appearance.  -> indices int64 [m]."""
+    q = np.floor(_f32(coordinates) / np.float32(quantization_size)).astype(np.int64)
+    _, first = np.unique(q, axis=0, return_index=True)
+    return np.sort(first)
+
+
+def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_feat, T_kp, rs, corr_ds, pc_corr_max_size,
+                      sigma, corr_num_nn=20):
+    """evaluate.py:258-296: voxel-thin the raw clouds, K=1 feature transfer, host-RNG sub-sampling, FeatureCorrelator.
+    -> best T [4,4] fp32."""
+    si = sparse_quantize(src_pts_raw, corr_ds)                                            # :261-262
+    ti = sparse_quantize(tgt_pts_raw, 0.3)                                                # :263-264
+    sraw, traw = _f32(src_pts_raw)[si], _f32(tgt_pts_raw)[ti]
+    sfeat = _f32(src_feat)[knn_points(sraw[None], _f32(src_pts)[None], K=1).idx[0, :, 0]]  # :272-273
+    tfeat = _f32(tgt_feat)[knn_points(traw[None], _f32(tgt_pts)[None], K=1).idx[0, :, 0]]  # :274-275
+    r = rs.choice(sraw.shape[0], min(pc_corr_max_size, sraw.shape[0]), replace=False)      # :278-281
+    sraw, sfeat = sraw[r], sfeat[r]
+    r = rs.choice(traw.shape[0], min(pc_corr_max_size, traw.shape[0]), replace=False)      # :282-285
+    traw, tfeat = traw[r], tfeat[r]
+    best, _ = feature_corr_hypothesis_test(sraw[None], traw[None], sfeat[None], tfeat[None], T_kp, sigma=sigma,
+                                           corr_num_nn=corr_num_nn, n_hypotheses=10, fast=True)
+    return best
+
+
+def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_max_nn=750, ume_r_nn=5.0, ume_n_samples=2500,
+                       tau=0.05, filter_by_ume_dist_cond=True, corr_ds=0.6, pc_corr_max_size=10000, sigma=1.5,
+                       icp_max_dist=0.2, icp_max_iteration=200):
+    """evaluate.py:195-309 for one pair, RNG consumption in the reference's order (two keypoint draws, the weighted
+    match draw, two correlation sub-sampling draws).  -> dict(T_sel, T_est, rre, rte, rre_sel, rte_sel)."""
+    n_s, n_t = src_pts.shape[0], tgt_pts.shape[0]
+    num_init_sel = min(10000, min(n_s, n_t)) if filter_by_ume_dist_cond else min(min(n_s, n_t), ume_n_samples)   # :195-198
+    src_inds = rs.choice(n_s, num_init_sel, replace=False)                                 # :199
+    tgt_inds = rs.choice(n_t, num_init_sel, replace=False)                                 # :200
+    ume_src = ume_moments(src_pts, _f32(src_pts)[src_inds], src_feat, ume_max_nn, float(ume_r_nn), "f32")
+    ume_tgt = ume_moments(tgt_pts, _f32(tgt_pts)[tgt_inds], tgt_feat, ume_max_nn, float(ume_r_nn), "f32")
+    D = ume_cdist(ume_src[None], ume_tgt[None])[0]                                         # :215
+    m = row_argmin(D)                                                                      # :224
+    if filter_by_ume_dist_cond:                                                            # :233-245
+        prob = match_prob(D[np.arange(D.shape[0]), m], tau)
+        cond = rs.choice(D.shape[0], min(D.shape[0], ume_n_samples), replace=False, p=prob)
+    else:
+        cond = np.arange(D.shape[0])
+    T, _ = batch_estimate_transform_ume_old(ume_src[cond], ume_tgt[m[cond]], with_dist=False)   # :248-254
+    T_sel = select_hypothesis(src_pts, tgt_pts, src_pts, tgt_pts, src_feat, tgt_feat, T, rs, corr_ds, pc_corr_max_size, sigma)
+    T_est, _, _, _ = icp_point_to_point(src_pts, tgt_pts, T_sel.astype(np.float64), icp_max_dist, icp_max_iteration)   # :93-96
+    T_est = T_est.astype(np.float32)
+    gt = _f32(gt_tform)
+    err = lambda Tm: (float(relative_rotation_error(Tm[None, :3, :3], gt[None, :3, :3])[0]),      # noqa: E731
+                      float(np.linalg.norm(Tm[:3, 3] - gt[:3, 3])))
+    rre, rte = err(T_est)                                                                   # :100-107
+    rre_sel, rte_sel = err(T_sel)
+    return dict(T_sel=T_sel, T_est=T_est, rre=rre, rte=rte, rre_sel=rre_sel, rte_sel=rte_sel, n_hyp=int(T.shape[0]))

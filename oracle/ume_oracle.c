@@ -278,3 +278,71 @@ ORC_API int orc_knn_points_f32(const float* p1, const float* p2, int64_t n1, int
     }
     return 0;
 }
+
+/* --------------------------------------------------------------------------
+ * f1: pc_corr_cost_pytorch3d -> pc_corr_pytorch3d -> pc_corr (reference utils/loc_utils.py:592-637, P=None,
+ * use_norm=False) for M hypotheses in one call -- the same arithmetic as oracle.py's numpy restatement
+ * (pc_corr_cost, pinned to golden G7), written as loops so that the CPU baseline / recall check of bench.py can
+ * afford thousands of hypotheses:
+ *   source_transformed = p R^T + t                                   (:629)
+ *   q_nn_to_p = knn_points(source_transformed, target, K)            (:623; ties -> lower index, see above)
+ *   dist = |p' - q_nn|, weight = 1 / (1 + (dist / sigma)^2)          (:593, :588-589, :596)
+ *   val = sum_c vals_p[n][c] * vals_q[nn][c]                         (:603)
+ *   score = sum_{n,k} weight * val / Ns                              (:610, :612)
+ * T [M,4,4] row-major fp32 (rotation block + translation column); sp [Ns,3]; tp [Nt,3]; vp [Ns,d]; vq [Nt,d].
+ * The per-point terms are fp32 like the reference's; the final sum over (n,k) is accumulated in fp64 (the
+ * reference's fp32 torch.sum is a pairwise reduction whose order is not reproducible; tests bound the difference).
+ * -------------------------------------------------------------------------- */
+ORC_API int orc_pc_corr_cost_f32(const float* T, int64_t M, const float* sp, int64_t Ns, const float* tp, int64_t Nt,
+                                 const float* vp, const float* vq, int d, int K, float sigma, float* scores)
+{
+    if (K > Nt || K > 256 || K < 1) return -1;
+    double* per_point = (double*)malloc(sizeof(double) * (size_t)(M * Ns));
+    if (!per_point) return -2;
+#pragma omp parallel for schedule(dynamic, 32)
+    for (int64_t w = 0; w < M * Ns; ++w) {
+        const int64_t h = w / Ns, n = w % Ns;
+        const float* Th = T + h * 16;
+        const float x = sp[3 * n], y = sp[3 * n + 1], z = sp[3 * n + 2];
+        float q[3];
+        for (int a = 0; a < 3; ++a) {
+            float v = Th[4 * a] * x;
+            v = v + Th[4 * a + 1] * y;
+            v = v + Th[4 * a + 2] * z;
+            q[a] = v + Th[4 * a + 3];
+        }
+        float bd[256]; int64_t bi[256]; int cnt = 0;
+        for (int64_t j = 0; j < Nt; ++j) {
+            const float dx = q[0] - tp[3 * j];
+            const float dy = q[1] - tp[3 * j + 1];
+            const float dz = q[2] - tp[3 * j + 2];
+            float d2 = dx * dx;
+            d2 = d2 + dy * dy;
+            d2 = d2 + dz * dz;
+            if (cnt == K && !(d2 < bd[K - 1])) continue;
+            int p = cnt < K ? cnt : K - 1;
+            while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; --p; }
+            bd[p] = d2; bi[p] = j;
+            if (cnt < K) ++cnt;
+        }
+        double s = 0.0;
+        for (int k = 0; k < cnt; ++k) {
+            const float dist = sqrtf(bd[k]);
+            const float r = dist / sigma;
+            const float wgt = 1.0f / (1.0f + r * r);
+            const float* a = vp + n * d;
+            const float* b = vq + bi[k] * d;
+            float val = 0.f;
+            for (int c = 0; c < d; ++c) val = val + a[c] * b[c];
+            s += (double)(wgt * val);
+        }
+        per_point[w] = s;
+    }
+    for (int64_t h = 0; h < M; ++h) {
+        double s = 0.0;
+        for (int64_t n = 0; n < Ns; ++n) s += per_point[h * Ns + n];
+        scores[h] = (float)(s / (double)Ns);
+    }
+    free(per_point);
+    return 0;
+}

@@ -148,6 +148,11 @@ def test_feature_correlator_vs_reference():
     assert np.allclose(scores, g["score"], rtol=2e-5, atol=1e-6)
     assert np.array_equal(best, g["best_T"])
     assert int(np.argmax(scores)) == int(g["gt_index"])          # the ground-truth transform wins
+    # the C loops bench.py's cpu_baseline leg uses for thousands of hypotheses: same scores, same selection
+    best_c, scores_c = orc.feature_corr_hypothesis_test(g["src_pts"][None], g["tgt_pts"][None], g["src_feat"][None],
+                                                        g["tgt_feat"][None], g["T_hyp"], sigma=1.5, corr_num_nn=20,
+                                                        n_hypotheses=10, fast=True)
+    assert np.allclose(scores_c, g["score"], rtol=2e-5, atol=1e-6) and np.array_equal(best_c, g["best_T"])
 
 
 def test_icp_oracle_recovers_ground_truth():
@@ -205,3 +210,49 @@ def test_calc_inliear_ratio_golden():
         ir = orc.calc_inliear_ratio(src, tgt, g["gt_tform"][None], keypoints_ignore_segments=[9], **kw)
         # Hungarian on a noisy fp32 distance matrix: a couple of assignments may differ from the reference's
         assert abs(float(ir[0]) - float(g[f"inlier_ratio_{tag}"][0])) <= 2.5 / kw["eval_num_kpts"]
+
+
+def test_hungarian_block_vs_reference():
+    """evaluate.py:215-254 with hungarian_matching_flag (golden G9 = the reference's own statements executed): the oracle's
+    pieces (ume_cdist, match_prob, the numpy draw, batch_estimate_transform_ume_old) chained the same way."""
+    from scipy.optimize import linear_sum_assignment
+    g = load_golden("g9_hungarian.npz")
+    D = orc.ume_cdist(g["ume_src"][None], g["ume_tgt"][None])[0]
+    src_m, tgt_m = linear_sum_assignment(D)
+    # the assignment minimises a SUM over an fp32 matrix; numpy's and torch's cdist differ by fp32 rounding, which can
+    # swap a few non-twin rows with near-equal costs: twins identical, total cost equal to 1e-3, >= 95 % of rows identical
+    m = np.stack([src_m, tgt_m], 1)
+    same = (m == g["m_all"]).all(axis=1)
+    assert same[:48].all() and same.mean() >= 0.95 and np.array_equal(g["m_all"], g["m_filt"])
+    assert abs(D[src_m, tgt_m].sum() - D[g["m_all"][:, 0], g["m_all"][:, 1]].sum()) < 1e-3 * D[src_m, tgt_m].sum()
+    src_m, tgt_m = g["m_all"][:, 0], g["m_all"][:, 1]
+    prob = orc.match_prob(D[src_m, tgt_m], float(g["tau"]))
+    wcp = well_conditioned(g["ume_src"])[src_m] & well_conditioned(g["ume_tgt"])[tgt_m]
+    assert np.allclose(prob[wcp], g["prob"][wcp], rtol=0.1, atol=1e-9)      # exp(d / 0.05) amplifies d noise 20x
+    np.random.seed(int(g["seed"]))
+    cond = np.random.choice(D.shape[0], int(g["ume_n_samples"]), replace=False, p=g["prob"])
+    assert np.array_equal(cond, g["cond"])
+    T, _ = orc.batch_estimate_transform_ume_old(g["ume_src"][src_m][cond], g["ume_tgt"][tgt_m][cond], with_dist=False)
+    wc = well_conditioned(g["ume_src"])[src_m][cond] & well_conditioned(g["ume_tgt"])[tgt_m][cond]
+    assert np.abs(T - g["T_filt"])[wc][:, :3, :3].max() < 1e-4
+
+
+def test_full_pipeline_oracle_on_a_hard_pair():
+    """bench.py's recall check uses oracle.evaluate_pair_full (evaluate.py:195-309 restated): it must register an easy
+    pair exactly and be deterministic given the RNG seed; sparse_quantize keeps the first point of every voxel."""
+    from umeregrobust_amd.synth import synth_pair, synth_pair_hard
+    pts = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [0.7, 0.1, 0.1], [-0.1, 0.0, 0.0], [0.65, 0.0, 0.0]], np.float32)
+    assert np.array_equal(orc.sparse_quantize(pts, 0.6), [0, 2, 3])
+    p = synth_pair(2, N=1500, n_kp=256, voxel=0.6)
+    kw = dict(ume_n_samples=64, pc_corr_max_size=1500)
+    r = orc.evaluate_pair_full(p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.gt_tform, np.random.RandomState(0), **kw)
+    assert r["rre"] < 0.05 and r["rte"] < 0.01 and r["n_hyp"] == 64
+    h = synth_pair_hard(2, N=1500, n_kp=256, voxel=0.6)
+    assert h.src_pts.shape == (1500, 3) and 0.2 < (h.tgt_twin_of_src >= 0).mean() < 0.8
+    tw = h.tgt_twin_of_src
+    ok = tw >= 0
+    e = (h.src_pts[ok].astype(np.float64) @ h.gt_tform[:3, :3].T.astype(np.float64) + h.gt_tform[:3, 3]) - h.tgt_pts[tw[ok]]
+    assert 0.005 < np.abs(e).std() < 0.06                                 # two independent N(0, 2 cm) noises
+    a = orc.evaluate_pair_full(h.src_pts, h.tgt_pts, h.src_feat, h.tgt_feat, h.gt_tform, np.random.RandomState(4), **kw)
+    b = orc.evaluate_pair_full(h.src_pts, h.tgt_pts, h.src_feat, h.tgt_feat, h.gt_tform, np.random.RandomState(4), **kw)
+    assert np.array_equal(a["T_est"], b["T_est"]) and np.isfinite(a["T_est"]).all()

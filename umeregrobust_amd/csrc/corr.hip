@@ -30,6 +30,9 @@
 
 namespace umereg {
 
+#ifndef UMEREG_F1_ABLATE
+#define UMEREG_F1_ABLATE 0   // timing experiments only (tools/exp_f1_ablate.sh): 1 skip epilogue, 2 skip append, 4 skip histogram, 8 skip grid fallback
+#endif
 constexpr int kBins = 32;
 constexpr float kKnnMaxCells = 6.0f;   // upper bound of the first search radius, in cells
 constexpr float kKnnTarget = 4.0f;     // expected points in the first search ball, in units of K
@@ -70,18 +73,27 @@ __device__ __forceinline__ float wave_sum_f(float v)
 // A lane's candidate list lives in LDS as two planes, d2 bits [cap][64] and the target's original index
 // [cap][64]; the index plane is 16 bits wide whenever the target cloud has <= 65 536 points (6 bytes per entry
 // instead of 8: what lets a fourth wave per SIMD fit at K = 20).  Keys compare as (d2 bits << 32) | index.
+// Both planes are LANE-PRIVATE at 32-bit word granularity (two consecutive 16-bit indices of one lane share a word), and
+// so is the histogram that shares the region (word b * 64 + lane): a lane's histogram passes can only ever overwrite
+// that lane's own list, never a neighbour's -- which is what lets lanes finished by one search structure keep their
+// lists while other lanes of the wave go through another (corr_score_kernel).
 template <class IdxT>
 struct KeyList {
     unsigned int* d2;
     IdxT* ix;
+    static __device__ __forceinline__ int ix_at(int e, int lane)
+    {
+        return sizeof(IdxT) == 2 ? (((e >> 1) * kWave + lane) << 1) | (e & 1) : e * kWave + lane;
+    }
+    __device__ __forceinline__ unsigned int index(int e, int lane) const { return (unsigned int)ix[ix_at(e, lane)]; }
     __device__ __forceinline__ unsigned long long get(int e, int lane) const
     {
-        return ((unsigned long long)d2[e * kWave + lane] << 32) | (unsigned int)ix[e * kWave + lane];
+        return ((unsigned long long)d2[e * kWave + lane] << 32) | (unsigned int)ix[ix_at(e, lane)];
     }
     __device__ __forceinline__ void set(int e, int lane, unsigned long long k) const
     {
         d2[e * kWave + lane] = (unsigned int)(k >> 32);
-        ix[e * kWave + lane] = (IdxT)(k & 0xffffffffull);
+        ix[ix_at(e, lane)] = (IdxT)(k & 0xffffffffull);
     }
 };
 
@@ -128,9 +140,9 @@ __device__ __forceinline__ int sel_bin(float d2, float lo, float sc)
 // point with d2 < r2 always lies in a visited cell (cell_axis is monotone and the chord is computed from the
 // row's distance to the query, a lower bound of the point's).  Rows are walked in lock-step over the union of
 // the active lanes' row ranges; inside a row every lane advances through its own run, 4 candidates per trip.
-// Adjacent lanes touch the same cache lines.  body(d2, original index, in_run) is called for every candidate
-// slot; slots beyond a lane's run arrive with in_run = false.
-template <class Body>
+// Adjacent lanes touch the same cache lines.  body(d2, point {x,y,z,original index}, table position, in_run) is
+// called for every candidate slot; slots beyond a lane's run arrive with in_run = false.
+template <bool FULLP = false, class Body>
 __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, float qz, bool act, float r2, int lane,
                                           Body&& body)
 {
@@ -158,7 +170,7 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
             while (__any(pos < end)) {
                 KNN_DBG(7, 4);
                 float d2[4];
-                int oi[4];
+                float4 pt[4];
                 bool in_run[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -173,29 +185,162 @@ __device__ __forceinline__ void walk_ball(const KnnCtx& c, float qx, float qy, f
                     t = t + dy * dy;
                     t = t + dz * dz;
                     d2[u] = t;
-                    oi[u] = __float_as_int(p.w);
+                    if (FULLP) pt[u] = p; else pt[u].w = p.w;   // the selection only needs the index word: 4 live registers, not 16
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) body(d2[u], oi[u], in_run[u]);   // !in_run: beyond this lane's run, d2 is of no meaning
+                for (int u = 0; u < 4; ++u) body(d2[u], pt[u], pos + u, in_run[u]);   // !in_run: beyond this lane's run, d2 is of no meaning
                 pos += 4;
             }
         }
     }
 }
 
-// Exact K nearest target points of one query per lane.  On return, valid lanes hold min(K, n2) keys
+// ---- selection of the K smallest (d2, index) keys of a candidate stream -----------------------------------------
+// Both search structures (the grid walk above, the per-cell candidate lists of the lattice below) deliver a
+// lane's candidates through a WALKER:  walk(active, r2, body)  calls  body(d2, point, position, in_run)  for every
+// candidate slot of the active lanes (r2: only candidates with d2 < r2 matter; a walker may or may not use it).
+//
+//   refine_loop   histogram pass(es): each unfinished lane histograms the d2 of its candidates inside [0, S.hi0)
+//                 (32 lane-private LDS counters) and either fixes its threshold -- the bin holding its K-th
+//                 neighbour, if everything up to that bin fits the list -- or zooms into that bin (x32) for the
+//                 next pass.  Lanes that see fewer than K candidates come back `starved` (or done, if `full`).
+//   append_pass   candidates up to the threshold go to the lane's LDS list (K .. K+6 of them); the few extras are
+//                 trimmed by repeated arg-max on (d2, index).
+// A lane only ever touches its own column of the histogram / list region, and only while it is active, so lanes
+// finished by one structure keep their lists while other lanes of the wave run through the other structure.
+template <class Walk>
+__device__ __forceinline__ void refine_loop(Walk&& walk, LaneSel& S, bool& done, bool full, int K, int cap,
+                                            unsigned int* hist, int lane, bool& starved, int& found)
+{
+    int c_lo = 0;          // candidates strictly below the current (deepest) range
+    starved = false;       // fewer than K candidates within hi0: needs a bigger radius
+    found = 0;             // candidates inside the ball when the lane turned out to be starved
+    for (;;) {             // refinement loop at this radius
+        KNN_DBG(2, 1);
+        const bool active = !done && !starved;
+        if (active) {
+#pragma unroll
+            for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
+        }
+        if (!__any(active && S.nlev > 1)) {
+            // common case, every lane still at level 0 (lo = 0): one multiply, one conversion, one LDS add
+            // branch-free: rejected candidates (and the 3e38 padding: inf -> saturated conversion -> last bin) add 0
+            walk(active, S.hi0, [&](float d2, const float4&, int, bool in_run) {
+                const int b = min((int)(d2 * S.sc[0]), kBins - 1);
+                atomicAdd(&hist[b * kWave + lane], in_run && d2 < S.hi0 ? 1u : 0u);   // lane-private counter (ds_add_u32)
+            });
+        } else {
+            walk(active, S.hi0, [&](float d2, const float4&, int, bool in_run) {
+                if (in_run && d2 < S.hi0) {
+                    int b = sel_bin(d2, S.lo[0], S.sc[0]);
+                    bool in = true;
+                    if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
+                    if (S.nlev > 2) { in = in && b == S.bs[1]; b = sel_bin(d2, S.lo[2], S.sc[2]); }
+                    if (in) atomicAdd(&hist[b * kWave + lane], 1u);
+                }
+            });
+        }
+        if (active) {
+            int cum = c_lo, bstar = -1, before = c_lo, inbin = 0;
+#pragma unroll
+            for (int b = 0; b < kBins; ++b) {
+                const int h = (int)hist[b * kWave + lane];
+                if (bstar < 0 && cum + h >= K) { bstar = b; before = cum; inbin = h; }
+                cum += h;
+            }
+            // (explicit per-level statements: runtime-indexed arrays would live in scratch memory)
+            if (bstar < 0) {
+                found = cum;
+                if (full) {   // fewer than K points exist: keep them all
+                    if (S.nlev == 1) S.bs[0] = kBins - 1; else if (S.nlev == 2) S.bs[1] = kBins - 1; else S.bs[2] = kBins - 1;
+                    done = true;
+                } else {
+                    starved = true;
+                }
+            } else {
+                if (S.nlev == 1) S.bs[0] = bstar; else if (S.nlev == 2) S.bs[1] = bstar; else S.bs[2] = bstar;
+                if (before + inbin <= cap || S.nlev == kLevels) {
+                    done = true;
+                } else {   // too many candidates up to this bin for the list: zoom into the bin
+                    c_lo = before;
+                    if (S.nlev == 1) {
+                        S.lo[1] = S.lo[0] + (float)bstar / S.sc[0];
+                        S.sc[1] = S.sc[0] * (float)kBins;
+                    } else {
+                        S.lo[2] = S.lo[1] + (float)bstar / S.sc[1];
+                        S.sc[2] = S.sc[1] * (float)kBins;
+                    }
+                    S.nlev += 1;
+                }
+            }
+        }
+        if (!__any(!done && !starved)) break;
+    }
+}
+
+// every lane with `act` walks the candidates that can lie at or below its threshold bin -- at level 0 a candidate
+// is admitted only if int(d2 * sc0) <= bs0, i.e. d2 < (bs0 + 1) / sc0 (the last bin also takes the clamped
+// overflow, so it keeps the full radius).  Returns the lane's key count (<= K).
+template <class IdxT, class Walk>
+__device__ __forceinline__ int append_pass(Walk&& walk, const LaneSel& S, bool act, int K, int cap, const KeyList<IdxT>& list, int lane)
+{
+    int cnt = 0;
+    unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
+    const float r2_app = S.bs[0] >= kBins - 1 ? S.hi0 : fminf(S.hi0, ((float)(S.bs[0] + 1) / S.sc[0]) * 1.0001f + 1e-30f);
+    auto admit = [&](bool ok, float d2, int oi) __attribute__((always_inline)) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
+        ok = ok && key < ukey;
+        if (__any(ok)) {
+            if (ok) { list.set(cnt, lane, key); ++cnt; }
+            if (__any(cnt >= cap)) {
+                // a list overflowed (exact ties beyond the finest bins): trim it to K, admit only better keys
+                const bool over = cnt >= cap;
+                KNN_DBG(3, 1);
+                while (__any(over && cnt > K)) { KNN_DBG(4, 1); drop_max(list, cnt, over && cnt > K, cap, lane); }
+                if (over) {
+                    unsigned long long mk = 0ull;
+                    for (int e = 0; e < K; ++e) { const unsigned long long k = list.get(e, lane); mk = k > mk ? k : mk; }
+                    ukey = mk;
+                }
+            }
+        }
+    };
+    if (!__any(act && S.nlev > 1)) {
+        // common case, level 0 only: int(d2 * sc0) <= bs0  <=>  d2 * sc0 < bs0 + 1 (the last bin takes everything)
+        const float thr = S.bs[0] >= kBins - 1 ? 3.0e38f : (float)(S.bs[0] + 1);
+        // At level 0 the histogram pass has already established that at most `cap` candidates pass this test
+        // (same arithmetic, same candidates), so the list cannot overflow: plain masked stores, no branches.
+        walk(act, r2_app, [&](float d2, const float4& p, int, bool in_run) {
+            const bool ok = in_run && d2 < S.hi0 && (d2 * S.sc[0] < thr || S.bs[0] >= kBins - 1) && cnt < cap;
+            if (ok) list.set(cnt, lane, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(p.w));
+            cnt += ok ? 1 : 0;
+        });
+    } else {
+        walk(act, r2_app, [&](float d2, const float4& p, int, bool in_run) {
+            bool ok = in_run && d2 < S.hi0;
+            if (ok) {
+                const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
+                ok = b0 <= S.bs[0];
+                if (S.nlev > 1 && b0 == S.bs[0]) {
+                    const int b1 = sel_bin(d2, S.lo[1], S.sc[1]);
+                    ok = b1 <= S.bs[1];
+                    if (S.nlev > 2 && b1 == S.bs[1]) ok = sel_bin(d2, S.lo[2], S.sc[2]) <= S.bs[2];
+                }
+            }
+            admit(ok, d2, __float_as_int(p.w));
+        });
+    }
+    while (__any(cnt > K)) { KNN_DBG(5, 1); drop_max(list, cnt, cnt > K, cap, lane); }
+    return cnt;
+}
+
+// Exact K nearest target points of one query per lane on the GRID.  On return, valid lanes hold min(K, n2) keys
 // ((bits(d2) << 32) | orig index, unsorted) in list[0 .. count).
 //
 // Every lane streams its own candidates (walk_ball); the walks run in lock-step over the union of the
-// lanes' row ranges:
-//   histogram pass(es)  each unfinished lane histograms the d2 of the candidates inside its current
-//                       range (32 lane-private LDS counters) and either fixes its threshold -- the
-//                       bin holding its K-th neighbour, if everything up to that bin fits the list --
-//                       or zooms into that bin (x32 resolution) for the next pass.  Typical lanes
-//                       finish in one pass; lanes of a scattered wave (huge union box) or queries far
-//                       outside the cloud need two or three.
-//   append pass         candidates up to the threshold go to the lane's LDS list (K .. K+6 of them);
-//                       the few extras are trimmed by repeated arg-max on (d2, index).
+// lanes' row ranges.  The first radius comes from the local point density and grows while the lane is starved,
+// until the ball provably holds the K nearest; typical lanes finish in one histogram pass, lanes of a scattered
+// wave (huge union box) or queries far outside the cloud need two or three.
 template <class IdxT>
 __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool valid, int K, int cap,
                         unsigned int* hist, const KeyList<IdxT>& list, int lane)
@@ -252,6 +397,9 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
         margin = fminf(kKnnMaxCells * c.cs_min, fmaxf(r, 0.25f * c.cs_min));
     }
 
+    auto walk = [&](bool act, float r2, auto&& body) __attribute__((always_inline)) {
+        walk_ball(c, qx, qy, qz, act, r2, lane, body);
+    };
     for (;;) {   // coverage loop: grow a starved lane's radius until it provably holds its K nearest
         KNN_DBG(1, 1);
         bool full = false;
@@ -263,125 +411,15 @@ __device__ int knn_wave(const KnnCtx& c, float qx, float qy, float qz, bool vali
             S.lo[0] = 0.f;
             S.sc[0] = (float)kBins / S.hi0;
         }
-        int found = 0;         // candidates inside the ball when the lane turned out to be starved
-        int c_lo = 0;          // candidates strictly below the current (deepest) range
-        bool starved = false;  // fewer than K candidates within hi0: needs a bigger radius
-        for (;;) {             // refinement loop at this radius
-            KNN_DBG(2, 1);
-#pragma unroll
-            for (int b = 0; b < kBins; ++b) hist[b * kWave + lane] = 0u;
-            const bool active = !done && !starved;
-            if (!__any(active && S.nlev > 1)) {
-                // common case, every lane still at level 0 (lo = 0): one multiply, one conversion, one LDS add
-                // branch-free: rejected candidates (and the 3e38 padding: inf -> saturated conversion -> last bin) add 0
-                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int, bool in_run) {
-                    const int b = min((int)(d2 * S.sc[0]), kBins - 1);
-                    atomicAdd(&hist[b * kWave + lane], in_run && d2 < S.hi0 ? 1u : 0u);   // lane-private counter (ds_add_u32)
-                });
-            } else {
-                walk_ball(c, qx, qy, qz, active, S.hi0, lane, [&](float d2, int, bool in_run) {
-                    if (in_run && d2 < S.hi0) {
-                        int b = sel_bin(d2, S.lo[0], S.sc[0]);
-                        bool in = true;
-                        if (S.nlev > 1) { in = b == S.bs[0]; b = sel_bin(d2, S.lo[1], S.sc[1]); }
-                        if (S.nlev > 2) { in = in && b == S.bs[1]; b = sel_bin(d2, S.lo[2], S.sc[2]); }
-                        if (in) atomicAdd(&hist[b * kWave + lane], 1u);
-                    }
-                });
-            }
-            if (active) {
-                int cum = c_lo, bstar = -1, before = c_lo, inbin = 0;
-#pragma unroll
-                for (int b = 0; b < kBins; ++b) {
-                    const int h = (int)hist[b * kWave + lane];
-                    if (bstar < 0 && cum + h >= K) { bstar = b; before = cum; inbin = h; }
-                    cum += h;
-                }
-                // (explicit per-level statements: runtime-indexed arrays would live in scratch memory)
-                if (bstar < 0) {
-                    found = cum;
-                    if (full) {   // fewer than K points exist: keep them all
-                        if (S.nlev == 1) S.bs[0] = kBins - 1; else if (S.nlev == 2) S.bs[1] = kBins - 1; else S.bs[2] = kBins - 1;
-                        done = true;
-                    } else {
-                        starved = true;
-                    }
-                } else {
-                    if (S.nlev == 1) S.bs[0] = bstar; else if (S.nlev == 2) S.bs[1] = bstar; else S.bs[2] = bstar;
-                    if (before + inbin <= cap || S.nlev == kLevels) {
-                        done = true;
-                    } else {   // too many candidates up to this bin for the list: zoom into the bin
-                        c_lo = before;
-                        if (S.nlev == 1) {
-                            S.lo[1] = S.lo[0] + (float)bstar / S.sc[0];
-                            S.sc[1] = S.sc[0] * (float)kBins;
-                        } else {
-                            S.lo[2] = S.lo[1] + (float)bstar / S.sc[1];
-                            S.sc[2] = S.sc[1] * (float)kBins;
-                        }
-                        S.nlev += 1;
-                    }
-                }
-            }
-            if (!__any(!done && !starved)) break;
-        }
+        bool starved;
+        int found;
+        refine_loop(walk, S, done, full, K, cap, hist, lane, starved, found);
         if (!__any(!done)) break;
         // a starved lane found `found` < K points inside its ball: LiDAR neighbourhoods are surface-like, so
         // the count grows ~ r^2 -- jump to the radius expected to hold 1.5 K (at least x1.25, at most x4)
         if (!done) margin = (dout + margin) * fminf(4.0f, fmaxf(1.25f, sqrtf(1.5f * (float)K / ((float)found + 0.5f)))) - dout;
     }
-
-    // append pass: every lane walks the ball that holds everything up to its threshold bin -- at level 0 a
-    // candidate is admitted only if int(d2 * sc0) <= bs0, i.e. d2 < (bs0 + 1) / sc0 (the last bin also takes the
-    // clamped overflow, so it keeps the full radius)
-    int cnt = 0;
-    unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
-    const float r2_app = S.bs[0] >= kBins - 1 ? S.hi0 : fminf(S.hi0, ((float)(S.bs[0] + 1) / S.sc[0]) * 1.0001f + 1e-30f);
-    auto admit = [&](bool ok, float d2, int oi) __attribute__((always_inline)) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
-        ok = ok && key < ukey;
-        if (__any(ok)) {
-            if (ok) { list.set(cnt, lane, key); ++cnt; }
-            if (__any(cnt >= cap)) {
-                // a list overflowed (exact ties beyond the finest bins): trim it to K, admit only better keys
-                const bool over = cnt >= cap;
-                KNN_DBG(3, 1);
-                while (__any(over && cnt > K)) { KNN_DBG(4, 1); drop_max(list, cnt, over && cnt > K, cap, lane); }
-                if (over) {
-                    unsigned long long mk = 0ull;
-                    for (int e = 0; e < K; ++e) { const unsigned long long k = list.get(e, lane); mk = k > mk ? k : mk; }
-                    ukey = mk;
-                }
-            }
-        }
-    };
-    if (!__any(valid && S.nlev > 1)) {
-        // common case, level 0 only: int(d2 * sc0) <= bs0  <=>  d2 * sc0 < bs0 + 1 (the last bin takes everything)
-        const float thr = S.bs[0] >= kBins - 1 ? 3.0e38f : (float)(S.bs[0] + 1);
-        // At level 0 the histogram pass has already established that at most `cap` candidates pass this test
-        // (same arithmetic, same candidates), so the list cannot overflow: plain masked stores, no branches.
-        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi, bool in_run) {
-            const bool ok = in_run && d2 < S.hi0 && (d2 * S.sc[0] < thr || S.bs[0] >= kBins - 1) && cnt < cap;
-            if (ok) list.set(cnt, lane, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi);
-            cnt += ok ? 1 : 0;
-        });
-    } else {
-        walk_ball(c, qx, qy, qz, valid, r2_app, lane, [&](float d2, int oi, bool in_run) {
-            bool ok = in_run && d2 < S.hi0;
-            if (ok) {
-                const int b0 = sel_bin(d2, S.lo[0], S.sc[0]);
-                ok = b0 <= S.bs[0];
-                if (S.nlev > 1 && b0 == S.bs[0]) {
-                    const int b1 = sel_bin(d2, S.lo[1], S.sc[1]);
-                    ok = b1 <= S.bs[1];
-                    if (S.nlev > 2 && b1 == S.bs[1]) ok = sel_bin(d2, S.lo[2], S.sc[2]) <= S.bs[2];
-                }
-            }
-            admit(ok, d2, oi);
-        });
-    }
-    while (__any(cnt > K)) { KNN_DBG(5, 1); drop_max(list, cnt, cnt > K, cap, lane); }
-    return cnt;
+    return append_pass(walk, S, valid, K, cap, list, lane);
 }
 
 // sort this lane's keys ascending (selection sort in LDS; K is small)
@@ -414,7 +452,8 @@ struct KnnLds {
 __host__ __device__ constexpr size_t knn_lds_per_wave(int cap, size_t idx_bytes)
 {
     // the histogram is only live during the threshold search, the list only afterwards: they share the region
-    const size_t list_bytes = (size_t)cap * kWave * (4 + idx_bytes), hist_bytes = (size_t)kBins * kWave * 4;
+    const size_t list_bytes = (size_t)cap * kWave * 4 + (idx_bytes == 2 ? (size_t)((cap + 1) / 2) * kWave * 4 : (size_t)cap * kWave * 4);
+    const size_t hist_bytes = (size_t)kBins * kWave * 4;
     return ((list_bytes > hist_bytes ? list_bytes : hist_bytes) + 15) & ~(size_t)15;
 }
 
@@ -437,6 +476,106 @@ __device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int 
     c.g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), -(float)K, N);
     c.cs_min = fminf(1.0f / c.g.invx, fminf(1.0f / c.g.invy, 1.0f / c.g.invz));
     return c;
+}
+
+// ---- candidate lattice on the target (hypothesis selection) -----------------------------------------------------
+// FeatureCorrelator scores M ~ 2 500 hypotheses against ONE target cloud: M x Ns = 2.5e7 kNN queries into the same
+// 10 000 points.  The grid walk above pays per query for finding a radius that covers the K nearest (2-3 histogram
+// walks over ~250 candidate slots each).  The lattice moves that work to a per-pair precomputation:
+//   * a fine uniform lattice over the target's bounding box (+ a margin), cell = h x h x 2h, stored in 4x4x4 bricks
+//     (spatially adjacent queries read adjacent table entries);
+//   * for every cell, with centre c and half diagonal hd:  d_K(c) = distance of c's K-th nearest target point
+//     (exact, by the grid search).  For any query q inside the cell  d_K(q) <= d_K(c) + |q - c| <= d_K(c) + hd,
+//     and a point among q's K nearest lies within d_K(q) of q, hence within d_K(c) + hd of the CELL BOX.  The
+//     cell's candidate list = all targets p with dist(p, box) <= r := (d_K(c) + hd) * (1 + 1e-4) + 1e-6
+//     -- a superset of the K nearest (ties included) of EVERY query in the cell, typically 1.5-2.5 K entries;
+//   * a query then streams its cell's list once for the histogram (range [0, r^2): all K nearest are inside) and
+//     once for the append: no coverage loop, no starved passes, ~40 candidates instead of ~700 slot visits.
+// Entries are 16-bit positions in the cell-sorted table (targets <= 65 535 points), padded to quads with the
+// position of a padding point (d2 ~ 3e36: never admitted).  Cells whose list would exceed kLatMaxQuads, cells that
+// do not fit the pool, and queries outside the lattice take the grid walk -- same result, by construction.
+constexpr int kLatMaxQuads = 128;                 // longest list (in quads of 4 entries)
+constexpr unsigned int kLatMinCells = 4096, kLatMaxCells = 1u << 20;
+constexpr size_t kLatPoolQuadsPerCell = 16;       // pool size = cells x this (quads): mean list <= 64 entries
+
+struct Lattice {
+    float lox, loy, loz, inv_h, inv_hz, h, hz, hd;
+    int bx, by, bz;        // bricks per axis (4 cells each)
+    int n_cells;           // bx * by * bz * 64
+};
+
+struct LatWs {
+    size_t off_header, off_marks, off_wave_tot, off_cids, off_cells, off_pool, total;
+    unsigned int c_max;
+    size_t pool_quads;
+};
+
+// header words: [0] pool quads handed out, [1] cells, [2] marked cells without a list, [3] marked cells,
+//               [4] fallback records, [6] fallback queries
+__host__ __device__ inline LatWs lat_ws(unsigned int c_max)
+{
+    LatWs w;
+    w.c_max = c_max;
+    w.pool_quads = (size_t)c_max * kLatPoolQuadsPerCell;
+    size_t o = 0;
+    w.off_header = o;   o += 256;
+    w.off_marks = o;    o += ((size_t)c_max + 255) / 256 * 256;          // one byte per cell: some query lands in it
+    w.off_wave_tot = o; o += ((size_t)c_max / 64 + 64) * 4;              // list quads per 64-cell brick, then their prefix sums
+    o = (o + 255) / 256 * 256;
+    w.off_cids = o;     o += (size_t)c_max * 4 + 256;                    // marked cells, ascending
+    w.off_cells = o;    o += (size_t)c_max * 16;
+    w.off_pool = o;     o += w.pool_quads * 8 + 256;
+    w.total = (o + 255) / 256 * 256;
+    return w;
+}
+
+// cells for a job of M x Ns queries: the build costs ~5 grid walks per cell, a query saves ~2 of them
+__host__ inline unsigned int lattice_cells_for(long queries, int Nt, int flags)
+{
+    if (Nt > 65535 - 64 || (flags & UMEREG_CORR_NO_LATTICE)) return 0;          // 16-bit list entries
+    if (queries < (1l << 17) && !(flags & UMEREG_CORR_FORCE_LATTICE)) return 0;   // tiny jobs keep the grid walk
+    long c = queries / 16;
+    c = c < (long)kLatMinCells ? kLatMinCells : (c > (long)kLatMaxCells ? kLatMaxCells : c);
+    return (unsigned int)c;
+}
+
+__device__ __forceinline__ Lattice load_lattice(const unsigned int* __restrict__ bbox, unsigned int c_max)
+{
+    Lattice L;
+    const float mn[3] = {dec_ord(~bbox[0]), dec_ord(~bbox[1]), dec_ord(~bbox[2])};
+    const float mx[3] = {dec_ord(bbox[3]), dec_ord(bbox[4]), dec_ord(bbox[5])};
+    const float ex = fmaxf(mx[0] - mn[0], 1e-3f), ey = fmaxf(mx[1] - mn[1], 1e-3f), ez = fmaxf(mx[2] - mn[2], 1e-3f);
+    // margin: sources overhang their targets, and a hypothesis that is a few degrees off lifts far points by metres;
+    // a query outside the lattice costs ~50x a query inside (corr_score_fallback_kernel), and only cells that some
+    // query lands in are ever built, so the margin is generous
+    const float mxy = fmaxf(0.2f * fmaxf(ex, ey), 3.0f), mz = fmaxf(0.06f * fmaxf(ex, ey), 3.0f);
+    const float X = ex + 2.f * mxy, Y = ey + 2.f * mxy, Z = ez + 2.f * mz;
+    float h = cbrtf(X * Y * Z / (2.0f * (float)c_max));
+    int bx = 1, by = 1, bz = 1;
+    for (int it = 0; it < 200; ++it) {
+        bx = ((int)ceilf(X / h) + 3) >> 2;
+        by = ((int)ceilf(Y / h) + 3) >> 2;
+        bz = ((int)ceilf(Z / (2.f * h)) + 3) >> 2;
+        if ((long)bx * by * bz * 64 <= (long)c_max && bx < 2048 && by < 2048 && bz < 2048) break;
+        h *= 1.03f;
+    }
+    L.lox = mn[0] - mxy; L.loy = mn[1] - mxy; L.loz = mn[2] - mz;
+    L.h = h; L.hz = 2.f * h;
+    L.inv_h = 1.0f / h; L.inv_hz = 1.0f / L.hz;
+    L.hd = 0.5f * sqrtf(2.f * h * h + L.hz * L.hz) * 1.0001f;
+    L.bx = bx; L.by = by; L.bz = bz;
+    L.n_cells = bx * by * bz * 64;
+    return L;
+}
+
+// cell id of a query (brick-major), or -1 outside the lattice (also for NaN coordinates)
+__device__ __forceinline__ int lattice_cell(const Lattice& L, float qx, float qy, float qz)
+{
+    const float tx = (qx - L.lox) * L.inv_h, ty = (qy - L.loy) * L.inv_h, tz = (qz - L.loz) * L.inv_hz;
+    const bool in = tx >= 0.f && ty >= 0.f && tz >= 0.f && tx < (float)(L.bx * 4) && ty < (float)(L.by * 4) && tz < (float)(L.bz * 4);
+    const int cx = (int)tx, cy = (int)ty, cz = (int)tz;
+    const int id = ((((cz >> 2) * L.by + (cy >> 2)) * L.bx + (cx >> 2)) << 6) | ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3);
+    return in ? id : -1;
 }
 
 // ---- pytorch3d.ops.knn_points ------------------------------------------------------------------
@@ -599,14 +738,272 @@ __global__ __launch_bounds__(256) void rotate_points_kernel(const float* __restr
     }
 }
 
+// ---- score epilogue ---------------------------------------------------------------------------------------------
+// sum over this wave's valid queries of  sum_{k < cnt} cauchy(d_k) <vp_n, vq_jk>  from the K kept keys of every lane.
+// A feature row is 128 B: read by one lane it costs eight 16-byte gathers that each touch 64 different cache lines
+// per wavefront.  Instead 8 lanes share a row (one line per 8 lanes, one gather per neighbour): group g = lanes
+// 8g..8g+7 serves its 8 queries one after the other, lane `sub` holding the sub-th quad of the query's and of the
+// neighbour's row; the keys are read from the owner's LDS list.  Returns the wave sum (all lanes).
+template <class IdxT>
+__device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int cnt, bool valid, int sidx, const float4* __restrict__ vp4,
+                                                const float4* __restrict__ vq4, int K, float sigma, int lane)
+{
+    // (1) owners turn the d2 of their keys into Cauchy weights in place
+    if (UMEREG_F1_ABLATE & 1) return wave_sum_f(valid ? (float)cnt : 0.f);
+    for (int e = 0; e < K; ++e) {
+        if (e < cnt) {
+            const float dist = sqrtf(__uint_as_float(list.d2[e * kWave + lane]));   // torch.linalg.norm (:593)
+            const float r = dist / sigma;
+            list.d2[e * kWave + lane] = __float_as_uint(1.0f / (1.0f + r * r));       // cauchy_kernel (:588-589)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int grp8 = lane & ~7, sub = lane & 7;
+    float acc = 0.f;
+    for (int it = 0; it < 8; ++it) {
+        const int q = grp8 + it;                       // the group's current query = that lane's id
+        const int cq = __shfl(cnt, q, kWave);
+        const int sq = __shfl(sidx, q, kWave);
+        const float4 a = vp4[(size_t)sq * 8 + sub];
+        float part = 0.f;
+#pragma unroll 4
+        for (int e = 0; e < K; ++e) {
+            if (e < cq) {
+                const float wgt = __uint_as_float(list.d2[e * kWave + q]);
+                const int j = (int)list.index(e, q);
+                const float4 o = vq4[(size_t)j * 8 + sub];
+                float d = a.x * o.x;
+                d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                part = fmaf(wgt, d, part);
+            }
+        }
+        part += __shfl_xor(part, 1, kWave);
+        part += __shfl_xor(part, 2, kWave);
+        part += __shfl_xor(part, 4, kWave);
+        acc = sub == it ? part : acc;                 // lane q keeps its query's sum
+    }
+    return wave_sum_f(valid ? acc : 0.f);
+}
+
+// ---- lattice build ---------------------------------------------------------------------------------------------------
+// (1) lattice_mark_kernel: marks[cell] = 1 for every cell some (hypothesis, source point) query lands in (~1/4 of them);
+// (2) lattice_compact_kernel: the marked cells in ascending order (one workgroup);
+// (3) lattice_count_kernel: one lane per marked cell: d_K of the centre, list radius, number of list entries;
+//     cells[id] = {-, quads, bits(r^2), flags}, quads per wavefront -> wave_tot;
+// (4) lattice_scan_kernel: exclusive prefix sums of wave_tot (one workgroup): every wavefront's first quad in the pool
+//     -- in cell order, so WHICH cells get a list when the pool runs out does not depend on timing;
+// (5) lattice_fill_kernel: the lists (positions in the cell-sorted table, four to a 64-bit word, padded with the
+//     position of a padding point).
+// cells[id].w != 0 or quads == 0: no list (the query is left to corr_score_fallback_kernel).
+__global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
+                                                           const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
+                                                           char* __restrict__ lat, unsigned int c_max)
+{
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    unsigned char* marks = reinterpret_cast<unsigned char*>(lat + lw.off_marks);
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h0 = blockIdx.y * hyp_per_thread, h1 = min(h0 + hyp_per_thread, M);
+    if (n >= Ns) return;
+    const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
+    for (int h = h0; h < h1; ++h) {
+        const float* Th = T + (size_t)h * 16;     // uniform: scalar loads
+        // (the same arithmetic as corr_score_kernel: a query must find its own cell marked)
+        const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        const int cell = lattice_cell(L, qx, qy, qz);
+        if (cell >= 0) marks[cell] = 1;
+    }
+}
+
+// ascending list of the marked cells (one workgroup; deterministic order): cids[0 .. header[3])
+__global__ __launch_bounds__(1024) void lattice_compact_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt)
+{
+    __shared__ unsigned int part[1024];
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const uint4* marks16 = reinterpret_cast<const uint4*>(lat + lw.off_marks);
+    unsigned int* cids = reinterpret_cast<unsigned int*>(lat + lw.off_cids);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    const int n16 = L.n_cells >> 4;                    // groups of 16 cells (n_cells is a multiple of 64)
+    const int per = (n16 + 1023) / 1024;
+    const int a = threadIdx.x * per, b = min(a + per, n16);
+    auto count16 = [](const uint4& m) { return __popc(m.x & 0x01010101u) + __popc(m.y & 0x01010101u) + __popc(m.z & 0x01010101u) + __popc(m.w & 0x01010101u); };
+    unsigned int s = 0u;
+    for (int i = a; i < b; ++i) s += (unsigned int)count16(marks16[i]);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - s;
+    for (int i = a; i < b; ++i) {
+        const uint4 m = marks16[i];
+        const unsigned int w[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((w[k >> 2] >> ((k & 3) * 8)) & 1u) cids[run++] = (unsigned int)(i * 16 + k);
+    }
+    if (threadIdx.x == 1023) { header[3] = part[1023]; header[1] = (unsigned int)L.n_cells; }
+}
+
+__device__ __forceinline__ void lattice_cell_centre(const Lattice& L, int id, float& ccx, float& ccy, float& ccz)
+{
+    const int brick = id >> 6, loc = id & 63;
+    const int bxi = brick % L.bx, byi = (brick / L.bx) % L.by, bzi = brick / (L.bx * L.by);
+    ccx = L.lox + ((float)(bxi * 4 + (loc & 3)) + 0.5f) * L.h;
+    ccy = L.loy + ((float)(byi * 4 + ((loc >> 2) & 3)) + 0.5f) * L.h;
+    ccz = L.loz + ((float)(bzi * 4 + (loc >> 4)) + 0.5f) * L.hz;
+}
+
+// is target point p a candidate of the cell (centre cc, list radius^2 r2)?  dist(p, cell box) <= r
+__device__ __forceinline__ bool lattice_in_list(const Lattice& L, const float4& p, float ccx, float ccy, float ccz, float r2)
+{
+    const float ax = fmaxf(fabsf(p.x - ccx) - 0.5f * L.h, 0.f), ay = fmaxf(fabsf(p.y - ccy) - 0.5f * L.h, 0.f);
+    const float az = fmaxf(fabsf(p.z - ccz) - 0.5f * L.hz, 0.f);
+    return ax * ax + ay * ay + az * az <= r2;
+}
+
+// one lane per marked cell (64 consecutive entries of cids per wavefront: neighbouring cells)
+template <class IdxT>
+__global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max,
+                                                            int Nt, int K, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
+    unsigned int* wave_tot = reinterpret_cast<unsigned int*>(lat + lw.off_wave_tot);
+    uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
+    const unsigned int n_marked = header[3];
+    const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (wid * kWave >= n_marked) return;
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const bool valid = wid * kWave + lane < n_marked;
+    const int id = (int)cids[valid ? wid * kWave + lane : wid * kWave];
+    const KnnLds<IdxT> Ls = carve_lds<IdxT>(lds, wave, cap);
+    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    float ccx, ccy, ccz;
+    lattice_cell_centre(L, id, ccx, ccy, ccz);
+    // d_K of the cell centre
+    const int cnt = knn_wave(c, ccx, ccy, ccz, valid, K, cap, Ls.hist, Ls.list, lane);
+    unsigned int d2k_bits = 0u;
+    for (int e = 0; e < K; ++e)
+        if (e < cnt) { const unsigned int b = Ls.list.d2[e * kWave + lane]; d2k_bits = b > d2k_bits ? b : d2k_bits; }
+    const float r = (sqrtf(__uint_as_float(d2k_bits)) + L.hd) * 1.0001f + 1e-6f;
+    const float r2 = r * r;
+    const float rw = r + L.hd;                       // ball around the centre that contains {dist(p, box) <= r}
+    int n = 0;
+    walk_ball<true>(c, ccx, ccy, ccz, valid, rw * rw * 1.001f, lane,
+                    [&](float, const float4& p, int, bool in_run) { n += in_run && lattice_in_list(L, p, ccx, ccy, ccz, r2) ? 1 : 0; });
+    int quads = (n + 3) >> 2;
+    const bool has = valid && cnt >= K && quads <= kLatMaxQuads;
+    quads = has ? quads : 0;
+    if (valid) cells[id] = make_uint4(0u, (unsigned int)quads, __float_as_uint(r2), has ? 0u : 1u);
+    int tot = quads;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m, kWave);
+    const unsigned long long n_nolist = __ballot(valid && !has);
+    if (lane == 0) {
+        wave_tot[wid] = (unsigned int)tot;
+        if (n_nolist != 0ull) atomicAdd(&header[2], (unsigned int)__popcll(n_nolist));
+    }
+}
+
+// exclusive prefix sums of the per-wavefront list sizes: every wavefront's first quad in the pool, in cell order
+__global__ __launch_bounds__(1024) void lattice_scan_kernel(char* __restrict__ lat, unsigned int c_max)
+{
+    __shared__ unsigned int part[1024];
+    const LatWs lw = lat_ws(c_max);
+    unsigned int* wave_tot = reinterpret_cast<unsigned int*>(lat + lw.off_wave_tot);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    const int n = (int)((header[3] + kWave - 1) / kWave);
+    const int per = (n + 1023) / 1024;
+    const int a = threadIdx.x * per, b = min(a + per, n);
+    unsigned int s = 0u;
+    for (int i = a; i < b; ++i) s += wave_tot[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {         // Hillis-Steele inclusive scan of the 1024 partial sums
+        const unsigned int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - s;          // exclusive
+    for (int i = a; i < b; ++i) { const unsigned int t = wave_tot[i]; wave_tot[i] = run; run += t; }
+    if (threadIdx.x == 1023) header[0] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void lattice_fill_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt, int K)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    const unsigned int* wave_tot = reinterpret_cast<const unsigned int*>(lat + lw.off_wave_tot);
+    const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
+    unsigned long long* pool = reinterpret_cast<unsigned long long*>(lat + lw.off_pool);
+    const unsigned int n_marked = header[3];
+    const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (wid * kWave >= n_marked) return;
+    const bool valid = wid * kWave + lane < n_marked;
+    const int id = (int)cids[valid ? wid * kWave + lane : wid * kWave];
+    const uint4 ce = valid ? cells[id] : make_uint4(0u, 0u, 0u, 1u);
+    const int quads = ce.w == 0u ? (int)ce.y : 0;
+    if (!__any(quads > 0)) return;
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    int incl = quads;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); incl += lane >= m ? o : 0; }
+    const unsigned long long first = (unsigned long long)wave_tot[wid] + (unsigned long long)(incl - quads);
+    bool has = quads > 0;
+    if (has && first + (unsigned long long)quads > (unsigned long long)lw.pool_quads) {      // pool exhausted: from this cell on, no lists
+        has = false;
+        cells[id] = make_uint4(0u, 0u, ce.z, 1u);
+    }
+    const unsigned long long n_lost = __ballot(quads > 0 && !has);
+    if (lane == 0 && n_lost != 0ull) atomicAdd(&header[2], (unsigned int)__popcll(n_lost));
+    float ccx, ccy, ccz;
+    lattice_cell_centre(L, id, ccx, ccy, ccz);
+    const float r2 = __uint_as_float(ce.z);
+    const float rw = sqrtf(r2) + L.hd;
+    unsigned long long word = 0ull;
+    int k = 0;
+    walk_ball<true>(c, ccx, ccy, ccz, has, rw * rw * 1.001f, lane, [&](float, const float4& p, int pos, bool in_run) {
+        if (in_run && lattice_in_list(L, p, ccx, ccy, ccz, r2)) {
+            word |= (unsigned long long)(unsigned int)pos << ((k & 3) * 16);
+            if ((k & 3) == 3) { pool[first + (unsigned long long)(k >> 2)] = word; word = 0ull; }
+            ++k;
+        }
+    });
+    if (has && (k & 3)) {
+        for (int e = k & 3; e < 4; ++e) word |= (unsigned long long)(unsigned int)Nt << (e * 16);
+        pool[first + (unsigned long long)(k >> 2)] = word;
+    }
+    if (has) cells[id] = make_uint4((unsigned int)first, (unsigned int)quads, ce.z, 0u);
+}
+
 // ---- per-hypothesis correlation score (utils/loc_utils.py:592-637) ---------------------------------
 // score[h] = (1/Ns) sum_n sum_{k<K} cauchy(|R_h p_n + t_h - q_jk|, sigma) <vp_n, vq_jk>
-template <class IdxT>
+template <class IdxT, bool LAT>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void corr_score_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                          const float* __restrict__ src_pts, const float4* __restrict__ vp4, const float4* __restrict__ vq4,
                                                          const float* __restrict__ T, int Ns, int Nt, int M, int K, int cap,
                                                          float sigma, int hyp_per_wave, int n_chunks,
-                                                         float* __restrict__ partial)
+                                                         float* __restrict__ partial, char* __restrict__ lat, unsigned int c_max)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -614,6 +1011,19 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
     const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    Lattice Lt;
+    const uint4* cells = nullptr;
+    const uint2* pool = nullptr;
+    unsigned int* lat_header = nullptr;
+    uint4* queue = nullptr;
+    if (LAT) {
+        const LatWs lw = lat_ws(c_max);
+        Lt = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+        cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
+        pool = reinterpret_cast<const uint2*>(lat + lw.off_pool);
+        lat_header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+        queue = reinterpret_cast<uint4*>(lat + lw.total);       // fallback records follow the lattice
+    }
     const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
     // consecutive wavefronts take the SAME 64 queries under different groups of hypotheses: what is resident on the
     // chip at any time then works in one neighbourhood of the target, and its table and feature rows are cache hits
@@ -637,46 +1047,165 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qx = fmaf(Th[2], sp.z, fmaf(Th[1], sp.y, Th[0] * sp.x)) + Th[3];
         const float qy = fmaf(Th[6], sp.z, fmaf(Th[5], sp.y, Th[4] * sp.x)) + Th[7];
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
-        const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
-        // Score epilogue.  A feature row is 128 B: read by one lane it costs eight 16-byte gathers that each touch 64
-        // different cache lines per wavefront.  Instead 8 lanes share a row (one line per 8 lanes, one gather per
-        // neighbour): group g = lanes 8g..8g+7 serves its 8 queries one after the other, lane `sub` holding the
-        // sub-th quad of the query's and of the neighbour's row; the keys are read from the owner's LDS list.
-        // (1) owners turn the d2 of their keys into Cauchy weights in place
-        for (int e = 0; e < K; ++e) {
-            if (e < cnt) {
-                const float dist = sqrtf(__uint_as_float(L.list.d2[e * kWave + lane]));   // torch.linalg.norm (:593)
-                const float r = dist / sigma;
-                L.list.d2[e * kWave + lane] = __float_as_uint(1.0f / (1.0f + r * r));       // cauchy_kernel (:588-589)
-            }
+        int cnt;
+        bool fb_lanes = false;
+        if (LAT) {
+            // the query's cell of the candidate lattice; lanes without a list (outside the lattice, oversized or
+            // unplaced list) are left to corr_score_fallback_kernel
+            const int cell = valid ? lattice_cell(Lt, qx, qy, qz) : -1;
+            const uint4 ce = cells[cell >= 0 ? cell : 0];
+            const bool use = cell >= 0 && ce.w == 0u && ce.y != 0u;
+            const unsigned int first = ce.x;
+            const int nquads = use ? (int)ce.y : 0;
+            LaneSel S;
+            S.nlev = 1;
+            S.hi0 = use ? __uint_as_float(ce.z) : 1.0f;
+#pragma unroll
+            for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
+            S.sc[0] = (float)kBins / S.hi0;
+            const unsigned int sentinel = (unsigned int)Nt | ((unsigned int)Nt << 16);
+            auto walk_l = [&](bool act, float, auto&& body) __attribute__((always_inline)) {
+                const int nq = wave_max_i(act ? nquads : 0);
+                KNN_DBG(9, nq);
+                KNN_DBG(10, 1);
+                for (int i = 0; i < nq; ++i) {
+                    const bool ok = act && i < nquads;
+                    uint2 w = pool[ok ? first + (unsigned int)i : 0u];
+                    w.x = ok ? w.x : sentinel;
+                    w.y = ok ? w.y : sentinel;
+                    const unsigned int pos[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+                    float d2[4];
+                    float4 pt[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(c.P4s) + (pos[u] << 4));
+                        const float dx = qx - p.x;
+                        const float dy = qy - p.y;
+                        const float dz = qz - p.z;
+                        float t = dx * dx;
+                        t = t + dy * dy;
+                        t = t + dz * dz;
+                        d2[u] = t;
+                        pt[u].w = p.w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) body(d2[u], pt[u], (int)pos[u], ok);
+                }
+            };
+            bool done = !use, starved = false;
+            int found;
+            if (!(UMEREG_F1_ABLATE & 4)) refine_loop(walk_l, S, done, false, K, cap, L.hist, lane, starved, found);
+            const bool got = use && !starved;
+            cnt = (UMEREG_F1_ABLATE & 2) ? (got ? K : 0) : append_pass(walk_l, S, got, K, cap, L.list, lane);
+            fb_lanes = valid && !got;
+            KNN_DBG(8, __popcll(__ballot(fb_lanes)));
+            cnt = got ? cnt : 0;
+        } else {
+            cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int grp8 = lane & ~7, sub = lane & 7;
-        float acc = 0.f;
-        for (int it = 0; it < 8; ++it) {
-            const int q = grp8 + it;                       // the group's current query = that lane's id
-            const int cq = __shfl(cnt, q, kWave);
-            const int sq = __shfl(sidx, q, kWave);
-            const float4 a = vp4[(size_t)sq * 8 + sub];
-            float part = 0.f;
-#pragma unroll 4
-            for (int e = 0; e < K; ++e) {
-                if (e < cq) {
-                    const float wgt = __uint_as_float(L.list.d2[e * kWave + q]);
-                    const int j = (int)L.list.ix[e * kWave + q];
-                    const float4 o = vq4[(size_t)j * 8 + sub];
-                    float d = a.x * o.x;
-                    d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
-                    part = fmaf(wgt, d, part);
+        const float acc = score_epilogue(L.list, cnt, valid, sidx, vp4, vq4, K, sigma, lane);
+        if (LAT) {
+            // lanes the lattice could not serve: one record per (hypothesis, chunk) for corr_score_fallback_kernel, which adds
+            // their terms to this partial sum afterwards (one writer per record: the result stays deterministic)
+            const unsigned long long todo = __ballot(fb_lanes);
+            if (lane == 0) {
+                partial[(size_t)h * n_chunks + chunk] = acc;
+                if (todo != 0ull) {
+                    atomicAdd(&lat_header[6], (unsigned int)__popcll(todo));
+                    const unsigned int r = atomicAdd(&lat_header[4], 1u);
+                    queue[r] = make_uint4((unsigned int)h, (unsigned int)chunk, (unsigned int)todo, (unsigned int)(todo >> 32));
                 }
             }
-            part += __shfl_xor(part, 1, kWave);
-            part += __shfl_xor(part, 2, kWave);
-            part += __shfl_xor(part, 4, kWave);
-            acc = sub == it ? part : acc;                 // lane q keeps its query's sum
+        } else {
+            if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
         }
-        acc = wave_sum_f(valid ? acc : 0.f);
-        if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
+    }
+}
+
+// ---- the queries the lattice could not serve ---------------------------------------------------------------------------
+// corr_score_kernel<., true> leaves (hypothesis, chunk, lane mask) records for queries outside the lattice or in cells
+// without a list.  They are few, but a grid search can be arbitrarily expensive for them (a query 30 m outside the
+// cloud needs a cap of hundreds of candidates; one such lane used to hold a kernel for milliseconds), so a record is
+// served by exact BRUTE FORCE with a fixed cost: every target point is a candidate of every marked lane -- the point
+// is the same for all lanes (scalar loads), the selection is the usual histogram search over [0, dmax^2) with up to
+// two x32 zooms, then the append pass and the shared epilogue.  4 passes over Nt points per record, whatever the
+// geometry; records run side by side, one per wavefront.
+template <class IdxT>
+__global__ __launch_bounds__(128) void corr_score_fallback_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+                                                                  const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+                                                                  const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
+                                                                  int K, int cap, float sigma, int n_chunks, float* __restrict__ partial,
+                                                                  const char* __restrict__ lat, unsigned int c_max)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
+    const LatWs lw = lat_ws(c_max);
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), -(float)K, Nt);
+    const unsigned int n_rec = header[4];
+    // records are dealt out statically (wave w takes w, w + #waves, ...): an atomic work counter in this loop made the
+    // kernel hang on gfx950 / ROCm 7.2 (the loop with the dequeue alone, or with the search alone, did not)
+    const unsigned int n_waves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned int r = blockIdx.x * (blockDim.x >> 6) + wave; r < n_rec; r += n_waves) {
+        const uint4 rec = queue[r];
+        const int h = (int)rec.x, chunk = (int)rec.y;
+        const unsigned long long mask = ((unsigned long long)rec.w << 32) | rec.z;
+        const int slot = chunk * kWave + lane;
+        const bool valid = slot < Ns && ((mask >> lane) & 1ull);
+        const int sidx = __float_as_int(S4s[slot < Ns ? slot : 0].w);
+        const float sx = src_pts[(size_t)sidx * 3], sy = src_pts[(size_t)sidx * 3 + 1], sz = src_pts[(size_t)sidx * 3 + 2];
+        const float* Th = T + (size_t)h * 16;
+        const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        // every point of the cloud lies within dmax of the query (bounding-box corners); NaN / inf queries get a huge
+        // finite range (they select nothing sensible, like everywhere else, but terminate)
+        float dmax2;
+        {
+            const float ex = fmaxf(fabsf(qx - g.minx), fabsf(qx - (g.minx + (float)g.nx / g.invx)));
+            const float ey = fmaxf(fabsf(qy - g.miny), fabsf(qy - (g.miny + (float)g.ny / g.invy)));
+            const float ez = fmaxf(fabsf(qz - g.minz), fabsf(qz - (g.minz + (float)g.nz / g.invz)));
+            dmax2 = (ex * ex + ey * ey + ez * ez) * 1.001f + 1e-12f;
+            dmax2 = dmax2 < 1.0e30f ? dmax2 : 1.0e30f;
+        }
+        LaneSel S;
+        S.nlev = 1;
+        S.hi0 = dmax2;
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
+        S.sc[0] = (float)kBins / S.hi0;
+        auto walk_all = [&](bool act, float, auto&& body) __attribute__((always_inline)) {
+            for (int j = 0; j < Nt; j += 4) {                  // (the table is padded with far points: reading past Nt is safe)
+                float d2[4];
+                float4 pt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 p = P4s[j + u];               // uniform address: scalar loads
+                    const float dx = qx - p.x;
+                    const float dy = qy - p.y;
+                    const float dz = qz - p.z;
+                    float t = dx * dx;
+                    t = t + dy * dy;
+                    t = t + dz * dz;
+                    d2[u] = t;
+                    pt[u].w = p.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(d2[u], pt[u], j + u, act && j + u < Nt);
+            }
+        };
+        bool done = !valid, starved;
+        int found;
+        refine_loop(walk_all, S, done, true, K, cap, L.hist, lane, starved, found);
+        const int cnt = append_pass(walk_all, S, valid, K, cap, L.list, lane);
+        const float acc = score_epilogue(L.list, valid ? cnt : 0, valid, sidx, vp4, vq4, K, sigma, lane);
+        if (lane == 0) partial[(size_t)h * n_chunks + chunk] += acc;
     }
 }
 
@@ -778,12 +1307,16 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
 
 static const int kColsumBlocks = 64;
 
-UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M)
+UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M) { return umereg_corr_workspace_bytes_ex(Ns, Nt, M, 0); }
+
+UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags)
 {
     if (Ns <= 0 || Nt <= 0 || M <= 0) return 0;
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
+    const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
-           align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256;
+           align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
+           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0);
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -814,15 +1347,23 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
                                       const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
                                       float* scores, void* workspace, size_t workspace_bytes, void* stream)
 {
+    return umereg_corr_scores_ex_f32(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, Ns, Nt, M, K, sigma, 0, scores, workspace,
+                                     workspace_bytes, stream);
+}
+
+UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
+                                         const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
+                                         int flags, float* scores, void* workspace, size_t workspace_bytes, void* stream)
+{
     UMEREG_REQUIRE(src_pts && tgt_pts && src_wfeat && tgt_wfeat && T && scores, "corr_scores: null pointer");
     UMEREG_REQUIRE(Ns > 0 && Nt > 0 && M > 0, "corr_scores: Ns, Nt, M must be positive");
     UMEREG_REQUIRE(K > 0 && K <= 64 && K <= Nt, "corr_scores: K must be in [1, min(64, Nt)] (got %d)", K);
     UMEREG_REQUIRE(sigma > 0.f, "corr_scores: sigma must be positive");
     UMEREG_REQUIRE(((uintptr_t)src_wfeat & 15) == 0 && ((uintptr_t)tgt_wfeat & 15) == 0, "corr_scores: features must be 16-byte aligned");
     if (int rc = check_device()) return rc;
-    if (!workspace || workspace_bytes < umereg_corr_workspace_bytes(Ns, Nt, M) || ((uintptr_t)workspace & 15)) {
+    if (!workspace || workspace_bytes < umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) || ((uintptr_t)workspace & 15)) {
         set_error("corr_scores: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
-                  umereg_corr_workspace_bytes(Ns, Nt, M));
+                  umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags));
         return UMEREG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -832,6 +1373,8 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
     const size_t n_chunks_sz = (size_t)((Ns + kWave - 1) / kWave);
     float* rotated = (float*)((char*)partial + align_up((size_t)M * n_chunks_sz * 4, 256) + align_up((size_t)kColsumBlocks * 32 * 8, 256));
     float* Rbar = (float*)((char*)rotated + align_up((size_t)Ns * 12, 256));
+    char* lat = (char*)Rbar + 256;
+    const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
     // target: the search structure; source: only a processing order (wavefronts of queries that stay row-aligned
     // with the target grid under the consensus rotation)
     if (int rc = launch_prep(tgt_pts, ws_tgt, 1, Nt, -(float)K, st)) return rc;
@@ -844,18 +1387,50 @@ UMEREG_API int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts
     size_t lds;
     bool idx16;
     knn_lds_plan(K, Nt, &cap, &waves, &lds, 2, &idx16);
+    if (c_max) {
+        // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> count -> scan -> fill
+        const LatWs lw = lat_ws(c_max);
+        if (hipMemsetAsync(lat, 0, lw.off_wave_tot, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header + marks) failed"); return UMEREG_ELAUNCH; }
+        const int hpt = 16;
+        hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
+                           Ns, Nt, M, hpt, lat, c_max);
+        UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
+        int bcap, bwaves;
+        size_t blds;
+        bool b16;
+        knn_lds_plan(K, Nt, &bcap, &bwaves, &blds, 4, &b16);
+        const unsigned int per_block = (unsigned int)bwaves * kWave;
+        hipLaunchKernelGGL(lattice_compact_kernel, dim3(1), dim3(1024), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
+        UMEREG_CHECK_LAUNCH("lattice_compact_kernel");
+        hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3((c_max + per_block - 1) / per_block), dim3(per_block), blds, st,
+                           (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
+        UMEREG_CHECK_LAUNCH("lattice_count_kernel");
+        hipLaunchKernelGGL(lattice_scan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max);
+        UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
+        hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max + 255) / 256), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
+        UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
+    }
     const int n_chunks = (Ns + kWave - 1) / kWave;
     const int hyp_per_wave = 2;   // 1..4 measured equal (6.4 us per hypothesis), 8: 6.7, 16: 7.3 (balance at the tail, parallelism)
     const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
     const long n_waves = (long)n_chunks * n_hg;
-    if (idx16)
-        hipLaunchKernelGGL(corr_score_kernel<unsigned short>, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
+    if (c_max) {
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max);
+        UMEREG_CHECK_LAUNCH("corr_score_kernel");
+        if (!(UMEREG_F1_ABLATE & 16))
+        hipLaunchKernelGGL(corr_score_fallback_kernel<unsigned short>, dim3(4096), dim3(waves * kWave), lds, st, (const char*)ws_tgt,
+                           (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, cap, sigma,
+                           n_chunks, partial, (const char*)lat, c_max);
+    } else if (idx16)
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
+                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u);
     else
-        hipLaunchKernelGGL(corr_score_kernel<unsigned int>, dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
+        hipLaunchKernelGGL((corr_score_kernel<unsigned int, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u);
     UMEREG_CHECK_LAUNCH("corr_score_kernel");
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");

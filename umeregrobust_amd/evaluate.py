@@ -150,10 +150,20 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
     num_kpts = min(ume_src.shape[1], ume_tgt.shape[1])
     ume_src = ume_src[:, :num_kpts]
     ume_tgt = ume_tgt[:, :num_kpts]
-    # Matches (:215-225).  Hungarian matching (:216-222) is off in every shipped config.
-    if getattr(args, "hungarian_matching_flag", False):
-        raise NotImplementedError("hungarian_matching_flag: off in all reference configs; host scipy path not wired")
+    # Matches (:215-225).  Hungarian matching (:216-222; off in every shipped config) needs the whole matrix on the
+    # host, exactly like the reference: D -> scipy.optimize.linear_sum_assignment -> (src rows, tgt columns)
     D = None
+    if getattr(args, "hungarian_matching_flag", False):
+        from scipy.optimize import linear_sum_assignment
+        D = ops.ume_cdist(ume_src, ume_tgt, timing=t_dist)
+        src_m, tgt_m = linear_sum_assignment(D[0].cpu().numpy())                              # :219
+        m_src = torch.from_numpy(src_m).long().to(dev)[None]                                  # m[..., 0]
+        m_tgt = torch.from_numpy(tgt_m).long().to(dev)[None]                                  # m[..., 1]
+        ume_d = D[0, m_src[0], m_tgt[0]][None]                                                # :234
+        prob = ops.match_prob(ume_d[0], args.tau) if args.filter_by_ume_dist_cond else None
+        return SimpleNamespace(ume_src=ume_src, ume_tgt=ume_tgt, match=m_tgt, match_src=m_src, match_d=ume_d, prob=prob,
+                               D=D if materialize_D else None, src_inds=src_inds, tgt_inds=tgt_inds,
+                               num_kpts=m_src.shape[1], dev=dev, src_pts=src_pts, tgt_pts=tgt_pts)
     if materialize_D:
         D = ops.ume_cdist(ume_src, ume_tgt, timing=t_dist)
         m_tgt = D.min(dim=-1)[1]
@@ -218,7 +228,13 @@ def _phase_b(a, args, cond):
         g_index = None
     # Hypotheses (:248-254); the match gathers (:228-231, 243-244) are fused into the solve through the
     # match table (target row of source row g = match[g])
-    T, _ = ops.rtume_solve(a.ume_src[0], a.ume_tgt[0], g_index, None, h_of_g=a.match[0])
+    if getattr(a, "match_src", None) is not None:
+        # Hungarian matches: match k pairs source row match_src[k] with target row match[k] (for a square or wide D the
+        # source rows are arange and this is the same table; explicit indices keep the tall case right)
+        sel = g_index if g_index is not None else torch.arange(a.num_kpts, device=dev)
+        T, _ = ops.rtume_solve(a.ume_src[0], a.ume_tgt[0], a.match_src[0][sel], a.match[0][sel])
+    else:
+        T, _ = ops.rtume_solve(a.ume_src[0], a.ume_tgt[0], g_index, None, h_of_g=a.match[0])
     out = PairResult(**vars(a))
     out.rtume_tform = T.view(1, -1, 4, 4)
     out.cond = cond
@@ -284,18 +300,26 @@ class RegistrationPipeline:
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(depth)]
         self.host_prob = [None] * depth
         self.host_cond = [None] * depth
+        self.cond_uploaded = [None] * depth     # event: the H2D copy out of host_cond[k] has completed
+        self.in_flight = [False] * depth        # slot k holds a submitted pair whose finish() has not run yet
         self.n_submitted = 0
 
-    def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None, pair=None):
+    def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None, pair=None, rng=None):
         """pair: optional PairBatch holding the same clouds/keypoints as a batch of 2 (then the per-cloud
-        arguments are only used for their shapes and as views for downstream consumers)."""
+        arguments are only used for their shapes and as views for downstream consumers).
+        rng: numpy generator for THIS pair's draws (default: the pipeline's)."""
         k = self.n_submitted % self.depth
+        if self.in_flight[k]:
+            raise RuntimeError(f"RegistrationPipeline: slot {k} still holds an unfinished pair -- at most depth={self.depth} "
+                               "pairs may be submitted before their finish() (its pinned buffers would be overwritten)")
+        self.in_flight[k] = True
         self.n_submitted += 1
         st = self.streams[k]
+        rng = rng if rng is not None else self.rng
         if pair is not None:
             src_inds, tgt_inds = pair.inds[0], pair.inds[1]
         else:
-            src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, self.rng, src_inds, tgt_inds)
+            src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, rng, src_inds, tgt_inds)
         st.wait_stream(torch.cuda.current_stream(self.dev))
         # (no ordering between the phase-A blocks of consecutive pairs: the single-workgroup kernels of one pair --
         # keypoint order, grid scan, softmax, RTUME -- then run beside the machine-filling kernels of the other:
@@ -309,6 +333,7 @@ class RegistrationPipeline:
             a.ready = torch.cuda.Event()
             a.ready.record(st)
         a.slot = k
+        a.rng = rng
         a.draw = None
         if self.pool is not None and self.args.filter_by_ume_dist_cond:
             a.draw = self.pool.submit(self._draw, a)
@@ -317,10 +342,13 @@ class RegistrationPipeline:
     def _draw(self, a):
         a.ready.synchronize()
         num_matches = min(a.num_kpts, self.args.ume_n_samples)
-        return choice_noreplace(self.rng, a.num_kpts, num_matches, self.host_prob[a.slot].numpy())
+        return choice_noreplace(a.rng, a.num_kpts, num_matches, self.host_prob[a.slot].numpy())
 
     def finish(self, a, cond=None):
         st = self.streams[a.slot]
+        if not self.in_flight[a.slot]:
+            raise RuntimeError("RegistrationPipeline.finish: this pair was already finished")
+        self.in_flight[a.slot] = False
         if self.args.filter_by_ume_dist_cond and cond is None:
             cond = a.draw.result() if a.draw is not None else self._draw(a)
         with torch.cuda.stream(st):
@@ -330,8 +358,13 @@ class RegistrationPipeline:
                 k = a.slot
                 if self.host_cond[k] is None or self.host_cond[k].numel() != c.size:
                     self.host_cond[k] = torch.empty(c.size, dtype=torch.int64, pin_memory=True)
+                elif self.cond_uploaded[k] is not None:
+                    self.cond_uploaded[k].synchronize()        # the previous pair's async upload out of this buffer is done
                 self.host_cond[k].numpy()[:] = c
-                out = _phase_b(a, self.args, self.host_cond[k].to(self.dev, non_blocking=True))
+                cond_dev = self.host_cond[k].to(self.dev, non_blocking=True)
+                self.cond_uploaded[k] = torch.cuda.Event()
+                self.cond_uploaded[k].record(st)
+                out = _phase_b(a, self.args, cond_dev)
                 out.cond = c
                 return out
             return _phase_b(a, self.args, cond)

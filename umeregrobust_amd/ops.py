@@ -439,9 +439,13 @@ def corr_weighted_features(src_feat, tgt_feat, src_w, tgt_w):
     return so, to
 
 
-def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None):
+CORR_NO_LATTICE, CORR_FORCE_LATTICE = 1, 2
+
+
+def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None, flags=0):
     """Correlation score of every hypothesis (reference utils/loc_utils.py:592-637).
-    src_pts [Ns,3], tgt_pts [Nt,3], *_wfeat [N,32], T [M,4,4] -> scores [M]."""
+    src_pts [Ns,3], tgt_pts [Nt,3], *_wfeat [N,32], T [M,4,4] -> scores [M].
+    flags: CORR_NO_LATTICE / CORR_FORCE_LATTICE choose the search structure explicitly (tuning and tests)."""
     lib = _lib.load()
     sp = _dev(src_pts, "src_pts"); tp = _dev(tgt_pts, "tgt_pts")
     sf = _dev(src_wfeat, "src_wfeat"); tf = _dev(tgt_wfeat, "tgt_wfeat"); T = _dev(T, "T")
@@ -452,12 +456,12 @@ def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, tim
     dev = sp.device
     scores = torch.empty((M,), dtype=torch.float32, device=dev)
     if M > 0:
-        ws = _workspace(dev, lib.umereg_corr_workspace_bytes(Ns, Nt, M), "corr")
+        ws = _workspace(dev, lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, int(flags)), "corr")
         with torch.cuda.device(dev):
             ev = _timed(timing, dev)
-            rc = lib.umereg_corr_scores_f32(_ptr(sp), _ptr(tp), _ptr(sf), _ptr(tf), _ptr(T), Ns, Nt, M, int(K),
-                                            float(sigma), _ptr(scores), _ptr(ws), ws.numel(), _stream_ptr(dev))
-            _lib.check(rc, "umereg_corr_scores_f32")
+            rc = lib.umereg_corr_scores_ex_f32(_ptr(sp), _ptr(tp), _ptr(sf), _ptr(tf), _ptr(T), Ns, Nt, M, int(K),
+                                               float(sigma), int(flags), _ptr(scores), _ptr(ws), ws.numel(), _stream_ptr(dev))
+            _lib.check(rc, "umereg_corr_scores_ex_f32")
             _timed_end(timing, ev, dev)
     return scores
 

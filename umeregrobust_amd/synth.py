@@ -108,6 +108,68 @@ def synth_pair(seed, N=50000, n_kp=10000, kind="test", voxel=0.3, d=32):
                      src_inds.astype(np.int64), tgt_inds.astype(np.int64), twin)
 
 
-def synth_pair_cfg(seed, config="KT", kind="test"):
+def synth_pair_hard(seed, N=50000, n_kp=10000, kind="test", voxel=0.3, d=32, sector_deg=240.0, sector_shift_deg=100.0,
+                    noise_sigma=0.02, feat_corrupt=0.2):
+    """A pair on which registration can FAIL (the plain pairs are exact rigid copies, so every recall is 100 %):
+      * partial overlap: the scene is scanned twice; each cloud keeps only the points inside its own angular sector
+        around the sensor (`sector_deg` wide, the two sectors `sector_shift_deg` apart => ~58 % of a cloud has a twin);
+      * independent N(0, noise_sigma^2) point noise on both clouds (off-lattice coordinates);
+      * `feat_corrupt` of the points of each cloud (independently) carry a random unit feature instead of the scene's.
+    Same contract as synth_pair: N points per cloud, randomly permuted; tgt_twin_of_src = -1 for points without a twin."""
+    rng = np.random.RandomState(seed)
+    deg = np.pi / 180.0
+    a0 = rng.uniform(0, 2 * np.pi)
+    half = 0.5 * sector_deg * deg
+
+    def in_sector(p, centre):
+        ang = np.arctan2(p[:, 1], p[:, 0])
+        return np.abs((ang - centre + np.pi) % (2 * np.pi) - np.pi) <= half
+
+    # enough scene points that both sectors hold >= N of them
+    scale = 1.25 * 360.0 / sector_deg
+    for _ in range(4):
+        scene = synth_scene(rng, int(scale * N), voxel)
+        in_s = np.flatnonzero(in_sector(scene, a0))
+        in_t = np.flatnonzero(in_sector(scene, a0 + sector_shift_deg * deg))
+        if in_s.size >= N and in_t.size >= N:
+            break
+        scale *= 1.3
+    else:
+        raise ValueError("synth_pair_hard: sectors too narrow for N")
+    si = in_s[:N]                               # the scene is randomly permuted: any prefix is a uniform subset
+    ti = in_t[rng.permutation(in_t.size)[:N]]
+    W = 0.2 * rng.standard_normal((3, d))
+    b = rng.uniform(0, 2 * np.pi, d)
+
+    def feats(p):
+        f = np.sin(p @ W + b)
+        bad = rng.uniform(size=p.shape[0]) < feat_corrupt
+        f[bad] = rng.standard_normal((int(bad.sum()), d))
+        return f / np.linalg.norm(f, axis=1, keepdims=True)
+
+    if kind == "rot":
+        yaw = rng.uniform(30.0, 180.0) * deg * rng.choice([-1.0, 1.0])
+    else:
+        yaw = rng.normal(0.0, 5.0) * deg
+    R = _rot(rng.normal(0, 1.0) * deg, rng.normal(0, 1.0) * deg, yaw)
+    tdir = rng.standard_normal(3) * np.array([1.0, 1.0, 0.05])
+    t = tdir / np.linalg.norm(tdir) * rng.uniform(4.0, 20.0)
+    src = scene[si] + noise_sigma * rng.standard_normal((N, 3))
+    tgt = (scene[ti] + noise_sigma * rng.standard_normal((N, 3))) @ R.T + t
+    sf, tf = feats(scene[si]), feats(scene[ti])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    pos_in_t = np.full(scene.shape[0], -1, np.int64)
+    pos_in_t[ti] = np.arange(N)
+    twin = pos_in_t[si]
+    src_inds = rng.choice(N, min(n_kp, N), replace=False)
+    tgt_inds = rng.choice(N, min(n_kp, N), replace=False)
+    return SynthPair(src.astype(np.float32), tgt.astype(np.float32), sf.astype(np.float32), tf.astype(np.float32),
+                     T.astype(np.float32), src_inds.astype(np.int64), tgt_inds.astype(np.int64), twin)
+
+
+def synth_pair_cfg(seed, config="KT", kind="test", hard=False):
     c = CONFIGS[config]
-    return synth_pair(seed, N=c["N"], n_kp=c["n_kp"], kind=kind, voxel=c["voxel"])
+    f = synth_pair_hard if hard else synth_pair
+    return f(seed, N=c["N"], n_kp=c["n_kp"], kind=kind, voxel=c["voxel"])
