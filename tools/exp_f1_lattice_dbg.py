@@ -38,4 +38,5 @@ for name, gen in (("plain", synth_pair), ("hard", synth_pair_hard)):
         lib.umereg_knn_debug_counters(cnt, 1)
         print(name, tag, "grid knn_wave calls", cnt[0], "coverage iters", cnt[1], "hist passes", cnt[2], "grid trips*4", cnt[7],
               "| fallback lanes", cnt[8], "lattice walks", cnt[10], "lattice quads walked", cnt[9],
-              "avg quads/walk %.1f" % (cnt[9] / max(cnt[10], 1)), flush=True)
+              "avg quads/walk %.1f" % (cnt[9] / max(cnt[10], 1)),
+              "| score waves", cnt[15], "mean clk %.0f" % (cnt[11] / max(cnt[15], 1)), "max clk", cnt[12], "waves > 0.4M clk", cnt[13], "> 2M clk", cnt[14], flush=True)

@@ -497,6 +497,8 @@ __device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int 
 constexpr int kLatMaxQuads = 128;                 // longest list (in quads of 4 entries)
 constexpr unsigned int kLatMinCells = 4096, kLatMaxCells = 1u << 20;
 constexpr size_t kLatPoolQuadsPerCell = 16;       // pool size = cells x this (quads): mean list <= 64 entries
+constexpr int kLatLanes = 16;                     // cells per wavefront in the build kernels: their walks are chains of dependent
+                                                  // loads, so more, thinner wavefronts (and the slowest of 16 cells instead of 64) win
 
 struct Lattice {
     float lox, loy, loz, inv_h, inv_hz, h, hz, hd;
@@ -520,7 +522,7 @@ __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
     size_t o = 0;
     w.off_header = o;   o += 256;
     w.off_marks = o;    o += ((size_t)c_max + 255) / 256 * 256;          // one byte per cell: some query lands in it
-    w.off_wave_tot = o; o += ((size_t)c_max / 64 + 64) * 4;              // list quads per 64-cell brick, then their prefix sums
+    w.off_wave_tot = o; o += ((size_t)c_max / kLatLanes + 64) * 4;       // list quads per build wavefront, then their prefix sums
     o = (o + 255) / 256 * 256;
     w.off_cids = o;     o += (size_t)c_max * 4 + 256;                    // marked cells, ascending
     w.off_cells = o;    o += (size_t)c_max * 16;
@@ -766,7 +768,7 @@ __device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int c
         const int sq = __shfl(sidx, q, kWave);
         const float4 a = vp4[(size_t)sq * 8 + sub];
         float part = 0.f;
-#pragma unroll 4
+#pragma unroll 5
         for (int e = 0; e < K; ++e) {
             if (e < cq) {
                 const float wgt = __uint_as_float(list.d2[e * kWave + q]);
@@ -886,23 +888,32 @@ __global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restri
     uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
     const unsigned int n_marked = header[3];
     const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (wid * kWave >= n_marked) return;
+    if (blockIdx.x * (blockDim.x >> 6) * kLatLanes >= n_marked) return;          // the whole workgroup is beyond the list
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
-    const bool valid = wid * kWave + lane < n_marked;
-    const int id = (int)cids[valid ? wid * kWave + lane : wid * kWave];
+    const bool valid = lane < kLatLanes && wid * kLatLanes + lane < n_marked;
+    const int id = (int)cids[valid ? wid * kLatLanes + lane : 0];
     const KnnLds<IdxT> Ls = carve_lds<IdxT>(lds, wave, cap);
-    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    {
+        // the walks of far cells cross hundreds of (mostly empty) grid rows, two dependent table reads each: keep the
+        // cell-start table in LDS (16 KiB per workgroup).  Whole workgroups leave above or stay: the barrier is safe.
+        int* start_lds = reinterpret_cast<int*>(lds + (blockDim.x >> 6) * knn_lds_per_wave(cap, sizeof(IdxT)));
+        for (int i = threadIdx.x; i <= kMaxCells; i += blockDim.x) start_lds[i] = c.start[i];
+        __syncthreads();
+        c.start = start_lds;
+    }
     float ccx, ccy, ccz;
     lattice_cell_centre(L, id, ccx, ccy, ccz);
     // d_K of the cell centre
-    const int cnt = knn_wave(c, ccx, ccy, ccz, valid, K, cap, Ls.hist, Ls.list, lane);
-    unsigned int d2k_bits = 0u;
+    const int cnt = (UMEREG_F1_ABLATE & 2048) ? K : knn_wave(c, ccx, ccy, ccz, valid, K, cap, Ls.hist, Ls.list, lane);
+    unsigned int d2k_bits = (UMEREG_F1_ABLATE & 2048) ? __float_as_uint(9.0f) : 0u;
     for (int e = 0; e < K; ++e)
-        if (e < cnt) { const unsigned int b = Ls.list.d2[e * kWave + lane]; d2k_bits = b > d2k_bits ? b : d2k_bits; }
+        if (!(UMEREG_F1_ABLATE & 2048) && e < cnt) { const unsigned int b = Ls.list.d2[e * kWave + lane]; d2k_bits = b > d2k_bits ? b : d2k_bits; }
     const float r = (sqrtf(__uint_as_float(d2k_bits)) + L.hd) * 1.0001f + 1e-6f;
     const float r2 = r * r;
     const float rw = r + L.hd;                       // ball around the centre that contains {dist(p, box) <= r}
-    int n = 0;
+    int n = (UMEREG_F1_ABLATE & 4096) ? 40 : 0;
+    if (!(UMEREG_F1_ABLATE & 4096))
     walk_ball<true>(c, ccx, ccy, ccz, valid, rw * rw * 1.001f, lane,
                     [&](float, const float4& p, int, bool in_run) { n += in_run && lattice_in_list(L, p, ccx, ccy, ccz, r2) ? 1 : 0; });
     int quads = (n + 3) >> 2;
@@ -913,7 +924,7 @@ __global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restri
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m, kWave);
     const unsigned long long n_nolist = __ballot(valid && !has);
-    if (lane == 0) {
+    if (lane == 0 && wid * kLatLanes < n_marked) {
         wave_tot[wid] = (unsigned int)tot;
         if (n_nolist != 0ull) atomicAdd(&header[2], (unsigned int)__popcll(n_nolist));
     }
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(1024) void lattice_scan_kernel(char* __restrict__ l
     const LatWs lw = lat_ws(c_max);
     unsigned int* wave_tot = reinterpret_cast<unsigned int*>(lat + lw.off_wave_tot);
     unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
-    const int n = (int)((header[3] + kWave - 1) / kWave);
+    const int n = (int)((header[3] + kLatLanes - 1) / kLatLanes);
     const int per = (n + 1023) / 1024;
     const int a = threadIdx.x * per, b = min(a + per, n);
     unsigned int s = 0u;
@@ -957,9 +968,9 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(const char* __restric
     unsigned long long* pool = reinterpret_cast<unsigned long long*>(lat + lw.off_pool);
     const unsigned int n_marked = header[3];
     const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (wid * kWave >= n_marked) return;
-    const bool valid = wid * kWave + lane < n_marked;
-    const int id = (int)cids[valid ? wid * kWave + lane : wid * kWave];
+    if (wid * kLatLanes >= n_marked) return;
+    const bool valid = lane < kLatLanes && wid * kLatLanes + lane < n_marked;
+    const int id = (int)cids[valid ? wid * kLatLanes + lane : wid * kLatLanes];
     const uint4 ce = valid ? cells[id] : make_uint4(0u, 0u, 0u, 1u);
     const int quads = ce.w == 0u ? (int)ce.y : 0;
     if (!__any(quads > 0)) return;
@@ -1024,6 +1035,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         lat_header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
         queue = reinterpret_cast<uint4*>(lat + lw.total);       // fallback records follow the lattice
     }
+#ifdef UMEREG_KNN_DEBUG
+    const long long t_start = clock64();
+#endif
     const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
     // consecutive wavefronts take the SAME 64 queries under different groups of hypotheses: what is resident on the
     // chip at any time then works in one neighbourhood of the target, and its table and feature rows are cache hits
@@ -1065,19 +1079,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             S.sc[0] = (float)kBins / S.hi0;
             const unsigned int sentinel = (unsigned int)Nt | ((unsigned int)Nt << 16);
             auto walk_l = [&](bool act, float, auto&& body) __attribute__((always_inline)) {
+                // two quads (8 candidates) per trip; the next trip's list words are requested before this trip's points,
+                // so a trip costs one memory latency (the points), not two
                 const int nq = wave_max_i(act ? nquads : 0);
                 KNN_DBG(9, nq);
                 KNN_DBG(10, 1);
-                for (int i = 0; i < nq; ++i) {
-                    const bool ok = act && i < nquads;
-                    uint2 w = pool[ok ? first + (unsigned int)i : 0u];
-                    w.x = ok ? w.x : sentinel;
-                    w.y = ok ? w.y : sentinel;
-                    const unsigned int pos[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
-                    float d2[4];
-                    float4 pt[4];
+                const uint2 sent2 = make_uint2(sentinel, sentinel);
+                uint2 n0 = act && 0 < nquads ? pool[first] : sent2;
+                uint2 n1 = act && 1 < nquads ? pool[first + 1u] : sent2;
+                for (int i = 0; i < nq; i += 2) {
+                    const uint2 w0 = n0, w1 = n1;
+                    n0 = act && i + 2 < nquads ? pool[first + (unsigned int)(i + 2)] : sent2;
+                    n1 = act && i + 3 < nquads ? pool[first + (unsigned int)(i + 3)] : sent2;
+                    const unsigned int pos[8] = {w0.x & 0xffffu, w0.x >> 16, w0.y & 0xffffu, w0.y >> 16,
+                                                 w1.x & 0xffffu, w1.x >> 16, w1.y & 0xffffu, w1.y >> 16};
+                    float d2[8];
+                    float4 pt[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(c.P4s) + (pos[u] << 4));
                         const float dx = qx - p.x;
                         const float dy = qy - p.y;
@@ -1089,7 +1108,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         pt[u].w = p.w;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) body(d2[u], pt[u], (int)pos[u], ok);
+                    for (int u = 0; u < 8; ++u) body(d2[u], pt[u], (int)pos[u], act);   // list padding = far points: never admitted
                 }
             };
             bool done = !use, starved = false;
@@ -1120,92 +1139,170 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
         }
     }
+#ifdef UMEREG_KNN_DEBUG
+    if (lane == 0) {
+        const unsigned long long dur = (unsigned long long)(clock64() - t_start);
+        atomicAdd(&g_knn_dbg[11], dur);
+        atomicMax(&g_knn_dbg[12], dur);
+        if (dur > 400000ull) atomicAdd(&g_knn_dbg[13], 1ull);
+        if (dur > 2000000ull) atomicAdd(&g_knn_dbg[14], 1ull);
+        atomicAdd(&g_knn_dbg[15], 1ull);
+    }
+#endif
 }
 
-// ---- the queries the lattice could not serve ---------------------------------------------------------------------------
+// ---- the queries the lattice could not serve: one WAVEFRONT per query -----------------------------------------------
 // corr_score_kernel<., true> leaves (hypothesis, chunk, lane mask) records for queries outside the lattice or in cells
-// without a list.  They are few, but a grid search can be arbitrarily expensive for them (a query 30 m outside the
-// cloud needs a cap of hundreds of candidates; one such lane used to hold a kernel for milliseconds), so a record is
-// served by exact BRUTE FORCE with a fixed cost: every target point is a candidate of every marked lane -- the point
-// is the same for all lanes (scalar loads), the selection is the usual histogram search over [0, dmax^2) with up to
-// two x32 zooms, then the append pass and the shared epilogue.  4 passes over Nt points per record, whatever the
-// geometry; records run side by side, one per wavefront.
-template <class IdxT>
-__global__ __launch_bounds__(128) void corr_score_fallback_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+// without a list.  They are few, but any one-lane-per-query search is arbitrarily expensive for them (a query 30 m
+// outside the cloud needs a cap of hundreds of candidates; variants tried here: the grid walk per lane 5.3 ms, brute
+// force per lane over the whole table 6.1 ms, a staged common candidate set 4.4 ms -- for 0.3 % of the queries).
+// So a whole wavefront serves one query, by exact brute force over the target table, and a workgroup of 8 wavefronts
+// shares the queries of one record:
+//   * bound: every lane takes the minimum d2 over kCoopSamples strided table entries; the 64 minima belong to 64
+//     distinct points, so the K-th smallest of them is >= the K-th smallest d2 of the table;
+//   * scan: all Nt points, 128 per step (coalesced); keys (bits(d2) << 32 | index) at or below the bound go to an LDS
+//     list (ballot + mbcnt); when the list could overflow it is cut back to its K smallest keys by rank counting (keys
+//     are unique, so ranks are a permutation) and the bound drops to the K-th key;
+//   * score: the K keys of the final cut, 8 lanes per neighbour's feature row.
+// The record's sum is formed by wavefront 0 from the per-query values in lane order: deterministic.
+constexpr int kCoopCap = 256;       // cooperative key list (keys)
+constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
+constexpr int kCoopWaves = 8;       // wavefronts per record
+
+// keep the K smallest of list[0 .. cnt) (cnt <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
+__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
+{
+    unsigned long long mine[kCoopCap / kWave];
+    int rank[kCoopCap / kWave];
+#pragma unroll
+    for (int u = 0; u < kCoopCap / kWave; ++u) {
+        mine[u] = u * kWave + lane < cnt ? list[u * kWave + lane] : ~0ull;
+        rank[u] = 0;
+    }
+    for (int f = 0; f < cnt; ++f) {
+        const unsigned long long k = list[f];               // same address in every lane: one broadcast read
+#pragma unroll
+        for (int u = 0; u < kCoopCap / kWave; ++u) rank[u] += k < mine[u] ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int u = 0; u < kCoopCap / kWave; ++u)
+        if (u * kWave + lane < cnt && rank[u] < K) out[rank[u]] = mine[u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return cnt < K ? cnt : K;
+}
+
+__global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                   const float* __restrict__ src_pts, const float4* __restrict__ vp4,
                                                                   const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
-                                                                  int K, int cap, float sigma, int n_chunks, float* __restrict__ partial,
+                                                                  int K, float sigma, int n_chunks, float* __restrict__ partial,
                                                                   const char* __restrict__ lat, unsigned int c_max)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
+    __shared__ float qval[kWave];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
-    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
     const LatWs lw = lat_ws(c_max);
     const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
     const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
     const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
-    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), -(float)K, Nt);
+    unsigned long long* la = lists[wave][0];
+    unsigned long long* lb = lists[wave][1];
     const unsigned int n_rec = header[4];
-    // records are dealt out statically (wave w takes w, w + #waves, ...): an atomic work counter in this loop made the
-    // kernel hang on gfx950 / ROCm 7.2 (the loop with the dequeue alone, or with the search alone, did not)
-    const unsigned int n_waves = gridDim.x * (blockDim.x >> 6);
-    for (unsigned int r = blockIdx.x * (blockDim.x >> 6) + wave; r < n_rec; r += n_waves) {
+    const int grp = lane >> 3, sub = lane & 7;
+    const int step = Nt / (kWave * kCoopSamples);
+    for (unsigned int r = blockIdx.x; r < n_rec; r += gridDim.x) {      // (static assignment: see DESIGN on the atomic-counter hang)
         const uint4 rec = queue[r];
         const int h = (int)rec.x, chunk = (int)rec.y;
         const unsigned long long mask = ((unsigned long long)rec.w << 32) | rec.z;
         const int slot = chunk * kWave + lane;
-        const bool valid = slot < Ns && ((mask >> lane) & 1ull);
         const int sidx = __float_as_int(S4s[slot < Ns ? slot : 0].w);
         const float sx = src_pts[(size_t)sidx * 3], sy = src_pts[(size_t)sidx * 3 + 1], sz = src_pts[(size_t)sidx * 3 + 2];
         const float* Th = T + (size_t)h * 16;
-        const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
-        const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
-        const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-        // every point of the cloud lies within dmax of the query (bounding-box corners); NaN / inf queries get a huge
-        // finite range (they select nothing sensible, like everywhere else, but terminate)
-        float dmax2;
-        {
-            const float ex = fmaxf(fabsf(qx - g.minx), fabsf(qx - (g.minx + (float)g.nx / g.invx)));
-            const float ey = fmaxf(fabsf(qy - g.miny), fabsf(qy - (g.miny + (float)g.ny / g.invy)));
-            const float ez = fmaxf(fabsf(qz - g.minz), fabsf(qz - (g.minz + (float)g.nz / g.invz)));
-            dmax2 = (ex * ex + ey * ey + ez * ez) * 1.001f + 1e-12f;
-            dmax2 = dmax2 < 1.0e30f ? dmax2 : 1.0e30f;
-        }
-        LaneSel S;
-        S.nlev = 1;
-        S.hi0 = dmax2;
-#pragma unroll
-        for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
-        S.sc[0] = (float)kBins / S.hi0;
-        auto walk_all = [&](bool act, float, auto&& body) __attribute__((always_inline)) {
-            for (int j = 0; j < Nt; j += 4) {                  // (the table is padded with far points: reading past Nt is safe)
-                float d2[4];
-                float4 pt[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 p = P4s[j + u];               // uniform address: scalar loads
-                    const float dx = qx - p.x;
-                    const float dy = qy - p.y;
-                    const float dz = qz - p.z;
-                    float t = dx * dx;
-                    t = t + dy * dy;
-                    t = t + dz * dz;
-                    d2[u] = t;
-                    pt[u].w = p.w;
+        const float lqx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float lqy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float lqz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        if (threadIdx.x < kWave) qval[threadIdx.x] = 0.f;
+        __syncthreads();
+        int rank_in_mask = 0;
+        for (unsigned long long todo = mask; todo != 0ull; todo &= todo - 1ull, ++rank_in_mask) {
+            if ((rank_in_mask % kCoopWaves) != wave) continue;           // this wavefront's share of the record's queries
+            const int ql = __ffsll((long long)todo) - 1;
+            if (chunk * kWave + ql >= Ns) continue;
+            const float qx = __shfl(lqx, ql, kWave), qy = __shfl(lqy, ql, kWave), qz = __shfl(lqz, ql, kWave);
+            const int qs = __shfl(sidx, ql, kWave);
+            auto dist2 = [&](const float4& p) __attribute__((always_inline)) {
+                const float dx = qx - p.x;
+                const float dy = qy - p.y;
+                const float dz = qz - p.z;
+                float t = dx * dx;
+                t = t + dy * dy;
+                t = t + dz * dz;
+                return t;
+            };
+            // (1) first bound
+            unsigned long long ukey = ~0ull;
+            if (step > 0) {
+                float m = 3.0e38f;
+                for (int sm = 0; sm < kCoopSamples; ++sm) m = fminf(m, dist2(P4s[(sm * kWave + lane) * step]));
+                int rk = 0;
+                for (int f = 0; f < kWave; ++f) {
+                    const float o = __shfl(m, f, kWave);
+                    rk += (o < m || (o == m && f < lane)) ? 1 : 0;
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) body(d2[u], pt[u], j + u, act && j + u < Nt);
+                const unsigned long long kth = __ballot(rk == K - 1);
+                if (kth != 0ull) ukey = ((unsigned long long)__float_as_uint(__shfl(m, __ffsll((long long)kth) - 1, kWave)) << 32) | 0xffffffffull;
             }
-        };
-        bool done = !valid, starved;
-        int found;
-        refine_loop(walk_all, S, done, true, K, cap, L.hist, lane, starved, found);
-        const int cnt = append_pass(walk_all, S, valid, K, cap, L.list, lane);
-        const float acc = score_epilogue(L.list, valid ? cnt : 0, valid, sidx, vp4, vq4, K, sigma, lane);
-        if (lane == 0) partial[(size_t)h * n_chunks + chunk] += acc;
+            // (2) scan the table, two 64-point tiles per step (the padded table makes reads up to Nt + 63 safe; beyond
+            //     that the index is clamped onto a padding point)
+            int cnt = 0;
+            for (int base = 0; base < Nt; base += 2 * kWave) {
+                if (cnt + 2 * kWave > kCoopCap) {
+                    cnt = coop_cut(la, lb, cnt, K, lane);
+                    unsigned long long* t_ = la; la = lb; lb = t_;
+                    if (cnt == K) ukey = la[K - 1];
+                }
+                const int j0 = base + lane, j1 = base + kWave + lane;
+                const float4 p0 = P4s[j0], p1 = P4s[j1 < Nt ? j1 : Nt];
+                const unsigned long long k0 = ((unsigned long long)__float_as_uint(dist2(p0)) << 32) | (unsigned int)__float_as_int(p0.w);
+                const unsigned long long k1 = ((unsigned long long)__float_as_uint(dist2(p1)) << 32) | (unsigned int)__float_as_int(p1.w);
+                const bool ok0 = j0 < Nt && k0 <= ukey, ok1 = j1 < Nt && k1 <= ukey;
+                const unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
+                if (ok0) la[cnt + mbcnt(b0)] = k0;
+                cnt += __popcll(b0);
+                if (ok1) la[cnt + mbcnt(b1)] = k1;
+                cnt += __popcll(b1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            cnt = coop_cut(la, lb, cnt, K, lane);
+            { unsigned long long* t_ = la; la = lb; lb = t_; }
+            // (3) score: 8 neighbours per round, 8 lanes per 128-byte feature row
+            const float4 a = vp4[(size_t)qs * 8 + sub];
+            float part = 0.f;
+            for (int e0 = 0; e0 < cnt; e0 += 8) {
+                const int e = e0 + grp;
+                const unsigned long long k = la[e < cnt ? e : 0];
+                const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));                 // torch.linalg.norm (:593)
+                const float rr = dist / sigma;
+                const float wgt = 1.0f / (1.0f + rr * rr);                                          // cauchy_kernel (:588-589)
+                const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
+                float d = a.x * o.x;
+                d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                part += e < cnt ? wgt * d : 0.f;
+            }
+            part = wave_sum_f(part);
+            if (lane == 0) qval[ql] = part;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float total = 0.f;                                            // the record's queries in lane order
+            for (int l = 0; l < kWave; ++l) total += qval[l];
+            if (lane == 0) partial[(size_t)h * n_chunks + chunk] += total;
+        }
+        __syncthreads();
     }
 }
 
@@ -1402,12 +1499,13 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         const unsigned int per_block = (unsigned int)bwaves * kWave;
         hipLaunchKernelGGL(lattice_compact_kernel, dim3(1), dim3(1024), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
         UMEREG_CHECK_LAUNCH("lattice_compact_kernel");
-        hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3((c_max + per_block - 1) / per_block), dim3(per_block), blds, st,
+        const unsigned int build_blocks = (c_max / kLatLanes + (unsigned int)bwaves - 1) / (unsigned int)bwaves;
+        hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), blds + (size_t)(kMaxCells + 64) * 4, st,
                            (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
         UMEREG_CHECK_LAUNCH("lattice_count_kernel");
         hipLaunchKernelGGL(lattice_scan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max);
         UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
-        hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max + 255) / 256), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
+        hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
     }
     const int n_chunks = (Ns + kWave - 1) / kWave;
@@ -1420,8 +1518,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                            Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         if (!(UMEREG_F1_ABLATE & 16))
-        hipLaunchKernelGGL(corr_score_fallback_kernel<unsigned short>, dim3(4096), dim3(waves * kWave), lds, st, (const char*)ws_tgt,
-                           (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, cap, sigma,
+        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
+                           (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);
     } else if (idx16)
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
