@@ -800,14 +800,21 @@ def test_corr_scores_lattice_vs_grid_vs_oracle(gpu, case):
     tf = rng.standard_normal((tgt.shape[0], 32)).astype(np.float32)
     args = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
     grid = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_NO_LATTICE))
-    lat = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE))
-    lat2 = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE))
-    ok = np.isfinite(grid)
-    assert np.array_equal(ok, np.isfinite(lat)) and ok.sum() >= len(Ts) - 1
+    lat = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS))
+    lat2 = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS))
+    # + the consensus pass in front of the lattice (hypotheses near the median one are scored from one staged set per
+    # source point; the others -- here: the far-off and the garbage transforms -- still go through the lattice)
+    cons = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS))
+    cons2 = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS))
+    # (a NaN hypothesis scores 0 or NaN depending on which structure meets it; the reference gives NaN.  What matters:
+    # it terminates and leaves the other hypotheses alone)
+    ok = np.isfinite(grid) & np.isfinite(lat) & np.isfinite(cons) & np.isfinite(Ts).all(axis=(1, 2))
+    assert ok.sum() >= len(Ts) - 1
     scale = np.abs(grid[ok]).max() + 1e-6
     # same neighbour sets; only the order in which a query's K terms are added differs between the two structures
     assert np.abs(grid[ok] - lat[ok]).max() <= 2e-6 * scale
-    assert np.array_equal(lat[ok], lat2[ok])                                # pool layout is timing dependent, results are not
+    assert np.array_equal(lat[ok], lat2[ok]) and np.array_equal(cons[ok], cons2[ok])     # run-to-run identical
+    assert np.abs(grid[ok] - cons[ok]).max() <= 1e-5 * scale
     ref = orc.pc_corr_cost_c(Ts[ok], src, tgt, K, sf, tf, 1.5)
     fin = np.isfinite(ref)                                                    # (the NaN hypothesis scores NaN in the oracle, 0 here)
     assert fin.sum() >= len(Ts) - 1 and np.abs(lat[ok][fin] - ref[fin]).max() <= 1e-4 * scale

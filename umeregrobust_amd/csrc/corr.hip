@@ -787,6 +787,253 @@ __device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int c
     return wave_sum_f(valid ? acc : 0.f);
 }
 
+// ---- consensus pass: one wavefront per SOURCE POINT, one lane per hypothesis -----------------------------------------
+// Most hypotheses of a pair agree (they are the output of the same matcher: ~85 % within a degree / half a metre of
+// each other), so for a fixed source point p_n the queries T_h p_n of most hypotheses fall within a metre or two of
+// ONE place q~_n = T~ p_n (T~ = component-wise median of the hypotheses).  Their neighbours all come from the same
+// ~100 target points -- and <vp_n, vq_j> does not depend on the hypothesis at all.  So:
+//   setup (per source point, cooperative): C_n = all target points within D of q~_n (grid walk, <= kConsCap points,
+//     sorted by original index so that ties keep resolving towards the lower index), staged in LDS with their
+//     feature dot products <vp_n, vq_j>, and d_K(q~_n);
+//   loop (64 hypotheses per step, one per lane): q = T_h p_n, delta = |q - q~_n|; the usual histogram + append
+//     selection over the STAGED points (broadcast LDS reads: no gathers, no per-lane lists), range
+//     [0, (d_K(q~) + delta)^2) -- the K nearest of q~ are K candidates inside it;  score term from the kept keys and
+//     the staged dot products;
+//   exactness (a posteriori, per lane): the K-th distance d found inside C_n plus delta must stay below D: any point
+//     outside C_n is farther than D from q~_n, hence farther than D - delta >= d from q.  Lanes that fail (hypotheses
+//     away from the consensus, source points whose image has < K targets within D) are left to the lattice kernels:
+//     served[n][h] bit = 0.
+// The inner loop has no vector-memory instruction at all; the lattice path was bound by the L1's line rate
+// (gathers), this one by plain VALU issue.
+constexpr int kConsCap = 160;            // staged target points per source point
+constexpr float kConsRadiusCells = 3.2f; // D in grid cells (kNN-mode cell edge c: a disc of radius 2c holds ~2K points)
+
+// component-wise median of the hypotheses' rotation rows and translations: Tmed[12] = {r00 r01 r02 tx, r10 ..}
+__global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restrict__ T, int M, float* __restrict__ Tmed)
+{
+    __shared__ unsigned int cnt_s;
+    const int m_use = M < 8192 ? M : 8192;
+    const int need = (m_use + 1) / 2;
+    for (int e = 0; e < 12; ++e) {
+        unsigned int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = k * 1024 + threadIdx.x;
+            v[k] = i < m_use ? enc_ord(T[(size_t)i * 16 + e]) : 0xffffffffu;
+        }
+        unsigned int ans = 0u;       // smallest encoding with count(x <= ans) >= need, built from the top bit down
+        for (int b = 31; b >= 0; --b) {
+            const unsigned int t = ans | ((1u << b) - 1u);
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c += (k * 1024 + (int)threadIdx.x < m_use && v[k] <= t) ? 1 : 0;
+            if (threadIdx.x == 0) cnt_s = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, kWave);
+            if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt_s, (unsigned int)c);
+            __syncthreads();
+            if ((int)cnt_s < need) ans |= 1u << b;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float f = dec_ord(ans);
+            Tmed[e] = f == f && fabsf(f) < 1e30f ? f : ((e % 5 == 0) ? 1.f : 0.f);     // NaN / inf: identity entry
+        }
+    }
+}
+
+__host__ __device__ constexpr size_t cons_lds_per_wave(int cap, size_t idx_bytes)
+{
+    return knn_lds_per_wave(cap, idx_bytes) + (size_t)(kConsCap + 4) * 16 + (size_t)kConsCap * 4;
+}
+
+template <class IdxT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) void corr_consensus_kernel(
+    const char* __restrict__ ws_tgt, const float* __restrict__ src_pts, const float4* __restrict__ vp4, const float4* __restrict__ vq4,
+    const float* __restrict__ T, const float* __restrict__ Tmed, int Ns, int Nt, int M, int K, int cap, float sigma,
+    float* __restrict__ val, unsigned long long* __restrict__ served, unsigned int* __restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (n >= Ns) return;
+    const GridWs wt = grid_ws(Nt);
+    char* my = lds + (size_t)wave * cons_lds_per_wave(cap, sizeof(IdxT));
+    KnnLds<IdxT> L;
+    L.list.d2 = reinterpret_cast<unsigned int*>(my);
+    L.list.ix = reinterpret_cast<IdxT*>(my + (size_t)cap * kWave * 4);
+    L.hist = reinterpret_cast<unsigned int*>(my);
+    float4* raw = reinterpret_cast<float4*>(my);                                        // setup only: collected, unsorted
+    float4* stage = reinterpret_cast<float4*>(my + knn_lds_per_wave(cap, sizeof(IdxT)));   // sorted by original index, quad-padded
+    float* dots = reinterpret_cast<float*>(stage + kConsCap + 4);
+    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    const Grid& g = c.g;
+    const int n_words = (M + 63) >> 6;
+    const float px = src_pts[(size_t)n * 3], py = src_pts[(size_t)n * 3 + 1], pz = src_pts[(size_t)n * 3 + 2];
+    const float cx = fmaf(Tmed[2], pz, fmaf(Tmed[1], py, Tmed[0] * px)) + Tmed[3];
+    const float cy = fmaf(Tmed[6], pz, fmaf(Tmed[5], py, Tmed[4] * px)) + Tmed[7];
+    const float cz = fmaf(Tmed[10], pz, fmaf(Tmed[9], py, Tmed[8] * px)) + Tmed[11];
+    auto give_up = [&]() __attribute__((always_inline)) {
+        for (int h = lane; h < M; h += kWave) val[(size_t)n * M + h] = 0.f;
+        for (int w = lane; w < n_words; w += kWave) served[(size_t)n * n_words + w] = 0ull;
+    };
+    // ---- setup (a): the target points within D of the consensus image, at most kConsCap (else D shrinks) ----
+    float D = kConsRadiusCells * c.cs_min;
+    int n_c = 0;
+    const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const float D2 = D * D, rq = D * 1.0001f + 1e-20f;
+        const int ylo = cell_axis(cy - rq, g.miny, g.invy, g.ny), yhi = cell_axis(cy + rq, g.miny, g.invy, g.ny);
+        const int zlo = cell_axis(cz - rq, g.minz, g.invz, g.nz), zhi = cell_axis(cz + rq, g.minz, g.invz, g.nz);
+        n_c = 0;
+        for (int z = zlo; z <= zhi; ++z) {
+            const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
+            const float dzc = fmaxf(fmaxf(z_a - cz, cz - z_b), 0.f) * 0.9999f;
+            for (int y = ylo; y <= yhi; ++y) {
+                const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
+                const float dyc = fmaxf(fmaxf(y_a - cy, cy - y_b), 0.f) * 0.9999f;
+                const float rem = D2 - dyc * dyc - dzc * dzc;
+                if (!(rem > 0.f)) continue;
+                const float sx = sqrtf(rem) * 1.0001f + 1e-20f;
+                const int cb = (z * g.ny + y) * g.nx;
+                const int a = c.start[cb + cell_axis(cx - sx, g.minx, g.invx, g.nx)];
+                const int b = c.start[cb + cell_axis(cx + sx, g.minx, g.invx, g.nx) + 1];
+                for (int pos0 = a; pos0 < b; pos0 += kWave) {
+                    const int pos = pos0 + lane;
+                    const float4 p = c.P4s[pos < b ? pos : a];
+                    const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+                    const bool in = pos < b && dx * dx + dy * dy + dz * dz <= D2;
+                    const unsigned long long bal = __ballot(in);
+                    const int at = n_c + mbcnt(bal);
+                    if (in && at < kConsCap) raw[at] = p;
+                    n_c += __popcll(bal);
+                }
+            }
+        }
+        if (n_c <= kConsCap) break;
+        D *= sqrtf(0.8f * (float)kConsCap / (float)n_c);
+    }
+    if (n_c < K || n_c > kConsCap || !(cx == cx) || !(cy == cy) || !(cz == cz)) { give_up(); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- setup (b): sort by original index (rank counting; indices are unique), (c) d_K of the consensus image ----
+    constexpr int kPer = (kConsCap + kWave - 1) / kWave;
+    float4 mine[kPer];
+    int rank_i[kPer], rank_d[kPer];
+    unsigned long long dkey[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = u * kWave + lane;
+        mine[u] = raw[e < n_c ? e : 0];
+        const float dx = cx - mine[u].x, dy = cy - mine[u].y, dz = cz - mine[u].z;
+        dkey[u] = e < n_c ? (((unsigned long long)__float_as_uint(dx * dx + dy * dy + dz * dz) << 32) | (unsigned int)__float_as_int(mine[u].w)) : ~0ull;
+        rank_i[u] = 0; rank_d[u] = 0;
+    }
+    for (int f = 0; f < n_c; ++f) {
+        const float4 o = raw[f];                                     // broadcast read
+        const float dx = cx - o.x, dy = cy - o.y, dz = cz - o.z;
+        const unsigned long long ok = ((unsigned long long)__float_as_uint(dx * dx + dy * dy + dz * dz) << 32) | (unsigned int)__float_as_int(o.w);
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            rank_i[u] += __float_as_int(o.w) < __float_as_int(mine[u].w) ? 1 : 0;
+            rank_d[u] += ok < dkey[u] ? 1 : 0;
+        }
+    }
+    float dk2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = u * kWave + lane;
+        if (e < n_c) stage[rank_i[u]] = mine[u];
+        const unsigned long long hit = __ballot(e < n_c && rank_d[u] == K - 1);
+        if (hit != 0ull) dk2 = __uint_as_float((unsigned int)(__shfl((int)(dkey[u] >> 32), __ffsll((long long)hit) - 1, kWave)));
+    }
+    if (lane < 4) stage[n_c + lane] = make_float4(kFar, kFar, kFar, 0.f);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float dk = sqrtf(dk2);
+    // ---- setup (d): <vp_n, vq_j> of the staged points, 8 lanes per feature row ----
+    {
+        const int grp = lane >> 3, sub = lane & 7;
+        const float4 a = vp4[(size_t)n * 8 + sub];
+        for (int j0 = 0; j0 < n_c; j0 += 8) {
+            const int j = j0 + grp;
+            const int oi = __float_as_int(stage[j < n_c ? j : 0].w);
+            const float4 o = vq4[(size_t)oi * 8 + sub];
+            float d = a.x * o.x;
+            d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+            d += __shfl_xor(d, 1, kWave);
+            d += __shfl_xor(d, 2, kWave);
+            d += __shfl_xor(d, 4, kWave);
+            if (sub == 0 && j < n_c) dots[j] = d;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- the hypotheses, 64 per step ----
+    unsigned int n_served = 0u;
+    for (int h0 = 0; h0 < M; h0 += kWave) {
+        const int h = h0 + lane;
+        const float4* Th = reinterpret_cast<const float4*>(T + (size_t)(h < M ? h : 0) * 16);    // (T is 16-byte aligned: checked by the host)
+        const float4 r0 = Th[0], r1 = Th[1], r2 = Th[2];
+        const float qx = fmaf(r0.z, pz, fmaf(r0.y, py, r0.x * px)) + r0.w;               // the arithmetic of corr_score_kernel
+        const float qy = fmaf(r1.z, pz, fmaf(r1.y, py, r1.x * px)) + r1.w;
+        const float qz = fmaf(r2.z, pz, fmaf(r2.y, py, r2.x * px)) + r2.w;
+        const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
+        const float delta = sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f;
+        const bool act = h < M && delta < D;                                            // (NaN transforms: false)
+        LaneSel S;
+        S.nlev = 1;
+        {
+            const float rb = (dk + delta) * 1.0001f + 1e-5f;                            // the K nearest of q~ lie within it
+            S.hi0 = act ? rb * rb : 1.0f;
+        }
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
+        S.sc[0] = (float)kBins / S.hi0;
+        auto walk_c = [&](bool on, float, auto&& body) __attribute__((always_inline)) {
+            for (int u0 = 0; u0 < n_c; u0 += 4) {
+                float d2[4];
+                float4 pt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 p = stage[u0 + u];              // same address in every lane: broadcast read
+                    const float dx = qx - p.x;
+                    const float dy = qy - p.y;
+                    const float dz = qz - p.z;
+                    float t = dx * dx;
+                    t = t + dy * dy;
+                    t = t + dz * dz;
+                    d2[u] = t;
+                    pt[u].w = __int_as_float(u0 + u);            // staged order = original index order: ties resolve the same way
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(d2[u], pt[u], u0 + u, on);   // padding = far points: never admitted
+            }
+        };
+        bool done = !act, starved;
+        int found;
+        refine_loop(walk_c, S, done, true, K, cap, L.hist, lane, starved, found);
+        const int cnt = append_pass(walk_c, S, act, K, cap, L.list, lane);
+        // the K-th distance found, the exactness test, and the score term
+        float d2max = 0.f, acc = 0.f;
+        for (int e = 0; e < K; ++e) {
+            if (e < cnt) {
+                const float d2 = __uint_as_float(L.list.d2[e * kWave + lane]);
+                d2max = fmaxf(d2max, d2);
+                const float dist = sqrtf(d2);                                           // torch.linalg.norm (:593)
+                const float r = dist / sigma;
+                acc = fmaf(1.0f / (1.0f + r * r), dots[L.list.index(e, lane)], acc);    // cauchy_kernel (:588-589)
+            }
+        }
+        const bool ok = act && cnt == K && sqrtf(d2max) * 1.0001f + delta <= D * 0.9999f - 1e-6f;
+        if (h < M) val[(size_t)n * M + h] = ok ? acc : 0.f;
+        const unsigned long long sb = __ballot(ok);
+        if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = sb;
+        n_served += (unsigned int)__popcll(sb);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0 && stats) atomicAdd(stats, n_served);
+}
+
 // ---- lattice build ---------------------------------------------------------------------------------------------------
 // (1) lattice_mark_kernel: marks[cell] = 1 for every cell some (hypothesis, source point) query lands in (~1/4 of them);
 // (2) lattice_compact_kernel: the marked cells in ascending order (one workgroup);
@@ -799,7 +1046,8 @@ __device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int c
 // cells[id].w != 0 or quads == 0: no list (the query is left to corr_score_fallback_kernel).
 __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
                                                            const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
-                                                           char* __restrict__ lat, unsigned int c_max)
+                                                           char* __restrict__ lat, unsigned int c_max,
+                                                           const unsigned long long* __restrict__ served, int n_words)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
@@ -815,6 +1063,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
         const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
         const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
         const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        if (served && ((served[(size_t)n * n_words + (h >> 6)] >> (h & 63)) & 1ull)) continue;   // done by the consensus pass
         const int cell = lattice_cell(L, qx, qy, qz);
         if (cell >= 0) marks[cell] = 1;
     }
@@ -1014,7 +1263,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          const float* __restrict__ src_pts, const float4* __restrict__ vp4, const float4* __restrict__ vq4,
                                                          const float* __restrict__ T, int Ns, int Nt, int M, int K, int cap,
                                                          float sigma, int hyp_per_wave, int n_chunks,
-                                                         float* __restrict__ partial, char* __restrict__ lat, unsigned int c_max)
+                                                         float* __restrict__ partial, char* __restrict__ lat, unsigned int c_max,
+                                                         const unsigned long long* __restrict__ served, int n_words)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1064,9 +1314,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         int cnt;
         bool fb_lanes = false;
         if (LAT) {
+            // queries the consensus pass has already scored are not this kernel's business
+            const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (h >> 6)] >> (h & 63)) & 1ull));
+            if (!__any(todo_q)) {
+                if (lane == 0) partial[(size_t)h * n_chunks + chunk] = 0.f;
+                continue;
+            }
             // the query's cell of the candidate lattice; lanes without a list (outside the lattice, oversized or
             // unplaced list) are left to corr_score_fallback_kernel
-            const int cell = valid ? lattice_cell(Lt, qx, qy, qz) : -1;
+            const int cell = todo_q ? lattice_cell(Lt, qx, qy, qz) : -1;
             const uint4 ce = cells[cell >= 0 ? cell : 0];
             const bool use = cell >= 0 && ce.w == 0u && ce.y != 0u;
             const unsigned int first = ce.x;
@@ -1116,7 +1372,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (!(UMEREG_F1_ABLATE & 4)) refine_loop(walk_l, S, done, false, K, cap, L.hist, lane, starved, found);
             const bool got = use && !starved;
             cnt = (UMEREG_F1_ABLATE & 2) ? (got ? K : 0) : append_pass(walk_l, S, got, K, cap, L.list, lane);
-            fb_lanes = valid && !got;
+            fb_lanes = todo_q && !got;
             KNN_DBG(8, __popcll(__ballot(fb_lanes)));
             cnt = got ? cnt : 0;
         } else {
@@ -1306,12 +1562,25 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
     }
 }
 
+// sums of the consensus pass's terms over slices of kValSlice source points (fixed order inside a slice)
+constexpr int kValSlice = 64;
+__global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __restrict__ val, int M, int Ns, float* __restrict__ slices)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= M) return;
+    const int n0 = blockIdx.y * kValSlice, n1 = min(n0 + kValSlice, Ns);
+    float s = 0.f;
+    for (int n = n0; n < n1; ++n) s += val[(size_t)n * M + h];                   // coalesced over h
+    slices[(size_t)blockIdx.y * M + h] = s;
+}
+
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restrict__ partial, int M, int n_chunks, int Ns,
-                                                          float* __restrict__ scores)
+                                                          const float* __restrict__ slices, int n_slices, float* __restrict__ scores)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= M) return;
     float s = 0.f;
+    for (int k = 0; k < n_slices; ++k) s += slices[(size_t)k * M + h];           // consensus pass, in source order
     for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
     scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
 }
@@ -1406,14 +1675,23 @@ static const int kColsumBlocks = 64;
 
 UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M) { return umereg_corr_workspace_bytes_ex(Ns, Nt, M, 0); }
 
+// the consensus pass rides on the lattice (it leaves the queries it cannot prove exact to it)
+static bool consensus_on(unsigned int c_max, int M, int flags, const void* T = nullptr)
+{
+    if (T && ((uintptr_t)T & 15)) return false;        // the pass reads hypothesis rows as 16-byte vectors
+    return c_max != 0 && !(flags & UMEREG_CORR_NO_CONSENSUS) && (M >= 256 || (flags & UMEREG_CORR_FORCE_CONSENSUS));
+}
+
 UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags)
 {
     if (Ns <= 0 || Nt <= 0 || M <= 0) return 0;
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
     const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
+    const size_t cons = consensus_on(c_max, M, flags) ? align_up((size_t)Ns * M * 4, 256) + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256) + 256 +
+                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
-           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0);
+           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -1484,13 +1762,33 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     size_t lds;
     bool idx16;
     knn_lds_plan(K, Nt, &cap, &waves, &lds, 2, &idx16);
+    const int n_words = (M + 63) / 64;
+    float* val = nullptr;
+    float* slices = nullptr;
+    unsigned long long* served = nullptr;
+    if (consensus_on(c_max, M, flags, T)) {
+        // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
+        char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256);
+        val = (float*)cons;
+        served = (unsigned long long*)(cons + align_up((size_t)Ns * M * 4, 256));
+        float* Tmed = (float*)((char*)served + align_up((size_t)Ns * n_words * 8, 256));
+        slices = Tmed + 64;
+        if (hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
+        hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, Tmed);
+        UMEREG_CHECK_LAUNCH("hyp_median_kernel");
+        hipLaunchKernelGGL(corr_consensus_kernel<unsigned short>, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap, 2), st,
+                           (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, Ns, Nt, M, K,
+                           cap, sigma, val, served, (unsigned int*)lat + 7);
+        UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
+    }
     if (c_max) {
         // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> count -> scan -> fill
         const LatWs lw = lat_ws(c_max);
-        if (hipMemsetAsync(lat, 0, lw.off_wave_tot, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header + marks) failed"); return UMEREG_ELAUNCH; }
+        // (header word 7 = queries served by the consensus pass survives: the memset starts behind the header when it ran)
+        if (hipMemsetAsync(lat + (served ? 256 : 0), 0, lw.off_wave_tot - (served ? 256 : 0), st) != hipSuccess) { set_error("hipMemsetAsync(lattice header + marks) failed"); return UMEREG_ELAUNCH; }
         const int hpt = 16;
         hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
-                           Ns, Nt, M, hpt, lat, c_max);
+                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words);
         UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
         int bcap, bwaves;
         size_t blds;
@@ -1515,7 +1813,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     if (c_max) {
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max, (const unsigned long long*)served, n_words);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         if (!(UMEREG_F1_ABLATE & 16))
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
@@ -1524,13 +1822,18 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     } else if (idx16)
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0);
     else
         hipLaunchKernelGGL((corr_score_kernel<unsigned int, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0);
     UMEREG_CHECK_LAUNCH("corr_score_kernel");
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, scores);
+    const int n_slices = val ? (Ns + kValSlice - 1) / kValSlice : 0;
+    if (val) {
+        hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, slices);
+        UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
+    }
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
     return UMEREG_OK;
 }
