@@ -31,7 +31,7 @@ for name, gen in (("plain", synth_pair), ("hard", synth_pair_hard), ("plain-rot"
     si, ti = t(rs.choice(50000, 10000, replace=False)), t(rs.choice(50000, 10000, replace=False))
     a, b, fa, fb = sp[0, si].contiguous(), tp[0, ti].contiguous(), sf[0, si].contiguous(), tf[0, ti].contiguous()
     res = {}
-    for tag, flags in (("grid", ops.CORR_NO_LATTICE), ("lattice", ops.CORR_NO_CONSENSUS), ("consensus", 0)):
+    for tag, flags in (("grid", ops.CORR_NO_LATTICE), ("lattice", ops.CORR_NO_CONSENSUS), ("consensus", 0), ("cons+grid", 16)):
         sc = ops.corr_scores(a, b, fa, fb, T, K=20, sigma=1.5, flags=flags)
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -47,5 +47,5 @@ for name, gen in (("plain", synth_pair), ("hard", synth_pair_hard), ("plain-rot"
     off = lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, ops.CORR_NO_LATTICE)
     ws = ops._workspace(dev, lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, 0), "corr")
     hdr = ws[off:off + 32].view(torch.int32).cpu().numpy()
-    print(f"{name}: grid {res['grid'][1]:.2f} ms  lattice {res['lattice'][1]:.2f} ms  consensus+lattice {res['consensus'][1]:.2f} ms | max |d| {np.abs(g - l).max():.3g} / {np.abs(g - cns).max():.3g} of {np.abs(g).max():.3g}"
+    print(f"{name}: grid {res['grid'][1]:.2f} ms  lattice {res['lattice'][1]:.2f} ms  consensus+lattice {res['consensus'][1]:.2f} ms  consensus+grid {res['cons+grid'][1]:.2f} ms (max |d| {np.abs(g - res['cons+grid'][0]).max():.3g}) | max |d| {np.abs(g - l).max():.3g} / {np.abs(g - cns).max():.3g} of {np.abs(g).max():.3g}"
           f" argmax {int(g.argmax())}/{int(l.argmax())}/{int(cns.argmax())} | served {hdr[7]} of {M * Ns} | pool quads {hdr[0]} cells {hdr[1]} marked {hdr[3]} marked w/o list {hdr[2]} fb records {hdr[4]} fb queries {hdr[6]}", flush=True)

@@ -805,13 +805,19 @@ __device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int c
 //     served[n][h] bit = 0.
 // The inner loop has no vector-memory instruction at all; the lattice path was bound by the L1's line rate
 // (gathers), this one by plain VALU issue.
-constexpr int kConsCap = 160;            // staged target points per source point
-constexpr float kConsRadiusCells = 3.2f; // D in grid cells (kNN-mode cell edge c: a disc of radius 2c holds ~2K points)
+constexpr int kConsCap = 256;            // staged target points per source point
+constexpr float kConsRadiusCells = 4.2f; // first D in grid cells (kNN-mode cell edge c: a disc of radius 2c holds ~2K points)
 
-// component-wise median of the hypotheses' rotation rows and translations: Tmed[12] = {r00 r01 r02 tx, r10 ..}
-__global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restrict__ T, int M, float* __restrict__ Tmed)
+// component-wise median of the hypotheses' rotation rows and translations: Tmed[12] = {r00 r01 r02 tx, r10 ..};
+// then the hypotheses in the order of their distance from it: perm[rank] = h, inv[h] = rank.  The distance is a bound
+// on how far a hypothesis moves any source point away from its consensus image, |dt + dR c0| + |dR|_F r0 (c0, r0:
+// centre and radius of the source cloud) -- it only serves to put similar hypotheses into the same 64-lane step.
+__global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restrict__ T, int M, const unsigned int* __restrict__ src_bbox,
+                                                          float* __restrict__ Tmed, int* __restrict__ perm, int* __restrict__ inv,
+                                                          float* __restrict__ err)
 {
     __shared__ unsigned int cnt_s;
+    __shared__ float med[12];
     const int m_use = M < 8192 ? M : 8192;
     const int need = (m_use + 1) / 2;
     for (int e = 0; e < 12; ++e) {
@@ -838,36 +844,64 @@ __global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restric
         }
         if (threadIdx.x == 0) {
             const float f = dec_ord(ans);
-            Tmed[e] = f == f && fabsf(f) < 1e30f ? f : ((e % 5 == 0) ? 1.f : 0.f);     // NaN / inf: identity entry
+            med[e] = Tmed[e] = f == f && fabsf(f) < 1e30f ? f : ((e % 5 == 0) ? 1.f : 0.f);     // NaN / inf: identity entry
         }
+    }
+    __syncthreads();
+    // distance of every hypothesis from the median one (the source bounding box here is that of the consensus-ROTATED
+    // copy the source order was built from: same radius, and the centre only matters roughly)
+    const float lo[3] = {dec_ord(~src_bbox[0]), dec_ord(~src_bbox[1]), dec_ord(~src_bbox[2])};
+    const float hi[3] = {dec_ord(src_bbox[3]), dec_ord(src_bbox[4]), dec_ord(src_bbox[5])};
+    const float r0 = 0.5f * sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    for (int h = threadIdx.x; h < M; h += 1024) {
+        float fro = 0.f, dt2 = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) { const float d = T[(size_t)h * 16 + r * 4 + c] - med[r * 4 + c]; fro += d * d; }
+            const float d = T[(size_t)h * 16 + r * 4 + 3] - med[r * 4 + 3];
+            dt2 += d * d;
+        }
+        const float e = sqrtf(dt2) + sqrtf(fro) * 2.0f * r0;
+        err[h] = e == e ? e : 3.0e38f;                                                      // NaN hypotheses last
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < M; h += 1024) {          // rank counting (ties by index): M^2 / 1024 comparisons per thread
+        const float e = err[h];
+        int rk = 0;
+        for (int f = 0; f < M; ++f) { const float o = err[f]; rk += (o < e || (o == e && f < h)) ? 1 : 0; }
+        perm[rk] = h;
+        inv[h] = rk;
     }
 }
 
-__host__ __device__ constexpr size_t cons_lds_per_wave(int cap, size_t idx_bytes)
+constexpr int kConsIdxBits = 9;          // low bits of a key's index word = position in the stage (kConsCap <= 512)
+
+__host__ __device__ constexpr size_t cons_lds_per_wave(int cap)
 {
-    return knn_lds_per_wave(cap, idx_bytes) + (size_t)(kConsCap + 4) * 16 + (size_t)kConsCap * 4;
+    // key list with a 32-bit index plane (original index << 9 | stage position) / histogram; stage; dot products; distances from the centre
+    return knn_lds_per_wave(cap, 4) + (size_t)(kConsCap + 4) * 16 + (size_t)(kConsCap + 4) * 4 * 2;
 }
 
-template <class IdxT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) void corr_consensus_kernel(
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void corr_consensus_kernel(
     const char* __restrict__ ws_tgt, const float* __restrict__ src_pts, const float4* __restrict__ vp4, const float4* __restrict__ vq4,
-    const float* __restrict__ T, const float* __restrict__ Tmed, int Ns, int Nt, int M, int K, int cap, float sigma,
-    float* __restrict__ val, unsigned long long* __restrict__ served, unsigned int* __restrict__ stats)
+    const float* __restrict__ T, const float* __restrict__ Tmed, const int* __restrict__ perm, int Ns, int Nt, int M, int K, int cap,
+    float sigma, float* __restrict__ val, unsigned long long* __restrict__ served, unsigned int* __restrict__ stats)
 {
+    typedef unsigned int IdxT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int n = blockIdx.x * (blockDim.x >> 6) + wave;
     if (n >= Ns) return;
     const GridWs wt = grid_ws(Nt);
-    char* my = lds + (size_t)wave * cons_lds_per_wave(cap, sizeof(IdxT));
+    char* my = lds + (size_t)wave * cons_lds_per_wave(cap);
     KnnLds<IdxT> L;
     L.list.d2 = reinterpret_cast<unsigned int*>(my);
     L.list.ix = reinterpret_cast<IdxT*>(my + (size_t)cap * kWave * 4);
     L.hist = reinterpret_cast<unsigned int*>(my);
-    float4* raw = reinterpret_cast<float4*>(my);                                        // setup only: collected, unsorted
-    float4* stage = reinterpret_cast<float4*>(my + knn_lds_per_wave(cap, sizeof(IdxT)));   // sorted by original index, quad-padded
+    float4* raw = reinterpret_cast<float4*>(my);                                  // setup only: collected, unsorted
+    float4* stage = reinterpret_cast<float4*>(my + knn_lds_per_wave(cap, 4));     // sorted by distance from the centre, quad-padded
     float* dots = reinterpret_cast<float*>(stage + kConsCap + 4);
+    float* dc2 = dots + kConsCap + 4;                                              // squared distance from the centre (ascending)
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     const Grid& g = c.g;
     const int n_words = (M + 63) >> 6;
@@ -879,11 +913,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int h = lane; h < M; h += kWave) val[(size_t)n * M + h] = 0.f;
         for (int w = lane; w < n_words; w += kWave) served[(size_t)n * n_words + w] = 0ull;
     };
-    // ---- setup (a): the target points within D of the consensus image, at most kConsCap (else D shrinks) ----
+    if (!(cx == cx) || !(cy == cy) || !(cz == cz)) { give_up(); return; }
+    // ---- setup (a): the target points within D of the consensus image: as many as the stage holds ----
+    // D starts at kConsRadiusCells grid cells, doubles while the ball holds fewer than 2 K points (images that fall into
+    // empty parts of the target: their neighbours are far, and so is everything else), shrinks when it overflows the stage
     float D = kConsRadiusCells * c.cs_min;
     int n_c = 0;
     const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    bool shrunk = false;
+    for (int attempt = 0; attempt < 10; ++attempt) {
         const float D2 = D * D, rq = D * 1.0001f + 1e-20f;
         const int ylo = cell_axis(cy - rq, g.miny, g.invy, g.ny), yhi = cell_axis(cy + rq, g.miny, g.invy, g.ny);
         const int zlo = cell_axis(cz - rq, g.minz, g.invz, g.nz), zhi = cell_axis(cz + rq, g.minz, g.invz, g.nz);
@@ -912,15 +950,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 }
             }
         }
-        if (n_c <= kConsCap) break;
-        D *= sqrtf(0.8f * (float)kConsCap / (float)n_c);
+        if (n_c > kConsCap) { D *= fminf(0.95f, sqrtf(0.85f * (float)kConsCap / (float)n_c)); shrunk = true; continue; }
+        if (n_c < 2 * K && n_c < Nt && !shrunk && D < 1.0e4f) { D *= 1.6f; continue; }     // (once shrunk, never grown again)
+        break;
     }
-    if (n_c < K || n_c > kConsCap || !(cx == cx) || !(cy == cy) || !(cz == cz)) { give_up(); return; }
+    if (n_c < K || n_c > kConsCap) { give_up(); return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- setup (b): sort by original index (rank counting; indices are unique), (c) d_K of the consensus image ----
+    // ---- setup (b): sort by (distance from the centre, original index) by rank counting; (c) d_K of the centre ----
     constexpr int kPer = (kConsCap + kWave - 1) / kWave;
     float4 mine[kPer];
-    int rank_i[kPer], rank_d[kPer];
+    int rank_d[kPer];
     unsigned long long dkey[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
@@ -928,29 +967,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         mine[u] = raw[e < n_c ? e : 0];
         const float dx = cx - mine[u].x, dy = cy - mine[u].y, dz = cz - mine[u].z;
         dkey[u] = e < n_c ? (((unsigned long long)__float_as_uint(dx * dx + dy * dy + dz * dz) << 32) | (unsigned int)__float_as_int(mine[u].w)) : ~0ull;
-        rank_i[u] = 0; rank_d[u] = 0;
+        rank_d[u] = 0;
     }
     for (int f = 0; f < n_c; ++f) {
         const float4 o = raw[f];                                     // broadcast read
         const float dx = cx - o.x, dy = cy - o.y, dz = cz - o.z;
         const unsigned long long ok = ((unsigned long long)__float_as_uint(dx * dx + dy * dy + dz * dz) << 32) | (unsigned int)__float_as_int(o.w);
 #pragma unroll
-        for (int u = 0; u < kPer; ++u) {
-            rank_i[u] += __float_as_int(o.w) < __float_as_int(mine[u].w) ? 1 : 0;
-            rank_d[u] += ok < dkey[u] ? 1 : 0;
-        }
+        for (int u = 0; u < kPer; ++u) rank_d[u] += ok < dkey[u] ? 1 : 0;
     }
-    float dk2 = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
         const int e = u * kWave + lane;
-        if (e < n_c) stage[rank_i[u]] = mine[u];
-        const unsigned long long hit = __ballot(e < n_c && rank_d[u] == K - 1);
-        if (hit != 0ull) dk2 = __uint_as_float((unsigned int)(__shfl((int)(dkey[u] >> 32), __ffsll((long long)hit) - 1, kWave)));
+        if (e < n_c) { stage[rank_d[u]] = mine[u]; dc2[rank_d[u]] = __uint_as_float((unsigned int)(dkey[u] >> 32)); }
     }
-    if (lane < 4) stage[n_c + lane] = make_float4(kFar, kFar, kFar, 0.f);
+    if (lane < 4) { stage[n_c + lane] = make_float4(kFar, kFar, kFar, 0.f); dc2[n_c + lane] = 3.0e38f; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const float dk = sqrtf(dk2);
+    const float dk = sqrtf(dc2[K - 1]);
     // ---- setup (d): <vp_n, vq_j> of the staged points, 8 lanes per feature row ----
     {
         const int grp = lane >> 3, sub = lane & 7;
@@ -968,18 +1002,37 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // ---- the hypotheses, 64 per step ----
+    // ---- the hypotheses, 64 per step, in the order of their distance from the median one ----
     unsigned int n_served = 0u;
     for (int h0 = 0; h0 < M; h0 += kWave) {
-        const int h = h0 + lane;
-        const float4* Th = reinterpret_cast<const float4*>(T + (size_t)(h < M ? h : 0) * 16);    // (T is 16-byte aligned: checked by the host)
+        const int pos_h = h0 + lane;
+        const int h = perm[pos_h < M ? pos_h : 0];
+        const float4* Th = reinterpret_cast<const float4*>(T + (size_t)h * 16);    // (T is 16-byte aligned: checked by the host)
         const float4 r0 = Th[0], r1 = Th[1], r2 = Th[2];
         const float qx = fmaf(r0.z, pz, fmaf(r0.y, py, r0.x * px)) + r0.w;               // the arithmetic of corr_score_kernel
         const float qy = fmaf(r1.z, pz, fmaf(r1.y, py, r1.x * px)) + r1.w;
         const float qz = fmaf(r2.z, pz, fmaf(r2.y, py, r2.x * px)) + r2.w;
         const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
         const float delta = sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f;
-        const bool act = h < M && delta < D;                                            // (NaN transforms: false)
+        // a lane can only pass the exactness test if d_K(q) + delta <= D, and d_K(q) >= d_K(q~) - delta
+        const bool act = pos_h < M && delta < D && dk <= D;                                 // (NaN transforms: false)
+        if (!__any(act)) {
+            if (pos_h < M) val[(size_t)n * M + pos_h] = 0.f;
+            if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = 0ull;
+            continue;
+        }
+        // candidates beyond d_K(q~) + 2 max delta of the centre cannot be among the K nearest of any lane of this step
+        float dmax = act ? delta : 0.f;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, m, kWave));
+        int m_use;
+        {
+            const float rc = (dk + 2.f * dmax) * 1.0001f + 1e-5f, rc2 = rc * rc;
+            int cnt_in = 0;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) cnt_in += __popcll(__ballot(u * kWave + lane < n_c && dc2[u * kWave + lane] <= rc2));
+            m_use = (cnt_in + 3) & ~3;                                                       // (the stage is quad-padded with far points)
+        }
         LaneSel S;
         S.nlev = 1;
         {
@@ -990,7 +1043,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
         S.sc[0] = (float)kBins / S.hi0;
         auto walk_c = [&](bool on, float, auto&& body) __attribute__((always_inline)) {
-            for (int u0 = 0; u0 < n_c; u0 += 4) {
+            for (int u0 = 0; u0 < m_use; u0 += 4) {
                 float d2[4];
                 float4 pt[4];
 #pragma unroll
@@ -1003,7 +1056,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                     t = t + dy * dy;
                     t = t + dz * dz;
                     d2[u] = t;
-                    pt[u].w = __int_as_float(u0 + u);            // staged order = original index order: ties resolve the same way
+                    // index word: original index (ties resolve towards the lower one, as everywhere), then the stage position
+                    pt[u].w = __int_as_float((__float_as_int(p.w) << kConsIdxBits) | (u0 + u));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) body(d2[u], pt[u], u0 + u, on);   // padding = far points: never admitted
@@ -1021,11 +1075,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 d2max = fmaxf(d2max, d2);
                 const float dist = sqrtf(d2);                                           // torch.linalg.norm (:593)
                 const float r = dist / sigma;
-                acc = fmaf(1.0f / (1.0f + r * r), dots[L.list.index(e, lane)], acc);    // cauchy_kernel (:588-589)
+                acc = fmaf(1.0f / (1.0f + r * r), dots[L.list.index(e, lane) & ((1u << kConsIdxBits) - 1u)], acc);    // cauchy_kernel (:588-589)
             }
         }
         const bool ok = act && cnt == K && sqrtf(d2max) * 1.0001f + delta <= D * 0.9999f - 1e-6f;
-        if (h < M) val[(size_t)n * M + h] = ok ? acc : 0.f;
+        if (pos_h < M) val[(size_t)n * M + pos_h] = ok ? acc : 0.f;                     // (in processing order: see corr_reduce_kernel)
         const unsigned long long sb = __ballot(ok);
         if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = sb;
         n_served += (unsigned int)__popcll(sb);
@@ -1047,7 +1101,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
                                                            const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
                                                            char* __restrict__ lat, unsigned int c_max,
-                                                           const unsigned long long* __restrict__ served, int n_words)
+                                                           const unsigned long long* __restrict__ served, int n_words,
+                                                           const int* __restrict__ inv)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
@@ -1063,7 +1118,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
         const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
         const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
         const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-        if (served && ((served[(size_t)n * n_words + (h >> 6)] >> (h & 63)) & 1ull)) continue;   // done by the consensus pass
+        if (served) { const int ph = inv[h]; if ((served[(size_t)n * n_words + (ph >> 6)] >> (ph & 63)) & 1ull) continue; }   // done by the consensus pass
         const int cell = lattice_cell(L, qx, qy, qz);
         if (cell >= 0) marks[cell] = 1;
     }
@@ -1264,7 +1319,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          const float* __restrict__ T, int Ns, int Nt, int M, int K, int cap,
                                                          float sigma, int hyp_per_wave, int n_chunks,
                                                          float* __restrict__ partial, char* __restrict__ lat, unsigned int c_max,
-                                                         const unsigned long long* __restrict__ served, int n_words)
+                                                         const unsigned long long* __restrict__ served, int n_words,
+                                                         const int* __restrict__ inv)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1313,13 +1369,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
         int cnt;
         bool fb_lanes = false;
+        // queries the consensus pass has already scored are not this kernel's business
+        const int ph = served ? inv[h] : 0;       // position of the hypothesis in the consensus pass's processing order
+        const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull));
+        if (!__any(todo_q)) {
+            if (lane == 0) partial[(size_t)h * n_chunks + chunk] = 0.f;
+            continue;
+        }
         if (LAT) {
-            // queries the consensus pass has already scored are not this kernel's business
-            const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (h >> 6)] >> (h & 63)) & 1ull));
-            if (!__any(todo_q)) {
-                if (lane == 0) partial[(size_t)h * n_chunks + chunk] = 0.f;
-                continue;
-            }
             // the query's cell of the candidate lattice; lanes without a list (outside the lattice, oversized or
             // unplaced list) are left to corr_score_fallback_kernel
             const int cell = todo_q ? lattice_cell(Lt, qx, qy, qz) : -1;
@@ -1376,7 +1433,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             KNN_DBG(8, __popcll(__ballot(fb_lanes)));
             cnt = got ? cnt : 0;
         } else {
-            cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
+            cnt = knn_wave(c, qx, qy, qz, todo_q, K, cap, L.hist, L.list, lane);
+            cnt = todo_q ? cnt : 0;
         }
         const float acc = score_epilogue(L.list, cnt, valid, sidx, vp4, vq4, K, sigma, lane);
         if (LAT) {
@@ -1575,12 +1633,14 @@ __global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restrict__ partial, int M, int n_chunks, int Ns,
-                                                          const float* __restrict__ slices, int n_slices, float* __restrict__ scores)
+                                                          const float* __restrict__ slices, int n_slices, const int* __restrict__ inv,
+                                                          float* __restrict__ scores)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= M) return;
     float s = 0.f;
-    for (int k = 0; k < n_slices; ++k) s += slices[(size_t)k * M + h];           // consensus pass, in source order
+    const int ph = n_slices ? inv[h] : 0;                                            // the consensus pass stores in its processing order
+    for (int k = 0; k < n_slices; ++k) s += slices[(size_t)k * M + ph];          // consensus pass, in source order
     for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
     scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
 }
@@ -1688,7 +1748,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
     const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
     const size_t cons = consensus_on(c_max, M, flags) ? align_up((size_t)Ns * M * 4, 256) + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256) + 256 +
-                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) : 0;
+                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
            (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
@@ -1765,6 +1825,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     const int n_words = (M + 63) / 64;
     float* val = nullptr;
     float* slices = nullptr;
+    int* perm = nullptr;
+    int* inv = nullptr;
     unsigned long long* served = nullptr;
     if (consensus_on(c_max, M, flags, T)) {
         // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
@@ -1773,22 +1835,26 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         served = (unsigned long long*)(cons + align_up((size_t)Ns * M * 4, 256));
         float* Tmed = (float*)((char*)served + align_up((size_t)Ns * n_words * 8, 256));
         slices = Tmed + 64;
+        perm = (int*)((char*)slices + align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256));
+        inv = perm + M;
+        float* err = (float*)(inv + M);
         if (hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
-        hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, Tmed);
+        hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox), Tmed, perm, inv, err);
         UMEREG_CHECK_LAUNCH("hyp_median_kernel");
-        hipLaunchKernelGGL(corr_consensus_kernel<unsigned short>, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap, 2), st,
-                           (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, Ns, Nt, M, K,
-                           cap, sigma, val, served, (unsigned int*)lat + 7);
+        hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
+                           (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, (const int*)perm,
+                           Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
         UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
     }
-    if (c_max) {
+    const bool leftovers_grid = served && (flags & 16);
+    if (c_max && !leftovers_grid) {
         // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> count -> scan -> fill
         const LatWs lw = lat_ws(c_max);
         // (header word 7 = queries served by the consensus pass survives: the memset starts behind the header when it ran)
         if (hipMemsetAsync(lat + (served ? 256 : 0), 0, lw.off_wave_tot - (served ? 256 : 0), st) != hipSuccess) { set_error("hipMemsetAsync(lattice header + marks) failed"); return UMEREG_ELAUNCH; }
         const int hpt = 16;
         hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
-                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words);
+                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
         int bcap, bwaves;
         size_t blds;
@@ -1810,10 +1876,14 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     const int hyp_per_wave = 2;   // 1..4 measured equal (6.4 us per hypothesis), 8: 6.7, 16: 7.3 (balance at the tail, parallelism)
     const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
     const long n_waves = (long)n_chunks * n_hg;
-    if (c_max) {
+    if (leftovers_grid) {
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
+                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)served, n_words, (const int*)inv);
+    } else if (c_max) {
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max, (const unsigned long long*)served, n_words);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         if (!(UMEREG_F1_ABLATE & 16))
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
@@ -1822,18 +1892,18 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     } else if (idx16)
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0, (const int*)nullptr);
     else
         hipLaunchKernelGGL((corr_score_kernel<unsigned int, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
                            lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0);
+                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0, (const int*)nullptr);
     UMEREG_CHECK_LAUNCH("corr_score_kernel");
     const int n_slices = val ? (Ns + kValSlice - 1) / kValSlice : 0;
     if (val) {
         hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, slices);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
     }
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, scores);
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv, scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
     return UMEREG_OK;
 }
