@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void rotate_points_kernel(const float* __restr
 // neighbour's row; the keys are read from the owner's LDS list.  Returns the wave sum (all lanes).
 template <class IdxT>
 __device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int cnt, bool valid, int sidx, const float4* __restrict__ vp4,
-                                                const float4* __restrict__ vq4, int K, float sigma, int lane)
+                                                const float4* __restrict__ vq4, int K, float sigma, int lane, bool lane_terms = false)
 {
     // (1) owners turn the d2 of their keys into Cauchy weights in place
     if (UMEREG_F1_ABLATE & 1) return wave_sum_f(valid ? (float)cnt : 0.f);
@@ -784,7 +784,7 @@ __device__ __forceinline__ float score_epilogue(const KeyList<IdxT>& list, int c
         part += __shfl_xor(part, 4, kWave);
         acc = sub == it ? part : acc;                 // lane q keeps its query's sum
     }
-    return wave_sum_f(valid ? acc : 0.f);
+    return lane_terms ? (valid ? acc : 0.f) : wave_sum_f(valid ? acc : 0.f);
 }
 
 // ---- consensus pass: one wavefront per SOURCE POINT, one lane per hypothesis -----------------------------------------
@@ -813,8 +813,7 @@ constexpr float kConsRadiusCells = 4.2f; // first D in grid cells (kNN-mode cell
 // on how far a hypothesis moves any source point away from its consensus image, |dt + dR c0| + |dR|_F r0 (c0, r0:
 // centre and radius of the source cloud) -- it only serves to put similar hypotheses into the same 64-lane step.
 __global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restrict__ T, int M, const unsigned int* __restrict__ src_bbox,
-                                                          float* __restrict__ Tmed, int* __restrict__ perm, int* __restrict__ inv,
-                                                          float* __restrict__ err)
+                                                          float* __restrict__ Tmed, float* __restrict__ err)
 {
     __shared__ unsigned int cnt_s;
     __shared__ float med[12];
@@ -863,14 +862,23 @@ __global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restric
         const float e = sqrtf(dt2) + sqrtf(fro) * 2.0f * r0;
         err[h] = e == e ? e : 3.0e38f;                                                      // NaN hypotheses last
     }
-    __syncthreads();
-    for (int h = threadIdx.x; h < M; h += 1024) {          // rank counting (ties by index): M^2 / 1024 comparisons per thread
-        const float e = err[h];
-        int rk = 0;
-        for (int f = 0; f < M; ++f) { const float o = err[f]; rk += (o < e || (o == e && f < h)) ? 1 : 0; }
-        perm[rk] = h;
-        inv[h] = rk;
+}
+
+// rank counting (ties by index) over the M distances: perm[rank] = h, inv[h] = rank
+__global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict__ err, int M, int* __restrict__ perm, int* __restrict__ inv)
+{
+    __shared__ float tile[256];
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const float e = h < M ? err[h] : 0.f;
+    int rk = 0;
+    for (int f0 = 0; f0 < M; f0 += 256) {
+        __syncthreads();
+        tile[threadIdx.x] = f0 + (int)threadIdx.x < M ? err[f0 + threadIdx.x] : 3.4e38f;
+        __syncthreads();
+        const int lim = min(256, M - f0);
+        for (int k = 0; k < lim; ++k) { const float o = tile[k]; rk += (o < e || (o == e && f0 + k < h)) ? 1 : 0; }
     }
+    if (h < M) { perm[rk] = h; inv[h] = rk; }
 }
 
 constexpr int kConsIdxBits = 9;          // low bits of a key's index word = position in the stage (kConsCap <= 512)
@@ -915,8 +923,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     };
     if (!(cx == cx) || !(cy == cy) || !(cz == cz)) { give_up(); return; }
     // ---- setup (a): the target points within D of the consensus image: as many as the stage holds ----
-    // D starts at kConsRadiusCells grid cells, doubles while the ball holds fewer than 2 K points (images that fall into
-    // empty parts of the target: their neighbours are far, and so is everything else), shrinks when it overflows the stage
+    // D starts at kConsRadiusCells grid cells and shrinks when the ball overflows the stage
     float D = kConsRadiusCells * c.cs_min;
     int n_c = 0;
     const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
@@ -951,7 +958,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
         }
         if (n_c > kConsCap) { D *= fminf(0.95f, sqrtf(0.85f * (float)kConsCap / (float)n_c)); shrunk = true; continue; }
-        if (n_c < 2 * K && n_c < Nt && !shrunk && D < 1.0e4f) { D *= 1.6f; continue; }     // (once shrunk, never grown again)
+        // (growing D for images in empty parts of the target was tried: it serves them -- 58 % -> 78 % of the queries of a
+        //  half-overlapping pair -- but their stages are full of far points and the pass got 3x slower: left to the lattice)
         break;
     }
     if (n_c < K || n_c > kConsCap) { give_up(); return; }
@@ -1088,6 +1096,144 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     if (lane == 0 && stats) atomicAdd(stats, n_served);
 }
 
+// ---- leftovers of the consensus pass -----------------------------------------------------------------------------------
+// What the consensus pass could not prove exact is ~1 % of the queries, spread thinly over most (hypothesis, chunk)
+// wavefronts (the far points of mediocre hypotheses) plus all points of the few bad ones.  Sent through the per-chunk
+// kernels they cost as much as everything (a wavefront with one live lane pays the full search).  So they are
+// COMPACTED first -- in (hypothesis, chunk, lane) order, by prefix sums, hence deterministic -- and searched 64 to a
+// wavefront on the grid; every query's term is stored and summed per hypothesis in list order.
+// If more than kLeftMax queries are left (hypotheses that do not agree, clouds that barely overlap), the candidate
+// lattice takes them instead; the choice is made on the device (header word 8) and both sets of kernels are enqueued.
+constexpr unsigned int kLeftMax = 1u << 21;
+constexpr int kScanTile = 4096;        // records per workgroup in the two-level prefix sum
+
+// records are CHUNK-major (record = chunk * M + hypothesis): the leftover queries of one chunk under different
+// hypotheses land in the same part of the target, so 64 consecutive entries of the compacted list are neighbours and
+// their lock-step grid walks share rows (hypothesis-major order -- a mediocre hypothesis' far points, spread along
+// the rim of the cloud -- measured 10x slower)
+__global__ __launch_bounds__(256) void leftover_mask_kernel(const char* __restrict__ ws_src, const unsigned long long* __restrict__ served,
+                                                            const int* __restrict__ inv, int Ns, int M, int n_chunks, int n_words,
+                                                            unsigned long long* __restrict__ masks, unsigned int* __restrict__ counts)
+{
+    const int lane = lane_id();
+    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= (long)M * n_chunks) return;
+    const int chunk = (int)(wid / M), h = (int)(wid % M);
+    const GridWs wsr = grid_ws(Ns);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const int slot = chunk * kWave + lane;
+    const int sidx = __float_as_int(S4s[slot < Ns ? slot : 0].w);
+    const int ph = inv[h];
+    const bool todo = slot < Ns && !((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull);
+    const unsigned long long b = __ballot(todo);
+    if (lane == 0) { masks[wid] = b; counts[wid] = (unsigned int)__popcll(b); }
+}
+
+// two-level exclusive prefix sum of counts[0 .. n): (1) inside tiles of kScanTile records, tile totals to tile_tot;
+// (2) one workgroup scans the tile totals into tile_base, total -> header[9], header[8] = 1 if the compacted path
+// takes the leftovers.  offset(record) = counts[record] + tile_base[record / kScanTile].
+__global__ __launch_bounds__(1024) void leftover_scan_tiles_kernel(unsigned int* __restrict__ counts, long n, unsigned int* __restrict__ tile_tot)
+{
+    __shared__ unsigned int part[1024];
+    const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * 4;
+    unsigned int v[4], s = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? counts[base + k] : 0u; s += v[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned int t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) counts[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 1023) tile_tot[blockIdx.x] = part[1023];
+}
+
+__global__ __launch_bounds__(1024) void leftover_scan_top_kernel(const unsigned int* __restrict__ tile_tot, int n_tiles,
+                                                                 unsigned int* __restrict__ tile_base, unsigned int* __restrict__ header)
+{
+    __shared__ unsigned int part[1024];
+    const int per = (n_tiles + 1023) / 1024;
+    const int a = threadIdx.x * per, b = min(a + per, n_tiles);
+    unsigned int s = 0u;
+    for (int i = a; i < b; ++i) s += tile_tot[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned int t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - s;
+    for (int i = a; i < b; ++i) { tile_base[i] = run; run += tile_tot[i]; }
+    if (threadIdx.x == 1023) { header[9] = part[1023]; header[8] = part[1023] <= kLeftMax ? 1u : 0u; }
+}
+
+__global__ __launch_bounds__(256) void leftover_list_kernel(const unsigned long long* __restrict__ masks, const unsigned int* __restrict__ offsets,
+                                                            const unsigned int* __restrict__ tile_base, int M, int n_chunks,
+                                                            const unsigned int* __restrict__ header, uint2* __restrict__ qlist)
+{
+    if (header[8] == 0u) return;
+    const int lane = lane_id();
+    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= (long)M * n_chunks) return;
+    const unsigned long long m = masks[wid];
+    if (m == 0ull) return;
+    const int chunk = (int)(wid / M), h = (int)(wid % M);
+    if ((m >> lane) & 1ull)
+        qlist[offsets[wid] + tile_base[wid / kScanTile] + (unsigned int)mbcnt(m)] = make_uint2((unsigned int)h, (unsigned int)(chunk * kWave + lane));
+}
+
+// sum of every record's terms, in lane order -> recsum[record]
+__global__ __launch_bounds__(256) void leftover_sum_kernel(const unsigned long long* __restrict__ masks, const unsigned int* __restrict__ offsets,
+                                                           const unsigned int* __restrict__ tile_base, long n_rec, const unsigned int* __restrict__ header,
+                                                           const float* __restrict__ qterm, float* __restrict__ recsum)
+{
+    if (header[8] == 0u) return;
+    const long wid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wid >= n_rec) return;
+    const int cnt = __popcll(masks[wid]);
+    const unsigned int at = offsets[wid] + tile_base[wid / kScanTile];
+    float s = 0.f;
+    for (int i = 0; i < cnt; ++i) s += qterm[at + i];
+    recsum[wid] = s;
+}
+
+template <class IdxT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void leftover_score_kernel(
+    const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+    const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt, int K, int cap, float sigma, const unsigned int* __restrict__ header,
+    const uint2* __restrict__ qlist, float* __restrict__ qterm)
+{
+    if (header[8] == 0u) return;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const unsigned int total = header[9];
+    const unsigned int i = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;
+    if ((i & ~63u) >= total) return;
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
+    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const bool valid = i < total;
+    const uint2 q = qlist[valid ? i : 0];
+    const int sidx = __float_as_int(S4s[q.y].w);
+    const float sx = src_pts[(size_t)sidx * 3], sy = src_pts[(size_t)sidx * 3 + 1], sz = src_pts[(size_t)sidx * 3 + 2];
+    const float* Th = T + (size_t)q.x * 16;
+    const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+    const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+    const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+    const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
+    const float term = score_epilogue(L.list, valid ? cnt : 0, valid, sidx, vp4, vq4, K, sigma, lane, true);
+    if (valid) qterm[i] = term;
+}
+
 // ---- lattice build ---------------------------------------------------------------------------------------------------
 // (1) lattice_mark_kernel: marks[cell] = 1 for every cell some (hypothesis, source point) query lands in (~1/4 of them);
 // (2) lattice_compact_kernel: the marked cells in ascending order (one workgroup);
@@ -1106,6 +1252,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
+    if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // the compacted path takes the leftovers
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
     unsigned char* marks = reinterpret_cast<unsigned char*>(lat + lw.off_marks);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1340,6 +1487,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         pool = reinterpret_cast<const uint2*>(lat + lw.off_pool);
         lat_header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
         queue = reinterpret_cast<uint4*>(lat + lw.total);       // fallback records follow the lattice
+        if (lat_header[8] != 0u) return;                        // the compacted path takes the leftovers
     }
 #ifdef UMEREG_KNN_DEBUG
     const long long t_start = clock64();
@@ -1634,6 +1782,7 @@ __global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restrict__ partial, int M, int n_chunks, int Ns,
                                                           const float* __restrict__ slices, int n_slices, const int* __restrict__ inv,
+                                                          const unsigned int* __restrict__ header, const float* __restrict__ recsum,
                                                           float* __restrict__ scores)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1641,7 +1790,11 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
     float s = 0.f;
     const int ph = n_slices ? inv[h] : 0;                                            // the consensus pass stores in its processing order
     for (int k = 0; k < n_slices; ++k) s += slices[(size_t)k * M + ph];          // consensus pass, in source order
-    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
+    if (header && header[8] != 0u) {                                                 // compacted leftovers: record sums, in chunk order
+        for (int k = 0; k < n_chunks; ++k) s += recsum[(size_t)k * M + h];
+    } else {
+        for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
+    }
     scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
 }
 
@@ -1748,7 +1901,10 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
     const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
     const size_t cons = consensus_on(c_max, M, flags) ? align_up((size_t)Ns * M * 4, 256) + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256) + 256 +
-                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) : 0;
+                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) +
+                                                        align_up((size_t)M * n_chunks * 8, 256) + align_up(((size_t)M * n_chunks + 1) * 4, 256) +
+                                                        (size_t)kLeftMax * 12 + 256 + align_up(((size_t)M * n_chunks / kScanTile + 2) * 8, 256) +
+                                                        align_up((size_t)M * n_chunks * 4, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
            (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
@@ -1827,6 +1983,12 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     float* slices = nullptr;
     int* perm = nullptr;
     int* inv = nullptr;
+    unsigned long long* left_masks = nullptr;
+    unsigned int* left_off = nullptr;
+    uint2* qlist = nullptr;
+    float* qterm = nullptr;
+    unsigned int* tile_tot = nullptr;
+    float* recsum = nullptr;
     unsigned long long* served = nullptr;
     if (consensus_on(c_max, M, flags, T)) {
         // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
@@ -1838,13 +2000,44 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         perm = (int*)((char*)slices + align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256));
         inv = perm + M;
         float* err = (float*)(inv + M);
+        left_masks = (unsigned long long*)((char*)perm + align_up((size_t)M * 12, 256));
+        left_off = (unsigned int*)((char*)left_masks + align_up((size_t)M * n_chunks_sz * 8, 256));
+        qlist = (uint2*)((char*)left_off + align_up(((size_t)M * n_chunks_sz + 1) * 4, 256));
+        qterm = (float*)(qlist + kLeftMax);
+        tile_tot = (unsigned int*)(qterm + kLeftMax);
+        recsum = (float*)((char*)tile_tot + align_up((size_t)(M * n_chunks_sz / kScanTile + 2) * 8, 256));
         if (hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
-        hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox), Tmed, perm, inv, err);
+        hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox), Tmed, err);
         UMEREG_CHECK_LAUNCH("hyp_median_kernel");
+        hipLaunchKernelGGL(hyp_order_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)err, M, perm, inv);
+        UMEREG_CHECK_LAUNCH("hyp_order_kernel");
         hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
                            (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, (const int*)perm,
                            Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
         UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
+        if (!(flags & 16)) {
+            // what it left: masks + counts per (hypothesis, chunk), prefix sums, and the decision who takes it (header word 8)
+            const long n_rec = (long)M * (long)n_chunks_sz;
+            hipLaunchKernelGGL(leftover_mask_kernel, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, st, (const char*)ws_src,
+                               (const unsigned long long*)served, (const int*)inv, Ns, M, (int)n_chunks_sz, n_words, left_masks, left_off);
+            UMEREG_CHECK_LAUNCH("leftover_mask_kernel");
+            const int n_tiles = (int)((n_rec + kScanTile - 1) / kScanTile);
+            hipLaunchKernelGGL(leftover_scan_tiles_kernel, dim3(n_tiles), dim3(1024), 0, st, left_off, n_rec, tile_tot);
+            UMEREG_CHECK_LAUNCH("leftover_scan_tiles_kernel");
+            hipLaunchKernelGGL(leftover_scan_top_kernel, dim3(1), dim3(1024), 0, st, (const unsigned int*)tile_tot, n_tiles, tile_tot + n_tiles, (unsigned int*)lat);
+            UMEREG_CHECK_LAUNCH("leftover_scan_top_kernel");
+            hipLaunchKernelGGL(leftover_list_kernel, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, st, (const unsigned long long*)left_masks,
+                               (const unsigned int*)left_off, (const unsigned int*)(tile_tot + n_tiles), M, (int)n_chunks_sz, (const unsigned int*)lat, qlist);
+            UMEREG_CHECK_LAUNCH("leftover_list_kernel");
+            hipLaunchKernelGGL(leftover_score_kernel<unsigned short>, dim3(kLeftMax / (2 * kWave)), dim3(2 * kWave), lds, st, (const char*)ws_tgt,
+                               (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, cap, sigma,
+                               (const unsigned int*)lat, (const uint2*)qlist, qterm);
+            UMEREG_CHECK_LAUNCH("leftover_score_kernel");
+            hipLaunchKernelGGL(leftover_sum_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, (const unsigned long long*)left_masks,
+                               (const unsigned int*)left_off, (const unsigned int*)(tile_tot + n_tiles), n_rec, (const unsigned int*)lat,
+                               (const float*)qterm, recsum);
+            UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
+        }
     }
     const bool leftovers_grid = served && (flags & 16);
     if (c_max && !leftovers_grid) {
@@ -1903,7 +2096,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, slices);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
     }
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv, scores);
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
+                       (const unsigned int*)(served && !(flags & 16) ? lat : nullptr), (const float*)recsum, scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
     return UMEREG_OK;
 }
