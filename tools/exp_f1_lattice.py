@@ -31,7 +31,7 @@ for name, gen in (("plain", synth_pair), ("hard", synth_pair_hard), ("plain-rot"
     si, ti = t(rs.choice(50000, 10000, replace=False)), t(rs.choice(50000, 10000, replace=False))
     a, b, fa, fb = sp[0, si].contiguous(), tp[0, ti].contiguous(), sf[0, si].contiguous(), tf[0, ti].contiguous()
     res = {}
-    for tag, flags in (("grid", ops.CORR_NO_LATTICE), ("lattice", ops.CORR_NO_CONSENSUS), ("consensus", 0), ("cons+grid", 16)):
+    for tag, flags in (("grid", ops.CORR_NO_LATTICE), ("lattice", ops.CORR_NO_CONSENSUS), ("cons+grid", 16), ("consensus", 0)):
         sc = ops.corr_scores(a, b, fa, fb, T, K=20, sigma=1.5, flags=flags)
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -46,6 +46,6 @@ for name, gen in (("plain", synth_pair), ("hard", synth_pair_hard), ("plain-rot"
     M, Ns, Nt = T.shape[0], a.shape[0], b.shape[0]
     off = lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, ops.CORR_NO_LATTICE)
     ws = ops._workspace(dev, lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, 0), "corr")
-    hdr = ws[off:off + 48].view(torch.int32).cpu().numpy()
+    hdr = ws[off:off + 64].view(torch.int32).cpu().numpy()
     print(f"{name}: grid {res['grid'][1]:.2f} ms  lattice {res['lattice'][1]:.2f} ms  consensus+lattice {res['consensus'][1]:.2f} ms  consensus+grid {res['cons+grid'][1]:.2f} ms (max |d| {np.abs(g - res['cons+grid'][0]).max():.3g}) | max |d| {np.abs(g - l).max():.3g} / {np.abs(g - cns).max():.3g} of {np.abs(g).max():.3g}"
-          f" argmax {int(g.argmax())}/{int(l.argmax())}/{int(cns.argmax())} | served {hdr[7]} of {M * Ns}, leftovers {hdr[9]} -> {('lattice', 'compacted grid')[int(hdr[8] != 0)]} | pool quads {hdr[0]} cells {hdr[1]} marked {hdr[3]} marked w/o list {hdr[2]} fb records {hdr[4]} fb queries {hdr[6]}", flush=True)
+          f" argmax {int(g.argmax())}/{int(l.argmax())}/{int(cns.argmax())} | served {hdr[7]} of {M * Ns}, leftovers {hdr[9]} -> {('lattice', 'grid')[int(hdr[8] != 0)]} | pool quads {hdr[0]} cells {hdr[1]} marked {hdr[3]} marked w/o list {hdr[2]} fb records {hdr[4]} fb queries {hdr[6]} | grid leftover records {hdr[10]} sum kclk {hdr[11]} max {hdr[12]} >100k {hdr[13]} >1M {hdr[14]} lanes {hdr[15]}", flush=True)

@@ -10,4 +10,4 @@ for r in list(csv.DictReader(open(sys.argv[1])))[:10]:
     print(r["Name"][:64], r["Calls"], "avg %.3f min %.3f max %.3f ms" % (float(r["AverageNs"])/1e6, float(r["MinNs"])/1e6, float(r["MaxNs"])/1e6), r["Percentage"])
 EOF
 rm -rf $R/gpurun_out/f1lat
-grep "^plain\|^hard" $R/gpurun_out/f1lat.log | cut -c1-250
+grep "^plain\|^hard" $R/gpurun_out/f1lat.log | cut -c1-700

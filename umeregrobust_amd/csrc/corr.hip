@@ -33,6 +33,7 @@ namespace umereg {
 #ifndef UMEREG_F1_ABLATE
 #define UMEREG_F1_ABLATE 0   // timing experiments only (tools/exp_f1_ablate.sh): 1 skip epilogue, 2 skip append, 4 skip histogram, 8 skip grid fallback
 #endif
+constexpr float kFarCells = 0.75f;    // "far outside the target": distance to its bounding box, in grid cells
 constexpr int kBins = 32;
 constexpr float kKnnMaxCells = 6.0f;   // upper bound of the first search radius, in cells
 constexpr float kKnnTarget = 4.0f;     // expected points in the first search ball, in units of K
@@ -1096,142 +1097,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     if (lane == 0 && stats) atomicAdd(stats, n_served);
 }
 
-// ---- leftovers of the consensus pass -----------------------------------------------------------------------------------
-// What the consensus pass could not prove exact is ~1 % of the queries, spread thinly over most (hypothesis, chunk)
-// wavefronts (the far points of mediocre hypotheses) plus all points of the few bad ones.  Sent through the per-chunk
-// kernels they cost as much as everything (a wavefront with one live lane pays the full search).  So they are
-// COMPACTED first -- in (hypothesis, chunk, lane) order, by prefix sums, hence deterministic -- and searched 64 to a
-// wavefront on the grid; every query's term is stored and summed per hypothesis in list order.
-// If more than kLeftMax queries are left (hypotheses that do not agree, clouds that barely overlap), the candidate
-// lattice takes them instead; the choice is made on the device (header word 8) and both sets of kernels are enqueued.
+constexpr int kCoopCap = 256;       // cooperative key list (keys)
+constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
+
+// keep the K smallest of list[0 .. cnt) (cnt <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
+__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
+{
+    unsigned long long mine[kCoopCap / kWave];
+    int rank[kCoopCap / kWave];
+#pragma unroll
+    for (int u = 0; u < kCoopCap / kWave; ++u) {
+        mine[u] = u * kWave + lane < cnt ? list[u * kWave + lane] : ~0ull;
+        rank[u] = 0;
+    }
+    for (int f = 0; f < cnt; ++f) {
+        const unsigned long long k = list[f];               // same address in every lane: one broadcast read
+#pragma unroll
+        for (int u = 0; u < kCoopCap / kWave; ++u) rank[u] += k < mine[u] ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int u = 0; u < kCoopCap / kWave; ++u)
+        if (u * kWave + lane < cnt && rank[u] < K) out[rank[u]] = mine[u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return cnt < K ? cnt : K;
+}
+
+// who takes what the consensus pass left (header word 8): 1 = the grid kernel (few leftovers: they sit in a few
+// thousand (hypothesis, chunk) wavefronts), 0 = the candidate lattice (many: hypotheses that do not agree, clouds that
+// barely overlap -- queries in empty parts of the target, where lists pay off).  Both sets of kernels are enqueued;
+// the ones not chosen return at once.
 constexpr unsigned int kLeftMax = 1u << 21;
-constexpr int kScanTile = 4096;        // records per workgroup in the two-level prefix sum
-
-// records are CHUNK-major (record = chunk * M + hypothesis): the leftover queries of one chunk under different
-// hypotheses land in the same part of the target, so 64 consecutive entries of the compacted list are neighbours and
-// their lock-step grid walks share rows (hypothesis-major order -- a mediocre hypothesis' far points, spread along
-// the rim of the cloud -- measured 10x slower)
-__global__ __launch_bounds__(256) void leftover_mask_kernel(const char* __restrict__ ws_src, const unsigned long long* __restrict__ served,
-                                                            const int* __restrict__ inv, int Ns, int M, int n_chunks, int n_words,
-                                                            unsigned long long* __restrict__ masks, unsigned int* __restrict__ counts)
+__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries)
 {
-    const int lane = lane_id();
-    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid >= (long)M * n_chunks) return;
-    const int chunk = (int)(wid / M), h = (int)(wid % M);
-    const GridWs wsr = grid_ws(Ns);
-    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
-    const int slot = chunk * kWave + lane;
-    const int sidx = __float_as_int(S4s[slot < Ns ? slot : 0].w);
-    const int ph = inv[h];
-    const bool todo = slot < Ns && !((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull);
-    const unsigned long long b = __ballot(todo);
-    if (lane == 0) { masks[wid] = b; counts[wid] = (unsigned int)__popcll(b); }
-}
-
-// two-level exclusive prefix sum of counts[0 .. n): (1) inside tiles of kScanTile records, tile totals to tile_tot;
-// (2) one workgroup scans the tile totals into tile_base, total -> header[9], header[8] = 1 if the compacted path
-// takes the leftovers.  offset(record) = counts[record] + tile_base[record / kScanTile].
-__global__ __launch_bounds__(1024) void leftover_scan_tiles_kernel(unsigned int* __restrict__ counts, long n, unsigned int* __restrict__ tile_tot)
-{
-    __shared__ unsigned int part[1024];
-    const long base = (long)blockIdx.x * kScanTile + (long)threadIdx.x * 4;
-    unsigned int v[4], s = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? counts[base + k] : 0u; s += v[k]; }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned int t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    unsigned int run = part[threadIdx.x] - s;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < n) counts[base + k] = run; run += v[k]; }
-    if (threadIdx.x == 1023) tile_tot[blockIdx.x] = part[1023];
-}
-
-__global__ __launch_bounds__(1024) void leftover_scan_top_kernel(const unsigned int* __restrict__ tile_tot, int n_tiles,
-                                                                 unsigned int* __restrict__ tile_base, unsigned int* __restrict__ header)
-{
-    __shared__ unsigned int part[1024];
-    const int per = (n_tiles + 1023) / 1024;
-    const int a = threadIdx.x * per, b = min(a + per, n_tiles);
-    unsigned int s = 0u;
-    for (int i = a; i < b; ++i) s += tile_tot[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned int t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    unsigned int run = part[threadIdx.x] - s;
-    for (int i = a; i < b; ++i) { tile_base[i] = run; run += tile_tot[i]; }
-    if (threadIdx.x == 1023) { header[9] = part[1023]; header[8] = part[1023] <= kLeftMax ? 1u : 0u; }
-}
-
-__global__ __launch_bounds__(256) void leftover_list_kernel(const unsigned long long* __restrict__ masks, const unsigned int* __restrict__ offsets,
-                                                            const unsigned int* __restrict__ tile_base, int M, int n_chunks,
-                                                            const unsigned int* __restrict__ header, uint2* __restrict__ qlist)
-{
-    if (header[8] == 0u) return;
-    const int lane = lane_id();
-    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid >= (long)M * n_chunks) return;
-    const unsigned long long m = masks[wid];
-    if (m == 0ull) return;
-    const int chunk = (int)(wid / M), h = (int)(wid % M);
-    if ((m >> lane) & 1ull)
-        qlist[offsets[wid] + tile_base[wid / kScanTile] + (unsigned int)mbcnt(m)] = make_uint2((unsigned int)h, (unsigned int)(chunk * kWave + lane));
-}
-
-// sum of every record's terms, in lane order -> recsum[record]
-__global__ __launch_bounds__(256) void leftover_sum_kernel(const unsigned long long* __restrict__ masks, const unsigned int* __restrict__ offsets,
-                                                           const unsigned int* __restrict__ tile_base, long n_rec, const unsigned int* __restrict__ header,
-                                                           const float* __restrict__ qterm, float* __restrict__ recsum)
-{
-    if (header[8] == 0u) return;
-    const long wid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wid >= n_rec) return;
-    const int cnt = __popcll(masks[wid]);
-    const unsigned int at = offsets[wid] + tile_base[wid / kScanTile];
-    float s = 0.f;
-    for (int i = 0; i < cnt; ++i) s += qterm[at + i];
-    recsum[wid] = s;
-}
-
-template <class IdxT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void leftover_score_kernel(
-    const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float4* __restrict__ vp4,
-    const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt, int K, int cap, float sigma, const unsigned int* __restrict__ header,
-    const uint2* __restrict__ qlist, float* __restrict__ qterm)
-{
-    if (header[8] == 0u) return;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = lane_id();
-    const unsigned int total = header[9];
-    const unsigned int i = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave + lane;
-    if ((i & ~63u) >= total) return;
-    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
-    const KnnLds<IdxT> L = carve_lds<IdxT>(lds, wave, cap);
-    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
-    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
-    const bool valid = i < total;
-    const uint2 q = qlist[valid ? i : 0];
-    const int sidx = __float_as_int(S4s[q.y].w);
-    const float sx = src_pts[(size_t)sidx * 3], sy = src_pts[(size_t)sidx * 3 + 1], sz = src_pts[(size_t)sidx * 3 + 2];
-    const float* Th = T + (size_t)q.x * 16;
-    const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
-    const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
-    const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-    const int cnt = knn_wave(c, qx, qy, qz, valid, K, cap, L.hist, L.list, lane);
-    const float term = score_epilogue(L.list, valid ? cnt : 0, valid, sidx, vp4, vq4, K, sigma, lane, true);
-    if (valid) qterm[i] = term;
+    const long left = n_queries - (long)header[7];
+    header[9] = (unsigned int)(left < 0xffffffffl ? left : 0xffffffffl);
+    header[8] = left <= (long)kLeftMax ? 1u : 0u;
 }
 
 // ---- lattice build ---------------------------------------------------------------------------------------------------
@@ -1480,6 +1381,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint2* pool = nullptr;
     unsigned int* lat_header = nullptr;
     uint4* queue = nullptr;
+    // the grid kernel as the taker of the consensus pass's leftovers: header + record queue of the (unused) lattice
+    unsigned int* gq_header = nullptr;
+    uint4* gqueue = nullptr;
+    if (!LAT && lat) {
+        gq_header = reinterpret_cast<unsigned int*>(lat);
+        if (gq_header[8] == 0u) return;                         // the lattice takes the leftovers
+        gqueue = reinterpret_cast<uint4*>(lat + lat_ws(c_max).total);
+    }
     if (LAT) {
         const LatWs lw = lat_ws(c_max);
         Lt = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
@@ -1516,14 +1425,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qy = fmaf(Th[6], sp.z, fmaf(Th[5], sp.y, Th[4] * sp.x)) + Th[7];
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
         int cnt;
-        bool fb_lanes = false;
+        unsigned long long __ballot_all_todo = 0ull;
         // queries the consensus pass has already scored are not this kernel's business
         const int ph = served ? inv[h] : 0;       // position of the hypothesis in the consensus pass's processing order
         const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull));
+        bool fb_lanes = false, far_rec = false, near_q = todo_q;
         if (!__any(todo_q)) {
             if (lane == 0) partial[(size_t)h * n_chunks + chunk] = 0.f;
             continue;
         }
+
         if (LAT) {
             // the query's cell of the candidate lattice; lanes without a list (outside the lattice, oversized or
             // unplaced list) are left to corr_score_fallback_kernel
@@ -1581,8 +1492,33 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             KNN_DBG(8, __popcll(__ballot(fb_lanes)));
             cnt = got ? cnt : 0;
         } else {
-            cnt = knn_wave(c, qx, qy, qz, todo_q, K, cap, L.hist, L.list, lane);
-            cnt = todo_q ? cnt : 0;
+            // records whose live lanes ALL lie further than kFarCells grid cells outside the target's bounding box (the
+            // chunks of a hypothesis that throws the cloud somewhere else) are not searched here: a per-lane grid search
+            // needs caps of hundreds of candidates and several radius-growing rounds for them -- such wavefronts ran for
+            // 4 ms (8 M clocks) and set the kernel time.  They are queued for corr_score_fallback_kernel.
+            if (gqueue) {
+                const Grid& g = c.g;
+                const float ox = fmaxf(fmaxf(g.minx - qx, qx - (g.minx + (float)g.nx / g.invx)), 0.f);
+                const float oy = fmaxf(fmaxf(g.miny - qy, qy - (g.miny + (float)g.ny / g.invy)), 0.f);
+                const float oz = fmaxf(fmaxf(g.minz - qz, qz - (g.minz + (float)g.nz / g.invz)), 0.f);
+                const bool lane_far = ox * ox + oy * oy + oz * oz > kFarCells * kFarCells * c.cs_min * c.cs_min;
+                // (NaN images compare false: not far, the grid search copes)
+                __ballot_all_todo = __ballot(todo_q && lane_far);    // these lanes go to corr_score_fallback_kernel
+                far_rec = __ballot_all_todo != 0ull;
+                near_q = todo_q && !lane_far;
+            }
+            const long long t_k = gqueue ? clock64() : 0;
+            cnt = __any(near_q) ? knn_wave(c, qx, qy, qz, near_q, K, cap, L.hist, L.list, lane) : 0;
+            cnt = near_q ? cnt : 0;
+            if (gqueue && __any(near_q) && lane == 0) {     // statistics (header words 10..15)
+                const unsigned int kc = (unsigned int)((clock64() - t_k) >> 10);
+                atomicAdd(&gq_header[10], 1u);
+                atomicAdd(&gq_header[11], kc);
+                atomicMax(&gq_header[12], kc);
+                if (kc > 100u) atomicAdd(&gq_header[13], 1u);
+                if (kc > 1000u) atomicAdd(&gq_header[14], 1u);
+                atomicAdd(&gq_header[15], (unsigned int)__popcll(__ballot_all_todo));
+            }
         }
         const float acc = score_epilogue(L.list, cnt, valid, sidx, vp4, vq4, K, sigma, lane);
         if (LAT) {
@@ -1598,7 +1534,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         } else {
-            if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
+            if (lane == 0) {
+                partial[(size_t)h * n_chunks + chunk] = acc;
+                if (far_rec) {                                  // the whole record goes to corr_score_fallback_kernel
+                    const unsigned long long todo = __ballot_all_todo;
+                    atomicAdd(&gq_header[6], (unsigned int)__popcll(todo));
+                    const unsigned int r = atomicAdd(&gq_header[4], 1u);
+                    gqueue[r] = make_uint4((unsigned int)h, (unsigned int)chunk, (unsigned int)todo, (unsigned int)(todo >> 32));
+                }
+            }
         }
     }
 #ifdef UMEREG_KNN_DEBUG
@@ -1627,32 +1571,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //     are unique, so ranks are a permutation) and the bound drops to the K-th key;
 //   * score: the K keys of the final cut, 8 lanes per neighbour's feature row.
 // The record's sum is formed by wavefront 0 from the per-query values in lane order: deterministic.
-constexpr int kCoopCap = 256;       // cooperative key list (keys)
-constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
 constexpr int kCoopWaves = 8;       // wavefronts per record
-
-// keep the K smallest of list[0 .. cnt) (cnt <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
-__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
-{
-    unsigned long long mine[kCoopCap / kWave];
-    int rank[kCoopCap / kWave];
-#pragma unroll
-    for (int u = 0; u < kCoopCap / kWave; ++u) {
-        mine[u] = u * kWave + lane < cnt ? list[u * kWave + lane] : ~0ull;
-        rank[u] = 0;
-    }
-    for (int f = 0; f < cnt; ++f) {
-        const unsigned long long k = list[f];               // same address in every lane: one broadcast read
-#pragma unroll
-        for (int u = 0; u < kCoopCap / kWave; ++u) rank[u] += k < mine[u] ? 1 : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int u = 0; u < kCoopCap / kWave; ++u)
-        if (u * kWave + lane < cnt && rank[u] < K) out[rank[u]] = mine[u];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return cnt < K ? cnt : K;
-}
 
 __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                   const float* __restrict__ src_pts, const float4* __restrict__ vp4,
@@ -1782,7 +1701,6 @@ __global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restrict__ partial, int M, int n_chunks, int Ns,
                                                           const float* __restrict__ slices, int n_slices, const int* __restrict__ inv,
-                                                          const unsigned int* __restrict__ header, const float* __restrict__ recsum,
                                                           float* __restrict__ scores)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1790,11 +1708,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
     float s = 0.f;
     const int ph = n_slices ? inv[h] : 0;                                            // the consensus pass stores in its processing order
     for (int k = 0; k < n_slices; ++k) s += slices[(size_t)k * M + ph];          // consensus pass, in source order
-    if (header && header[8] != 0u) {                                                 // compacted leftovers: record sums, in chunk order
-        for (int k = 0; k < n_chunks; ++k) s += recsum[(size_t)k * M + h];
-    } else {
-        for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
-    }
+    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
     scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
 }
 
@@ -1901,10 +1815,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
     const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
     const size_t cons = consensus_on(c_max, M, flags) ? align_up((size_t)Ns * M * 4, 256) + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256) + 256 +
-                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) +
-                                                        align_up((size_t)M * n_chunks * 8, 256) + align_up(((size_t)M * n_chunks + 1) * 4, 256) +
-                                                        (size_t)kLeftMax * 12 + 256 + align_up(((size_t)M * n_chunks / kScanTile + 2) * 8, 256) +
-                                                        align_up((size_t)M * n_chunks * 4, 256) : 0;
+                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
            (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
@@ -1979,17 +1890,17 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     bool idx16;
     knn_lds_plan(K, Nt, &cap, &waves, &lds, 2, &idx16);
     const int n_words = (M + 63) / 64;
+    const int n_chunks = (Ns + kWave - 1) / kWave;
+    const int hyp_per_wave = 2;   // 1..4 measured equal (6.4 us per hypothesis), 8: 6.7, 16: 7.3 (balance at the tail, parallelism)
+    const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
+    const long n_waves = (long)n_chunks * n_hg;
+    const dim3 score_grid((unsigned)((n_waves + waves - 1) / waves)), score_block(waves * kWave);
     float* val = nullptr;
     float* slices = nullptr;
     int* perm = nullptr;
     int* inv = nullptr;
-    unsigned long long* left_masks = nullptr;
-    unsigned int* left_off = nullptr;
-    uint2* qlist = nullptr;
-    float* qterm = nullptr;
-    unsigned int* tile_tot = nullptr;
-    float* recsum = nullptr;
     unsigned long long* served = nullptr;
+    if (c_max && hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
     if (consensus_on(c_max, M, flags, T)) {
         // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
         char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256);
@@ -2000,13 +1911,6 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         perm = (int*)((char*)slices + align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256));
         inv = perm + M;
         float* err = (float*)(inv + M);
-        left_masks = (unsigned long long*)((char*)perm + align_up((size_t)M * 12, 256));
-        left_off = (unsigned int*)((char*)left_masks + align_up((size_t)M * n_chunks_sz * 8, 256));
-        qlist = (uint2*)((char*)left_off + align_up(((size_t)M * n_chunks_sz + 1) * 4, 256));
-        qterm = (float*)(qlist + kLeftMax);
-        tile_tot = (unsigned int*)(qterm + kLeftMax);
-        recsum = (float*)((char*)tile_tot + align_up((size_t)(M * n_chunks_sz / kScanTile + 2) * 8, 256));
-        if (hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
         hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox), Tmed, err);
         UMEREG_CHECK_LAUNCH("hyp_median_kernel");
         hipLaunchKernelGGL(hyp_order_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)err, M, perm, inv);
@@ -2015,36 +1919,19 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                            (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, (const int*)perm,
                            Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
         UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
-        if (!(flags & 16)) {
-            // what it left: masks + counts per (hypothesis, chunk), prefix sums, and the decision who takes it (header word 8)
-            const long n_rec = (long)M * (long)n_chunks_sz;
-            hipLaunchKernelGGL(leftover_mask_kernel, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, st, (const char*)ws_src,
-                               (const unsigned long long*)served, (const int*)inv, Ns, M, (int)n_chunks_sz, n_words, left_masks, left_off);
-            UMEREG_CHECK_LAUNCH("leftover_mask_kernel");
-            const int n_tiles = (int)((n_rec + kScanTile - 1) / kScanTile);
-            hipLaunchKernelGGL(leftover_scan_tiles_kernel, dim3(n_tiles), dim3(1024), 0, st, left_off, n_rec, tile_tot);
-            UMEREG_CHECK_LAUNCH("leftover_scan_tiles_kernel");
-            hipLaunchKernelGGL(leftover_scan_top_kernel, dim3(1), dim3(1024), 0, st, (const unsigned int*)tile_tot, n_tiles, tile_tot + n_tiles, (unsigned int*)lat);
-            UMEREG_CHECK_LAUNCH("leftover_scan_top_kernel");
-            hipLaunchKernelGGL(leftover_list_kernel, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, st, (const unsigned long long*)left_masks,
-                               (const unsigned int*)left_off, (const unsigned int*)(tile_tot + n_tiles), M, (int)n_chunks_sz, (const unsigned int*)lat, qlist);
-            UMEREG_CHECK_LAUNCH("leftover_list_kernel");
-            hipLaunchKernelGGL(leftover_score_kernel<unsigned short>, dim3(kLeftMax / (2 * kWave)), dim3(2 * kWave), lds, st, (const char*)ws_tgt,
-                               (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, cap, sigma,
-                               (const unsigned int*)lat, (const uint2*)qlist, qterm);
-            UMEREG_CHECK_LAUNCH("leftover_score_kernel");
-            hipLaunchKernelGGL(leftover_sum_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, (const unsigned long long*)left_masks,
-                               (const unsigned int*)left_off, (const unsigned int*)(tile_tot + n_tiles), n_rec, (const unsigned int*)lat,
-                               (const float*)qterm, recsum);
-            UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
-        }
+        // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
+        hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns);
+        UMEREG_CHECK_LAUNCH("leftover_decide_kernel");
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
+                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
+                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
+        UMEREG_CHECK_LAUNCH("corr_score_kernel");
     }
-    const bool leftovers_grid = served && (flags & 16);
-    if (c_max && !leftovers_grid) {
-        // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> count -> scan -> fill
+    if (c_max) {
+        // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> compact -> count -> scan -> fill
+        // (with a consensus pass in front, every one of these kernels returns at once unless header word 8 says "lattice")
         const LatWs lw = lat_ws(c_max);
-        // (header word 7 = queries served by the consensus pass survives: the memset starts behind the header when it ran)
-        if (hipMemsetAsync(lat + (served ? 256 : 0), 0, lw.off_wave_tot - (served ? 256 : 0), st) != hipSuccess) { set_error("hipMemsetAsync(lattice header + marks) failed"); return UMEREG_ELAUNCH; }
+        if (hipMemsetAsync(lat + 256, 0, lw.off_wave_tot - 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice marks) failed"); return UMEREG_ELAUNCH; }
         const int hpt = 16;
         hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
                            Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
@@ -2064,40 +1951,33 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
         hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
-    }
-    const int n_chunks = (Ns + kWave - 1) / kWave;
-    const int hyp_per_wave = 2;   // 1..4 measured equal (6.4 us per hypothesis), 8: 6.7, 16: 7.3 (balance at the tail, parallelism)
-    const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
-    const long n_waves = (long)n_chunks * n_hg;
-    if (leftovers_grid) {
-        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
-                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)served, n_words, (const int*)inv);
-    } else if (c_max) {
-        hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
-                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
+                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
+                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
-        if (!(UMEREG_F1_ABLATE & 16))
+        // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);
-    } else if (idx16)
-        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
-                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0, (const int*)nullptr);
-    else
-        hipLaunchKernelGGL((corr_score_kernel<unsigned int, false>), dim3((unsigned)((n_waves + waves - 1) / waves)), dim3(waves * kWave),
-                           lds, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T,
-                           Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial, (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0, (const int*)nullptr);
-    UMEREG_CHECK_LAUNCH("corr_score_kernel");
+        UMEREG_CHECK_LAUNCH("corr_score_fallback_kernel");
+    } else if (idx16) {
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
+                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
+                           (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0, (const int*)nullptr);
+        UMEREG_CHECK_LAUNCH("corr_score_kernel");
+    } else {
+        hipLaunchKernelGGL((corr_score_kernel<unsigned int, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
+                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
+                           (char*)nullptr, 0u, (const unsigned long long*)nullptr, 0, (const int*)nullptr);
+        UMEREG_CHECK_LAUNCH("corr_score_kernel");
+    }
     const int n_slices = val ? (Ns + kValSlice - 1) / kValSlice : 0;
     if (val) {
         hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, slices);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
     }
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
-                       (const unsigned int*)(served && !(flags & 16) ? lat : nullptr), (const float*)recsum, scores);
+                       scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
     return UMEREG_OK;
 }
