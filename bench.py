@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
     ap.add_argument("--dist-backend", default=None, help="(testing) torch.distributed backend override, e.g. gloo")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="(testing) create the process group and run every collective even for a world of 1 (RCCL on one GPU)")
     ap.add_argument("--force-device", type=int, default=None,
                     help="(testing) put every rank on this device index, to exercise the N>1 path on a 1-GPU box")
     ap.add_argument("--e2e-pairs", type=int, default=32, help="pairs per GPU in the end-to-end leg (0 = skip)")
@@ -89,7 +91,8 @@ def main():
     ops.DEFAULT_MATCH_PRECISION = a.precision
     if a.force_device is not None:
         os.environ["LOCAL_RANK"] = str(a.force_device)
-    rank, local_rank, world = init_distributed(backend=a.dist_backend)
+    rank, local_rank, world = init_distributed(backend=a.dist_backend, force=a.force_dist)
+    collective = world > 1 or a.force_dist
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     umeregrobust_amd.require_native()
@@ -165,7 +168,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +182,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     counts = torch.stack(counts).sum(0).double()
-    if world > 1:
+    if collective:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -315,7 +318,7 @@ def main():
         sums = torch.stack([rre.sum(), rte.sum()])
         stage = torch.tensor([[s[k].elapsed_time(s[k + 1]) for k in range(3)] for s in ev], dtype=torch.float64).sum(0).to(dev)
         f1ms = torch.tensor([sum(s_.elapsed_time(e_) for s_, e_ in sel_timing)], dtype=torch.float64, device=dev)
-        if world > 1:
+        if collective:
             tm = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             el = float(tm.item())
@@ -389,7 +392,7 @@ def main():
         result["cpu_baseline"]["rr_check"] = rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

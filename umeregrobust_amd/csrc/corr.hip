@@ -226,8 +226,9 @@ __device__ __forceinline__ void refine_loop(Walk&& walk, LaneSel& S, bool& done,
         if (!__any(active && S.nlev > 1)) {
             // common case, every lane still at level 0 (lo = 0): one multiply, one conversion, one LDS add
             // branch-free: rejected candidates (and the 3e38 padding: inf -> saturated conversion -> last bin) add 0
+            // (level 0 covers [lo0, hi0); lo0 is 0 except where the caller knows a lower bound of every candidate's d2)
             walk(active, S.hi0, [&](float d2, const float4&, int, bool in_run) {
-                const int b = min((int)(d2 * S.sc[0]), kBins - 1);
+                const int b = min((int)((d2 - S.lo[0]) * S.sc[0]), kBins - 1);
                 atomicAdd(&hist[b * kWave + lane], in_run && d2 < S.hi0 ? 1u : 0u);   // lane-private counter (ds_add_u32)
             });
         } else {
@@ -287,7 +288,7 @@ __device__ __forceinline__ int append_pass(Walk&& walk, const LaneSel& S, bool a
 {
     int cnt = 0;
     unsigned long long ukey = ~0ull;   // extra admission bound, set if a list ever overflows
-    const float r2_app = S.bs[0] >= kBins - 1 ? S.hi0 : fminf(S.hi0, ((float)(S.bs[0] + 1) / S.sc[0]) * 1.0001f + 1e-30f);
+    const float r2_app = S.bs[0] >= kBins - 1 ? S.hi0 : fminf(S.hi0, (S.lo[0] + (float)(S.bs[0] + 1) / S.sc[0]) * 1.0001f + 1e-30f);
     auto admit = [&](bool ok, float d2, int oi) __attribute__((always_inline)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)oi;
         ok = ok && key < ukey;
@@ -312,7 +313,7 @@ __device__ __forceinline__ int append_pass(Walk&& walk, const LaneSel& S, bool a
         // At level 0 the histogram pass has already established that at most `cap` candidates pass this test
         // (same arithmetic, same candidates), so the list cannot overflow: plain masked stores, no branches.
         walk(act, r2_app, [&](float d2, const float4& p, int, bool in_run) {
-            const bool ok = in_run && d2 < S.hi0 && (d2 * S.sc[0] < thr || S.bs[0] >= kBins - 1) && cnt < cap;
+            const bool ok = in_run && d2 < S.hi0 && ((d2 - S.lo[0]) * S.sc[0] < thr || S.bs[0] >= kBins - 1) && cnt < cap;
             if (ok) list.set(cnt, lane, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(p.w));
             cnt += ok ? 1 : 0;
         });
@@ -882,6 +883,37 @@ __global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict_
     if (h < M) { perm[rk] = h; inv[h] = rk; }
 }
 
+constexpr int kCoopCap = 256;       // cooperative key list (keys)
+constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
+
+// keep the K smallest of list[0 .. cnt) (cnt <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
+__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
+{
+    unsigned long long mine[kCoopCap / kWave];
+    int rank[kCoopCap / kWave];
+#pragma unroll
+    for (int u = 0; u < kCoopCap / kWave; ++u) {
+        mine[u] = u * kWave + lane < cnt ? list[u * kWave + lane] : ~0ull;
+        rank[u] = 0;
+    }
+    for (int f = 0; f < cnt; ++f) {
+        const unsigned long long k = list[f];               // same address in every lane: one broadcast read
+#pragma unroll
+        for (int u = 0; u < kCoopCap / kWave; ++u) rank[u] += k < mine[u] ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int u = 0; u < kCoopCap / kWave; ++u)
+        if (u * kWave + lane < cnt && rank[u] < K) out[rank[u]] = mine[u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return cnt < K ? cnt : K;
+}
+
+// images in empty parts of the target (partly overlapping clouds): served with D = d_K + margin (78 % -> 91 % of the queries of a
+// half-overlapping pair), but their steps are so much heavier that the pass gets slower than the lattice it relieves
+// (15 ms vs 7.5 ms): off, such source points are left to the lattice
+constexpr bool kConsSparse = false;
+constexpr float kConsSparseMargin = 1.6f; // D = d_K + this many grid cells
 constexpr int kConsIdxBits = 9;          // low bits of a key's index word = position in the stage (kConsCap <= 512)
 
 __host__ __device__ constexpr size_t cons_lds_per_wave(int cap)
@@ -928,7 +960,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     float D = kConsRadiusCells * c.cs_min;
     int n_c = 0;
     const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
-    bool shrunk = false;
+    bool shrunk = false, sparse_done = false;
     for (int attempt = 0; attempt < 10; ++attempt) {
         const float D2 = D * D, rq = D * 1.0001f + 1e-20f;
         const int ylo = cell_axis(cy - rq, g.miny, g.invy, g.ny), yhi = cell_axis(cy + rq, g.miny, g.invy, g.ny);
@@ -959,8 +991,47 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
         }
         if (n_c > kConsCap) { D *= fminf(0.95f, sqrtf(0.85f * (float)kConsCap / (float)n_c)); shrunk = true; continue; }
-        // (growing D for images in empty parts of the target was tried: it serves them -- 58 % -> 78 % of the queries of a
-        //  half-overlapping pair -- but their stages are full of far points and the pass got 3x slower: left to the lattice)
+        if (kConsSparse && n_c < K + 4 && !shrunk && !sparse_done && Nt >= kWave * kCoopSamples) {
+            // the image lies in an empty part of the target (clouds that overlap partly: ~40 % of the source points): its
+            // neighbours are far, but all agreeing hypotheses still share them.  Exact d_K by one cooperative scan of the
+            // table (64 points per step, sampled bound, rank-counting cuts), then D = d_K + kConsSparseMargin cells.
+            // (Doubling D until the ball held 2 K points was tried first: it overshoots into the dense part of the cloud --
+            // full stages, 3x the kernel time.)
+            sparse_done = true;
+            unsigned long long* la = reinterpret_cast<unsigned long long*>(my);
+            unsigned long long* lb = la + kCoopCap;
+            auto d2c = [&](const float4& p) __attribute__((always_inline)) { const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z; return dx * dx + dy * dy + dz * dz; };
+            unsigned long long ukey = ~0ull;
+            {
+                const int step = Nt / (kWave * kCoopSamples);
+                float m = 3.0e38f;
+                for (int sm = 0; sm < kCoopSamples; ++sm) m = fminf(m, d2c(c.P4s[(sm * kWave + lane) * step]));
+                int rk = 0;
+                for (int f = 0; f < kWave; ++f) { const float o = __shfl(m, f, kWave); rk += (o < m || (o == m && f < lane)) ? 1 : 0; }
+                const unsigned long long kth = __ballot(rk == K - 1);
+                if (kth != 0ull) ukey = ((unsigned long long)__float_as_uint(__shfl(m, __ffsll((long long)kth) - 1, kWave)) << 32) | 0xffffffffull;
+            }
+            int kc = 0;
+            for (int base = 0; base < Nt; base += kWave) {
+                if (kc + kWave > kCoopCap) {
+                    kc = coop_cut(la, lb, kc, K, lane);
+                    unsigned long long* t_ = la; la = lb; lb = t_;
+                    if (kc == K) ukey = la[K - 1];
+                }
+                const int j = base + lane;
+                const float4 p = c.P4s[j];                          // (padded table: reading past Nt is safe)
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2c(p)) << 32) | (unsigned int)__float_as_int(p.w);
+                const bool okk = j < Nt && key <= ukey;
+                const unsigned long long bb = __ballot(okk);
+                if (okk) la[kc + mbcnt(bb)] = key;
+                kc += __popcll(bb);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            kc = coop_cut(la, lb, kc, K, lane);
+            const float dks = kc == K ? sqrtf(__uint_as_float((unsigned int)(lb[K - 1] >> 32))) : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (kc == K) { D = dks + kConsSparseMargin * c.cs_min; continue; }
+        }
         break;
     }
     if (n_c < K || n_c > kConsCap) { give_up(); return; }
@@ -993,7 +1064,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
     if (lane < 4) { stage[n_c + lane] = make_float4(kFar, kFar, kFar, 0.f); dc2[n_c + lane] = 3.0e38f; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const float dk = sqrtf(dc2[K - 1]);
+    const float dk = sqrtf(dc2[K - 1]), d1 = sqrtf(dc2[0]);
     // ---- setup (d): <vp_n, vq_j> of the staged points, 8 lanes per feature row ----
     {
         const int grp = lane >> 3, sub = lane & 7;
@@ -1050,7 +1121,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         }
 #pragma unroll
         for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
-        S.sc[0] = (float)kBins / S.hi0;
+        {
+            // no staged point is closer to q than d_1(q~) - delta: for images in empty parts of the target (d_1 ~ 15 m) the
+            // histogram then resolves the shell the candidates live in instead of spending 30 of its 32 bins on nothing
+            const float rl = fmaxf((d1 - delta) * 0.999f - 1e-5f, 0.f);
+            S.lo[0] = act ? rl * rl : 0.f;
+        }
+        S.sc[0] = (float)kBins / (S.hi0 - S.lo[0]);
         auto walk_c = [&](bool on, float, auto&& body) __attribute__((always_inline)) {
             for (int u0 = 0; u0 < m_use; u0 += 4) {
                 float d2[4];
@@ -1095,32 +1172,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (lane == 0 && stats) atomicAdd(stats, n_served);
-}
-
-constexpr int kCoopCap = 256;       // cooperative key list (keys)
-constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
-
-// keep the K smallest of list[0 .. cnt) (cnt <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
-__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
-{
-    unsigned long long mine[kCoopCap / kWave];
-    int rank[kCoopCap / kWave];
-#pragma unroll
-    for (int u = 0; u < kCoopCap / kWave; ++u) {
-        mine[u] = u * kWave + lane < cnt ? list[u * kWave + lane] : ~0ull;
-        rank[u] = 0;
-    }
-    for (int f = 0; f < cnt; ++f) {
-        const unsigned long long k = list[f];               // same address in every lane: one broadcast read
-#pragma unroll
-        for (int u = 0; u < kCoopCap / kWave; ++u) rank[u] += k < mine[u] ? 1 : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int u = 0; u < kCoopCap / kWave; ++u)
-        if (u * kWave + lane < cnt && rank[u] < K) out[rank[u]] = mine[u];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return cnt < K ? cnt : K;
 }
 
 // who takes what the consensus pass left (header word 8): 1 = the grid kernel (few leftovers: they sit in a few

@@ -17,13 +17,15 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_distributed(backend=None, device_index=None):
+def init_distributed(backend=None, device_index=None, force=False):
     """One process per GPU; rendezvous through MASTER_ADDR/MASTER_PORT (torch.distributed.run).
-    device_index: GPU of this rank (default LOCAL_RANK); bound to the process group so RCCL does not have to guess."""
+    device_index: GPU of this rank (default LOCAL_RANK); bound to the process group so RCCL does not have to guess.
+    force: create the process group even for a world of 1 (tests: runs the RCCL code path on a single GPU -- RCCL
+    refuses two ranks on one device, "Duplicate GPU detected", so a 1-GPU box cannot host a world of 2)."""
     rank, local_rank, world = env_world()
     if device_index is None:
         device_index = local_rank
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
