@@ -220,6 +220,13 @@ int umereg_host_choice_mt19937(uint32_t* mt_key_host, int* mt_pos_host, const vo
                                int size, int64_t* found_host, double* work_host, unsigned char* seen_host,
                                int* rounds_out_host);
 
+/* np.random.choice(n, size, replace=False) without p -- the keypoint draws of evaluate.py:199-200 and the correlation
+ * sub-sampling of :280, :284 -- on the caller's MT19937 state (numpy's legacy RandomState): permutation(n)[:size] by
+ * numpy's own shuffle (legacy random_interval, 32-bit words).  Bit-identical indices and generator state.
+ *   mt_key uint32[624], mt_pos: the generator state (BitGenerator.ctypes.state_address); perm: int64 [n] scratch;
+ *   out: int64 [size].  Host-only: runs without a device. */
+int umereg_host_permutation_mt19937(uint32_t* mt_key, int* mt_pos, int64_t n, int64_t size, int64_t* perm, int64_t* out);
+
 /* ---------------------------------------------------------------------------------------------
  * a6  utils.loc_utils.batch_estimate_transform_ume_old(G, H)         utils/loc_utils.py:292-350
  * Closed-form SE(3) from a (source G, target H) UME pair; T maps source -> target.

@@ -759,6 +759,69 @@ def test_bench_collectives_on_rccl(gpu, tmp_path):
     assert j1["end_to_end"]["rr_1deg_0.1m"] == j2["end_to_end"]["rr_1deg_0.1m"]
 
 
+@pytest.mark.parametrize("case", ["kitti", "lattice_ties", "sparse_far", "tiny"])
+def test_corr_scores_lattice_vs_grid_vs_oracle(gpu, case):
+    """f1: the per-cell candidate lattice must deliver the same K nearest as the grid walk (and as the brute-force
+    oracle) for every kind of query: near the data, between structures, in empty regions of the lattice (long lists ->
+    grid fallback), outside the lattice, on exact distance ties, NaN transforms."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_pair, synth_pair_hard
+    rng = np.random.RandomState(5)
+    K = 20
+    if case == "kitti":
+        p = synth_pair_hard(17, N=6000, n_kp=100, voxel=0.6)
+        src, tgt = p.src_pts, p.tgt_pts
+        gt = p.gt_tform.astype(np.float64)
+    elif case == "lattice_ties":
+        g3 = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
+        tgt = (g3[rng.permutation(len(g3))] * 0.5).astype(np.float32)
+        src = tgt[rng.permutation(len(tgt))[:3000]].copy()              # queries ON target points: exact ties everywhere
+        gt = np.eye(4)
+    elif case == "sparse_far":
+        tgt = np.concatenate([rng.uniform(-30, -20, (1500, 3)), rng.uniform(20, 30, (1500, 3))]).astype(np.float32)   # two far clusters
+        src = rng.uniform(-35, 35, (4000, 3)).astype(np.float32)        # most queries in the empty middle
+        gt = np.eye(4)
+    else:
+        tgt = rng.uniform(-3, 3, (40, 3)).astype(np.float32)
+        src = rng.uniform(-4, 4, (300, 3)).astype(np.float32)
+        gt = np.eye(4)
+        K = 7
+    Ts = [gt]
+    for i in range(11):
+        dT = np.eye(4)
+        a = rng.standard_normal(3); a /= np.linalg.norm(a)
+        ang = np.deg2rad(rng.uniform(0.2, 5.0) if i < 7 else rng.uniform(20, 180))
+        Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        dT[:3, :3] = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        dT[:3, 3] = rng.standard_normal(3) * (0.3 if i < 7 else 60.0)
+        Ts.append(dT @ gt)
+    Ts = np.stack(Ts).astype(np.float32)
+    if case == "tiny":
+        Ts[3, 0, 0] = np.nan                                             # a NaN hypothesis must not hang or poison the others
+    sf = rng.standard_normal((src.shape[0], 32)).astype(np.float32)
+    tf = rng.standard_normal((tgt.shape[0], 32)).astype(np.float32)
+    args = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    grid = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_NO_LATTICE))
+    lat = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS))
+    lat2 = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS))
+    # + the consensus pass in front of the lattice (hypotheses near the median one are scored from one staged set per
+    # source point; the others -- here: the far-off and the garbage transforms -- still go through the lattice)
+    cons = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS))
+    cons2 = N_(ops.corr_scores(*args, K=K, sigma=1.5, flags=ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS))
+    # (a NaN hypothesis scores 0 or NaN depending on which structure meets it; the reference gives NaN.  What matters:
+    # it terminates and leaves the other hypotheses alone)
+    ok = np.isfinite(grid) & np.isfinite(lat) & np.isfinite(cons) & np.isfinite(Ts).all(axis=(1, 2))
+    assert ok.sum() >= len(Ts) - 1
+    scale = np.abs(grid[ok]).max() + 1e-6
+    # same neighbour sets; only the order in which a query's K terms are added differs between the two structures
+    assert np.abs(grid[ok] - lat[ok]).max() <= 2e-6 * scale
+    assert np.array_equal(lat[ok], lat2[ok]) and np.array_equal(cons[ok], cons2[ok])     # run-to-run identical
+    assert np.abs(grid[ok] - cons[ok]).max() <= 1e-5 * scale
+    ref = orc.pc_corr_cost_c(Ts[ok], src, tgt, K, sf, tf, 1.5)
+    fin = np.isfinite(ref)                                                    # (the NaN hypothesis scores NaN in the oracle, 0 here)
+    assert fin.sum() >= len(Ts) - 1 and np.abs(lat[ok][fin] - ref[fin]).max() <= 1e-4 * scale
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_errors_are_loud(gpu):
     from umeregrobust_amd import ops, _lib

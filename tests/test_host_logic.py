@@ -41,6 +41,33 @@ def test_choice_noreplace_is_numpy_bit_identical():
     assert np.array_equal(c1, choice_noreplace(np.random, 50, 20, np.full(50, 0.02)))
 
 
+def test_uniform_choice_is_numpy_bit_identical():
+    """evaluate.py:199-200, 280, 284 -- np.random.choice(n, size, replace=False): same indices, order and RNG state."""
+    import time
+    from umeregrobust_amd.host_rng import choice_uniform_noreplace
+    for seed, (n, size) in enumerate(((50000, 10000), (35000, 5000), (4096, 4096), (7, 3), (1, 1), (12345, 1), (65537, 65000))):
+        r1, r2 = np.random.RandomState(seed), np.random.RandomState(seed)
+        c1 = r1.choice(n, size, replace=False)
+        c2 = choice_uniform_noreplace(r2, n, size)
+        assert np.array_equal(c1, c2) and c2.dtype == c1.dtype
+        assert r1.rand() == r2.rand()
+    np.random.seed(5)
+    c1 = np.random.choice(1000, 10, replace=False)
+    np.random.seed(5)
+    assert np.array_equal(c1, choice_uniform_noreplace(np.random, 1000, 10))
+    # interleaved with the weighted draw on the same stream, as the evaluation loop does
+    from umeregrobust_amd.host_rng import choice_noreplace
+    r1, r2 = np.random.RandomState(9), np.random.RandomState(9)
+    pr = np.full(100, 0.01)
+    a1 = (r1.choice(500, 50, replace=False), r1.choice(100, 20, replace=False, p=pr), r1.choice(300, 30, replace=False))
+    a2 = (choice_uniform_noreplace(r2, 500, 50), choice_noreplace(r2, 100, 20, pr), choice_uniform_noreplace(r2, 300, 30))
+    assert all(np.array_equal(x, y) for x, y in zip(a1, a2))
+    r = np.random.RandomState(0)
+    t0 = time.perf_counter(); r.choice(50000, 10000, replace=False); t_np = time.perf_counter() - t0
+    t0 = time.perf_counter(); choice_uniform_noreplace(r, 50000, 10000); t_nat = time.perf_counter() - t0
+    print(f"uniform draw 50000 -> 10000: numpy {1e3 * t_np:.2f} ms, native {1e3 * t_nat:.2f} ms")
+
+
 def test_choice_noreplace_errors_like_numpy():
     from umeregrobust_amd.host_rng import choice_noreplace
     rs = np.random.RandomState(0)

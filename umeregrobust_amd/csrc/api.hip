@@ -195,6 +195,26 @@ inline double mt19937_double(uint32_t* key, int* pos)
 
 }  // namespace
 
+// numpy's legacy RandomState.choice(n, size, replace=False) WITHOUT p (reference evaluate.py:199-200, 280, 284):
+// `self.permutation(n)[:size]`, i.e. arange(n) shuffled by _shuffle_raw -- for i = n-1 .. 1: j = random_interval(i),
+// swap(i, j) -- with legacy random_interval: mask = smallest 2^k - 1 >= i, draw 32-bit words & mask until <= i
+// (n <= 2^32).  perm: n int64 (scratch, holds the whole permutation afterwards); out: the first `size` entries.
+// Same indices, same order, same generator state as numpy; ~0.1 ms for n = 50 000 instead of 0.45 ms.
+UMEREG_API int umereg_host_permutation_mt19937(uint32_t* mt_key, int* mt_pos, int64_t n, int64_t size, int64_t* perm, int64_t* out)
+{
+    if (!mt_key || !mt_pos || !perm || !out || n <= 0 || size < 0 || size > n || n > 0xffffffffll || *mt_pos < 0 || *mt_pos > kMtN) return -1;
+    for (int64_t i = 0; i < n; ++i) perm[i] = i;
+    for (int64_t i = n - 1; i > 0; --i) {
+        uint32_t mask = (uint32_t)i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = mt19937_next(mt_key, mt_pos) & mask; } while (v > (uint32_t)i);
+        const int64_t t = perm[i]; perm[i] = perm[v]; perm[v] = t;
+    }
+    memcpy(out, perm, (size_t)size * sizeof(int64_t));
+    return 0;
+}
+
 // p: f32 (p_is_f32 != 0) or f64 probabilities [n] (not modified); work: 2n + size doubles; seen: n bytes.
 // returns 0, or numpy's argument errors: 1 = NaN / negative entries, 2 = probabilities do not sum to 1,
 // 3 = fewer non-zero entries than size; -1 = bad arguments.  *rounds (optional) = rounds taken.

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .host_rng import choice_noreplace
+from .host_rng import choice_noreplace, choice_uniform_noreplace
 from .utils.eval_utils import relative_rotation_error  # noqa: F401
 from .utils.loc_utils import (FeatureCorrelator, batch_estimate_transform_ume_old, ume_cdist,  # noqa: F401
                                ume_kp_layer)
@@ -79,11 +79,11 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     ind = ops.knn_points(tgt_pts_raw.contiguous(), tgt_pts, K=1)                                        # :274
     tgt_feat_corr = torch.gather(tgt_feat, 1, ind[1][:, :, 0:1].expand(-1, -1, tgt_feat.shape[2]))
     num_pts = min(args.pc_corr_max_size, src_pts_raw.shape[1])                                          # :278-285
-    rand_idxs = _index_tensor(rng.choice(src_pts_raw.shape[1], num_pts, replace=False), dev)
+    rand_idxs = _index_tensor(choice_uniform_noreplace(rng, src_pts_raw.shape[1], num_pts), dev)
     src_pts_raw = src_pts_raw[:, rand_idxs]
     src_feat_corr = src_feat_corr[:, rand_idxs]
     num_pts = min(args.pc_corr_max_size, tgt_pts_raw.shape[1])
-    rand_idxs = _index_tensor(rng.choice(tgt_pts_raw.shape[1], num_pts, replace=False), dev)
+    rand_idxs = _index_tensor(choice_uniform_noreplace(rng, tgt_pts_raw.shape[1], num_pts), dev)
     tgt_pts_raw = tgt_pts_raw[:, rand_idxs]
     tgt_feat_corr = tgt_feat_corr[:, rand_idxs]
     return pc_fcht(pc1_pts=src_pts_raw.contiguous(), pc2_pts=tgt_pts_raw.contiguous(), pc1_feat=src_feat_corr.contiguous(),
@@ -249,9 +249,9 @@ def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):
     else:
         num_init_sel = min(min(src_pts.shape[1], tgt_pts.shape[1]), args.ume_n_samples)
     if src_inds is None:
-        src_inds = rng.choice(src_pts.shape[1], num_init_sel, replace=False)
+        src_inds = choice_uniform_noreplace(rng, src_pts.shape[1], num_init_sel)
     if tgt_inds is None:
-        tgt_inds = rng.choice(tgt_pts.shape[1], num_init_sel, replace=False)
+        tgt_inds = choice_uniform_noreplace(rng, tgt_pts.shape[1], num_init_sel)
     return _index_tensor(src_inds, src_pts.device), _index_tensor(tgt_inds, src_pts.device)
 
 

@@ -92,3 +92,30 @@ def choice_noreplace(rng, n, size, p):
     if rc != 0:
         raise ValueError(_ERRORS.get(rc, "umereg_host_choice_mt19937 failed"))
     return found
+
+
+_perm_scratch = {}
+
+
+def choice_uniform_noreplace(rng, n, size):
+    """Bit-identical replacement for rng.choice(n, size, replace=False) WITHOUT p (the keypoint draws of reference
+    evaluate.py:199-200 and the correlation sub-sampling of :280, :284): numpy's legacy RandomState computes
+    permutation(n)[:size]; one native call does the same shuffle on the generator's MT19937 state (same indices, same
+    order, same state afterwards; ~4x faster).  Other generators are forwarded to their own .choice()."""
+    n, size = int(n), int(size)
+    bitgen = _mt19937_of(rng) if _is_legacy(rng) else None
+    if bitgen is None or size > n or n <= 0 or n > 0xffffffff:
+        return rng.choice(n, size, replace=False)
+    lib = _lib.load()
+    perm = _perm_scratch.get(n)
+    if perm is None:
+        if len(_perm_scratch) > 16:
+            _perm_scratch.clear()
+        perm = _perm_scratch[n] = np.empty(n, dtype=np.int64)
+    out = np.empty(size, dtype=np.int64)
+    addr = _state_address(bitgen)
+    with bitgen.lock:
+        rc = lib.umereg_host_permutation_mt19937(addr, addr + 624 * 4, n, size, perm.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise ValueError("umereg_host_permutation_mt19937 failed")
+    return out
