@@ -169,6 +169,12 @@ size_t umereg_ume_match_q_scratch_bytes(int n1, int n2);
 int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
                             int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
                             void* stream);
+/* Tuning / test knobs of the filter + refine matcher, process-wide (no environment variables are read by this
+ * library): splits = target splits of the coarse pass (0: automatic; it changes umereg_ume_match_q_scratch_bytes, so
+ * set it before the size query), share_mask = limit-sharing schedule (-1: default), force_exhaustive != 0: refine every
+ * block of rows exhaustively (a parity test uses it). */
+int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive);
+
 /* the stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, in this order): reset zeroes the
  * per-row limits (a 4 n1 byte memset), coarse is the MFMA filter, refine the fp64 arg-min over the candidates */
 int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, int n1, int n2, void* stream);

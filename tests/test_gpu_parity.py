@@ -363,19 +363,19 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
 
 
 def test_ume_match_f16r_forced_exhaustive_refine(gpu):
-    """The refine kernel's exhaustive fallback on every block of rows (testing probe UMEREG_FORCE_EXHAUSTIVE): it must
-    reproduce the exact-fp32 scan at sizes where several target splits and many row blocks exist."""
-    import os
-    from umeregrobust_amd import ops
+    """The refine kernel's exhaustive fallback on every block of rows (umereg_ume_match_set_tuning(force_exhaustive)): it
+    must reproduce the exact-fp32 scan at sizes where several target splits and many row blocks exist."""
+    from umeregrobust_amd import _lib, ops
     rng = np.random.RandomState(3)
     u1 = T_(rng.standard_normal((1, 1500, 32, 4)).astype(np.float32), gpu)
     u2 = T_(rng.standard_normal((1, 7000, 32, 4)).astype(np.float32), gpu)
     mx, dx = ops.ume_match(u1, u2, precision="f32")
-    os.environ["UMEREG_FORCE_EXHAUSTIVE"] = "1"
+    lib = _lib.load()
+    assert lib.umereg_ume_match_set_tuning(0, -1, 1) == 0
     try:
         mr, dr = ops.ume_match(u1, u2, precision="f16r")
     finally:
-        del os.environ["UMEREG_FORCE_EXHAUSTIVE"]
+        assert lib.umereg_ume_match_set_tuning(0, -1, 0) == 0
     assert torch.equal(mr, mx) and float((dr - dx).abs().max()) < 1e-5
     mr2, dr2 = ops.ume_match(u1, u2, precision="f16r")          # and the normal path agrees with it bit for bit
     assert torch.equal(mr2, mr) and torch.equal(dr2, dr)
@@ -820,6 +820,31 @@ def test_corr_scores_lattice_vs_grid_vs_oracle(gpu, case):
     ref = orc.pc_corr_cost_c(Ts[ok], src, tgt, K, sf, tf, 1.5)
     fin = np.isfinite(ref)                                                    # (the NaN hypothesis scores NaN in the oracle, 0 here)
     assert fin.sum() >= len(Ts) - 1 and np.abs(lat[ok][fin] - ref[fin]).max() <= 1e-4 * scale
+
+
+def test_out_of_range_indices_poison_instead_of_faulting(gpu):
+    """Caller-supplied index arrays are range-checked on the device: a stale or -1-padded index (the reference's own
+    ball_query pads with -1) yields NaN rows -- never an out-of-bounds read -- and leaves every other row untouched."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_pair
+    p = synth_pair(3, N=4096, n_kp=256)
+    pts, feat = T_(p.src_pts, gpu)[None], T_(p.src_feat, gpu)[None]
+    inds = p.src_inds[:256].copy()
+    ref = ops.ume_moments(pts, None, feat, 750, 5.0, kp_index=T_(inds, gpu)[None])
+    bad = inds.copy()
+    bad[[3, 77, 200]] = [-1, 4096, 10 ** 9]
+    out, cnt = ops.ume_moments(pts, None, feat, 750, 5.0, kp_index=T_(bad, gpu)[None], return_count=True)
+    o, r = N_(out[0]), N_(ref[0])
+    good = np.ones(256, bool); good[[3, 77, 200]] = False
+    assert np.isnan(o[~good]).all() and np.array_equal(o[good], r[good]) and (N_(cnt[0])[~good] == 0).all()
+    G = ref[0].contiguous()
+    gi = torch.tensor([0, 5, -1, 256, 7], device=gpu)
+    hog = torch.arange(256, device=gpu); hog[5] = 999
+    T, _ = ops.rtume_solve(G, G, gi, None, h_of_g=hog)
+    T = N_(T)
+    assert np.isfinite(T[[0, 4]]).all() and np.isnan(T[[1, 2, 3]]).all()
+    T2, D2 = ops.rtume_solve(G, G, torch.tensor([1, 2], device=gpu), torch.tensor([-1, 3], device=gpu), with_dist=True)
+    assert np.isnan(N_(T2)[0]).all() and np.isfinite(N_(T2)[1]).all() and np.isnan(N_(D2)[0])
 
 
 # ------------------------------------------------------------------------------- error behaviour

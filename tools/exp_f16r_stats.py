@@ -2,6 +2,8 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from umeregrobust_amd import ops, _lib
+if os.environ.get('TUNE_SPLITS') or os.environ.get('TUNE_SHARE_MASK'):
+    _lib.load().umereg_ume_match_set_tuning(int(os.environ.get('TUNE_SPLITS', '0')), int(os.environ.get('TUNE_SHARE_MASK', '-1'), 0), 0)
 from umeregrobust_amd.synth import synth_pair_cfg
 dev = torch.device("cuda:0")
 lib = _lib.load()

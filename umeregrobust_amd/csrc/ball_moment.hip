@@ -404,7 +404,10 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) cnt[c] = 0;
     __syncthreads();
     auto cell_of_kp = [&](int k) {
-        if (kp_index) return cell_of[kp_index[(size_t)b * n_kp + k]];   // the point's cell, from the hist pass
+        if (kp_index) {   // the point's cell, from the hist pass (an out-of-range index only affects the ORDER here: clamped)
+            const int64_t i = kp_index[(size_t)b * n_kp + k];
+            return cell_of[i < 0 ? 0 : (i >= N ? N - 1 : i)];
+        }
         const float* q = kpts + ((size_t)b * n_kp + k) * 3;
         return (cell_axis(q[2], g.minz, g.invz, g.nz) * g.ny + cell_axis(q[1], g.miny, g.invy, g.ny)) * g.nx +
                cell_axis(q[0], g.minx, g.invx, g.nx);
@@ -483,7 +486,16 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const float4* fb = feat4 + (size_t)b * N * 8;
     float qx, qy, qz;
     if (kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
-        const float4 qp = Pb[kp_index[(size_t)b * n_kp + kp]];
+        const int64_t ki = kp_index[(size_t)b * n_kp + kp];
+        if (ki < 0 || ki >= N) {
+            // an index outside the cloud (stale, or the -1 padding the reference's own code produces) must not read out of
+            // bounds: the keypoint's matrix is all NaN -- loud downstream, where torch indexing would have raised
+            for (int e = lane; e < 128; e += kWave) F[((size_t)b * n_kp + kp) * 128 + e] = __int_as_float(0x7fc00000);
+            if (nn_count && lane == 0) nn_count[(size_t)b * n_kp + kp] = 0;
+            if (nn_idx) for (int e = lane; e < K; e += kWave) nn_idx[((size_t)b * n_kp + kp) * K + e] = -1;
+            return;
+        }
+        const float4 qp = Pb[ki];
         qx = qp.x; qy = qp.y; qz = qp.z;
     } else {
         const float* q = kpts + ((size_t)b * n_kp + kp) * 3;

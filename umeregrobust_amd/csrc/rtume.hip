@@ -17,14 +17,23 @@ __global__ __launch_bounds__(256) void rtume_kernel(const float4* __restrict__ G
                                                     const float4* __restrict__ H_all,
                                                     const int64_t* __restrict__ g_index,
                                                     const int64_t* __restrict__ h_index,
-                                                    const int64_t* __restrict__ h_of_g, int n,
+                                                    const int64_t* __restrict__ h_of_g, int nG, int nH, int n,
                                                     float* __restrict__ T, float* __restrict__ dist)
 {
     const int row = threadIdx.x & 31;
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (k >= n) return;  // uniform per 32-lane group
+    // Caller-supplied indices are range-checked here (a stale or -1-padded index -- the reference's own ball_query
+    // pads with -1 -- must not read out of bounds): an invalid row gets an all-NaN transform, loud in every result
+    // computed from it, where torch.gather would have raised a device assert.
     const int64_t gi = g_index ? g_index[k] : k;
-    const int64_t hi = h_of_g ? h_of_g[gi] : (h_index ? h_index[k] : k);
+    const bool gi_ok = gi >= 0 && gi < nG;
+    const int64_t hi = h_of_g ? (gi_ok ? h_of_g[gi] : -1) : (h_index ? h_index[k] : k);
+    if (!gi_ok || hi < 0 || hi >= nH) {
+        if (row < 16) T[(size_t)k * 16 + row] = __int_as_float(0x7fc00000);
+        if (dist && row == 0) dist[k] = __int_as_float(0x7fc00000);
+        return;
+    }
     const float4 gv = G_all[gi * 32 + row];
     const float4 hv = H_all[hi * 32 + row];
     const double mg = gv.x, mh = hv.x;                       // utils/loc_utils.py:304-305
@@ -174,7 +183,7 @@ UMEREG_API int umereg_rtume_solve_f32(const float* G_all, const float* H_all, co
     if (int rc = check_device()) return rc;
     const int groups_per_wg = 256 / 32;
     hipLaunchKernelGGL(rtume_kernel, dim3((n + groups_per_wg - 1) / groups_per_wg), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)G_all, (const float4*)H_all, g_index, h_index, h_of_g, n, T, dist);
+                       (hipStream_t)stream, (const float4*)G_all, (const float4*)H_all, g_index, h_index, h_of_g, nG, nH, n, T, dist);
     UMEREG_CHECK_LAUNCH("rtume_kernel");
     return UMEREG_OK;
 }

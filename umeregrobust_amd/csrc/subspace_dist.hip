@@ -678,6 +678,12 @@ static size_t qb_bytes(int n2) { return align_up((size_t)n2, 32) * 128 * sizeof(
 struct CoarsePlan {
     int n_ablk, n_blocks, n_btiles, splits, tiles_per_split;
 };
+// explicit tuning knobs of the filter + refine matcher (umereg_ume_match_set_tuning; process-wide, set them before the
+// scratch-size query of the calls they should affect).  0 / -1 = automatic.
+static int g_tune_splits = 0;
+static long g_tune_share_mask = -1;
+static int g_tune_exhaustive = 0;
+
 static CoarsePlan coarse_plan(int n1, int n2)
 {
     CoarsePlan p;
@@ -685,7 +691,7 @@ static CoarsePlan coarse_plan(int n1, int n2)
     p.n_blocks = p.n_ablk * kDistWaves;
     p.n_btiles = (n2 + 31) / 32;
     int splits = (2560 + p.n_ablk - 1) / p.n_ablk;   // ~10 workgroups per CU
-    if (const char* e = getenv("UMEREG_SPLITS")) splits = atoi(e);   // tuning probe
+    if (g_tune_splits > 0) splits = g_tune_splits;   // umereg_ume_match_set_tuning
     if (splits > kMaxSplits) splits = kMaxSplits;
     if (splits > p.n_btiles) splits = p.n_btiles;
     if (splits < 1) splits = 1;
@@ -740,8 +746,8 @@ static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
     ms.cand = ms.cnt + (size_t)p.n_blocks * p.splits;
     ms.splits = p.splits;
     ms.share_mask = kShareMask;
-    ms.force_exhaustive = getenv("UMEREG_FORCE_EXHAUSTIVE") ? 1 : 0;
-    if (const char* e = getenv("UMEREG_SHARE_MASK")) ms.share_mask = (unsigned int)strtoul(e, nullptr, 0);   // tuning probe
+    ms.force_exhaustive = g_tune_exhaustive ? 1 : 0;
+    if (g_tune_share_mask >= 0) ms.share_mask = (unsigned int)g_tune_share_mask;
     return ms;
 }
 
@@ -1000,5 +1006,15 @@ UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const 
         return rc;
     if (prob)
         if (int rc = umereg_match_prob_f32(match_dist, n_kp, tau, prob, stream)) return rc;
+    return UMEREG_OK;
+}
+
+
+UMEREG_API int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive)
+{
+    if (splits < 0 || force_exhaustive < 0) { set_error("ume_match_set_tuning: negative argument"); return UMEREG_EINVAL; }
+    g_tune_splits = splits;
+    g_tune_share_mask = share_mask;
+    g_tune_exhaustive = force_exhaustive;
     return UMEREG_OK;
 }
