@@ -1,27 +1,36 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/collect_profiles.sh <tag>
-# Collects the evidence the bench line's roofline object refers to, into gpurun_out/<tag>/:
-#   bench_default.json           default bench run (with the CPU baseline leg)
-#   kernel_stats.csv             rocprofv3 --kernel-trace --stats of the same command (no CPU leg)
-#   pmc_{FETCH,WRITE}_SIZE.csv   separate --pmc passes (kernel-trace only, as gpurun requires)
-#   bench_with_selection.json    named path + f1 hypothesis selection
-#   bench_end_to_end.json        + f2 ICP; kernel_stats_end_to_end.csv: rocprofv3 stats of that command
+# Collects the evidence the bench line refers to, into gpurun_out/<tag>/ (copy what is to be judged to profiles/<round>/):
+#   bench_default.json     the default bench run: named-path value + roofline + end_to_end legs + cpu_baseline
+#   kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (without the CPU leg)
+#   pmc_{FETCH,WRITE}_SIZE.csv   separate --pmc passes of the named-path leg (kernel-trace only, as gpurun requires)
+#   sq/                    SQ / TCC counter passes of the named-path leg (tools/make_sq_summary.py turns them into sq_summary.json)
+#   f1_kernel_stats.txt    per-kernel times of the hypothesis-selection probe (tools/exp_f1_lattice.py)
 TAG=${1:-profiles_run}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 600 python $ROOT/bench.py > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_default.json
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout -s KILL 900 python $ROOT/bench.py > $OUT/bench_default.log 2>&1; grep "^{" $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 f=$(ls $OUT/stats/*/run_kernel_stats.csv $OUT/stats/run_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
+rm -rf $OUT/stats
+SMALL="--steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --steps 6 --warmup 2 --depth 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py $SMALL > $OUT/pmc_$c.log 2>&1
   f=$(ls $OUT/pmc_$c/*/pmc_counter_collection.csv $OUT/pmc_$c/pmc_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/pmc_$c.csv
+  rm -rf $OUT/pmc_$c
 done
-timeout -s KILL 600 python $ROOT/bench.py --no-cpu-baseline --with-selection --steps 40 --warmup 5 > $OUT/bench_with_selection.log 2>&1; tail -1 $OUT/bench_with_selection.log > $OUT/bench_with_selection.json
-timeout -s KILL 600 python $ROOT/bench.py --no-cpu-baseline --with-selection --with-refinement --steps 40 --warmup 5 > $OUT/bench_end_to_end.log 2>&1; tail -1 $OUT/bench_end_to_end.log > $OUT/bench_end_to_end.json
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_e2e -o run -- python $ROOT/bench.py --no-cpu-baseline --with-selection --with-refinement --steps 20 --warmup 3 > $OUT/stats_e2e.log 2>&1
-f=$(ls $OUT/stats_e2e/*/run_kernel_stats.csv $OUT/stats_e2e/run_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_end_to_end.csv
-rm -rf $OUT/stats_e2e
-rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
-ls -la $OUT
+mkdir -p $OUT/sq
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" \
+           "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE GRBM_COUNT" \
+           "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  i=$((i+1))
+  timeout -s KILL 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/sq/p$i -o pmc -- python $ROOT/bench.py $SMALL > $OUT/sq/p$i.log 2>&1
+  f=$(ls $OUT/sq/p$i/*/pmc_counter_collection.csv $OUT/sq/p$i/pmc_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/sq/pass$i.csv
+  rm -rf $OUT/sq/p$i
+done
+timeout -s KILL 300 $ROOT/tools/f1_stats.sh 3 > $OUT/f1_kernel_stats.txt 2>&1
+ls -la $OUT $OUT/sq

@@ -1,0 +1,62 @@
+"""profiles/sq_summary.json (read by bench.py) from the SQ / TCC counter passes of tools/collect_profiles.sh.
+usage: python tools/make_sq_summary.py gpurun_out/<tag> [profiles/<round>]   (copies the evidence too)
+Per kernel (largest grid of its name only: bench.py's setup also launches single-cloud variants): averages per launch of
+every counter, and the derived fractions the bench line quotes."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src = sys.argv[1]
+dst = sys.argv[2] if len(sys.argv) > 2 else None
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+N_SIMD = 1024                      # 256 CUs x 4 SIMDs (guides/MI355X_MICROARCH.md)
+KERNELS = ("ume_moments_kernel", "ume_coarse_h_kernel", "match_refine_kernel", "rtume_kernel", "orthobasis_pair_kernel")
+rows = []
+for f in sorted(glob.glob(os.path.join(src, "sq", "pass*.csv"))):
+    rows += list(csv.DictReader(open(f)))
+biggest = collections.defaultdict(int)
+for r in rows:
+    biggest[r["Kernel_Name"]] = max(biggest[r["Kernel_Name"]], int(r["Grid_Size"]))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    if int(r["Grid_Size"]) != biggest[r["Kernel_Name"]]:
+        continue
+    for short in KERNELS:
+        if short in r["Kernel_Name"]:
+            acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {"_comment": "per-launch averages of rocprofv3 --pmc passes (SQ, GRBM, TCC, TCP) of `bench.py --steps 2 --warmup 1 "
+                   "--pairs-per-step 8 --depth 1 --no-e2e`, KT workload, one pass per counter set (tools/collect_profiles.sh). "
+                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts; "
+                   "SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE = kernel duration in "
+                   "shader clocks.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024)."}
+for k, c in acc.items():
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    d = {"counters": {n: round(v, 1) for n, v in sorted(m.items())}, "launches_sampled": max(len(v) for v in c.values())}
+    g = m.get("GRBM_GUI_ACTIVE")
+    if g:
+        if m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            d["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * N_SIMD), 4)
+    if m.get("SQ_INSTS_MFMA"):
+        d["valu_per_mfma"] = round((m.get("SQ_INSTS_VALU", 0.0) - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"], 2)
+    if m.get("SQ_WAVE_CYCLES"):
+        w = m["SQ_WAVE_CYCLES"]
+        for key, name in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac"), ("SQ_ACTIVE_INST_ANY", "issue_frac"),
+                          ("SQ_INST_CYCLES_VMEM", "vmem_busy_frac")):
+            if key in m:
+                d[name] = round(m[key] / w, 4)
+    if m.get("TCC_HIT_sum") is not None and m.get("TCC_MISS_sum") is not None and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
+        d["l2_hit_rate"] = round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4)
+    if m.get("TCP_TOTAL_CACHE_ACCESSES_sum") and m.get("TCP_TCC_READ_REQ_sum") is not None:
+        d["l1_hit_rate_est"] = round(1.0 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+    out[k] = d
+json.dump(out, open(os.path.join(ROOT, "profiles", "sq_summary.json"), "w"), indent=1)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in out.items() if k != "_comment"}, indent=1))
+if dst:
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "profiles", "sq_summary.json"), os.path.join(dst, "sq_summary.json"))
+    for f in sorted(glob.glob(os.path.join(src, "sq", "pass*.csv"))):
+        shutil.copy(f, os.path.join(dst, "sq_" + os.path.basename(f)))

@@ -450,6 +450,17 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
 }
 
 // ---- a1+a2: fused ball query + gather + UME moments -------------------------------------------
+// value of lane 8g (the first lane of every aligned group of 8) in all 8 lanes of the group: quad_perm [0,0,0,0]
+// spreads it over its quad, row_shr:4 restricted to banks 1 and 3 (lanes 4-7, 12-15 of a row) copies quad 0 / 2 of
+// every row onto quad 1 / 3
+__device__ __forceinline__ float bcast8(float v)
+{
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true);                       // quad_perm [0,0,0,0]
+    x = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xa, false);              // row_shr:4, bank_mask 0b1010
+    return __int_as_float(x);
+}
+
 constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 measured no faster, and costs 2 waves/SIMD)
 
 __global__ __launch_bounds__(256) void ume_moments_kernel(
@@ -526,8 +537,17 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
         float4 pp[kMomUnroll], ff[kMomUnroll];
 #pragma unroll
         for (int u = 0; u < kMomUnroll; ++u) {
-            pp[u] = Pb[jj[u]];
+            // the 8 lanes of a slot need the SAME neighbour's coordinates: one of them loads (the gather returns 128 B per
+            // wave instead of 1 KiB), the others get them by two DPP moves per word (lane 0 of the quad, then quad 0 -> quad 1)
+            pp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qd == 0) pp[u] = Pb[jj[u]];
             ff[u] = fb[(size_t)jj[u] * 8 + qd];
+        }
+#pragma unroll
+        for (int u = 0; u < kMomUnroll; ++u) {
+            pp[u].x = bcast8(pp[u].x);
+            pp[u].y = bcast8(pp[u].y);
+            pp[u].z = bcast8(pp[u].z);
         }
 #pragma unroll
         for (int u = 0; u < kMomUnroll; ++u) {
