@@ -14,6 +14,7 @@ src = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else None
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 N_SIMD = 1024                      # 256 CUs x 4 SIMDs (guides/MI355X_MICROARCH.md)
+N_XCD = 8                          # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (8 x the kernel's duration in shader clocks)
 KERNELS = ("ume_moments_kernel", "ume_coarse_h_kernel", "match_refine_kernel", "rtume_kernel", "orthobasis_pair_kernel")
 rows = []
 for f in sorted(glob.glob(os.path.join(src, "sq", "pass*.csv"))):
@@ -32,14 +33,17 @@ out = {"_comment": "per-launch averages of rocprofv3 --pmc passes (SQ, GRBM, TCC
                    "--pairs-per-step 8 --depth 1 --no-e2e`, KT workload, one pass per counter set (tools/collect_profiles.sh). "
                    "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts; "
                    "SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE = kernel duration in "
-                   "shader clocks.  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024)."}
+                   "shader clocks, summed over the 8 XCDs (checked: / 8 / launch duration = 2.09 GHz).  mfma_busy_frac = "
+                   "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024); cross-check for the coarse matcher: 3.125e6 MFMAs "
+                   "(= 1.024e11 flop / 32768) x 32 cycles = 1.0e8 busy cycles, as counted."}
 for k, c in acc.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
     d = {"counters": {n: round(v, 1) for n, v in sorted(m.items())}, "launches_sampled": max(len(v) for v in c.values())}
     g = m.get("GRBM_GUI_ACTIVE")
     if g:
         if m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-            d["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * N_SIMD), 4)
+            d["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (g / N_XCD * N_SIMD), 4)
+        d["duration_shader_clocks"] = round(g / N_XCD, 0)
     if m.get("SQ_INSTS_MFMA"):
         d["valu_per_mfma"] = round((m.get("SQ_INSTS_VALU", 0.0) - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"], 2)
     if m.get("SQ_WAVE_CYCLES"):
