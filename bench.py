@@ -55,6 +55,8 @@ def parse():
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=2,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
+    ap.add_argument("--no-graphs", dest="graphs", action="store_false",
+                    help="enqueue phase A (a1-a5) as 12 launches per pair instead of replaying one captured hipGraph")
     ap.add_argument("--threaded-draw", action="store_true", help="host RNG draw on a worker thread (off: slower, see DESIGN 3.5)")
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
@@ -134,7 +136,7 @@ def main():
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
     depth = max(1, a.depth)
-    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw)
+    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     timing = {"moments": [], "dist": ops.TimingList()}
@@ -159,9 +161,9 @@ def main():
     def run(first, n, record):
         pending = []
         for i in range(first, first + n):
-            # per-kernel event pairs (the roofline leg) on every 4th timed pair only: they need the layered entry points;
+            # per-kernel event pairs (the roofline leg) on every 8th timed pair only: they need the layered entry points;
             # the other pairs go through the one-call a1..a5 entry
-            pending.append(submit(i, record and i % 4 == 0))
+            pending.append(submit(i, record and i % 8 == 0))
             if len(pending) >= depth:
                 finish(pending.pop(0))
         while pending:
@@ -263,7 +265,7 @@ def main():
                    "pairs_per_step_per_gpu": P, "ms_per_pair": round(1e3 * elapsed / (a.steps * P), 4),
                    "sharding": f"pairs[rank::{world}] (no data-path collective)",
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
-                   "pairs_in_flight": depth, "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
+                   "pairs_in_flight": depth, "phase_a_as_hipgraph": bool(a.graphs), "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
                    "excluded_from_value": "the two keypoint draws of evaluate.py:199-200 (indices pre-drawn with the pair; they are "
                                           "inside `end_to_end`), the feature network, hypothesis selection and ICP (see `end_to_end`)"},
         "roofline": dominant,

@@ -706,6 +706,39 @@ def test_hungarian_matching_golden(gpu):
     assert torch.equal(o.match, out.match) and torch.equal(o.rtume_tform, out.rtume_tform)
 
 
+def test_pipeline_with_hipgraph_equals_plain(gpu):
+    """RegistrationPipeline(use_graphs=True) replays phase A (a1..a5, 12 launches) as one captured hipGraph per
+    (slot, PairBatch): same results, bit for bit, as the launches it was captured from, pair after pair."""
+    from types import SimpleNamespace
+    from umeregrobust_amd import evaluate
+    from umeregrobust_amd.synth import synth_pair
+    args = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0, filter_by_ume_dist_cond=True, ume_n_samples=512, tau=0.05)
+    entries = []
+    for seed in (21, 22, 23):
+        p = synth_pair(seed, N=8192, n_kp=2048)
+        t = lambda a: T_(a, gpu)[None]
+        c = (t(p.src_pts), t(p.tgt_pts), t(p.src_feat), t(p.tgt_feat))
+        entries.append((c, evaluate.PairBatch.from_clouds(*c, T_(p.src_inds, gpu), T_(p.tgt_inds, gpu))))
+    outs = {}
+    for graphs in (False, True):
+        pipe = evaluate.RegistrationPipeline(args, gpu, depth=2, rng=None, use_graphs=graphs)
+        res, pending = [], []
+        for i in range(9):                                   # every (slot, entry) combination is replayed at least once
+            c, pb = entries[i % 3]
+            pending.append(pipe.submit(*c, pair=pb, rng=np.random.RandomState(100 + i)))
+            if len(pending) == 2:
+                o = pipe.finish(pending.pop(0))
+                res.append((o.rtume_tform.clone(), o.match.clone(), o.match_d.clone(), np.asarray(o.cond).copy()))
+        while pending:
+            o = pipe.finish(pending.pop(0))
+            res.append((o.rtume_tform.clone(), o.match.clone(), o.match_d.clone(), np.asarray(o.cond).copy()))
+        torch.cuda.synchronize()
+        outs[graphs] = res
+    assert len(outs[True]) == 9
+    for a_, b_ in zip(outs[False], outs[True]):
+        assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1]) and torch.equal(a_[2], b_[2]) and np.array_equal(a_[3], b_[3])
+
+
 def test_pipeline_slot_guard_and_per_pair_rng(gpu):
     """RegistrationPipeline: submitting more than `depth` pairs before finish() raises (the slot's pinned buffers would
     be overwritten); a per-pair generator passed to submit() gives the same result as register_pair with it."""

@@ -124,9 +124,15 @@ def my_ume_generation(pts, kpts, feat, args):
 
 
 def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D=False, timing=None,
-             pair=None):
-    """evaluate.py:195-236 up to the match probabilities: everything before the host RNG draw."""
+             pair=None, graph=None):
+    """evaluate.py:195-236 up to the match probabilities: everything before the host RNG draw.
+    graph: an ops.PairMatchGraph built over `pair`'s buffers -- the same kernels replayed as one hipGraph launch."""
     dev = src_pts.device
+    if graph is not None:
+        F, m_tgt, ume_d, prob = graph.launch()
+        return SimpleNamespace(ume_src=F[0:1], ume_tgt=F[1:2], match=m_tgt, match_d=ume_d, prob=prob, D=None,
+                               src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=F.shape[1], dev=dev,
+                               src_pts=src_pts, tgt_pts=tgt_pts)
     # UME matrices (:206-212); the keypoint gathers src_pts[0, src_inds] (:201-202) are fused into the kernel
     t_mom = None if timing is None else timing.setdefault("moments", [])
     t_dist = None if timing is None else timing.setdefault("dist", ops.TimingList())
@@ -286,12 +292,17 @@ class RegistrationPipeline:
     be called in order.
     """
 
-    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False):
+    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False, use_graphs=False):
         """threaded_draw: run the host draw (event wait + choice) on one worker thread, in submission
         order, so it also overlaps the main thread's kernel enqueues (the native draw releases the GIL).
         Use depth >= 3 with it.  The worker is then the only consumer of `rng` between submit and finish,
         so inject the keypoint indices (or draw them from a different generator)."""
         self.args, self.rng, self.depth = args, rng, depth
+        # use_graphs: replay phase A (12 launches) as one hipGraph per (slot, PairBatch): for loops that keep submitting
+        # the same PairBatch objects (resident or double-buffered inputs).  The graph writes into buffers it owns, so the
+        # tensors of a pair are valid until the same (slot, PairBatch) is submitted again.
+        self.use_graphs = use_graphs
+        self.graphs = {}
         self.pool = None
         if threaded_draw:
             from concurrent.futures import ThreadPoolExecutor
@@ -324,8 +335,18 @@ class RegistrationPipeline:
         # (no ordering between the phase-A blocks of consecutive pairs: the single-workgroup kernels of one pair --
         # keypoint order, grid scan, softmax, RTUME -- then run beside the machine-filling kernels of the other:
         # 0.416 -> 0.36 ms per pair)
+        graph = None
+        if self.use_graphs and pair is not None and timing is None and ops.DEFAULT_MATCH_PRECISION == "f16r" \
+                and not getattr(self.args, "hungarian_matching_flag", False):
+            key = (k, id(pair))
+            graph = self.graphs.get(key)
+            if graph is None or graph.pts is not pair.pts:
+                if len(self.graphs) > 64:
+                    self.graphs.clear()
+                graph = self.graphs[key] = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, self.args.ume_max_nn, self.args.ume_r_nn,
+                                                              self.args.tau if self.args.filter_by_ume_dist_cond else None)
         with torch.cuda.stream(st):
-            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair)
+            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, graph)
             if a.prob is not None:
                 if self.host_prob[k] is None or self.host_prob[k].numel() != a.prob.numel():
                     self.host_prob[k] = torch.empty(a.prob.numel(), dtype=torch.float32, pin_memory=True)

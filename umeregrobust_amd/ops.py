@@ -537,3 +537,50 @@ def pair_match(pts, feat, kp_index, K, radius, tau=None):
                                        _ptr(ws), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "umereg_pair_match_f32")
     return F, m, d, prob
+
+
+class PairMatchGraph:
+    """a1..a5 of one registration pair (pair_match) captured as ONE hipGraph over fixed buffers: the inputs given here,
+    and outputs / workspace owned by this object.  launch() replays it on the current stream and returns the same
+    (F, match, match_d, prob) tensors every time -- valid until the next launch() of this object."""
+
+    def __init__(self, pts, feat, kp_index, K, radius, tau=None):
+        import ctypes
+        lib = _lib.load()
+        self.pts = _dev(pts, "pts"); self.feat = _dev(feat, "feat"); self.kp_index = _dev(kp_index, "kp_index", torch.int64)
+        if self.pts.dim() != 3 or self.pts.shape[0] != 2 or self.feat.shape[:2] != self.pts.shape[:2] or self.feat.shape[2] != 32 \
+                or self.kp_index.dim() != 2 or self.kp_index.shape[0] != 2 or self.kp_index.shape[1] == 0:
+            raise ValueError("PairMatchGraph: expected pts [2,N,3], feat [2,N,32], kp_index [2,n_kp]")
+        N, n = self.pts.shape[1], self.kp_index.shape[1]
+        dev = self.pts.device
+        self.dev = dev
+        self.F = torch.empty((2, n, 32, 4), dtype=torch.float32, device=dev)
+        self.m = torch.empty((1, n), dtype=torch.int64, device=dev)
+        self.d = torch.empty((1, n), dtype=torch.float32, device=dev)
+        self.prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
+        self.ws = torch.empty(lib.umereg_pair_match_workspace_bytes(N, n), dtype=torch.uint8, device=dev)
+        self._lib = lib
+        handle = ctypes.c_void_p()
+        cap = torch.cuda.Stream(dev)                     # capture needs a non-default stream; nothing runs on it
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.device(dev):
+            rc = lib.umereg_pair_match_graph_create(_ptr(self.pts), _ptr(self.feat), _ptr(self.kp_index), N, n, int(K), float(radius),
+                                                    float(tau) if tau is not None else 0.0, _ptr(self.F), _ptr(self.m), _ptr(self.d),
+                                                    _ptr(self.prob), _ptr(self.ws), self.ws.numel(), cap.cuda_stream,
+                                                    ctypes.byref(handle))
+        _lib.check(rc, "umereg_pair_match_graph_create")
+        self.handle = handle
+
+    def launch(self):
+        with torch.cuda.device(self.dev):
+            rc = self._lib.umereg_pair_match_graph_launch(self.handle, _stream_ptr(self.dev))
+        _lib.check(rc, "umereg_pair_match_graph_launch")
+        return self.F, self.m, self.d, self.prob
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.umereg_pair_match_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
