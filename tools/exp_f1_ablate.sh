@@ -2,7 +2,7 @@
 # usage (build container): tools/exp_f1_ablate.sh build   -> tools/libumereg_abl<mask>.so for a few masks
 #       (GPU box):         tools/exp_f1_ablate.sh run     -> lattice-kernel time of each variant on the KT pair
 cd "$(dirname "$0")/.."
-MASKS="0 256 512 1024 2048 4096 6144 1 3 7"
+MASKS="${MASKS:-0 8192}"
 if [ "$1" = build ]; then
   for m in $MASKS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Xarch_device -fno-slp-vectorize -fPIC -shared \

@@ -33,7 +33,6 @@ namespace umereg {
 #ifndef UMEREG_F1_ABLATE
 #define UMEREG_F1_ABLATE 0   // timing experiments only (tools/exp_f1_ablate.sh): 1 skip epilogue, 2 skip append, 4 skip histogram, 8 skip grid fallback
 #endif
-constexpr float kFarCells = 0.75f;    // "far outside the target": distance to its bounding box, in grid cells
 constexpr int kBins = 32;
 constexpr float kKnnMaxCells = 6.0f;   // upper bound of the first search radius, in cells
 constexpr float kKnnTarget = 4.0f;     // expected points in the first search ball, in units of K
@@ -886,27 +885,108 @@ __global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict_
 constexpr int kCoopCap = 256;       // cooperative key list (keys)
 constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
 
-// keep the K smallest of list[0 .. cnt) (cnt <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
-__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
+// keep the K smallest of list[0 .. cnt) (cnt <= SLOTS * 64 <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
+// Rank counting: keys are unique, so ranks are a permutation.  cnt * SLOTS compare-and-adds per lane.
+template <int SLOTS>
+__device__ __forceinline__ int coop_cut_n(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
 {
-    unsigned long long mine[kCoopCap / kWave];
-    int rank[kCoopCap / kWave];
+    unsigned long long mine[SLOTS];
+    int rank[SLOTS];
 #pragma unroll
-    for (int u = 0; u < kCoopCap / kWave; ++u) {
+    for (int u = 0; u < SLOTS; ++u) {
         mine[u] = u * kWave + lane < cnt ? list[u * kWave + lane] : ~0ull;
         rank[u] = 0;
     }
     for (int f = 0; f < cnt; ++f) {
         const unsigned long long k = list[f];               // same address in every lane: one broadcast read
 #pragma unroll
-        for (int u = 0; u < kCoopCap / kWave; ++u) rank[u] += k < mine[u] ? 1 : 0;
+        for (int u = 0; u < SLOTS; ++u) rank[u] += k < mine[u] ? 1 : 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-    for (int u = 0; u < kCoopCap / kWave; ++u)
+    for (int u = 0; u < SLOTS; ++u)
         if (u * kWave + lane < cnt && rank[u] < K) out[rank[u]] = mine[u];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     return cnt < K ? cnt : K;
+}
+__device__ __forceinline__ int coop_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane)
+{
+    if (cnt <= kWave) return coop_cut_n<1>(list, out, cnt, K, lane);
+    if (cnt <= 2 * kWave) return coop_cut_n<2>(list, out, cnt, K, lane);
+    return coop_cut_n<kCoopCap / kWave>(list, out, cnt, K, lane);
+}
+
+// approximate cut of list[0 .. cnt) (cnt <= SLOTS * 64): a 64-bin histogram of d2 over the list's range finds the bin the
+// K-th smallest key falls in; every key of that bin and below is kept (bin index = monotone function of d2, so the K
+// smallest keys are among them), the rest is dropped.  out[0 .. returned count) = the kept keys (unordered); bound =
+// largest kept d2 as a key that admits every index.  ~1/15 of the instructions of the exact rank-counting cut; exact
+// cuts remain for the final K and for lists the histogram cannot split (equal d2).
+template <int SLOTS>
+__device__ __forceinline__ int coop_hist_cut(const unsigned long long* list, unsigned long long* out, int cnt, int K, int lane,
+                                             unsigned int* hist, unsigned long long& bound)
+{
+    unsigned long long mine[SLOTS];
+    float lo = 3.0e38f, hi = 0.f;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const bool valid = u * kWave + lane < cnt;
+        mine[u] = valid ? list[u * kWave + lane] : ~0ull;
+        const float d = __uint_as_float((unsigned int)(mine[u] >> 32));
+        if (valid) { lo = fminf(lo, d); hi = fmaxf(hi, d); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, kWave));
+        hi = fmaxf(hi, __shfl_xor(hi, o, kWave));
+    }
+    if (!(hi > lo) || cnt <= K) {            // nothing to split (or NaN keys): exact cut
+        const int n = coop_cut(list, out, cnt, K, lane);
+        if (n == K) bound = out[K - 1];
+        return n;
+    }
+    const float sc = 64.0f / (hi - lo);
+    hist[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int bin[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const float d = __uint_as_float((unsigned int)(mine[u] >> 32));
+        const int b = (int)((d - lo) * sc);
+        bin[u] = b > 63 ? 63 : b;
+        if (u * kWave + lane < cnt) atomicAdd(&hist[bin[u]], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int incl = (int)hist[lane];
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int v = __shfl_up(incl, o, kWave);
+        incl += lane >= o ? v : 0;
+    }
+    const unsigned long long reach = __ballot(incl >= K);      // non-empty: cnt > K
+    const int tb = __ffsll((long long)reach) - 1;
+    const int kept = __shfl(incl, tb, kWave);
+    if (kept > 2 * kWave) {                   // a crowded bin: exact cut
+        const int n = coop_cut(list, out, cnt, K, lane);
+        if (n == K) bound = out[K - 1];
+        return n;
+    }
+    int n = 0;
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const bool keep = u * kWave + lane < cnt && bin[u] <= tb;
+        const unsigned long long b = __ballot(keep);
+        if (keep) {
+            out[n + mbcnt(b)] = mine[u];
+            mx = fmaxf(mx, __uint_as_float((unsigned int)(mine[u] >> 32)));
+        }
+        n += __popcll(b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+    bound = ((unsigned long long)__float_as_uint(mx) << 32) | 0xffffffffull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return n;
 }
 
 // images in empty parts of the target (partly overlapping clouds): served with D = d_K + margin (78 % -> 91 % of the queries of a
@@ -1432,14 +1512,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint2* pool = nullptr;
     unsigned int* lat_header = nullptr;
     uint4* queue = nullptr;
-    // the grid kernel as the taker of the consensus pass's leftovers: header + record queue of the (unused) lattice
-    unsigned int* gq_header = nullptr;
-    uint4* gqueue = nullptr;
-    if (!LAT && lat) {
-        gq_header = reinterpret_cast<unsigned int*>(lat);
-        if (gq_header[8] == 0u) return;                         // the lattice takes the leftovers
-        gqueue = reinterpret_cast<uint4*>(lat + lat_ws(c_max).total);
-    }
     if (LAT) {
         const LatWs lw = lat_ws(c_max);
         Lt = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
@@ -1476,11 +1548,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qy = fmaf(Th[6], sp.z, fmaf(Th[5], sp.y, Th[4] * sp.x)) + Th[7];
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
         int cnt;
-        unsigned long long __ballot_all_todo = 0ull;
         // queries the consensus pass has already scored are not this kernel's business
         const int ph = served ? inv[h] : 0;       // position of the hypothesis in the consensus pass's processing order
         const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull));
-        bool fb_lanes = false, far_rec = false, near_q = todo_q;
+        bool fb_lanes = false;
+        const bool near_q = todo_q;
         if (!__any(todo_q)) {
             if (lane == 0) partial[(size_t)h * n_chunks + chunk] = 0.f;
             continue;
@@ -1543,33 +1615,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             KNN_DBG(8, __popcll(__ballot(fb_lanes)));
             cnt = got ? cnt : 0;
         } else {
-            // records whose live lanes ALL lie further than kFarCells grid cells outside the target's bounding box (the
-            // chunks of a hypothesis that throws the cloud somewhere else) are not searched here: a per-lane grid search
-            // needs caps of hundreds of candidates and several radius-growing rounds for them -- such wavefronts ran for
-            // 4 ms (8 M clocks) and set the kernel time.  They are queued for corr_score_fallback_kernel.
-            if (gqueue) {
-                const Grid& g = c.g;
-                const float ox = fmaxf(fmaxf(g.minx - qx, qx - (g.minx + (float)g.nx / g.invx)), 0.f);
-                const float oy = fmaxf(fmaxf(g.miny - qy, qy - (g.miny + (float)g.ny / g.invy)), 0.f);
-                const float oz = fmaxf(fmaxf(g.minz - qz, qz - (g.minz + (float)g.nz / g.invz)), 0.f);
-                const bool lane_far = ox * ox + oy * oy + oz * oz > kFarCells * kFarCells * c.cs_min * c.cs_min;
-                // (NaN images compare false: not far, the grid search copes)
-                __ballot_all_todo = __ballot(todo_q && lane_far);    // these lanes go to corr_score_fallback_kernel
-                far_rec = __ballot_all_todo != 0ull;
-                near_q = todo_q && !lane_far;
-            }
-            const long long t_k = gqueue ? clock64() : 0;
             cnt = __any(near_q) ? knn_wave(c, qx, qy, qz, near_q, K, cap, L.hist, L.list, lane) : 0;
             cnt = near_q ? cnt : 0;
-            if (gqueue && __any(near_q) && lane == 0) {     // statistics (header words 10..15)
-                const unsigned int kc = (unsigned int)((clock64() - t_k) >> 10);
-                atomicAdd(&gq_header[10], 1u);
-                atomicAdd(&gq_header[11], kc);
-                atomicMax(&gq_header[12], kc);
-                if (kc > 100u) atomicAdd(&gq_header[13], 1u);
-                if (kc > 1000u) atomicAdd(&gq_header[14], 1u);
-                atomicAdd(&gq_header[15], (unsigned int)__popcll(__ballot_all_todo));
-            }
         }
         const float acc = score_epilogue(L.list, cnt, valid, sidx, vp4, vq4, K, sigma, lane);
         if (LAT) {
@@ -1585,15 +1632,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         } else {
-            if (lane == 0) {
-                partial[(size_t)h * n_chunks + chunk] = acc;
-                if (far_rec) {                                  // the whole record goes to corr_score_fallback_kernel
-                    const unsigned long long todo = __ballot_all_todo;
-                    atomicAdd(&gq_header[6], (unsigned int)__popcll(todo));
-                    const unsigned int r = atomicAdd(&gq_header[4], 1u);
-                    gqueue[r] = make_uint4((unsigned int)h, (unsigned int)chunk, (unsigned int)todo, (unsigned int)(todo >> 32));
-                }
-            }
+            if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
         }
     }
 #ifdef UMEREG_KNN_DEBUG
@@ -1608,18 +1647,89 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
 }
 
+// ---- the consensus pass's leftovers, when they are few (header word 8 = 1): queued for corr_score_fallback_kernel ----
+// They are ~1 % of the queries, scattered over the (hypothesis, chunk) records with a dozen live lanes each.  A
+// per-lane grid walk runs at the pace of its slowest lane (measured: 25 k clocks per live lane, millions for images
+// thrown 30 m outside the target); the one-wavefront-per-query kernel serves such a query in ~6 k (1.55 + 0.94 ms ->
+// 0.25 + 1.46 ms, and 0.05 ms for this kernel in place of a pass of the score kernel over all records).
+// One wavefront per (chunk of 64 source slots, word of 64 hypotheses in processing order): lane = slot reads its served
+// word, 64 ballots transpose it into one slot mask per hypothesis (lane = hypothesis), masks that are not empty become
+// records.  partial[] is zeroed beforehand; every record has one writer.
+__global__ __launch_bounds__(256) void leftover_queue_kernel(const char* __restrict__ ws_src, int Ns, int M, int n_chunks,
+                                                             const unsigned long long* __restrict__ served, int n_words,
+                                                             const int* __restrict__ perm, char* __restrict__ lat, unsigned int c_max)
+{
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat);
+    if (header[8] == 0u) return;                                 // the lattice takes the leftovers
+    uint4* queue = reinterpret_cast<uint4*>(lat + lat_ws(c_max).total);
+    const int lane = lane_id();
+    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int chunk = wid / n_words, w = wid % n_words;
+    if (chunk >= n_chunks) return;
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s);
+    const int slot = chunk * kWave + lane;
+    const bool valid = slot < Ns;
+    const int sidx = __float_as_int(S4s[valid ? slot : 0].w);
+    const unsigned long long word = valid ? served[(size_t)sidx * n_words + w] : ~0ull;
+    unsigned long long mine = 0ull;                              // slots of this chunk still to do under hypothesis position w * 64 + lane
+    for (int b = 0; b < kWave; ++b) {
+        const unsigned long long m = __ballot(((word >> b) & 1ull) == 0ull);
+        if (lane == b) mine = m;
+    }
+    const int pos = w * kWave + lane;
+    const bool rec = pos < M && mine != 0ull;
+    const unsigned long long recs = __ballot(rec);
+    if (recs == 0ull) return;
+    unsigned int base = 0u;
+    if (lane == 0) base = atomicAdd(&header[4], (unsigned int)__popcll(recs));
+    base = (unsigned int)__shfl((int)base, 0, kWave);
+    if (rec) {
+        queue[base + (unsigned int)mbcnt(recs)] = make_uint4((unsigned int)perm[pos], (unsigned int)chunk, (unsigned int)mine, (unsigned int)(mine >> 32));
+        atomicAdd(&header[6], (unsigned int)__popcll(mine));
+    }
+}
+
+// ---- bounding boxes of the target table's 64-point chunks (cell-sorted order: a chunk is a short strip of cells) ----
+// box[2c] = minimum, box[2c + 1] = maximum of the chunk's points; .w of the minimum = number of valid points.
+__global__ __launch_bounds__(256) void tgt_chunk_box_kernel(const char* __restrict__ ws_tgt, int Nt, float4* __restrict__ box)
+{
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int n_tch = (Nt + kWave - 1) / kWave;
+    if (c >= n_tch) return;
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + grid_ws(Nt).off_p4s);
+    const int j = c * kWave + lane;
+    const float4 p = P4s[j < Nt ? j : c * kWave];          // an invalid lane repeats the chunk's first point
+    float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
+        }
+    if (lane == 0) {
+        box[2 * c] = make_float4(lo[0], lo[1], lo[2], __int_as_float(min(kWave, Nt - c * kWave)));
+        box[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+}
+static inline size_t tgt_box_bytes(int Nt) { return align_up((size_t)((Nt + kWave - 1) / kWave) * 32, 256); }
+
 // ---- the queries the lattice could not serve: one WAVEFRONT per query -----------------------------------------------
 // corr_score_kernel<., true> leaves (hypothesis, chunk, lane mask) records for queries outside the lattice or in cells
 // without a list.  They are few, but any one-lane-per-query search is arbitrarily expensive for them (a query 30 m
 // outside the cloud needs a cap of hundreds of candidates; variants tried here: the grid walk per lane 5.3 ms, brute
 // force per lane over the whole table 6.1 ms, a staged common candidate set 4.4 ms -- for 0.3 % of the queries).
-// So a whole wavefront serves one query, by exact brute force over the target table, and a workgroup of 8 wavefronts
-// shares the queries of one record:
-//   * bound: every lane takes the minimum d2 over kCoopSamples strided table entries; the 64 minima belong to 64
-//     distinct points, so the K-th smallest of them is >= the K-th smallest d2 of the table;
-//   * scan: all Nt points, 128 per step (coalesced); keys (bits(d2) << 32 | index) at or below the bound go to an LDS
-//     list (ballot + mbcnt); when the list could overflow it is cut back to its K smallest keys by rank counting (keys
-//     are unique, so ranks are a permutation) and the bound drops to the K-th key;
+// So a whole wavefront serves one query, exactly, over the target table's 64-point chunks, and a workgroup of 8
+// wavefronts shares the queries of one record:
+//   * seed: the chunk whose bounding box (tgt_chunk_box_kernel) is nearest to the query, among those with >= K points;
+//     the K-th smallest key of its points bounds the K-th smallest key of the table;
+//   * scan: only chunks whose box distance does not exceed the bound (the box distance is formed with the same fp32
+//     operations as a point's d2, each of which is monotone, so it never exceeds the d2 of a point inside the box);
+//     keys (bits(d2) << 32 | index) at or below the bound go to an LDS list (ballot + mbcnt); when the list could
+//     overflow it is cut back to its K smallest keys by rank counting and the bound drops to the K-th key.  A query in
+//     the cloud touches ~10 of KITTI's 157 chunks, one 30 m outside it a few dozen (round 1 scanned them all: 2.6 ms
+//     for 170 k queries, with a bound from strided samples that admitted hundreds of keys);
 //   * score: the K keys of the final cut, 8 lanes per neighbour's feature row.
 // The record's sum is formed by wavefront 0 from the per-query values in lane order: deterministic.
 constexpr int kCoopWaves = 8;       // wavefronts per record
@@ -1628,9 +1738,10 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
                                                                   const float* __restrict__ src_pts, const float4* __restrict__ vp4,
                                                                   const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
                                                                   int K, float sigma, int n_chunks, float* __restrict__ partial,
-                                                                  const char* __restrict__ lat, unsigned int c_max)
+                                                                  const char* __restrict__ lat, unsigned int c_max, const float4* __restrict__ box)
 {
     __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
+    __shared__ unsigned int chist[kCoopWaves][kWave];
     __shared__ float qval[kWave];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -1644,7 +1755,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
     unsigned long long* lb = lists[wave][1];
     const unsigned int n_rec = header[4];
     const int grp = lane >> 3, sub = lane & 7;
-    const int step = Nt / (kWave * kCoopSamples);
+    const int n_tch = (Nt + kWave - 1) / kWave;
     for (unsigned int r = blockIdx.x; r < n_rec; r += gridDim.x) {      // (static assignment: see DESIGN on the atomic-counter hang)
         const uint4 rec = queue[r];
         const int h = (int)rec.x, chunk = (int)rec.y;
@@ -1674,39 +1785,71 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
                 t = t + dz * dz;
                 return t;
             };
-            // (1) first bound
-            unsigned long long ukey = ~0ull;
-            if (step > 0) {
-                float m = 3.0e38f;
-                for (int sm = 0; sm < kCoopSamples; ++sm) m = fminf(m, dist2(P4s[(sm * kWave + lane) * step]));
-                int rk = 0;
-                for (int f = 0; f < kWave; ++f) {
-                    const float o = __shfl(m, f, kWave);
-                    rk += (o < m || (o == m && f < lane)) ? 1 : 0;
-                }
-                const unsigned long long kth = __ballot(rk == K - 1);
-                if (kth != 0ull) ukey = ((unsigned long long)__float_as_uint(__shfl(m, __ffsll((long long)kth) - 1, kWave)) << 32) | 0xffffffffull;
-            }
-            // (2) scan the table, two 64-point tiles per step (the padded table makes reads up to Nt + 63 safe; beyond
-            //     that the index is clamped onto a padding point)
-            int cnt = 0;
-            for (int base = 0; base < Nt; base += 2 * kWave) {
-                if (cnt + 2 * kWave > kCoopCap) {
-                    cnt = coop_cut(la, lb, cnt, K, lane);
-                    unsigned long long* t_ = la; la = lb; lb = t_;
-                    if (cnt == K) ukey = la[K - 1];
-                }
-                const int j0 = base + lane, j1 = base + kWave + lane;
-                const float4 p0 = P4s[j0], p1 = P4s[j1 < Nt ? j1 : Nt];
-                const unsigned long long k0 = ((unsigned long long)__float_as_uint(dist2(p0)) << 32) | (unsigned int)__float_as_int(p0.w);
-                const unsigned long long k1 = ((unsigned long long)__float_as_uint(dist2(p1)) << 32) | (unsigned int)__float_as_int(p1.w);
-                const bool ok0 = j0 < Nt && k0 <= ukey, ok1 = j1 < Nt && k1 <= ukey;
-                const unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
-                if (ok0) la[cnt + mbcnt(b0)] = k0;
-                cnt += __popcll(b0);
-                if (ok1) la[cnt + mbcnt(b1)] = k1;
-                cnt += __popcll(b1);
+            // box distance: the same operation sequence as dist2 on the nearest point of the box
+            auto box2 = [&](int c) __attribute__((always_inline)) {
+                const float4 lo = box[2 * c], hi = box[2 * c + 1];
+                const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
+                const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
+                const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+                float t = dx * dx;
+                t = t + dy * dy;
+                t = t + dz * dz;
+                return t;
+            };
+            auto scan_chunk = [&](int c, unsigned long long ukey, int cnt) __attribute__((always_inline)) {
+                const int j = c * kWave + lane;
+                const float4 p = P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
+                const unsigned long long k = ((unsigned long long)__float_as_uint(dist2(p)) << 32) | (unsigned int)__float_as_int(p.w);
+                const bool ok = j < Nt && k <= ukey;
+                const unsigned long long b = __ballot(ok);
+                if (ok) la[cnt + mbcnt(b)] = k;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                return cnt + __popcll(b);
+            };
+            // (1) seed: the nearest chunk with at least K points (NaN images: every comparison fails, chunk 0 is taken
+            //     and nothing is ever pruned or admitted beyond it -- the result is NaN-free garbage of a NaN hypothesis,
+            //     as in the other paths the score of such a hypothesis is NaN through its terms)
+            float best = 3.0e38f;
+            int best_c = 0;
+            for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+                const int c = c0 + lane;
+                if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
+                    const float t = box2(c);
+                    if (t < best) { best = t; best_c = c; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, kWave);
+                const int oc = __shfl_xor(best_c, o, kWave);
+                if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+            }
+            const int seed = __builtin_amdgcn_readfirstlane(best_c);
+            int cnt = scan_chunk(seed, ~0ull, 0);
+            cnt = coop_cut(la, lb, cnt, K, lane);
+            { unsigned long long* t_ = la; la = lb; lb = t_; }
+            unsigned long long ukey = cnt == K ? la[K - 1] : ~0ull;
+            // (2) the chunks whose box reaches inside the bound
+            for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+                const int c = c0 + lane;
+                const float t = c < n_tch ? box2(c) : 3.0e38f;
+                const float bd = __uint_as_float((unsigned int)(ukey >> 32));
+                unsigned long long pend = __ballot(c < n_tch && c != seed && (ukey == ~0ull || !(t > bd)));
+                while (pend != 0ull) {
+                    const int l = __ffsll((long long)pend) - 1;
+                    pend &= pend - 1ull;
+                    // the bound may have dropped since the ballot
+                    if (ukey != ~0ull && __shfl(t, l, kWave) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
+                    if (cnt > 2 * kWave) {                      // (<= 3 * 64 keys: every scan adds at most 64)
+                        cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, chist[wave], ukey);
+                        unsigned long long* t_ = la; la = lb; lb = t_;
+                    }
+                    cnt = scan_chunk(c0 + l, ukey, cnt);
+                }
+            }
+            if (cnt > kWave) {
+                cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, chist[wave], ukey);
+                unsigned long long* t_ = la; la = lb; lb = t_;
             }
             cnt = coop_cut(la, lb, cnt, K, lane);
             { unsigned long long* t_ = la; la = lb; lb = t_; }
@@ -1869,7 +2012,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
                                                         align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
-           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
+           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + tgt_box_bytes(Nt) : 0) + cons;
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -1954,7 +2097,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     if (c_max && hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
     if (consensus_on(c_max, M, flags, T)) {
         // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
-        char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256);
+        char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256) + tgt_box_bytes(Nt);
         val = (float*)cons;
         served = (unsigned long long*)(cons + align_up((size_t)Ns * M * 4, 256));
         float* Tmed = (float*)((char*)served + align_up((size_t)Ns * n_words * 8, 256));
@@ -1973,10 +2116,10 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
         hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns);
         UMEREG_CHECK_LAUNCH("leftover_decide_kernel");
-        hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
-                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
-                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
-        UMEREG_CHECK_LAUNCH("corr_score_kernel");
+        if (hipMemsetAsync(partial, 0, (size_t)M * n_chunks_sz * 4, st) != hipSuccess) { set_error("hipMemsetAsync(partial) failed"); return UMEREG_ELAUNCH; }
+        hipLaunchKernelGGL(leftover_queue_kernel, dim3((unsigned)(((long)n_chunks * n_words + 3) / 4)), dim3(256), 0, st, (const char*)ws_src, Ns, M,
+                           n_chunks, (const unsigned long long*)served, n_words, (const int*)perm, lat, c_max);
+        UMEREG_CHECK_LAUNCH("leftover_queue_kernel");
     }
     if (c_max) {
         // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> compact -> count -> scan -> fill
@@ -2007,9 +2150,12 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
+        float4* box = (float4*)(lat + lw.total + align_up((size_t)M * n_chunks_sz * 16, 256));
+        hipLaunchKernelGGL(tgt_chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, Nt, box);
+        UMEREG_CHECK_LAUNCH("tgt_chunk_box_kernel");
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
-                           n_chunks, partial, (const char*)lat, c_max);
+                           n_chunks, partial, (const char*)lat, c_max, (const float4*)box);
         UMEREG_CHECK_LAUNCH("corr_score_fallback_kernel");
     } else if (idx16) {
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
