@@ -163,7 +163,7 @@ def main():
         for i in range(first, first + n):
             # per-kernel event pairs (the roofline leg) on every 8th timed pair only: they need the layered entry points;
             # the other pairs go through the one-call a1..a5 entry
-            pending.append(submit(i, record and i % 8 == 0))
+            pending.append(submit(i, record and (i - first) % 8 == 0))
             if len(pending) >= depth:
                 finish(pending.pop(0))
         while pending:

@@ -813,73 +813,83 @@ constexpr float kConsRadiusCells = 4.2f; // first D in grid cells (kNN-mode cell
 // then the hypotheses in the order of their distance from it: perm[rank] = h, inv[h] = rank.  The distance is a bound
 // on how far a hypothesis moves any source point away from its consensus image, |dt + dR c0| + |dR|_F r0 (c0, r0:
 // centre and radius of the source cloud) -- it only serves to put similar hypotheses into the same 64-lane step.
-__global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restrict__ T, int M, const unsigned int* __restrict__ src_bbox,
-                                                          float* __restrict__ Tmed, float* __restrict__ err)
+// (one workgroup per entry: the 12 x 32 bit-by-bit selection rounds of a single workgroup took 0.27 ms)
+__global__ __launch_bounds__(1024) void hyp_median_kernel(const float* __restrict__ T, int M, float* __restrict__ Tmed)
 {
-    __shared__ unsigned int cnt_s;
-    __shared__ float med[12];
+    __shared__ unsigned int cnt_s[32];
+    const int e = blockIdx.x;                      // 0 .. 11
     const int m_use = M < 8192 ? M : 8192;
     const int need = (m_use + 1) / 2;
-    for (int e = 0; e < 12; ++e) {
-        unsigned int v[8];
+    unsigned int v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = k * 1024 + threadIdx.x;
-            v[k] = i < m_use ? enc_ord(T[(size_t)i * 16 + e]) : 0xffffffffu;
-        }
-        unsigned int ans = 0u;       // smallest encoding with count(x <= ans) >= need, built from the top bit down
-        for (int b = 31; b >= 0; --b) {
-            const unsigned int t = ans | ((1u << b) - 1u);
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c += (k * 1024 + (int)threadIdx.x < m_use && v[k] <= t) ? 1 : 0;
-            if (threadIdx.x == 0) cnt_s = 0u;
-            __syncthreads();
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, kWave);
-            if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt_s, (unsigned int)c);
-            __syncthreads();
-            if ((int)cnt_s < need) ans |= 1u << b;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const float f = dec_ord(ans);
-            med[e] = Tmed[e] = f == f && fabsf(f) < 1e30f ? f : ((e % 5 == 0) ? 1.f : 0.f);     // NaN / inf: identity entry
-        }
+    for (int k = 0; k < 8; ++k) {
+        const int i = k * 1024 + threadIdx.x;
+        v[k] = i < m_use ? enc_ord(T[(size_t)i * 16 + e]) : 0xffffffffu;
     }
+    if (threadIdx.x < 32) cnt_s[threadIdx.x] = 0u;
     __syncthreads();
-    // distance of every hypothesis from the median one (the source bounding box here is that of the consensus-ROTATED
-    // copy the source order was built from: same radius, and the centre only matters roughly)
-    const float lo[3] = {dec_ord(~src_bbox[0]), dec_ord(~src_bbox[1]), dec_ord(~src_bbox[2])};
-    const float hi[3] = {dec_ord(src_bbox[3]), dec_ord(src_bbox[4]), dec_ord(src_bbox[5])};
-    const float r0 = 0.5f * sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-    for (int h = threadIdx.x; h < M; h += 1024) {
-        float fro = 0.f, dt2 = 0.f;
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) { const float d = T[(size_t)h * 16 + r * 4 + c] - med[r * 4 + c]; fro += d * d; }
-            const float d = T[(size_t)h * 16 + r * 4 + 3] - med[r * 4 + 3];
-            dt2 += d * d;
-        }
-        const float e = sqrtf(dt2) + sqrtf(fro) * 2.0f * r0;
-        err[h] = e == e ? e : 3.0e38f;                                                      // NaN hypotheses last
+    unsigned int ans = 0u;       // smallest encoding with count(x <= ans) >= need, built from the top bit down
+    for (int b = 31; b >= 0; --b) {
+        const unsigned int t = ans | ((1u << b) - 1u);
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += (k * 1024 + (int)threadIdx.x < m_use && v[k] <= t) ? 1 : 0;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, kWave);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt_s[b], (unsigned int)c);
+        __syncthreads();
+        if ((int)cnt_s[b] < need) ans |= 1u << b;
+    }
+    if (threadIdx.x == 0) {
+        const float f = dec_ord(ans);
+        Tmed[e] = f == f && fabsf(f) < 1e30f ? f : ((e % 5 == 0) ? 1.f : 0.f);     // NaN / inf: identity entry
     }
 }
 
-// rank counting (ties by index) over the M distances: perm[rank] = h, inv[h] = rank
+// distance of every hypothesis from the median one (the source bounding box here is that of the consensus-ROTATED
+// copy the source order was built from: same radius, and the centre only matters roughly)
+__global__ __launch_bounds__(256) void hyp_err_kernel(const float* __restrict__ T, int M, const unsigned int* __restrict__ src_bbox,
+                                                      const float* __restrict__ Tmed, float* __restrict__ err)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= M) return;
+    const float lo[3] = {dec_ord(~src_bbox[0]), dec_ord(~src_bbox[1]), dec_ord(~src_bbox[2])};
+    const float hi[3] = {dec_ord(src_bbox[3]), dec_ord(src_bbox[4]), dec_ord(src_bbox[5])};
+    const float r0 = 0.5f * sqrtf((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    float fro = 0.f, dt2 = 0.f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) { const float d = T[(size_t)h * 16 + r * 4 + c] - Tmed[r * 4 + c]; fro += d * d; }
+        const float d = T[(size_t)h * 16 + r * 4 + 3] - Tmed[r * 4 + 3];
+        dt2 += d * d;
+    }
+    const float e = sqrtf(dt2) + sqrtf(fro) * 2.0f * r0;
+    err[h] = e == e ? e : 3.0e38f;                                                      // NaN hypotheses last
+}
+
+// rank counting (ties by index) over the M distances: perm[rank] = h, inv[h] = rank.  64 hypotheses per workgroup, the
+// others' distances split over its four wavefronts.
 __global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict__ err, int M, int* __restrict__ perm, int* __restrict__ inv)
 {
     __shared__ float tile[256];
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int ranks[4][kWave];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int h = blockIdx.x * kWave + lane;
     const float e = h < M ? err[h] : 0.f;
     int rk = 0;
     for (int f0 = 0; f0 < M; f0 += 256) {
         __syncthreads();
         tile[threadIdx.x] = f0 + (int)threadIdx.x < M ? err[f0 + threadIdx.x] : 3.4e38f;
         __syncthreads();
-        const int lim = min(256, M - f0);
-        for (int k = 0; k < lim; ++k) { const float o = tile[k]; rk += (o < e || (o == e && f0 + k < h)) ? 1 : 0; }
+        const int k0 = part * 64, lim = min(64, M - f0 - k0);
+        for (int k = 0; k < lim; ++k) { const float o = tile[k0 + k]; rk += (o < e || (o == e && f0 + k0 + k < h)) ? 1 : 0; }
     }
-    if (h < M) { perm[rk] = h; inv[h] = rk; }
+    ranks[part][lane] = rk;
+    __syncthreads();
+    if (part == 0 && h < M) {
+        rk = ranks[0][lane] + ranks[1][lane] + ranks[2][lane] + ranks[3][lane];
+        perm[rk] = h;
+        inv[h] = rk;
+    }
 }
 
 constexpr int kCoopCap = 256;       // cooperative key list (keys)
@@ -1313,6 +1323,10 @@ __global__ __launch_bounds__(1024) void lattice_compact_kernel(const char* __res
     const uint4* marks16 = reinterpret_cast<const uint4*>(lat + lw.off_marks);
     unsigned int* cids = reinterpret_cast<unsigned int*>(lat + lw.off_cids);
     unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    if (header[8] != 0u) {                             // the leftovers went to the queue: nothing is marked
+        if (threadIdx.x == 0) { header[3] = 0u; header[1] = (unsigned int)L.n_cells; }
+        return;
+    }
     const int n16 = L.n_cells >> 4;                    // groups of 16 cells (n_cells is a multiple of 64)
     const int per = (n16 + 1023) / 1024;
     const int a = threadIdx.x * per, b = min(a + per, n16);
@@ -1689,17 +1703,20 @@ __global__ __launch_bounds__(256) void leftover_queue_kernel(const char* __restr
     }
 }
 
-// ---- bounding boxes of the target table's 64-point chunks (cell-sorted order: a chunk is a short strip of cells) ----
-// box[2c] = minimum, box[2c + 1] = maximum of the chunk's points; .w of the minimum = number of valid points.
-__global__ __launch_bounds__(256) void tgt_chunk_box_kernel(const char* __restrict__ ws_tgt, int Nt, float4* __restrict__ box)
+// ---- bounding boxes of a sorted table's 64-point chunks (cell-sorted order: a chunk is a short strip of cells) ----
+// box[2c] = minimum, box[2c + 1] = maximum of the chunk's points (workspace region off_box).
+__global__ __launch_bounds__(256) void chunk_box_kernel(char* __restrict__ ws, size_t ws_stride, int N)
 {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = lane_id();
-    const int n_tch = (Nt + kWave - 1) / kWave;
-    if (c >= n_tch) return;
-    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + grid_ws(Nt).off_p4s);
+    const int n_ch = (N + kWave - 1) / kWave;
+    if (c >= n_ch) return;
+    const GridWs w = grid_ws(N);
+    char* wb = ws + blockIdx.y * ws_stride;
+    const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    float4* box = reinterpret_cast<float4*>(wb + w.off_box);
     const int j = c * kWave + lane;
-    const float4 p = P4s[j < Nt ? j : c * kWave];          // an invalid lane repeats the chunk's first point
+    const float4 p = P4s[j < N ? j : c * kWave];          // an invalid lane repeats the chunk's first point
     float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -1709,28 +1726,156 @@ __global__ __launch_bounds__(256) void tgt_chunk_box_kernel(const char* __restri
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
         }
     if (lane == 0) {
-        box[2 * c] = make_float4(lo[0], lo[1], lo[2], __int_as_float(min(kWave, Nt - c * kWave)));
+        box[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
         box[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
 }
-static inline size_t tgt_box_bytes(int Nt) { return align_up((size_t)((Nt + kWave - 1) / kWave) * 32, 256); }
+
+// ---- exact K nearest of ONE query by a whole wavefront, over the sorted table's 64-point chunks ---------------------
+//   * seed: the chunk whose bounding box is nearest to the query, among those with >= K points; the K-th smallest key
+//     of its points bounds the K-th smallest key of the table;
+//   * scan: only chunks whose box distance does not exceed the bound (the box distance is formed with the same fp32
+//     operations as a point's d2, each of which is monotone, so it never exceeds the d2 of a point inside the box);
+//     keys (bits(d2) << 32 | index) at or below the bound go to an LDS list (ballot + mbcnt); a list beyond 128 keys is
+//     cut by histogram (coop_hist_cut) and the bound drops.  A query in the cloud touches ~10 of KITTI's 157 chunks,
+//     one 30 m outside it a few dozen;
+//   * final cut: histogram, then exact rank counting: la[0 .. returned count) = the K smallest keys in ascending order.
+// la / lb: two kCoopCap-key LDS lists of this wavefront (swapped as cuts go), hist: 64 words.
+__device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const float4* __restrict__ box, int Nt, int K, float qx, float qy,
+                                        float qz, unsigned long long*& la, unsigned long long*& lb, unsigned int* hist, int lane)
+{
+    const int n_tch = (Nt + kWave - 1) / kWave;
+    auto dist2 = [&](const float4& p) __attribute__((always_inline)) {
+        const float dx = qx - p.x;
+        const float dy = qy - p.y;
+        const float dz = qz - p.z;
+        float t = dx * dx;
+        t = t + dy * dy;
+        t = t + dz * dz;
+        return t;
+    };
+    // box distance: the same operation sequence as dist2 on the nearest point of the box
+    auto box2 = [&](int c) __attribute__((always_inline)) {
+        const float4 lo = box[2 * c], hi = box[2 * c + 1];
+        const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
+        const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
+        const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+        float t = dx * dx;
+        t = t + dy * dy;
+        t = t + dz * dz;
+        return t;
+    };
+    auto scan_chunk = [&](int c, unsigned long long ukey, int cnt) __attribute__((always_inline)) {
+        const int j = c * kWave + lane;
+        const float4 p = P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
+        const unsigned long long k = ((unsigned long long)__float_as_uint(dist2(p)) << 32) | (unsigned int)__float_as_int(p.w);
+        const bool ok = j < Nt && k <= ukey;
+        const unsigned long long b = __ballot(ok);
+        if (ok) la[cnt + mbcnt(b)] = k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        return cnt + __popcll(b);
+    };
+    // (1) seed: the nearest chunk with at least K points (a NaN query fails every comparison: chunk 0, nothing pruned,
+    //     NaN keys -- its terms come out NaN as on the other paths)
+    float best = 3.0e38f;
+    int best_c = 0;
+    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+        const int c = c0 + lane;
+        if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
+            const float t = box2(c);
+            if (t < best) { best = t; best_c = c; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, kWave);
+        const int oc = __shfl_xor(best_c, o, kWave);
+        if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    }
+    const int seed = __builtin_amdgcn_readfirstlane(best_c);
+    int cnt = scan_chunk(seed, ~0ull, 0);
+    cnt = coop_cut(la, lb, cnt, K, lane);
+    { unsigned long long* t_ = la; la = lb; lb = t_; }
+    unsigned long long ukey = cnt == K ? la[K - 1] : ~0ull;
+    // (2) the chunks whose box reaches inside the bound
+    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+        const int c = c0 + lane;
+        const float t = c < n_tch ? box2(c) : 3.0e38f;
+        const float bd = __uint_as_float((unsigned int)(ukey >> 32));
+        unsigned long long pend = __ballot(c < n_tch && c != seed && (ukey == ~0ull || !(t > bd)));
+        while (pend != 0ull) {
+            const int l = __ffsll((long long)pend) - 1;
+            pend &= pend - 1ull;
+            // the bound may have dropped since the ballot
+            if (ukey != ~0ull && __shfl(t, l, kWave) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
+            if (cnt > 2 * kWave) {                      // (<= 3 * 64 keys: every scan adds at most 64)
+                cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
+                unsigned long long* t_ = la; la = lb; lb = t_;
+            }
+            cnt = scan_chunk(c0 + l, ukey, cnt);
+        }
+    }
+    if (cnt > kWave) {
+        cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
+        unsigned long long* t_ = la; la = lb; lb = t_;
+    }
+    cnt = coop_cut(la, lb, cnt, K, lane);
+    { unsigned long long* t_ = la; la = lb; lb = t_; }
+    return cnt;
+}
+
+// ---- feature_spatial_var for clouds that do not fill the chip with one query per lane: one wavefront per query ----
+// (10 000 points: the per-lane kernel ran 0.28 ms at the pace of its slowest lanes on a quarter-filled chip; this one
+// ~0.05 ms).  Neighbours = coop_knn's K keys in ascending order, rank 0 (the point itself unless an exact duplicate has a
+// lower index) dropped; 8 lanes per neighbour's feature row; sum of the K - 1 distances by a fixed butterfly.
+__global__ __launch_bounds__(8 * 64) void spatial_var_coop_kernel(const char* __restrict__ ws, size_t ws_stride, const float4* __restrict__ feat4,
+                                                                  int N, int K, float* __restrict__ out)
+{
+    __shared__ unsigned long long lists[8][2][kCoopCap];
+    __shared__ unsigned int chist[8][kWave];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int b = blockIdx.y;
+    const GridWs w = grid_ws(N);
+    const char* wb = ws + b * ws_stride;
+    const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(wb + w.off_box);
+    const float4* fb = feat4 + (size_t)b * N * 8;
+    const int grp = lane >> 3, sub = lane & 7;
+    unsigned long long* la = lists[wave][0];
+    unsigned long long* lb = lists[wave][1];
+    for (int slot = blockIdx.x * 8 + wave; slot < N; slot += gridDim.x * 8) {
+        const float4 p = P4s[slot];
+        const int me = __float_as_int(p.w);
+        const int cnt = coop_knn(P4s, box, N, K, p.x, p.y, p.z, la, lb, chist[wave], lane);
+        const float4 a = fb[(size_t)me * 8 + sub];
+        float part = 0.f;
+        for (int e0 = 1; e0 < cnt; e0 += 8) {
+            const int e = e0 + grp;
+            const unsigned long long k = la[e < cnt ? e : 0];
+            const float4 o = fb[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
+            const float a0 = a.x - o.x, a1 = a.y - o.y, a2 = a.z - o.z, a3 = a.w - o.w;
+            float s = a0 * a0;
+            s = fmaf(a1, a1, s); s = fmaf(a2, a2, s); s = fmaf(a3, a3, s);
+            s += __shfl_xor(s, 1, kWave);
+            s += __shfl_xor(s, 2, kWave);
+            s += __shfl_xor(s, 4, kWave);
+            part += (sub == 0 && e < cnt) ? sqrtf(s) : 0.f;
+        }
+        part = wave_sum_f(part);
+        if (lane == 0) out[(size_t)b * N + me] = part / (float)(K - 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
 
 // ---- the queries the lattice could not serve: one WAVEFRONT per query -----------------------------------------------
 // corr_score_kernel<., true> leaves (hypothesis, chunk, lane mask) records for queries outside the lattice or in cells
 // without a list.  They are few, but any one-lane-per-query search is arbitrarily expensive for them (a query 30 m
 // outside the cloud needs a cap of hundreds of candidates; variants tried here: the grid walk per lane 5.3 ms, brute
 // force per lane over the whole table 6.1 ms, a staged common candidate set 4.4 ms -- for 0.3 % of the queries).
-// So a whole wavefront serves one query, exactly, over the target table's 64-point chunks, and a workgroup of 8
-// wavefronts shares the queries of one record:
-//   * seed: the chunk whose bounding box (tgt_chunk_box_kernel) is nearest to the query, among those with >= K points;
-//     the K-th smallest key of its points bounds the K-th smallest key of the table;
-//   * scan: only chunks whose box distance does not exceed the bound (the box distance is formed with the same fp32
-//     operations as a point's d2, each of which is monotone, so it never exceeds the d2 of a point inside the box);
-//     keys (bits(d2) << 32 | index) at or below the bound go to an LDS list (ballot + mbcnt); when the list could
-//     overflow it is cut back to its K smallest keys by rank counting and the bound drops to the K-th key.  A query in
-//     the cloud touches ~10 of KITTI's 157 chunks, one 30 m outside it a few dozen (round 1 scanned them all: 2.6 ms
-//     for 170 k queries, with a bound from strided samples that admitted hundreds of keys);
-//   * score: the K keys of the final cut, 8 lanes per neighbour's feature row.
+// So a whole wavefront serves one query (coop_knn; round 1 scanned the whole table per query with a bound from strided
+// samples that admitted hundreds of keys: 2.6 ms for 170 k queries, now 0.94 ms), a workgroup of 8 wavefronts shares the
+// queries of one record, and the K keys are scored with 8 lanes per neighbour's feature row.
 // The record's sum is formed by wavefront 0 from the per-query values in lane order: deterministic.
 constexpr int kCoopWaves = 8;       // wavefronts per record
 
@@ -1738,7 +1883,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
                                                                   const float* __restrict__ src_pts, const float4* __restrict__ vp4,
                                                                   const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
                                                                   int K, float sigma, int n_chunks, float* __restrict__ partial,
-                                                                  const char* __restrict__ lat, unsigned int c_max, const float4* __restrict__ box)
+                                                                  const char* __restrict__ lat, unsigned int c_max)
 {
     __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
     __shared__ unsigned int chist[kCoopWaves][kWave];
@@ -1751,11 +1896,11 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
     const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
     const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
     unsigned long long* la = lists[wave][0];
     unsigned long long* lb = lists[wave][1];
     const unsigned int n_rec = header[4];
     const int grp = lane >> 3, sub = lane & 7;
-    const int n_tch = (Nt + kWave - 1) / kWave;
     for (unsigned int r = blockIdx.x; r < n_rec; r += gridDim.x) {      // (static assignment: see DESIGN on the atomic-counter hang)
         const uint4 rec = queue[r];
         const int h = (int)rec.x, chunk = (int)rec.y;
@@ -1776,83 +1921,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
             if (chunk * kWave + ql >= Ns) continue;
             const float qx = __shfl(lqx, ql, kWave), qy = __shfl(lqy, ql, kWave), qz = __shfl(lqz, ql, kWave);
             const int qs = __shfl(sidx, ql, kWave);
-            auto dist2 = [&](const float4& p) __attribute__((always_inline)) {
-                const float dx = qx - p.x;
-                const float dy = qy - p.y;
-                const float dz = qz - p.z;
-                float t = dx * dx;
-                t = t + dy * dy;
-                t = t + dz * dz;
-                return t;
-            };
-            // box distance: the same operation sequence as dist2 on the nearest point of the box
-            auto box2 = [&](int c) __attribute__((always_inline)) {
-                const float4 lo = box[2 * c], hi = box[2 * c + 1];
-                const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
-                const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
-                const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
-                float t = dx * dx;
-                t = t + dy * dy;
-                t = t + dz * dz;
-                return t;
-            };
-            auto scan_chunk = [&](int c, unsigned long long ukey, int cnt) __attribute__((always_inline)) {
-                const int j = c * kWave + lane;
-                const float4 p = P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
-                const unsigned long long k = ((unsigned long long)__float_as_uint(dist2(p)) << 32) | (unsigned int)__float_as_int(p.w);
-                const bool ok = j < Nt && k <= ukey;
-                const unsigned long long b = __ballot(ok);
-                if (ok) la[cnt + mbcnt(b)] = k;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                return cnt + __popcll(b);
-            };
-            // (1) seed: the nearest chunk with at least K points (NaN images: every comparison fails, chunk 0 is taken
-            //     and nothing is ever pruned or admitted beyond it -- the result is NaN-free garbage of a NaN hypothesis,
-            //     as in the other paths the score of such a hypothesis is NaN through its terms)
-            float best = 3.0e38f;
-            int best_c = 0;
-            for (int c0 = 0; c0 < n_tch; c0 += kWave) {
-                const int c = c0 + lane;
-                if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
-                    const float t = box2(c);
-                    if (t < best) { best = t; best_c = c; }
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o, kWave);
-                const int oc = __shfl_xor(best_c, o, kWave);
-                if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
-            }
-            const int seed = __builtin_amdgcn_readfirstlane(best_c);
-            int cnt = scan_chunk(seed, ~0ull, 0);
-            cnt = coop_cut(la, lb, cnt, K, lane);
-            { unsigned long long* t_ = la; la = lb; lb = t_; }
-            unsigned long long ukey = cnt == K ? la[K - 1] : ~0ull;
-            // (2) the chunks whose box reaches inside the bound
-            for (int c0 = 0; c0 < n_tch; c0 += kWave) {
-                const int c = c0 + lane;
-                const float t = c < n_tch ? box2(c) : 3.0e38f;
-                const float bd = __uint_as_float((unsigned int)(ukey >> 32));
-                unsigned long long pend = __ballot(c < n_tch && c != seed && (ukey == ~0ull || !(t > bd)));
-                while (pend != 0ull) {
-                    const int l = __ffsll((long long)pend) - 1;
-                    pend &= pend - 1ull;
-                    // the bound may have dropped since the ballot
-                    if (ukey != ~0ull && __shfl(t, l, kWave) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
-                    if (cnt > 2 * kWave) {                      // (<= 3 * 64 keys: every scan adds at most 64)
-                        cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, chist[wave], ukey);
-                        unsigned long long* t_ = la; la = lb; lb = t_;
-                    }
-                    cnt = scan_chunk(c0 + l, ukey, cnt);
-                }
-            }
-            if (cnt > kWave) {
-                cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, chist[wave], ukey);
-                unsigned long long* t_ = la; la = lb; lb = t_;
-            }
-            cnt = coop_cut(la, lb, cnt, K, lane);
-            { unsigned long long* t_ = la; la = lb; lb = t_; }
+            const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
             // (3) score: 8 neighbours per round, 8 lanes per 128-byte feature row
             const float4 a = vp4[(size_t)qs * 8 + sub];
             float part = 0.f;
@@ -1893,17 +1962,20 @@ __global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __res
     slices[(size_t)blockIdx.y * M + h] = s;
 }
 
+// one wavefront per hypothesis: lanes stride over the slices / chunks, then a fixed butterfly: deterministic
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restrict__ partial, int M, int n_chunks, int Ns,
                                                           const float* __restrict__ slices, int n_slices, const int* __restrict__ inv,
                                                           float* __restrict__ scores)
 {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = lane_id();
     if (h >= M) return;
     float s = 0.f;
     const int ph = n_slices ? inv[h] : 0;                                            // the consensus pass stores in its processing order
-    for (int k = 0; k < n_slices; ++k) s += slices[(size_t)k * M + ph];          // consensus pass, in source order
-    for (int k = 0; k < n_chunks; ++k) s += partial[(size_t)h * n_chunks + k];   // fixed order
-    scores[h] = s / (float)Ns;                                                       // utils/loc_utils.py:610
+    for (int k = lane; k < n_slices; k += kWave) s += slices[(size_t)k * M + ph];    // consensus pass
+    for (int k = lane; k < n_chunks; k += kWave) s += partial[(size_t)h * n_chunks + k];
+    s = wave_sum_f(s);
+    if (lane == 0) scores[h] = s / (float)Ns;                                        // utils/loc_utils.py:610
 }
 
 static void knn_lds_plan(int K, int n2, int* cap, int* waves, size_t* bytes, int max_waves, bool* idx16)
@@ -1979,6 +2051,15 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
     size_t lds;
     bool idx16;
     knn_lds_plan(knn, N, &cap, &waves, &lds, 4, &idx16);
+    if (N <= 32768) {
+        // small clouds: one wavefront per query
+        hipLaunchKernelGGL(chunk_box_kernel, dim3(((N + kWave - 1) / kWave + 3) / 4, B), dim3(256), 0, st, (char*)workspace, grid_ws(N).total, N);
+        UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+        hipLaunchKernelGGL(spatial_var_coop_kernel, dim3(min((N + 7) / 8, 4096), B), dim3(8 * kWave), 0, st, (const char*)workspace,
+                           grid_ws(N).total, (const float4*)feat, N, knn, out);
+        UMEREG_CHECK_LAUNCH("spatial_var_coop_kernel");
+        return UMEREG_OK;
+    }
     int lanes_used = kWave;   // queries per wavefront: halve while the launch has fewer wavefronts than the chip has SIMDs
     while (lanes_used > 8 && (N + lanes_used - 1) / lanes_used < 1024) lanes_used >>= 1;
     const int qpb = waves * lanes_used;
@@ -2012,7 +2093,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
                                                         align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
-           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + tgt_box_bytes(Nt) : 0) + cons;
+           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -2097,7 +2178,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     if (c_max && hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
     if (consensus_on(c_max, M, flags, T)) {
         // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
-        char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256) + tgt_box_bytes(Nt);
+        char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256);
         val = (float*)cons;
         served = (unsigned long long*)(cons + align_up((size_t)Ns * M * 4, 256));
         float* Tmed = (float*)((char*)served + align_up((size_t)Ns * n_words * 8, 256));
@@ -2105,9 +2186,12 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         perm = (int*)((char*)slices + align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256));
         inv = perm + M;
         float* err = (float*)(inv + M);
-        hipLaunchKernelGGL(hyp_median_kernel, dim3(1), dim3(1024), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox), Tmed, err);
+        hipLaunchKernelGGL(hyp_median_kernel, dim3(12), dim3(1024), 0, st, T, M, Tmed);
         UMEREG_CHECK_LAUNCH("hyp_median_kernel");
-        hipLaunchKernelGGL(hyp_order_kernel, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)err, M, perm, inv);
+        hipLaunchKernelGGL(hyp_err_kernel, dim3((M + 255) / 256), dim3(256), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox),
+                           (const float*)Tmed, err);
+        UMEREG_CHECK_LAUNCH("hyp_err_kernel");
+        hipLaunchKernelGGL(hyp_order_kernel, dim3((M + kWave - 1) / kWave), dim3(256), 0, st, (const float*)err, M, perm, inv);
         UMEREG_CHECK_LAUNCH("hyp_order_kernel");
         hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
                            (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, (const int*)perm,
@@ -2150,12 +2234,11 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
-        float4* box = (float4*)(lat + lw.total + align_up((size_t)M * n_chunks_sz * 16, 256));
-        hipLaunchKernelGGL(tgt_chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, Nt, box);
-        UMEREG_CHECK_LAUNCH("tgt_chunk_box_kernel");
+        hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
+        UMEREG_CHECK_LAUNCH("chunk_box_kernel");
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
-                           n_chunks, partial, (const char*)lat, c_max, (const float4*)box);
+                           n_chunks, partial, (const char*)lat, c_max);
         UMEREG_CHECK_LAUNCH("corr_score_fallback_kernel");
     } else if (idx16) {
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
@@ -2173,7 +2256,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, slices);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
     }
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 3) / 4), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
                        scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
     return UMEREG_OK;
