@@ -161,3 +161,31 @@ def test_shard_and_allreduce_gloo(world, tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert f"SHARD_OK {world}" in out.stdout
+
+
+def test_host_draws_from_concurrent_threads():
+    """bench.py's end-to-end leg runs several pairs side by side (one host thread each): the native draws release the GIL,
+    so their scratch buffers must not be shared between threads (they were: `probabilities do not sum to 1` at 3 threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from umeregrobust_amd.host_rng import choice_noreplace, choice_uniform_noreplace
+    n, size = 10000, 2500
+    base = np.random.RandomState(123).rand(n).astype(np.float32)
+    prob = base / base.sum(dtype=np.float64)
+
+    def expected(seed):
+        r = np.random.RandomState(seed)
+        return r.choice(50000, 10000, replace=False), r.choice(n, size, replace=False, p=prob.astype(np.float64) / prob.astype(np.float64).sum())
+
+    def native(seed):
+        out = []
+        for _ in range(6):
+            r = np.random.RandomState(seed)
+            out.append((choice_uniform_noreplace(r, 50000, 10000), choice_noreplace(r, n, size, prob.astype(np.float64) / prob.astype(np.float64).sum())))
+        return out
+
+    want = [expected(s) for s in range(4)]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        got = list(ex.map(native, range(4)))
+    for s in range(4):
+        for u, w in got[s]:
+            assert np.array_equal(u, want[s][0]) and np.array_equal(w, want[s][1])

@@ -6,6 +6,8 @@ order, same RNG state afterwards): the uniforms still come from the caller's Ran
 np.random stream, only the per-round cumsum / searchsorted / unique bookkeeping runs natively
 (umereg_host_choice_round) instead of ~10 small numpy calls per round.
 """
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -40,7 +42,15 @@ def _state_address(bitgen):
 
 _ERRORS = {1: "probabilities contain NaN or are not non-negative", 2: "probabilities do not sum to 1",
            3: "Fewer non-zero entries in p than size"}
-_scratch = {}
+_tls = threading.local()     # scratch buffers are per host thread: the native calls run without the GIL
+
+
+def _thread_scratch(name):
+    d = getattr(_tls, name, None)
+    if d is None:
+        d = {}
+        setattr(_tls, name, d)
+    return d
 
 
 def choice_noreplace(rng, n, size, p):
@@ -60,6 +70,7 @@ def choice_noreplace(rng, n, size, p):
         raise ValueError("Cannot take a larger sample than population when 'replace=False'")
     if size <= 0:
         return rng.choice(n, size, replace=False, p=p)
+    _scratch = _thread_scratch("choice")
     sc = _scratch.get((n, size))
     if sc is None:
         work = np.empty(2 * n + size, dtype=np.float64)
@@ -94,9 +105,6 @@ def choice_noreplace(rng, n, size, p):
     return found
 
 
-_perm_scratch = {}
-
-
 def choice_uniform_noreplace(rng, n, size):
     """Bit-identical replacement for rng.choice(n, size, replace=False) WITHOUT p (the keypoint draws of reference
     evaluate.py:199-200 and the correlation sub-sampling of :280, :284): numpy's legacy RandomState computes
@@ -107,6 +115,7 @@ def choice_uniform_noreplace(rng, n, size):
     if bitgen is None or size > n or n <= 0 or n > 0xffffffff:
         return rng.choice(n, size, replace=False)
     lib = _lib.load()
+    _perm_scratch = _thread_scratch("perm")
     perm = _perm_scratch.get(n)
     if perm is None:
         if len(_perm_scratch) > 16:
