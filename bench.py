@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs (cycled; pair g uses pool[g %% pool])")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
-    ap.add_argument("--depth", type=int, default=2,
+    ap.add_argument("--depth", type=int, default=4,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false",
                     help="enqueue phase A (a1-a5) as 12 launches per pair instead of replaying one captured hipGraph")
@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--e2e-hard-pairs", type=int, default=16, help="hard pairs per GPU in the end-to-end leg (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip both end-to-end legs")
     ap.add_argument("--e2e-in-flight", type=int, default=1, help="pairs processed side by side in the end-to-end legs (threads + streams)")
+    ap.add_argument("--e2e-side-by-side", type=int, default=3,
+                    help="additionally time the end-to-end legs with this many pairs in flight (reported as `side_by_side`; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="max pairs timed by the CPU baseline leg (stops after ~10 s)")
     ap.add_argument("--cpu-rr-pairs", type=int, default=64, help="max hard pairs of the CPU-vs-HIP recall check (stops after ~25 s)")
@@ -277,13 +279,13 @@ def main():
     }
 
     # ---- end-to-end legs: the whole loop iteration of evaluate.py:195-309, timed separately ----------------------------
-    def e2e_leg(entries, n_pairs, seed_base, label):
+    def e2e_leg(entries, n_pairs, seed_base, label, n_fl):
         """host keypoint draws + a1-a7 + raw-cloud prep + f1 + f2 per pair.  `--e2e-in-flight` pairs are processed side by
         side (one host thread + one HIP stream each, pairs dealt round-robin): a pair is a chain of dependent kernels with
         host round trips in between (the tau-weighted draw, the ICP stop test), many of them single-workgroup; a second
         pair fills those holes.  Every pair still sees exactly the reference's sequence of steps and its own RNG stream."""
         from concurrent.futures import ThreadPoolExecutor
-        n_fl = max(1, a.e2e_in_flight)
+        n_fl = max(1, n_fl)
         sel_timing, ev, errs, icp_it = [[] for _ in range(n_fl)], [[] for _ in range(n_fl)], [[] for _ in range(n_fl)], [[] for _ in range(n_fl)]
         sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
         ref_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
@@ -376,15 +378,26 @@ def main():
                         "point-to-point ICP 0.2 m / <= 200 iterations (f2); N.P / S.P / mRRE / mRTE as printed at :304-309 "
                         "(N.P uses 0.6 m in the code, 0.3 m in the README: both given); raw clouds = the network points"}
 
+    def side_by_side(r):
+        return {"pairs_in_flight": r["pairs_in_flight"], "pairs_per_s": r["pairs_per_s"], "ms_per_pair_per_gpu": r["ms_per_pair_per_gpu"],
+                "rr_1.5deg_0.6m": r["rr_1.5deg_0.6m"], "rr_1deg_0.1m": r["rr_1deg_0.1m"],
+                "note": "the same pairs and seeds with several pairs in flight (one host thread + one HIP stream each): the host round "
+                        "trips of one pair (tau-weighted draw, voxel counts, ICP stop test) are filled by another pair's kernels"}
+
     if not a.no_e2e and a.e2e_pairs > 0:
-        result["end_to_end"] = e2e_leg(pool, a.e2e_pairs, 500000, f"{a.config} pairs of the named-path leg (exact rigid copies, kind={a.kind})")
+        result["end_to_end"] = e2e_leg(pool, a.e2e_pairs, 500000, f"{a.config} pairs of the named-path leg (exact rigid copies, kind={a.kind})",
+                                       a.e2e_in_flight)
+        if a.e2e_side_by_side > a.e2e_in_flight:
+            result["end_to_end"]["side_by_side"] = side_by_side(e2e_leg(pool, a.e2e_pairs, 500000, "", a.e2e_side_by_side))
     hard_pool = None
     if not a.no_e2e and a.e2e_hard_pairs > 0:
         hard_pool = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))
                      for i in range(min(4, a.e2e_hard_pairs))]
         result["end_to_end_hard"] = e2e_leg(hard_pool, a.e2e_hard_pairs, 600000,
                                             f"{a.config}-size HARD pairs: partial overlap (two 240-deg sectors 100 deg apart), "
-                                            "sigma = 2 cm point noise, 20 % corrupted features")
+                                            "sigma = 2 cm point noise, 20 % corrupted features", a.e2e_in_flight)
+        if a.e2e_side_by_side > a.e2e_in_flight:
+            result["end_to_end_hard"]["side_by_side"] = side_by_side(e2e_leg(hard_pool, a.e2e_hard_pairs, 600000, "", a.e2e_side_by_side))
         del hard_pool
 
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----

@@ -40,4 +40,11 @@ for _ in range(reps):
     sc = ops.corr_scores(a, b, fa, fb, T, K=20, sigma=1.5, flags=flags)
 ev[1].record()
 torch.cuda.synchronize()
+if os.environ.get("F1_HDR"):
+    from umeregrobust_amd import _lib
+    lib = _lib.load()
+    M, Ns, Nt = T.shape[0], a.shape[0], b.shape[0]
+    off = lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, ops.CORR_NO_LATTICE)
+    ws = ops._workspace(dev, lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags), "corr")
+    print("header", ws[off:off + 128].view(torch.int32).cpu().numpy().tolist(), flush=True)
 print(f"{which}: corr_scores {ev[0].elapsed_time(ev[1]) / reps:.3f} ms per call, argmax {int(sc.argmax())} max {float(sc.max()):.6f}", flush=True)

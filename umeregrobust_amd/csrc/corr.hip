@@ -331,7 +331,8 @@ __device__ __forceinline__ int append_pass(Walk&& walk, const LaneSel& S, bool a
             admit(ok, d2, __float_as_int(p.w));
         });
     }
-    while (__any(cnt > K)) { KNN_DBG(5, 1); drop_max(list, cnt, cnt > K, cap, lane); }
+    if (!(UMEREG_F1_ABLATE & 0x10000))
+        while (__any(cnt > K)) { KNN_DBG(5, 1); drop_max(list, cnt, cnt > K, cap, lane); }
     return cnt;
 }
 
@@ -1006,10 +1007,15 @@ constexpr bool kConsSparse = false;
 constexpr float kConsSparseMargin = 1.6f; // D = d_K + this many grid cells
 constexpr int kConsIdxBits = 9;          // low bits of a key's index word = position in the stage (kConsCap <= 512)
 
+// (the consensus pass's level-0 histogram has one more row than kBins: the overflow bin)
+__host__ __device__ constexpr size_t cons_list_bytes(int cap)
+{
+    return knn_lds_per_wave(cap, 4) > (size_t)(kBins + 1) * kWave * 4 ? knn_lds_per_wave(cap, 4) : (size_t)(kBins + 1) * kWave * 4;
+}
 __host__ __device__ constexpr size_t cons_lds_per_wave(int cap)
 {
     // key list with a 32-bit index plane (original index << 9 | stage position) / histogram; stage; dot products; distances from the centre
-    return knn_lds_per_wave(cap, 4) + (size_t)(kConsCap + 4) * 16 + (size_t)(kConsCap + 4) * 4 * 2;
+    return cons_list_bytes(cap) + (size_t)(kConsCap + 4) * 16 + (size_t)(kConsCap + 4) * 4 * 2;
 }
 
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void corr_consensus_kernel(
@@ -1030,8 +1036,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     L.list.ix = reinterpret_cast<IdxT*>(my + (size_t)cap * kWave * 4);
     L.hist = reinterpret_cast<unsigned int*>(my);
     float4* raw = reinterpret_cast<float4*>(my);                                  // setup only: collected, unsorted
-    float4* stage = reinterpret_cast<float4*>(my + knn_lds_per_wave(cap, 4));     // sorted by distance from the centre, quad-padded
-    float* dots = reinterpret_cast<float*>(stage + kConsCap + 4);
+    // the stage: sorted by distance from the centre, quad-padded, one 64-byte record per quad of points:
+    // x[4] y[4] z[4] w[4] (w = original index << kConsIdxBits | stage position) -- operand pairs for packed fp32 math
+    float* stage = reinterpret_cast<float*>(my + cons_list_bytes(cap));
+    float* dots = stage + (kConsCap + 4) * 4;
     float* dc2 = dots + kConsCap + 4;                                              // squared distance from the centre (ascending)
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     const Grid& g = c.g;
@@ -1150,9 +1158,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
         const int e = u * kWave + lane;
-        if (e < n_c) { stage[rank_d[u]] = mine[u]; dc2[rank_d[u]] = __uint_as_float((unsigned int)(dkey[u] >> 32)); }
+        if (e < n_c) {
+            const int r = rank_d[u];
+            float* q4 = stage + (r >> 2) * 16 + (r & 3);
+            q4[0] = mine[u].x; q4[4] = mine[u].y; q4[8] = mine[u].z;
+            q4[12] = __int_as_float((__float_as_int(mine[u].w) << kConsIdxBits) | r);
+            dc2[r] = __uint_as_float((unsigned int)(dkey[u] >> 32));
+        }
     }
-    if (lane < 4) { stage[n_c + lane] = make_float4(kFar, kFar, kFar, 0.f); dc2[n_c + lane] = 3.0e38f; }
+    if (lane < 4) {
+        const int r = n_c + lane;
+        float* q4 = stage + (r >> 2) * 16 + (r & 3);
+        q4[0] = kFar; q4[4] = kFar; q4[8] = kFar; q4[12] = __int_as_float(r);
+        dc2[r] = 3.0e38f;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const float dk = sqrtf(dc2[K - 1]), d1 = sqrtf(dc2[0]);
     // ---- setup (d): <vp_n, vq_j> of the staged points, 8 lanes per feature row ----
@@ -1161,7 +1180,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         const float4 a = vp4[(size_t)n * 8 + sub];
         for (int j0 = 0; j0 < n_c; j0 += 8) {
             const int j = j0 + grp;
-            const int oi = __float_as_int(stage[j < n_c ? j : 0].w);
+            const int jj = j < n_c ? j : 0;
+            const int oi = __float_as_int(stage[(jj >> 2) * 16 + 12 + (jj & 3)]) >> kConsIdxBits;
             const float4 o = vq4[(size_t)oi * 8 + sub];
             float d = a.x * o.x;
             d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
@@ -1203,6 +1223,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             for (int u = 0; u < kPer; ++u) cnt_in += __popcll(__ballot(u * kWave + lane < n_c && dc2[u * kWave + lane] <= rc2));
             m_use = (cnt_in + 3) & ~3;                                                       // (the stage is quad-padded with far points)
         }
+        if ((UMEREG_F1_ABLATE & 0x100000) && lane == 0 && stats) {        // (debug statistics: header words 16..)
+            atomicAdd(stats + 9, 1u);
+            atomicAdd(stats + 10, (unsigned int)m_use);
+            atomicAdd(stats + 11 + (m_use <= 28 ? 0 : m_use <= 40 ? 1 : m_use <= 64 ? 2 : m_use <= 128 ? 3 : 4), 1u);
+        }
         LaneSel S;
         S.nlev = 1;
         {
@@ -1218,34 +1243,114 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             S.lo[0] = act ? rl * rl : 0.f;
         }
         S.sc[0] = (float)kBins / (S.hi0 - S.lo[0]);
+        // generic walker over the stage (only used when a lane has to zoom into a histogram bin)
         auto walk_c = [&](bool on, float, auto&& body) __attribute__((always_inline)) {
             for (int u0 = 0; u0 < m_use; u0 += 4) {
+                const float* q4 = stage + u0 * 4;
                 float d2[4];
                 float4 pt[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float4 p = stage[u0 + u];              // same address in every lane: broadcast read
-                    const float dx = qx - p.x;
-                    const float dy = qy - p.y;
-                    const float dz = qz - p.z;
+                    const float dx = qx - q4[u];                 // same address in every lane: broadcast reads
+                    const float dy = qy - q4[4 + u];
+                    const float dz = qz - q4[8 + u];
                     float t = dx * dx;
                     t = t + dy * dy;
                     t = t + dz * dz;
                     d2[u] = t;
-                    // index word: original index (ties resolve towards the lower one, as everywhere), then the stage position
-                    pt[u].w = __int_as_float((__float_as_int(p.w) << kConsIdxBits) | (u0 + u));
+                    pt[u].w = q4[12 + u];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) body(d2[u], pt[u], u0 + u, on);   // padding = far points: never admitted
             }
         };
-        bool done = !act, starved;
-        int found;
-        refine_loop(walk_c, S, done, true, K, cap, L.hist, lane, starved, found);
-        const int cnt = append_pass(walk_c, S, act, K, cap, L.list, lane);
+        // d2 of a quad of staged points as two packed pairs (v_pk_add / v_pk_mul: the operation sequence of the scalar
+        // form, two candidates per instruction)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        auto quad_d2 = [&](int u0, f2& t01, f2& t23) __attribute__((always_inline)) {
+            const f4* q4 = reinterpret_cast<const f4*>(stage + u0 * 4);
+            const f4 X = q4[0], Y = q4[1], Z = q4[2];
+            const f2 dx01 = qx2 - X.xy, dx23 = qx2 - X.zw;
+            const f2 dy01 = qy2 - Y.xy, dy23 = qy2 - Y.zw;
+            const f2 dz01 = qz2 - Z.xy, dz23 = qz2 - Z.zw;
+            t01 = dx01 * dx01; t23 = dx23 * dx23;
+            t01 = t01 + dy01 * dy01; t23 = t23 + dy23 * dy23;
+            t01 = t01 + dz01 * dz01; t23 = t23 + dz23 * dz23;
+        };
+        int cnt;
+        bool zoom = false;
+        float thr = -1.f;                  // admitted: (d2 - lo) * sc < thr
+        if (m_use <= cap) {
+            // the whole cut-off stage fits a lane's list: nothing to select by histogram, everything below hi0 is appended and
+            // trimmed to K -- the case of the agreeing hypotheses (the cut-off keeps little more than the K nearest of q~)
+            thr = act ? (float)kBins : -1.f;
+        } else {
+            // level-0 histogram over [lo, hi0) in kBins bins + one overflow bin (everything at or beyond hi0, and every
+            // candidate of an inactive lane's degenerate range): one subtract, one multiply, one conversion, one LDS add
+            unsigned int* hist = L.hist;
+#pragma unroll
+            for (int b = 0; b <= kBins; ++b) hist[b * kWave + lane] = 0u;
+            const f2 lo2 = {S.lo[0], S.lo[0]}, sc2 = {S.sc[0], S.sc[0]};
+            for (int u0 = 0; u0 < m_use; u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                const f2 v01 = (t01 - lo2) * sc2, v23 = (t23 - lo2) * sc2;
+                const int b0 = min(max((int)v01.x, 0), kBins), b1 = min(max((int)v01.y, 0), kBins), b2 = min(max((int)v23.x, 0), kBins), b3 = min(max((int)v23.y, 0), kBins);   // (v_med3_i32)
+                atomicAdd(&hist[b0 * kWave + lane], 1u);     // lane-private counters (ds_add_u32)
+                atomicAdd(&hist[b1 * kWave + lane], 1u);
+                atomicAdd(&hist[b2 * kWave + lane], 1u);
+                atomicAdd(&hist[b3 * kWave + lane], 1u);
+            }
+            int cum = 0, bstar = -1, before = 0, inbin = 0;
+#pragma unroll
+            for (int b = 0; b < kBins; ++b) {
+                const int hc = (int)hist[b * kWave + lane];
+                if (bstar < 0 && cum + hc >= K) { bstar = b; before = cum; inbin = hc; }
+                cum += hc;
+            }
+            if (bstar < 0) thr = act ? (float)kBins : -1.f;          // fewer than K below hi0: all of them (the lane fails: cnt < K)
+            else if (before + inbin <= cap) thr = act ? (float)(bstar + 1) : -1.f;
+            else zoom = act;                                          // too many up to the K-th's bin for the list
+        }
+        if ((UMEREG_F1_ABLATE & 0x100000) && stats && __any(zoom) && lane == 0) atomicAdd(stats + 16, 1u);
+        if (__any(zoom)) {
+            // rare: the generic multi-level search for the whole wavefront
+            bool done = !act, starved;
+            int found;
+            refine_loop(walk_c, S, done, true, K, cap, L.hist, lane, starved, found);
+            cnt = append_pass(walk_c, S, act, K, cap, L.list, lane);
+        } else {
+            // append: at most `cap` candidates pass (the histogram counted them with the same arithmetic)
+            cnt = 0;
+            const f2 lo2 = {S.lo[0], S.lo[0]}, sc2 = {S.sc[0], S.sc[0]};
+            for (int u0 = 0; u0 < m_use; u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                const f2 v01 = (t01 - lo2) * sc2, v23 = (t23 - lo2) * sc2;
+                const float d2[4] = {t01.x, t01.y, t23.x, t23.y}, v[4] = {v01.x, v01.y, v23.x, v23.y};
+                const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
+                const float w[4] = {W.x, W.y, W.z, W.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = v[u] < thr && cnt < cap;
+                    if (ok) L.list.set(cnt, lane, ((unsigned long long)__float_as_uint(d2[u]) << 32) | (unsigned int)__float_as_int(w[u]));
+                    cnt += ok ? 1 : 0;
+                }
+            }
+            if (!(UMEREG_F1_ABLATE & 0x10000)) {
+                const int bound = wave_max_i(cnt);
+                if ((UMEREG_F1_ABLATE & 0x100000) && stats) {
+                    const int xr = wave_max_i(cnt - K);
+                    if (lane == 0) { atomicAdd(stats + (m_use <= cap ? 17 : 18), (unsigned int)max(xr, 0)); atomicAdd(stats + (m_use <= cap ? 19 : 20), (unsigned int)bound); }
+                }
+                while (__any(cnt > K)) drop_max(L.list, cnt, cnt > K, bound, lane);
+            }
+        }
         // the K-th distance found, the exactness test, and the score term
         float d2max = 0.f, acc = 0.f;
-        for (int e = 0; e < K; ++e) {
+        for (int e = 0; e < ((UMEREG_F1_ABLATE & 0x80000) ? 1 : K); ++e) {
             if (e < cnt) {
                 const float d2 = __uint_as_float(L.list.d2[e * kWave + lane]);
                 d2max = fmaxf(d2max, d2);
