@@ -207,7 +207,10 @@ def main():
                 "note": "algorithmic bytes = SURVEY 8(d) per-keypoint figure (140 n_i + 524) summed over both clouds of a pair. "
                         "They are neighbour gathers from 8 MB tables that L2 / Infinity Cache serve (`traffic` = fabric bytes is "
                         "~5 % of them), so `frac` against the HBM peak can exceed 1 and is NOT a utilisation; the rate that "
-                        "actually bounds the gathers is the aggregate L2 -> CU bandwidth: `l2_frac` = achieved / 34.5 TB/s"}
+                        "actually bounds the gathers is the aggregate L2 -> CU bandwidth: `l2_frac` = achieved / 34.5 TB/s.  What the "
+                        "kernel is closest to is neither: `valu_busy_frac` (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles) ~0.8 -- the fp64 "
+                        "accumulation (16 DFMA/DADD + 7 conversions per lane and neighbour slot) that buys the order-independent, "
+                        "3e-7-of-fp64 result"}
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
@@ -248,7 +251,7 @@ def main():
         for r_ in (roof_mom, roof_dist):
             k_ = sqs.get(r_["kernel"])
             if k_:
-                for key in ("mfma_busy_frac", "valu_per_mfma", "vmem_busy_frac", "wait_any_frac", "issue_frac", "l2_hit_rate",
+                for key in ("mfma_busy_frac", "valu_busy_frac", "valu_per_mfma", "vmem_busy_frac", "wait_any_frac", "issue_frac", "l2_hit_rate",
                             "effective_clock_ghz"):
                     if key in k_:
                         r_[key] = k_[key]

@@ -33,4 +33,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   rm -rf $OUT/sq/p$i
 done
 timeout -s KILL 300 $ROOT/tools/f1_stats.sh 3 > $OUT/f1_kernel_stats.txt 2>&1
+echo "---- production path alone (tools/f1_prod_stats.sh): plain KT pair, then the half-overlapping one" >> $OUT/f1_kernel_stats.txt
+timeout -s KILL 300 $ROOT/tools/f1_prod_stats.sh 10 plain >> $OUT/f1_kernel_stats.txt 2>&1
+timeout -s KILL 300 $ROOT/tools/f1_prod_stats.sh 5 hard >> $OUT/f1_kernel_stats.txt 2>&1
 ls -la $OUT $OUT/sq

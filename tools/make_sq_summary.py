@@ -44,6 +44,9 @@ for k, c in acc.items():
         if m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             d["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (g / N_XCD * N_SIMD), 4)
         d["duration_shader_clocks"] = round(g / N_XCD, 0)
+        if m.get("SQ_ACTIVE_INST_VALU"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles (one per non-MFMA VALU instruction issued), summed over the SIMDs
+            d["valu_busy_frac"] = round(4.0 * m["SQ_ACTIVE_INST_VALU"] / (g / N_XCD * N_SIMD), 4)
     if m.get("SQ_INSTS_MFMA"):
         d["valu_per_mfma"] = round((m.get("SQ_INSTS_VALU", 0.0) - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"], 2)
     if m.get("SQ_WAVE_CYCLES"):
