@@ -141,17 +141,20 @@ def main():
     pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
+    # per-kernel HIP-event samples: `timing` from pairs that run ALONE (the kernel's own duration: what `roofline` prices),
+    # `timing_situ` from pairs inside the pipeline (what a profiler of this command sees: kernels of 4 pairs share the chip)
     timing = {"moments": [], "dist": ops.TimingList()}
+    timing_situ = {"moments": [], "dist": ops.TimingList()}
     mom_bytes_log = []
     n_local = (a.warmup + a.steps) * P
     rngs = [np.random.RandomState(1234 + rank + world * i) for i in range(n_local)]   # pair g draws from RandomState(1234 + g)
 
-    def submit(i, record):
+    def submit(i, tm=None):
         e = pool[(rank + world * i) % len(pool)]
         h = pipe.submit(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, src_inds=e.src_inds, tgt_inds=e.tgt_inds,
-                        timing=timing if record else None, pair=e.pair, rng=rngs[i])
+                        timing=tm, pair=e.pair, rng=rngs[i])
         h.entry = e
-        if record:
+        if tm is timing:
             mom_bytes_log.extend(e.mom_bytes)
         return h
 
@@ -163,9 +166,20 @@ def main():
     def run(first, n, record):
         pending = []
         for i in range(first, first + n):
-            # per-kernel event pairs (the roofline leg) on every 8th timed pair only: they need the layered entry points;
-            # the other pairs go through the one-call a1..a5 entry
-            pending.append(submit(i, record and (i - first) % 8 == 0))
+            # per-kernel event pairs (the roofline leg) need the layered entry points; the other pairs go through the one-call
+            # a1..a5 entry.  Once per step a pair runs ALONE (pipeline drained on both sides -- inside the timed region, it
+            # costs ~2 % of `value`): with 4 pairs in flight a kernel's wall duration is mostly time-sharing (coarse matcher
+            # 0.29 ms in situ, 0.135 ms alone), and a roofline fraction has to price the kernel, not its neighbours.  Once
+            # per step another pair is timed in situ, for comparison with a profiler's summary of this command.
+            k = (i - first) % P
+            if record and k == 0:
+                while pending:
+                    finish(pending.pop(0))
+                torch.cuda.synchronize()
+                finish(submit(i, timing))
+                torch.cuda.synchronize()
+                continue
+            pending.append(submit(i, timing_situ if (record and k == P // 2) else None))
             if len(pending) >= depth:
                 finish(pending.pop(0))
         while pending:
@@ -194,6 +208,10 @@ def main():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (32 B)
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
+    def situ(lst):
+        v = [s.elapsed_time(e_) for s, e_ in lst]
+        return round(float(np.mean(v)), 4) if v else None
+
     mom_ms = [s.elapsed_time(e_) for s, e_ in timing["moments"]]
     dist_ms = [s.elapsed_time(e_) for s, e_ in timing["dist"]]
     mom_total_ms, dist_total_ms = float(np.sum(mom_ms)), float(np.sum(dist_ms))
@@ -203,6 +221,7 @@ def main():
                 "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "l2_frac": round(mom_gbs / L2_PEAK_GBS, 4),
                 "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
+                "in_situ_avg_launch_ms": situ(timing_situ["moments"]),
                 "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0),
                 "note": "algorithmic bytes = SURVEY 8(d) per-keypoint figure (140 n_i + 524) summed over both clouds of a pair. "
                         "They are neighbour gathers from 8 MB tables that L2 / Infinity Cache serve (`traffic` = fabric bytes is "
@@ -219,6 +238,7 @@ def main():
         roof_dist = {"kernel": "ume_coarse_h_kernel", "bound": "mfma", "achieved": round(dist_tfs, 2),
                      "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dist_tfs / MFMA_F16_PEAK_TFLOPS, 4),
                      "traffic": None, "avg_launch_ms": round(float(np.mean(dist_ms)), 4), "launches": len(dist_ms),
+                     "in_situ_avg_launch_ms": situ(timing_situ["dist"]),
                      "algorithmic_flops_per_launch": dist_flops,
                      "refine_avg_launch_ms": round(float(np.mean(ref_ms)), 4) if ref_ms else None,
                      "d_used": "512-equivalent (Q-form), single f16 MFMA product (hi planes) + fp64 refine of the candidates"}
@@ -270,7 +290,10 @@ def main():
                    "pairs_per_step_per_gpu": P, "ms_per_pair": round(1e3 * elapsed / (a.steps * P), 4),
                    "sharding": f"pairs[rank::{world}] (no data-path collective)",
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
-                   "pairs_in_flight": depth, "phase_a_as_hipgraph": bool(a.graphs), "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
+                   "pairs_in_flight": depth, "phase_a_as_hipgraph": bool(a.graphs),
+                   "roofline_sampling": "one pair per step runs alone (pipeline drained before and after, inside the timed region): "
+                                        "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per step "
+                                        "timed inside the pipeline, beside the kernels of the other pairs in flight", "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
                    "excluded_from_value": "the two keypoint draws of evaluate.py:199-200 (indices pre-drawn with the pair; they are "
                                           "inside `end_to_end`), the feature network, hypothesis selection and ICP (see `end_to_end`)"},
         "roofline": dominant,
