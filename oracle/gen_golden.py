@@ -77,7 +77,20 @@ def install_stubs():
     p3d.ops = mod("pytorch3d.ops", ball_query=_stub_ball_query, knn_points=_stub_knn_points,
                   knn_gather=_stub_knn_gather, sample_farthest_points=_Anything())
     p3d.structures = mod("pytorch3d.structures", Pointclouds=_Anything, padded_to_list=_Anything())
-    me = mod("MinkowskiEngine", MinkowskiNetwork=torch.nn.Module, utils=_Anything(),
+    class _MEUtils(_Anything):
+        """MinkowskiEngine.utils: sparse_collate restated (MinkowskiEngine 0.5.4, parity unpinned) -- batch index in column 0
+        of the int32 coordinates, features concatenated; everything else stays a placeholder."""
+        @staticmethod
+        def sparse_collate(coords, feats, labels=None, dtype=torch.int32, device=None):
+            bc, bf = [], []
+            for b, (c, f) in enumerate(zip(coords, feats)):
+                c = torch.as_tensor(c)
+                c = (torch.floor(c) if c.is_floating_point() else c).to(dtype)
+                bc.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=dtype), c], dim=1))
+                bf.append(torch.as_tensor(f))
+            return torch.cat(bc, 0), torch.cat(bf, 0)
+
+    me = mod("MinkowskiEngine", MinkowskiNetwork=torch.nn.Module, utils=_MEUtils(),
              SparseTensor=_Anything)
     me.__getattr__ = lambda name: _Anything()
     me.MinkowskiFunctional = mod("MinkowskiEngine.MinkowskiFunctional")
@@ -183,7 +196,40 @@ def gen_g9(loc_utils, evaluate):
     print("G9 hungarian: twins matched", twins, "| kept", out["cond"].shape, "| T", out["T_filt"].shape, out["T_all"].shape)
 
 
+def gen_g10():
+    """G10: the reference's own `batch_collate_fn_dset` (datasets/kitti/kitti_dataset.py:546-616) on three seeded items
+    of different sizes, batch of 3 with dilution (max_pc_size below every cloud) and a batch of 1 without."""
+    import datasets.kitti.kitti_dataset as kd
+    rs = np.random.RandomState(10)
+    items = []
+    for n, m in ((900, 800), (700, 950), (820, 760)):
+        sp = rs.uniform(-20, 20, (n, 3)).astype(np.float32)
+        tp = rs.uniform(-20, 20, (m, 3)).astype(np.float32)
+        k = min(n, m) // 2
+        mt = np.stack([rs.choice(n, k, replace=False), rs.choice(m, k, replace=False)], 1).astype(np.int64)
+        gt = np.eye(4, dtype=np.float32); gt[:3, 3] = rs.uniform(-1, 1, 3)
+        items.append((_t(sp), torch.from_numpy(rs.randint(1, 20, n)).long(), torch.from_numpy(np.floor(sp / 0.3).astype(np.int32)),
+                      _t(tp), torch.from_numpy(rs.randint(1, 20, m)).long(), torch.from_numpy(np.floor(tp / 0.3).astype(np.int32)),
+                      _t(sp + gt[:3, 3]), _t(gt), torch.from_numpy(mt)))
+    out = {}
+    for tag, data, nm, mx in (("b3", items, 60, 600), ("b1", items[1:2], 10000, 100000)):
+        np.random.seed(10)
+        res = kd.batch_collate_fn_dset(data, num_matches=nm, max_pc_size=mx)
+        for name, v in zip(("src_pts", "src_seg", "src_coords", "src_feat", "tgt_pts", "tgt_seg", "tgt_coords", "tgt_feat",
+                            "src_pts_tform", "gt_tform", "matches"), res):
+            out[f"{tag}_{name}"] = v.numpy()
+        out[f"{tag}_next_rand"] = np.float64(np.random.rand())          # the RNG stream position afterwards
+    keys = ("src_pts", "src_seg", "src_coords", "tgt_pts", "tgt_seg", "tgt_coords", "src_pts_tform", "gt_tform", "matches")
+    inp = {f"in{i}_{k}": it[j].numpy() for i, it in enumerate(items) for j, k in enumerate(keys)}
+    np.savez_compressed(os.path.join(OUT, "g10_collate.npz"), **inp, **out)
+    print("G10 collate:", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 0 and k.startswith("b3")})
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g10":
+        import_reference()
+        gen_g10()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
         loc_utils, eval_utils, evaluate = import_reference()
         gen_g9(loc_utils, evaluate)

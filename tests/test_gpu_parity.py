@@ -1307,3 +1307,31 @@ def test_evaluate_command_line(gpu, tmp_path, capsys):
     assert s2["n_pairs"] == 2 and s2["rr_np_06"] == 100.0
     s3 = main(["--benchmark", "rotnuscenes", "--synthetic", "1"])
     assert s3["n_pairs"] == 1 and s3["rr_np_06"] == 100.0
+
+
+@pytest.mark.gpu
+def test_evaluate_from_the_reference_pair_cache(gpu, tmp_path, capsys):
+    """SURVEY 8(f4) in front of the path: pairs in the reference's cache layout (kitti_dataset.py:441-458, :647-657) with the
+    feature network's outputs added, through CachedPairDataset + batch_collate_fn_dset (:546-616; dilution to max_pc_size
+    with the host RNG) into the evaluation loop -- the result lines of evaluate.py:304-309."""
+    from umeregrobust_amd.datasets import write_cached_pair
+    from umeregrobust_amd.evaluate import main
+    from umeregrobust_amd.synth import synth_pair
+    for k, seed in enumerate((6, 7)):
+        p = synth_pair(seed, N=12000, n_kp=64)
+        # synthetic twins: target = R src + t re-permuted -> matches from the twin table
+        m = np.stack([np.arange(12000), p.tgt_twin_of_src], 1).astype(np.int64)
+        item = (torch.from_numpy(p.src_pts), torch.zeros(12000, dtype=torch.long), torch.from_numpy(np.floor(p.src_pts / 0.3).astype(np.int32)),
+                torch.from_numpy(p.tgt_pts), torch.zeros(12000, dtype=torch.long), torch.from_numpy(np.floor(p.tgt_pts / 0.3).astype(np.int32)),
+                torch.from_numpy((p.src_pts.astype(np.float64) @ p.gt_tform[:3, :3].T.astype(np.float64) + p.gt_tform[:3, 3]).astype(np.float32)),
+                torch.from_numpy(p.gt_tform), torch.from_numpy(m))
+        write_cached_pair(str(tmp_path / "test" / "08" / f"{k:06d}_{k + 11:06d}.pickle"), item,
+                          src_feat=torch.from_numpy(p.src_feat), tgt_feat=torch.from_numpy(p.tgt_feat))
+    s = main(["--benchmark", "kitti_test", "--cache", str(tmp_path)])
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].startswith("Evaluate kitti Benchmark: kitti_test") and out[-2] == "N.P: 100.000 | S.P: 100.000"
+    assert s["n_pairs"] == 2 and s["rr_sp"] == 100.0
+    # a cache without features fails with a message that names what is missing
+    write_cached_pair(str(tmp_path / "nofeat" / "test" / "08" / "000000_000011.pickle"), item)
+    with pytest.raises(KeyError, match="feature network"):
+        main(["--benchmark", "kitti_test", "--cache", str(tmp_path / "nofeat")])

@@ -460,6 +460,23 @@ def synthetic_pairs(benchmark, indices, device):
                    tgt_feat=t(p.tgt_feat)[None], gt_tform=t(p.gt_tform))
 
 
+def cached_pairs(cache, cache_raw, split, indices, args, device, rng=np.random):
+    """Pairs from the reference's pre-processed cache (`datasets.CachedPairDataset`) through the reference's
+    collate (`batch_collate_fn_dset`, batch_size 1: the dilution to args.max_pc_size with the host RNG), as the evaluation
+    loop unpacks them (evaluate.py:175-187).  The cache files must carry the feature network's outputs (`src_feat` /
+    `tgt_feat`); the raw clouds of the correlation stage (`dset_no_nksr[itr]`, :260) come from `cache_raw` (default: the
+    same files)."""
+    from .datasets import CachedPairDataset, batch_collate_fn_dset
+    ds = CachedPairDataset(cache, split=split, with_features=True)
+    ds_raw = CachedPairDataset(cache_raw or cache, split=split, files=ds.files)
+    for i in indices(len(ds)) if callable(indices) else indices:
+        b = batch_collate_fn_dset([ds[i]], num_matches=args.num_samples, max_pc_size=args.max_pc_size, rng=rng)
+        raw = ds_raw[i]
+        yield dict(src_pts=b[0].float().to(device), tgt_pts=b[4].float().to(device), src_feat=b[11].float().to(device),
+                   tgt_feat=b[12].float().to(device), gt_tform=b[9][0].float().to(device),
+                   src_pts_raw=raw[0].float().to(device), tgt_pts_raw=raw[3].float().to(device))
+
+
 def main(argv=None):
     """`python -m umeregrobust_amd.evaluate --benchmark kitti_test` - the reference's command line (evaluate.py:113-124)
     and result lines (:304-309).  Datasets and the feature network are not part of this library: pairs come
@@ -474,6 +491,9 @@ def main(argv=None):
     parser = argparse.ArgumentParser(description=main.__doc__)
     parser.add_argument("--benchmark", type=str, choices=list(BENCHMARK_CONFIGS), default="kitti_test")
     parser.add_argument("--pairs", nargs="*", default=None, help=".npz pair files or directories of them (see load_pair_file)")
+    parser.add_argument("--cache", default=None, help="the reference's pair cache (<dir>/<split>/<seq>/<f0>_<f1>.pickle) with "
+                                                      "`src_feat`/`tgt_feat` added: datasets.CachedPairDataset + batch_collate_fn_dset")
+    parser.add_argument("--cache-raw", default=None, help="cache of the raw clouds for the correlation stage (dset_no_nksr); default: --cache")
     parser.add_argument("--synthetic", type=int, default=8, help="number of synthetic pairs when no --pairs are given")
     parser.add_argument("--no-refine", action="store_true", help="skip the ICP refinement (evaluate.py:301)")
     cli = parser.parse_args(argv)
@@ -489,7 +509,9 @@ def main(argv=None):
         np.random.seed(args.seed)                                                                     # :127
     if rank == 0:
         print(f"Evaluate {args.dataset} Benchmark: {args.benchmark} config file: {config_path}")
-    if cli.pairs:
+    if cli.cache:
+        pairs = cached_pairs(cli.cache, cli.cache_raw, args.split, lambda n: shard_indices(n, rank, world), args, device, rng=rng)
+    elif cli.pairs:
         files = []
         for p in cli.pairs:
             files += sorted(glob.glob(os.path.join(p, "*.npz"))) if os.path.isdir(p) else [p]
