@@ -68,6 +68,10 @@ def test_cache_roundtrip_and_dataset(tmp_path):
     for i in range(3):
         got = ds[i]
         assert len(got) == 9 and all(torch.equal(x, y) for x, y in zip(got, items[i]))
+    # nuScenes layout: the sequence directory name is the id (nuscenes_dataset.py:452)
+    write_cached_pair(os.path.join(tmp_path, "ns", "test", "0103", "000002_000007.pickle"), items[0])
+    dn = CachedPairDataset(os.path.join(tmp_path, "ns"), split="test", dataset="nuscenes")
+    assert dn.files == [("0103", 2, 7)] and torch.equal(dn[0][0], items[0][0])
     with pytest.raises(KeyError, match="src_feat"):
         read_cached_pair(ds.path(0), with_features=True)
     write_cached_pair(ds.path(0), items[0], src_feat=torch.zeros(items[0][0].shape[0], 32), tgt_feat=torch.ones(items[0][3].shape[0], 32))

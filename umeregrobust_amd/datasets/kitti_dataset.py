@@ -67,19 +67,22 @@ class CachedPairDataset(torch.utils.data.Dataset):
     pose files; here it is the sorted content of `<cache_data_path>/<split>/*/` (or an explicit list of
     (seq_id, frame0_id, frame1_id))."""
 
-    def __init__(self, cache_data_path, split="test", files=None, with_features=False):
-        self.cache_data_path, self.split, self.with_features = cache_data_path, split, with_features
+    def __init__(self, cache_data_path, split="test", files=None, with_features=False, dataset="kitti"):
+        """dataset: "kitti" -- sequence ids are integers, directories `%02d` (kitti_dataset.py:444); "nuscenes" -- sequence
+        ids are the directory names themselves (nuscenes_dataset.py:452)."""
+        self.cache_data_path, self.split, self.with_features, self.dataset = cache_data_path, split, with_features, dataset
         if files is None:
             files = []
             for p in sorted(glob.glob(os.path.join(cache_data_path, split, "*", "*.pickle"))):
                 seq, name = os.path.basename(os.path.dirname(p)), os.path.splitext(os.path.basename(p))[0]
                 f0, f1 = name.split("_")
-                files.append((int(seq), int(f0), int(f1)))
+                files.append((int(seq) if dataset == "kitti" else seq, int(f0), int(f1)))
         self.files = list(files)
 
     def path(self, idx):
         seq_id, frame0_id, frame1_id = self.files[idx]
-        return os.path.join(self.cache_data_path, self.split, f"{seq_id:02d}", f"{frame0_id:06d}_{frame1_id:06d}.pickle")
+        seq_dir = seq_id if isinstance(seq_id, str) else f"{seq_id:02d}"
+        return os.path.join(self.cache_data_path, self.split, seq_dir, f"{frame0_id:06d}_{frame1_id:06d}.pickle")
 
     def __len__(self):
         return len(self.files)

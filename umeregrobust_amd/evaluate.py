@@ -467,8 +467,9 @@ def cached_pairs(cache, cache_raw, split, indices, args, device, rng=np.random):
     `tgt_feat`); the raw clouds of the correlation stage (`dset_no_nksr[itr]`, :260) come from `cache_raw` (default: the
     same files)."""
     from .datasets import CachedPairDataset, batch_collate_fn_dset
-    ds = CachedPairDataset(cache, split=split, with_features=True)
-    ds_raw = CachedPairDataset(cache_raw or cache, split=split, files=ds.files)
+    kind = getattr(args, "dataset", "kitti")
+    ds = CachedPairDataset(cache, split=split, with_features=True, dataset=kind)
+    ds_raw = CachedPairDataset(cache_raw or cache, split=split, files=ds.files, dataset=kind)
     for i in indices(len(ds)) if callable(indices) else indices:
         b = batch_collate_fn_dset([ds[i]], num_matches=args.num_samples, max_pc_size=args.max_pc_size, rng=rng)
         raw = ds_raw[i]
