@@ -1000,6 +1000,127 @@ __device__ __forceinline__ int coop_hist_cut(const unsigned long long* list, uns
     return n;
 }
 
+// ---- bounding boxes of a sorted table's 64-point chunks (cell-sorted order: a chunk is a short strip of cells) ----
+// box[2c] = minimum, box[2c + 1] = maximum of the chunk's points (workspace region off_box).
+__global__ __launch_bounds__(256) void chunk_box_kernel(char* __restrict__ ws, size_t ws_stride, int N)
+{
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int n_ch = (N + kWave - 1) / kWave;
+    if (c >= n_ch) return;
+    const GridWs w = grid_ws(N);
+    char* wb = ws + blockIdx.y * ws_stride;
+    const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    float4* box = reinterpret_cast<float4*>(wb + w.off_box);
+    const int j = c * kWave + lane;
+    const float4 p = P4s[j < N ? j : c * kWave];          // an invalid lane repeats the chunk's first point
+    float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
+        }
+    if (lane == 0) {
+        box[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        box[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+}
+
+// ---- exact K nearest of ONE query by a whole wavefront, over the sorted table's 64-point chunks ---------------------
+//   * seed: the chunk whose bounding box is nearest to the query, among those with >= K points; the K-th smallest key
+//     of its points bounds the K-th smallest key of the table;
+//   * scan: only chunks whose box distance does not exceed the bound (the box distance is formed with the same fp32
+//     operations as a point's d2, each of which is monotone, so it never exceeds the d2 of a point inside the box);
+//     keys (bits(d2) << 32 | index) at or below the bound go to an LDS list (ballot + mbcnt); a list beyond 128 keys is
+//     cut by histogram (coop_hist_cut) and the bound drops.  A query in the cloud touches ~10 of KITTI's 157 chunks,
+//     one 30 m outside it a few dozen;
+//   * final cut: histogram, then exact rank counting: la[0 .. returned count) = the K smallest keys in ascending order.
+// la / lb: two kCoopCap-key LDS lists of this wavefront (swapped as cuts go), hist: 64 words.
+__device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const float4* __restrict__ box, int Nt, int K, float qx, float qy,
+                                        float qz, unsigned long long*& la, unsigned long long*& lb, unsigned int* hist, int lane)
+{
+    const int n_tch = (Nt + kWave - 1) / kWave;
+    auto dist2 = [&](const float4& p) __attribute__((always_inline)) {
+        const float dx = qx - p.x;
+        const float dy = qy - p.y;
+        const float dz = qz - p.z;
+        float t = dx * dx;
+        t = t + dy * dy;
+        t = t + dz * dz;
+        return t;
+    };
+    // box distance: the same operation sequence as dist2 on the nearest point of the box
+    auto box2 = [&](int c) __attribute__((always_inline)) {
+        const float4 lo = box[2 * c], hi = box[2 * c + 1];
+        const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
+        const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
+        const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+        float t = dx * dx;
+        t = t + dy * dy;
+        t = t + dz * dz;
+        return t;
+    };
+    auto scan_chunk = [&](int c, unsigned long long ukey, int cnt) __attribute__((always_inline)) {
+        const int j = c * kWave + lane;
+        const float4 p = P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
+        const unsigned long long k = ((unsigned long long)__float_as_uint(dist2(p)) << 32) | (unsigned int)__float_as_int(p.w);
+        const bool ok = j < Nt && k <= ukey;
+        const unsigned long long b = __ballot(ok);
+        if (ok) la[cnt + mbcnt(b)] = k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        return cnt + __popcll(b);
+    };
+    // (1) seed: the nearest chunk with at least K points (a NaN query fails every comparison: chunk 0, nothing pruned,
+    //     NaN keys -- its terms come out NaN as on the other paths)
+    float best = 3.0e38f;
+    int best_c = 0;
+    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+        const int c = c0 + lane;
+        if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
+            const float t = box2(c);
+            if (t < best) { best = t; best_c = c; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, kWave);
+        const int oc = __shfl_xor(best_c, o, kWave);
+        if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    }
+    const int seed = __builtin_amdgcn_readfirstlane(best_c);
+    int cnt = scan_chunk(seed, ~0ull, 0);
+    cnt = coop_cut(la, lb, cnt, K, lane);
+    { unsigned long long* t_ = la; la = lb; lb = t_; }
+    unsigned long long ukey = cnt == K ? la[K - 1] : ~0ull;
+    // (2) the chunks whose box reaches inside the bound
+    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+        const int c = c0 + lane;
+        const float t = c < n_tch ? box2(c) : 3.0e38f;
+        const float bd = __uint_as_float((unsigned int)(ukey >> 32));
+        unsigned long long pend = __ballot(c < n_tch && c != seed && (ukey == ~0ull || !(t > bd)));
+        while (pend != 0ull) {
+            const int l = __ffsll((long long)pend) - 1;
+            pend &= pend - 1ull;
+            // the bound may have dropped since the ballot
+            if (ukey != ~0ull && __shfl(t, l, kWave) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
+            if (cnt > 2 * kWave) {                      // (<= 3 * 64 keys: every scan adds at most 64)
+                cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
+                unsigned long long* t_ = la; la = lb; lb = t_;
+            }
+            cnt = scan_chunk(c0 + l, ukey, cnt);
+        }
+    }
+    if (cnt > kWave) {
+        cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
+        unsigned long long* t_ = la; la = lb; lb = t_;
+    }
+    cnt = coop_cut(la, lb, cnt, K, lane);
+    { unsigned long long* t_ = la; la = lb; lb = t_; }
+    return cnt;
+}
+
 // images in empty parts of the target (partly overlapping clouds): served with D = d_K + margin (78 % -> 91 % of the queries of a
 // half-overlapping pair), but their steps are so much heavier that the pass gets slower than the lattice it relieves
 // (15 ms vs 7.5 ms): off, such source points are left to the lattice
@@ -1474,6 +1595,39 @@ __device__ __forceinline__ bool lattice_in_list(const Lattice& L, const float4& 
     return ax * ax + ay * ay + az * az <= r2;
 }
 
+// d_K of every marked cell's centre, one WAVEFRONT per cell (coop_knn): cells[id] = (0, neighbours found, bits(d_K^2), 0).
+// (As one lane per cell inside lattice_count_kernel -- 16 grid searches in lock-step -- this step took 6.7 of that
+// kernel's 7.0 ms on a half-overlapping pair: the marked cells of such a pair lie in the empty part of the target, 5-15 m
+// from its nearest points, exactly the queries a per-lane search is worst at.)
+__global__ __launch_bounds__(8 * 64) void lattice_dk_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt, int K)
+{
+    __shared__ unsigned long long lists[8][2][kCoopCap];
+    __shared__ unsigned int chist[8][kWave];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    if (header[8] != 0u) return;
+    const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
+    uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
+    const unsigned int n_marked = header[3];
+    unsigned long long* la = lists[wave][0];
+    unsigned long long* lb = lists[wave][1];
+    for (unsigned int i = blockIdx.x * 8 + wave; i < n_marked; i += gridDim.x * 8) {
+        const int id = (int)cids[i];
+        float ccx, ccy, ccz;
+        lattice_cell_centre(L, id, ccx, ccy, ccz);
+        const int cnt = coop_knn(P4s, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane);
+        const unsigned int d2k = cnt > 0 ? (unsigned int)(la[cnt - 1] >> 32) : 0u;       // keys ascend: the last one is the K-th
+        if (lane == 0) cells[id] = make_uint4(0u, (unsigned int)cnt, d2k, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // one lane per marked cell (64 consecutive entries of cids per wavefront: neighbouring cells)
 template <class IdxT>
 __global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max,
@@ -1494,23 +1648,21 @@ __global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restri
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
     const bool valid = lane < kLatLanes && wid * kLatLanes + lane < n_marked;
     const int id = (int)cids[valid ? wid * kLatLanes + lane : 0];
-    const KnnLds<IdxT> Ls = carve_lds<IdxT>(lds, wave, cap);
     KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     {
         // the walks of far cells cross hundreds of (mostly empty) grid rows, two dependent table reads each: keep the
         // cell-start table in LDS (16 KiB per workgroup).  Whole workgroups leave above or stay: the barrier is safe.
-        int* start_lds = reinterpret_cast<int*>(lds + (blockDim.x >> 6) * knn_lds_per_wave(cap, sizeof(IdxT)));
+        int* start_lds = reinterpret_cast<int*>(lds);
         for (int i = threadIdx.x; i <= kMaxCells; i += blockDim.x) start_lds[i] = c.start[i];
         __syncthreads();
         c.start = start_lds;
     }
     float ccx, ccy, ccz;
     lattice_cell_centre(L, id, ccx, ccy, ccz);
-    // d_K of the cell centre
-    const int cnt = (UMEREG_F1_ABLATE & 2048) ? K : knn_wave(c, ccx, ccy, ccz, valid, K, cap, Ls.hist, Ls.list, lane);
-    unsigned int d2k_bits = (UMEREG_F1_ABLATE & 2048) ? __float_as_uint(9.0f) : 0u;
-    for (int e = 0; e < K; ++e)
-        if (!(UMEREG_F1_ABLATE & 2048) && e < cnt) { const unsigned int b = Ls.list.d2[e * kWave + lane]; d2k_bits = b > d2k_bits ? b : d2k_bits; }
+    // d_K of the cell centre: found by lattice_dk_kernel (one wavefront per cell), left in the cell record
+    const uint4 pre = cells[id];
+    const int cnt = valid ? (int)pre.y : 0;
+    const unsigned int d2k_bits = pre.z;
     const float r = (sqrtf(__uint_as_float(d2k_bits)) + L.hd) * 1.0001f + 1e-6f;
     const float r2 = r * r;
     const float rw = r + L.hd;                       // ball around the centre that contains {dist(p, box) <= r}
@@ -1806,127 +1958,6 @@ __global__ __launch_bounds__(256) void leftover_queue_kernel(const char* __restr
         queue[base + (unsigned int)mbcnt(recs)] = make_uint4((unsigned int)perm[pos], (unsigned int)chunk, (unsigned int)mine, (unsigned int)(mine >> 32));
         atomicAdd(&header[6], (unsigned int)__popcll(mine));
     }
-}
-
-// ---- bounding boxes of a sorted table's 64-point chunks (cell-sorted order: a chunk is a short strip of cells) ----
-// box[2c] = minimum, box[2c + 1] = maximum of the chunk's points (workspace region off_box).
-__global__ __launch_bounds__(256) void chunk_box_kernel(char* __restrict__ ws, size_t ws_stride, int N)
-{
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = lane_id();
-    const int n_ch = (N + kWave - 1) / kWave;
-    if (c >= n_ch) return;
-    const GridWs w = grid_ws(N);
-    char* wb = ws + blockIdx.y * ws_stride;
-    const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
-    float4* box = reinterpret_cast<float4*>(wb + w.off_box);
-    const int j = c * kWave + lane;
-    const float4 p = P4s[j < N ? j : c * kWave];          // an invalid lane repeats the chunk's first point
-    float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
-            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
-        }
-    if (lane == 0) {
-        box[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        box[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-    }
-}
-
-// ---- exact K nearest of ONE query by a whole wavefront, over the sorted table's 64-point chunks ---------------------
-//   * seed: the chunk whose bounding box is nearest to the query, among those with >= K points; the K-th smallest key
-//     of its points bounds the K-th smallest key of the table;
-//   * scan: only chunks whose box distance does not exceed the bound (the box distance is formed with the same fp32
-//     operations as a point's d2, each of which is monotone, so it never exceeds the d2 of a point inside the box);
-//     keys (bits(d2) << 32 | index) at or below the bound go to an LDS list (ballot + mbcnt); a list beyond 128 keys is
-//     cut by histogram (coop_hist_cut) and the bound drops.  A query in the cloud touches ~10 of KITTI's 157 chunks,
-//     one 30 m outside it a few dozen;
-//   * final cut: histogram, then exact rank counting: la[0 .. returned count) = the K smallest keys in ascending order.
-// la / lb: two kCoopCap-key LDS lists of this wavefront (swapped as cuts go), hist: 64 words.
-__device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const float4* __restrict__ box, int Nt, int K, float qx, float qy,
-                                        float qz, unsigned long long*& la, unsigned long long*& lb, unsigned int* hist, int lane)
-{
-    const int n_tch = (Nt + kWave - 1) / kWave;
-    auto dist2 = [&](const float4& p) __attribute__((always_inline)) {
-        const float dx = qx - p.x;
-        const float dy = qy - p.y;
-        const float dz = qz - p.z;
-        float t = dx * dx;
-        t = t + dy * dy;
-        t = t + dz * dz;
-        return t;
-    };
-    // box distance: the same operation sequence as dist2 on the nearest point of the box
-    auto box2 = [&](int c) __attribute__((always_inline)) {
-        const float4 lo = box[2 * c], hi = box[2 * c + 1];
-        const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
-        const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
-        const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
-        float t = dx * dx;
-        t = t + dy * dy;
-        t = t + dz * dz;
-        return t;
-    };
-    auto scan_chunk = [&](int c, unsigned long long ukey, int cnt) __attribute__((always_inline)) {
-        const int j = c * kWave + lane;
-        const float4 p = P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
-        const unsigned long long k = ((unsigned long long)__float_as_uint(dist2(p)) << 32) | (unsigned int)__float_as_int(p.w);
-        const bool ok = j < Nt && k <= ukey;
-        const unsigned long long b = __ballot(ok);
-        if (ok) la[cnt + mbcnt(b)] = k;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        return cnt + __popcll(b);
-    };
-    // (1) seed: the nearest chunk with at least K points (a NaN query fails every comparison: chunk 0, nothing pruned,
-    //     NaN keys -- its terms come out NaN as on the other paths)
-    float best = 3.0e38f;
-    int best_c = 0;
-    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
-        const int c = c0 + lane;
-        if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
-            const float t = box2(c);
-            if (t < best) { best = t; best_c = c; }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, kWave);
-        const int oc = __shfl_xor(best_c, o, kWave);
-        if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
-    }
-    const int seed = __builtin_amdgcn_readfirstlane(best_c);
-    int cnt = scan_chunk(seed, ~0ull, 0);
-    cnt = coop_cut(la, lb, cnt, K, lane);
-    { unsigned long long* t_ = la; la = lb; lb = t_; }
-    unsigned long long ukey = cnt == K ? la[K - 1] : ~0ull;
-    // (2) the chunks whose box reaches inside the bound
-    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
-        const int c = c0 + lane;
-        const float t = c < n_tch ? box2(c) : 3.0e38f;
-        const float bd = __uint_as_float((unsigned int)(ukey >> 32));
-        unsigned long long pend = __ballot(c < n_tch && c != seed && (ukey == ~0ull || !(t > bd)));
-        while (pend != 0ull) {
-            const int l = __ffsll((long long)pend) - 1;
-            pend &= pend - 1ull;
-            // the bound may have dropped since the ballot
-            if (ukey != ~0ull && __shfl(t, l, kWave) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
-            if (cnt > 2 * kWave) {                      // (<= 3 * 64 keys: every scan adds at most 64)
-                cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
-                unsigned long long* t_ = la; la = lb; lb = t_;
-            }
-            cnt = scan_chunk(c0 + l, ukey, cnt);
-        }
-    }
-    if (cnt > kWave) {
-        cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
-        unsigned long long* t_ = la; la = lb; lb = t_;
-    }
-    cnt = coop_cut(la, lb, cnt, K, lane);
-    { unsigned long long* t_ = la; la = lb; lb = t_; }
-    return cnt;
 }
 
 // ---- feature_spatial_var for clouds that do not fill the chip with one query per lane: one wavefront per query ----
@@ -2327,7 +2358,11 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(lattice_compact_kernel, dim3(1), dim3(1024), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
         UMEREG_CHECK_LAUNCH("lattice_compact_kernel");
         const unsigned int build_blocks = (c_max / kLatLanes + (unsigned int)bwaves - 1) / (unsigned int)bwaves;
-        hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), blds + (size_t)(kMaxCells + 64) * 4, st,
+        hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
+        UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+        hipLaunchKernelGGL(lattice_dk_kernel, dim3(4096), dim3(8 * kWave), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
+        UMEREG_CHECK_LAUNCH("lattice_dk_kernel");
+        hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), (size_t)(kMaxCells + 64) * 4, st,
                            (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
         UMEREG_CHECK_LAUNCH("lattice_count_kernel");
         hipLaunchKernelGGL(lattice_scan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max);
@@ -2339,8 +2374,6 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
-        hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
-        UMEREG_CHECK_LAUNCH("chunk_box_kernel");
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);
