@@ -889,7 +889,7 @@ def test_errors_are_loud(gpu):
     with pytest.raises(RuntimeError, match="feature dim"):
         ops.ume_moments(pts, pts, torch.zeros((1, 100, 16), device=gpu), 16, 1.0)
     with pytest.raises(RuntimeError, match="K must be"):
-        ops.ball_query(pts, pts, K=5000, radius=1.0)
+        ops.ball_query(pts, pts, K=8000, radius=1.0)
     lib = _lib.load()
     assert lib.umereg_ume_dist_q_f32(None, None, 1, 1, None, None, None, None, None) == -1
     assert b"null" in lib.umereg_last_error()
@@ -1335,3 +1335,24 @@ def test_evaluate_from_the_reference_pair_cache(gpu, tmp_path, capsys):
     write_cached_pair(str(tmp_path / "nofeat" / "test" / "08" / "000000_000011.pickle"), item)
     with pytest.raises(KeyError, match="feature network"):
         main(["--benchmark", "kitti_test", "--cache", str(tmp_path / "nofeat")])
+
+
+def test_moments_with_the_reference_default_max_nn(gpu):
+    """generate_ume_from_keypoints2's default max_nn = 5000 (reference utils/loc_utils.py:87): K above 4096 (one wavefront
+    per workgroup, 40 KiB list) -- saturated and unsaturated balls, indices bit-exact, moments to a few ulp."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(18)
+    pts = (rng.uniform(-9, 9, (60000, 3)) * np.array([1, 1, 0.25])).astype(np.float32)
+    kp = np.concatenate([pts[rng.choice(60000, 20, replace=False)], np.array([[30.0, 30.0, 0.0], [12.0, 12.0, 0.0]], np.float32)])
+    f = rng.standard_normal((60000, 32)).astype(np.float32)
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    F, cnt, idx = ops.ume_moments(T_(pts, gpu)[None], T_(kp, gpu)[None], T_(f, gpu)[None], 5000, 6.0, return_count=True, return_idx=True)
+    ref = orc.ball_query(kp[None], pts[None], K=5000, radius=6.0, return_nn=False)
+    assert np.array_equal(N_(idx), ref.idx)
+    c = N_(cnt[0])
+    assert c.max() == 5000 and c.min() == 0 and 0 < c[-1] < 5000
+    F64 = orc.ume_moments(pts, kp, f, 5000, 6.0, accum="f64")
+    scale = np.abs(F64).max(axis=(1, 2), keepdims=True) + 1e-30
+    assert (np.abs(N_(F[0]) - F64) / scale).max() < 3e-7
+    with pytest.raises(RuntimeError, match="7680"):
+        ops.ume_moments(T_(pts, gpu)[None], T_(kp, gpu)[None], T_(f, gpu)[None], 8000, 6.0)

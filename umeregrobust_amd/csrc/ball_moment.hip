@@ -658,7 +658,7 @@ UMEREG_API int umereg_ball_query_f32(const float* p1, const float* p2, const int
 {
     UMEREG_REQUIRE(p1 && p2 && idx, "ball_query: null pointer (p1/p2/idx)");
     UMEREG_REQUIRE(B > 0 && n1 > 0 && n2 > 0, "ball_query: B, n1, n2 must be positive (got %d, %d, %d)", B, n1, n2);
-    UMEREG_REQUIRE(K > 0 && K <= 4096, "ball_query: K must be in [1, 4096] (got %d)", K);
+    UMEREG_REQUIRE(K > 0 && K <= 7680, "ball_query: K must be in [1, 7680] (got %d)", K);
     UMEREG_REQUIRE(radius > 0.f, "ball_query: radius must be positive");
     if (int rc = check_device()) return rc;
     if (!workspace || workspace_bytes < umereg_ball_query_workspace_bytes(B, n2) || ((uintptr_t)workspace & 15)) {
@@ -715,7 +715,7 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     UMEREG_REQUIRE(feat_dim == UMEREG_FEAT_DIM,
                    "ume_moments: feature dim must be 32 like the reference (evaluate.py:55), got %d", feat_dim);
     UMEREG_REQUIRE(B > 0 && N > 0 && n_kp > 0, "ume_moments: B, N, n_kp must be positive (got %d, %d, %d)", B, N, n_kp);
-    UMEREG_REQUIRE(K > 0 && K <= 4096, "ume_moments: K must be in [1, 4096] (got %d)", K);
+    UMEREG_REQUIRE(K > 0 && K <= 7680, "ume_moments: K must be in [1, 7680] (got %d)", K);
     UMEREG_REQUIRE(radius > 0.f, "ume_moments: radius must be positive");
     UMEREG_REQUIRE(((uintptr_t)feat & 15) == 0 && ((uintptr_t)F & 15) == 0 && ((uintptr_t)packed & 15) == 0,
                    "ume_moments: packed, feat and F must be 16-byte aligned");

@@ -36,6 +36,14 @@ def _workspace(device, nbytes, tag):
     return buf
 
 
+def release_workspaces(device=None):
+    """Drops the cached scratch buffers (all devices, or one): they are grow-only and keyed by (device, stream, purpose), so
+    a long-lived process that cycles through many streams or problem sizes can hand the memory back between phases.  Only
+    call it when no library call is in flight on those streams."""
+    for key in [k for k in _workspaces if device is None or k[0] == torch.device(device).index]:
+        del _workspaces[key]
+
+
 def _dev(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
@@ -379,9 +387,13 @@ KNN = namedtuple("KNN", "dists idx knn")   # pytorch3d's _KNN
 
 def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **_ignored):
     """pytorch3d.ops.knn_points drop-in (reference utils/loc_utils.py:580,623; evaluate.py:272,274).
-    p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] squared, ascending; idx [B,n1,K] i64; knn [B,n1,K,3] | None)."""
+    p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] squared, ascending; idx [B,n1,K] i64; knn [B,n1,K,3] | None).
+    Limits (the reference's calls are K = 1, 20 and 50 on full clouds): 1 <= K <= min(64, n2) -- a larger K raises
+    ValueError here --, lengths1 / lengths2 must be None (ragged batches: call once per cloud)."""
     if lengths1 is not None or lengths2 is not None:
         raise NotImplementedError("knn_points: lengths1/lengths2 are not used on the reference's hot path")
+    if not 1 <= int(K) <= 64:
+        raise ValueError(f"knn_points: K must be in [1, 64] (got {K}): the per-lane neighbour lists live in LDS")
     lib = _lib.load()
     p1 = _dev(p1, "p1"); p2 = _dev(p2, "p2")
     if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3 or p1.shape[0] != p2.shape[0]:
@@ -404,8 +416,11 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **_ig
 
 
 def feature_spatial_var(pts, feat, knn=10):
-    """reference utils/loc_utils.py:579-585, fused.  pts [B,N,3], feat [B,N,32] -> [B,N]."""
+    """reference utils/loc_utils.py:579-585, fused.  pts [B,N,3], feat [B,N,32] -> [B,N].  2 <= knn <= min(64, N)
+    (the reference default is 10, FeatureCorrelator uses 50)."""
     lib = _lib.load()
+    if not 2 <= int(knn) <= 64:
+        raise ValueError(f"feature_spatial_var: knn must be in [2, 64] (got {knn})")
     pts = _dev(pts, "pts"); feat = _dev(feat, "feat")
     if pts.dim() != 3 or feat.dim() != 3 or feat.shape[:2] != pts.shape[:2]:
         raise ValueError(f"feature_spatial_var: expected pts [B,N,3], feat [B,N,32]; got {tuple(pts.shape)}, {tuple(feat.shape)}")

@@ -40,7 +40,9 @@ def generate_ume_from_keypoints2(velo_pts, velo_seg, velo_feat, ref_pts, ref_fea
     -> F_velo, F_ref [bs',ns,D,4], velo_keypoint_pts, ref_keypoint_pts [bs',ns,3], ratio [bs',ns], with_kpts [bs].
 
     Same outputs as the reference; the [bs,N,max_nn,3] neighbour tensor it builds for EVERY candidate (:113-116)
-    is replaced by the fused count + moment kernel, neighbour lists are only formed for the selected keypoints."""
+    is replaced by the fused count + moment kernel, neighbour lists are only formed for the selected keypoints.
+    Limits of the native search: max_nn <= 7680 (the reference default 5000 is inside; above it the C ABI returns
+    UMEREG_EINVAL, raised here as RuntimeError)."""
     bs, velo_pc_size, dim_size = velo_feat.shape
     dev = velo_pts.device
     non_floor_mask = (velo_seg != torch.tensor(flat_labels, device=velo_seg.device)).all(dim=-1).flatten(1)     # :93
