@@ -71,21 +71,20 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     dev = src_pts.device
     _, src_inds = sparse_quantize(src_pts_raw, return_index=True, quantization_size=args.corr_ds)       # :261-262
     _, tgt_inds = sparse_quantize(tgt_pts_raw, return_index=True, quantization_size=0.3)                # :263-264
-    src_pts_raw = src_pts_raw[src_inds][None].to(dev)
-    tgt_pts_raw = tgt_pts_raw[tgt_inds][None].to(dev)
     gt_tform = gt_tform[None].to(dev)
-    ind = ops.knn_points(src_pts_raw.contiguous(), src_pts, K=1)                                        # :272
-    src_feat_corr = torch.gather(src_feat, 1, ind[1][:, :, 0:1].expand(-1, -1, src_feat.shape[2]))     # knn_gather(...)[:, :, 0, :]
-    ind = ops.knn_points(tgt_pts_raw.contiguous(), tgt_pts, K=1)                                        # :274
-    tgt_feat_corr = torch.gather(tgt_feat, 1, ind[1][:, :, 0:1].expand(-1, -1, tgt_feat.shape[2]))
-    num_pts = min(args.pc_corr_max_size, src_pts_raw.shape[1])                                          # :278-285
-    rand_idxs = _index_tensor(choice_uniform_noreplace(rng, src_pts_raw.shape[1], num_pts), dev)
-    src_pts_raw = src_pts_raw[:, rand_idxs]
-    src_feat_corr = src_feat_corr[:, rand_idxs]
-    num_pts = min(args.pc_corr_max_size, tgt_pts_raw.shape[1])
-    rand_idxs = _index_tensor(choice_uniform_noreplace(rng, tgt_pts_raw.shape[1], num_pts), dev)
-    tgt_pts_raw = tgt_pts_raw[:, rand_idxs]
-    tgt_feat_corr = tgt_feat_corr[:, rand_idxs]
+    # The reference transfers features to EVERY kept raw point (K=1 search, :272-275) and sub-samples afterwards (:278-285).
+    # A point's feature does not depend on the other points, so the sub-sample is drawn first (same draws, same order on
+    # the host stream) and only its <= pc_corr_max_size points are searched: identical tensors, a quarter of the queries.
+    src_inds, tgt_inds = src_inds.to(dev), tgt_inds.to(dev)
+    n_src, n_tgt = int(src_inds.shape[0]), int(tgt_inds.shape[0])
+    src_sel = _index_tensor(choice_uniform_noreplace(rng, n_src, min(args.pc_corr_max_size, n_src)), dev)          # :279-280
+    tgt_sel = _index_tensor(choice_uniform_noreplace(rng, n_tgt, min(args.pc_corr_max_size, n_tgt)), dev)          # :283-284
+    src_pts_raw = src_pts_raw.to(dev)[src_inds[src_sel]][None].contiguous()
+    tgt_pts_raw = tgt_pts_raw.to(dev)[tgt_inds[tgt_sel]][None].contiguous()
+    ind = ops.knn_points(src_pts_raw, src_pts, K=1)                                                              # :272
+    src_feat_corr = src_feat[0][ind[1][0, :, 0]][None]                                                           # knn_gather(...)[:, :, 0, :]
+    ind = ops.knn_points(tgt_pts_raw, tgt_pts, K=1)                                                              # :274
+    tgt_feat_corr = tgt_feat[0][ind[1][0, :, 0]][None]
     return pc_fcht(pc1_pts=src_pts_raw.contiguous(), pc2_pts=tgt_pts_raw.contiguous(), pc1_feat=src_feat_corr.contiguous(),
                    pc2_feat=tgt_feat_corr.contiguous(), rtume_hypotises=rtume_tform, gt_tform=gt_tform,
                    corr_sigma=args.corr_kernel_sigma, args=args, timing=timing)
