@@ -246,6 +246,19 @@ int umereg_host_choice_mt19937(uint32_t* mt_key_host, int* mt_pos_host, const vo
 int umereg_host_permutation_mt19937(uint32_t* mt_key, int* mt_pos, int64_t n, int64_t size, int64_t* perm, int64_t* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * f1 (raw-cloud prep)  ME.utils.sparse_quantize(coordinates, return_index=True, quantization_size)
+ *                      evaluate.py:261-264, datasets/kitti/kitti_dataset.py:416-419
+ * One representative per occupied voxel of edge `voxel`: the FIRST point (lowest index) of every voxel
+ * floor(p / voxel), indices ascending (MinkowskiEngine 0.5.4 not installable: restated, parity unpinned).
+ *   pts [n,3] f32; out_idx int64 [n] (the first out_count[0] entries are written);
+ *   out_count int32 [2] (device): [0] = number of voxels, [1] != 0 if a coordinate was NaN / inf / outside
+ *   |floor(p / voxel)| < 2^20 (such points are left out; callers should treat it as an error).
+ * Asynchronous like every entry point: read out_count after synchronising the stream. */
+size_t umereg_voxel_first_index_workspace_bytes(int n);
+int umereg_voxel_first_index_f32(const float* pts, int n, float voxel, int64_t* out_idx, int* out_count, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a6  utils.loc_utils.batch_estimate_transform_ume_old(G, H)         utils/loc_utils.py:292-350
  * Closed-form SE(3) from a (source G, target H) UME pair; T maps source -> target.
  *   G_all [nG,32,4], H_all [nH,32,4]; g_index/h_index int64 [n] select the rows used by

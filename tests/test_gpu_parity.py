@@ -1356,3 +1356,34 @@ def test_moments_with_the_reference_default_max_nn(gpu):
     assert (np.abs(N_(F[0]) - F64) / scale).max() < 3e-7
     with pytest.raises(RuntimeError, match="7680"):
         ops.ume_moments(T_(pts, gpu)[None], T_(kp, gpu)[None], T_(f, gpu)[None], 8000, 6.0)
+
+
+def test_voxel_first_index_vs_numpy(gpu):
+    """umereg_voxel_first_index_f32 (ME.utils.sparse_quantize(return_index=True) of evaluate.py:261-264, restated): first
+    point of every voxel floor(p / voxel), ascending -- against numpy's unique on the same fp32 quotient, on a KITTI-sized
+    raw cloud with negative coordinates, exact duplicates and a voxel edge that does not divide the lattice; the torch form
+    (host tensors) and the oracle give the same indices; bitwise repeatable; bad coordinates are reported."""
+    from umeregrobust_amd import evaluate, ops
+    rng = np.random.RandomState(4)
+    pts = np.concatenate([rng.uniform(-60, 60, (120000, 3)) * np.array([1, 1, 0.05]), rng.normal(0, 2.0, (8000, 3))]).astype(np.float32)
+    pts[5000:5100] = pts[100:200]                               # exact duplicates of earlier points
+    pts[7] = [0.0, -0.0, 0.29999998]                            # signed zero / just below a voxel boundary
+    for voxel in (0.3, 0.6, 0.05, 7.0):
+        q = np.floor(pts / np.float32(voxel)).astype(np.int64)
+        _, first = np.unique(q, axis=0, return_index=True)
+        want = np.sort(first)
+        got = N_(ops.voxel_first_index(T_(pts, gpu), voxel))
+        assert got.dtype == np.int64 and np.array_equal(got, want), voxel
+        assert np.array_equal(N_(ops.voxel_first_index(T_(pts, gpu), voxel)), got)               # repeatable
+        assert np.array_equal(orc.sparse_quantize(pts, voxel), want)
+    c_dev, i_dev = evaluate.sparse_quantize(T_(pts, gpu), return_index=True, quantization_size=0.3)
+    c_cpu, i_cpu = evaluate.sparse_quantize(torch.from_numpy(pts), return_index=True, quantization_size=0.3)
+    assert torch.equal(i_dev.cpu(), i_cpu) and torch.equal(c_dev.cpu(), c_cpu)
+    a, b = ops.voxel_first_index(T_(pts, gpu), 0.3, T_(pts[::-1].copy(), gpu), 0.6)
+    assert np.array_equal(N_(a), N_(i_dev)) and np.array_equal(N_(b), N_(ops.voxel_first_index(T_(pts[::-1].copy(), gpu), 0.6)))
+    assert ops.voxel_first_index(T_(pts[:1], gpu), 0.3).tolist() == [0]
+    bad = pts.copy(); bad[17, 1] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        ops.voxel_first_index(T_(bad, gpu), 0.3)
+    with pytest.raises(RuntimeError, match="voxel edge"):
+        ops.voxel_first_index(T_(pts, gpu), 0.0)

@@ -47,7 +47,13 @@ def sparse_quantize(coordinates, return_index=True, quantization_size=1.0):
     occupied voxel of edge `quantization_size`.  -> (voxel coords int32 [m,3], index int64 [m]).
     MinkowskiEngine is not installable here (parity unpinned): this restates its documented behaviour --
     floor(coordinates / quantization_size), the FIRST point of every voxel, in order of first appearance.
-    Device-side (stable sort of the voxel keys); coordinates [n,3] float tensor."""
+    Device tensors go through the native kernel (`umereg_voxel_first_index_f32`: hash table + atomicMin, no sort); host
+    tensors through the torch form below (the same rule; CPU-side callers such as dataset preprocessing)."""
+    if coordinates.is_cuda and coordinates.dtype == torch.float32 and coordinates.dim() == 2 and coordinates.shape[1] == 3:
+        inds = ops.voxel_first_index(coordinates, quantization_size)
+        if not return_index:
+            return torch.floor(coordinates[inds] / quantization_size).to(torch.int32)
+        return torch.floor(coordinates[inds] / quantization_size).to(torch.int32), inds
     q = torch.floor(coordinates / quantization_size).to(torch.int64)
     qmin = q.min(dim=0).values
     span = (q.max(dim=0).values - qmin + 1)
@@ -69,8 +75,13 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     src_pts_raw [n,3], tgt_pts_raw [m,3]; src_pts/tgt_pts [1,N,3] with src_feat/tgt_feat [1,N,32];
     rtume_tform [1,M,4,4]; gt_tform [4,4].  -> (R_err, t_err, R_hat_corr [1,3,3], t_hat_corr [1,3])."""
     dev = src_pts.device
-    _, src_inds = sparse_quantize(src_pts_raw, return_index=True, quantization_size=args.corr_ds)       # :261-262
-    _, tgt_inds = sparse_quantize(tgt_pts_raw, return_index=True, quantization_size=0.3)                # :263-264
+    src_pts_raw, tgt_pts_raw = src_pts_raw.to(dev), tgt_pts_raw.to(dev)
+    if src_pts_raw.is_cuda and src_pts_raw.dtype == torch.float32 and tgt_pts_raw.dtype == torch.float32:
+        # both clouds behind one host read of the two voxel counts (the voxel coordinates themselves are not used, :261-264)
+        src_inds, tgt_inds = ops.voxel_first_index(src_pts_raw.contiguous(), args.corr_ds, tgt_pts_raw.contiguous(), 0.3)
+    else:
+        _, src_inds = sparse_quantize(src_pts_raw, return_index=True, quantization_size=args.corr_ds)       # :261-262
+        _, tgt_inds = sparse_quantize(tgt_pts_raw, return_index=True, quantization_size=0.3)                # :263-264
     gt_tform = gt_tform[None].to(dev)
     # The reference transfers features to EVERY kept raw point (K=1 search, :272-275) and sub-samples afterwards (:278-285).
     # A point's feature does not depend on the other points, so the sub-sample is drawn first (same draws, same order on
@@ -79,8 +90,8 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     n_src, n_tgt = int(src_inds.shape[0]), int(tgt_inds.shape[0])
     src_sel = _index_tensor(choice_uniform_noreplace(rng, n_src, min(args.pc_corr_max_size, n_src)), dev)          # :279-280
     tgt_sel = _index_tensor(choice_uniform_noreplace(rng, n_tgt, min(args.pc_corr_max_size, n_tgt)), dev)          # :283-284
-    src_pts_raw = src_pts_raw.to(dev)[src_inds[src_sel]][None].contiguous()
-    tgt_pts_raw = tgt_pts_raw.to(dev)[tgt_inds[tgt_sel]][None].contiguous()
+    src_pts_raw = src_pts_raw[src_inds[src_sel]][None].contiguous()
+    tgt_pts_raw = tgt_pts_raw[tgt_inds[tgt_sel]][None].contiguous()
     ind = ops.knn_points(src_pts_raw, src_pts, K=1)                                                              # :272
     src_feat_corr = src_feat[0][ind[1][0, :, 0]][None]                                                           # knn_gather(...)[:, :, 0, :]
     ind = ops.knn_points(tgt_pts_raw, tgt_pts, K=1)                                                              # :274

@@ -385,6 +385,40 @@ def hypothesis_gates(T, gt_tform, counts, return_errors=False):
 KNN = namedtuple("KNN", "dists idx knn")   # pytorch3d's _KNN
 
 
+def _voxel_first_index_launch(pts, voxel, cnt):
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError(f"voxel_first_index: expected pts [n,3]; got {tuple(pts.shape)}")
+    n, dev = pts.shape[0], pts.device
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    if n == 0:
+        cnt.zero_()
+        return idx
+    ws = _workspace(dev, lib.umereg_voxel_first_index_workspace_bytes(n), "voxel")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_voxel_first_index_f32(_ptr(pts), n, float(voxel), _ptr(idx), _ptr(cnt), _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_voxel_first_index_f32")
+    return idx
+
+
+def voxel_first_index(pts, voxel, pts2=None, voxel2=None):
+    """First point of every occupied voxel floor(p / voxel), indices ascending (ME.utils.sparse_quantize(return_index=True) as
+    used at reference evaluate.py:261-264; restated, parity unpinned).  pts [n,3] f32 on the device -> int64 [m].
+    One device -> host read (the number of voxels), like the boolean-mask indexing of the torch form; with a second cloud
+    (pts2, voxel2) both are thinned behind the same read -> (idx, idx2)."""
+    dev = pts.device
+    cnt = torch.empty(4, dtype=torch.int32, device=dev)
+    idx = _voxel_first_index_launch(pts, voxel, cnt[0:2])
+    idx2 = _voxel_first_index_launch(pts2, voxel if voxel2 is None else voxel2, cnt[2:4]) if pts2 is not None else None
+    if idx2 is None:
+        cnt[2:4].zero_()
+    m, bad, m2, bad2 = cnt.tolist()
+    if bad or bad2:
+        raise ValueError("voxel_first_index: a coordinate is NaN, infinite or beyond 2^20 voxels from the origin")
+    return idx[:m] if idx2 is None else (idx[:m], idx2[:m2])
+
+
 def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **_ignored):
     """pytorch3d.ops.knn_points drop-in (reference utils/loc_utils.py:580,623; evaluate.py:272,274).
     p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] squared, ascending; idx [B,n1,K] i64; knn [B,n1,K,3] | None).
