@@ -1,6 +1,11 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
+if os.environ.get('ALTLIB'):       # time another build of the library
+    import umeregrobust_amd._build as _b
+    _b.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ['ALTLIB'])
+    import umeregrobust_amd._lib as _L
+    _L.LIB_PATH = _b.LIB_PATH
 from umeregrobust_amd import ops, _lib
 if os.environ.get('TUNE_SPLITS') or os.environ.get('TUNE_SHARE_MASK'):
     _lib.load().umereg_ume_match_set_tuning(int(os.environ.get('TUNE_SPLITS', '0')), int(os.environ.get('TUNE_SHARE_MASK', '-1'), 0), 0)
