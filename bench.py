@@ -513,14 +513,16 @@ def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M
     small = SimpleNamespace(**vars(args))
     small.ume_n_samples = M
     small.pc_corr_max_size = N
+    from umeregrobust_amd.host_rng import RecordingRNG as Recorder, ReplayRNG as Replay
     rows = []
     t_cpu = 0.0
     for i in range(a.cpu_rr_pairs):
         if t_cpu > budget_s:
             break
         p = synth_pair_hard(seed=20000 + i, N=N, n_kp=N, kind=a.kind, voxel=0.3, **RR_CHECK_HARD)
+        rec = Recorder(np.random.RandomState(31 + i))
         tc = time.perf_counter()
-        rc = orc.evaluate_pair_full(p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.gt_tform, np.random.RandomState(31 + i),
+        rc = orc.evaluate_pair_full(p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.gt_tform, rec,
                                     ume_max_nn=small.ume_max_nn, ume_r_nn=small.ume_r_nn, ume_n_samples=M, tau=small.tau,
                                     filter_by_ume_dist_cond=small.filter_by_ume_dist_cond, corr_ds=small.corr_ds,
                                     pc_corr_max_size=N, sigma=small.corr_kernel_sigma)
@@ -528,21 +530,38 @@ def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M
         t = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
         pair = dict(src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
                     tgt_feat=t(p.tgt_feat)[None], gt_tform=t(p.gt_tform))
-        rg = evaluate.evaluate_pairs([pair], small, rng=np.random.RandomState(31 + i), refine=True)
-        rows.append((rc["rre"], rc["rte"], float(rg["rre"][0]), float(rg["rte"][0])))
+        rg = evaluate.evaluate_pairs([pair], small, rng=np.random.RandomState(31 + i), refine=True)       # its own draws on the same seed
+        try:
+            rp = evaluate.evaluate_pairs([pair], small, rng=Replay(rec.log), refine=True)                  # the oracle's draws, replayed
+            same = (float(rp["rre"][0]), float(rp["rte"][0]))
+        except ValueError:
+            same = (float("nan"), float("nan"))
+        rows.append((rc["rre"], rc["rte"], float(rg["rre"][0]), float(rg["rte"][0])) + same)
     r = np.array(rows, np.float64)
     n = r.shape[0]
     cpu_ok = np.stack([(r[:, 0] <= g0) & (r[:, 1] <= g1) for g0, g1 in GATES], 1)
     gpu_ok = np.stack([(r[:, 2] <= g0) & (r[:, 3] <= g1) for g0, g1 in GATES], 1)
+    rep_ok = np.stack([(r[:, 4] <= g0) & (r[:, 5] <= g1) for g0, g1 in GATES], 1)
     differing = [{"pair": int(i), "cpu_rre_rte": [round(r[i, 0], 4), round(r[i, 1], 4)], "hip_rre_rte": [round(r[i, 2], 4), round(r[i, 3], 4)]}
                  for i in np.flatnonzero((cpu_ok != gpu_ok).any(1))]
+    differing_rep = [{"pair": int(i), "cpu_rre_rte": [round(r[i, 0], 4), round(r[i, 1], 4)], "hip_rre_rte": [round(r[i, 4], 4), round(r[i, 5], 4)]}
+                     for i in np.flatnonzero((cpu_ok != rep_ok).any(1))]
     return {"pairs": int(n), "size": f"N={N} pts/cloud, {N} keypoints, M={M} hypotheses; hard pairs: {RR_CHECK_HARD}",
             "gates": ["1.5deg,0.6m", "1.5deg,0.3m", "1deg,0.1m"],
             "cpu_rr_percent": [round(100.0 * float(v), 3) for v in cpu_ok.mean(0)],
             "hip_rr_percent": [round(100.0 * float(v), 3) for v in gpu_ok.mean(0)],
+            "hip_same_draws_rr_percent": [round(100.0 * float(v), 3) for v in rep_ok.mean(0)],
             "cpu_mRRE_mRTE": [round(float(r[:, 0].mean()), 4), round(float(r[:, 1].mean()), 4)],
             "hip_mRRE_mRTE": [round(float(r[:, 2].mean()), 4), round(float(r[:, 3].mean()), 4)],
-            "pairs_with_a_different_gate_outcome": differing, "cpu_s": round(t_cpu, 1), "cpu_pairs_per_s": round(n / max(t_cpu, 1e-9), 3)}
+            "hip_same_draws_mRRE_mRTE": [round(float(np.nanmean(r[:, 4])), 4), round(float(np.nanmean(r[:, 5])), 4)],
+            "max_abs_diff_same_draws": {"rre_deg": round(float(np.nanmax(np.abs(r[:, 4] - r[:, 0]))), 5),
+                                        "rte_m": round(float(np.nanmax(np.abs(r[:, 5] - r[:, 1]))), 5)},
+            "pairs_with_a_different_gate_outcome": differing,
+            "pairs_with_a_different_gate_outcome_same_draws": differing_rep,
+            "note": "`hip_rr_percent`: this library drawing from its own generator on the same seed (the two paths' match distances "
+                    "differ in the last bits, so the weighted draws part after the first sub-sample: agreement is statistical). "
+                    "`hip_same_draws_*`: the oracle's five host draws per pair replayed into this library: agreement pair by pair",
+            "cpu_s": round(t_cpu, 1), "cpu_pairs_per_s": round(n / max(t_cpu, 1e-9), 3)}
 
 
 if __name__ == "__main__":

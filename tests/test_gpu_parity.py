@@ -1387,3 +1387,32 @@ def test_voxel_first_index_vs_numpy(gpu):
         ops.voxel_first_index(T_(bad, gpu), 0.3)
     with pytest.raises(RuntimeError, match="voxel edge"):
         ops.voxel_first_index(T_(pts, gpu), 0.0)
+
+
+def test_full_pipeline_equals_the_oracle_on_replayed_draws(gpu):
+    """The whole loop iteration (evaluate.py:195-309: a1-a7, raw-cloud prep, f1, f2) through this library with the oracle's five
+    host draws replayed: the same selected hypothesis, the same refined registration -- pair by pair, on hard pairs (partial
+    overlap, noise, corrupted features) where some registrations fail on both sides."""
+    from types import SimpleNamespace
+    from umeregrobust_amd import evaluate
+    from umeregrobust_amd.host_rng import RecordingRNG, ReplayRNG
+    from umeregrobust_amd.synth import synth_pair_hard
+    from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
+    args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("kitti_test"))
+    args.batch_size, args.ume_n_samples, args.pc_corr_max_size = 1, 128, 2048
+    n_ok = 0
+    for i in range(4):
+        p = synth_pair_hard(seed=20000 + i, N=2048, n_kp=2048, sector_deg=180.0, sector_shift_deg=120.0, noise_sigma=0.03, feat_corrupt=0.5)
+        rec = RecordingRNG(np.random.RandomState(31 + i))
+        rc = orc.evaluate_pair_full(p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.gt_tform, rec, ume_n_samples=128, tau=args.tau,
+                                    corr_ds=args.corr_ds, pc_corr_max_size=2048, sigma=args.corr_kernel_sigma)
+        assert len(rec.log) == 5
+        pair = dict(src_pts=T_(p.src_pts, gpu)[None], tgt_pts=T_(p.tgt_pts, gpu)[None], src_feat=T_(p.src_feat, gpu)[None],
+                    tgt_feat=T_(p.tgt_feat, gpu)[None], gt_tform=T_(p.gt_tform, gpu))
+        rg = evaluate.evaluate_pairs([pair], args, rng=ReplayRNG(rec.log), refine=True)
+        # the selected hypothesis is the same one (the two paths' hypotheses agree to ~1e-5), and ICP ends in the same place
+        assert np.abs(N_(rg["R_sel"][0]) - rc["T_sel"][:3, :3]).max() < 1e-3 and np.abs(N_(rg["t_sel"][0]) - rc["T_sel"][:3, 3]).max() < 1e-2
+        assert abs(float(rg["rte"][0]) - rc["rte"]) < 2e-3 and abs(float(rg["rre"][0]) - rc["rre"]) < 5e-2
+        n_ok += int(rc["rre"] <= 1.5 and rc["rte"] <= 0.6)
+    with pytest.raises(ValueError, match="does not fit"):
+        ReplayRNG([np.arange(5)]).choice(4, 5, replace=False)

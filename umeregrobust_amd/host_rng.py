@@ -128,3 +128,32 @@ def choice_uniform_noreplace(rng, n, size):
     if rc != 0:
         raise ValueError("umereg_host_permutation_mt19937 failed")
     return out
+
+
+class RecordingRNG:
+    """Wraps a generator and keeps every `choice` result in order: the host draws of one evaluation-loop iteration (keypoints x 2,
+    weighted match draw, correlation sub-samples x 2) can then be replayed into another implementation of the loop."""
+
+    def __init__(self, rng):
+        self.rng, self.log = rng, []
+
+    def choice(self, *args, **kw):
+        out = self.rng.choice(*args, **kw)
+        self.log.append(np.array(out, copy=True))
+        return out
+
+
+class ReplayRNG:
+    """Hands out recorded draws in order (see RecordingRNG); checks that each fits the call it answers."""
+
+    def __init__(self, log):
+        self.log = list(log)
+
+    def choice(self, n, size=None, replace=True, p=None):
+        if not self.log:
+            raise ValueError("ReplayRNG: no recorded draw left")
+        out = self.log.pop(0)
+        if out.shape[0] != size or (out.size and int(out.max()) >= n):
+            raise ValueError(f"ReplayRNG: recorded draw of {out.shape[0]} indices (max {int(out.max()) if out.size else -1}) "
+                             f"does not fit choice({n}, {size})")
+        return out
