@@ -1795,14 +1795,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifdef UMEREG_KNN_DEBUG
     const long long t_start = clock64();
 #endif
-    const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
     // consecutive wavefronts take the SAME 64 queries under different groups of hypotheses: what is resident on the
-    // chip at any time then works in one neighbourhood of the target, and its table and feature rows are cache hits
+    // chip at any time then works in one neighbourhood of the target, and its table and feature rows are cache hits.
+    // (Grid-stride over the (chunk, hypothesis group) items: the launch may be smaller than their number -- a kernel that
+    // is enqueued only to find that it has nothing to do should not cost 98 k workgroup launches.)
     const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
-    const int chunk = wid / n_hg;
-    const int hg = wid % n_hg;
+    const long n_items = (long)n_chunks * n_hg;
+    for (long wid = (long)blockIdx.x * (blockDim.x >> 6) + wave; wid < n_items; wid += (long)gridDim.x * (blockDim.x >> 6)) {
+    const int chunk = (int)(wid / n_hg);
+    const int hg = (int)(wid % n_hg);
     const int h0 = hg * hyp_per_wave;
-    if (chunk >= n_chunks) return;
     const int h1 = min(h0 + hyp_per_wave, M);
     // source points in the cell-sorted order of their consensus-rotated copies (see mean_rotation_kernel): the
     // sorted table only supplies the order, coordinates are the caller's
@@ -1906,6 +1908,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
         }
     }
+    }   // (chunk, hypothesis group) items
 #ifdef UMEREG_KNN_DEBUG
     if (lane == 0) {
         const unsigned long long dur = (unsigned long long)(clock64() - t_start);
@@ -2360,7 +2363,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         const unsigned int build_blocks = (c_max / kLatLanes + (unsigned int)bwaves - 1) / (unsigned int)bwaves;
         hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
         UMEREG_CHECK_LAUNCH("chunk_box_kernel");
-        hipLaunchKernelGGL(lattice_dk_kernel, dim3(4096), dim3(8 * kWave), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
+        hipLaunchKernelGGL(lattice_dk_kernel, dim3(1024), dim3(8 * kWave), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_dk_kernel");
         hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), (size_t)(kMaxCells + 64) * 4, st,
                            (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
@@ -2369,7 +2372,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
         hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
-        hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
+        const dim3 lat_grid(score_grid.x < 16384u ? score_grid.x : 16384u);
+        hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), lat_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
