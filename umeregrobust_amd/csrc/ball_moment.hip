@@ -567,9 +567,12 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
             }
         }
     };
-    const int full = count & ~(8 * kMomUnroll - 1);
+#ifndef UMEREG_MOM_ABLATE
+#define UMEREG_MOM_ABLATE 0   // timing experiments only: 1 = no gather / accumulation (search cost alone)
+#endif
+    const int full = (UMEREG_MOM_ABLATE & 1) ? 0 : count & ~(8 * kMomUnroll - 1);
     for (int e0 = 0; e0 < full; e0 += 8 * kMomUnroll) trip(e0, false);
-    if (full < count) trip(full, true);
+    if (!(UMEREG_MOM_ABLATE & 1) && full < count) trip(full, true);
     // fold the 8 neighbour slots (lanes that share qd differ in bits 3..5)
 #pragma unroll
     for (int m = 8; m < 64; m <<= 1) {
@@ -586,13 +589,15 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) s += shfl_xor_f64(s, m);
     // UMEREG_MOMENTS_RAW: the un-normalised matrix of generate_ume_from_keypoints2 (utils/loc_utils.py:160-162)
-    const double den = (flags & UMEREG_MOMENTS_RAW) ? 1.0 : s + 1e-6;
+    // one fp64 division per keypoint, then 16 multiplications: a * (1 / den) differs from a / den by <= 1 ulp of fp64 before
+    // the rounding to fp32 (the 16 IEEE divisions were 230 of the kernel's ~3 000 instructions per keypoint)
+    const double inv_den = (flags & UMEREG_MOMENTS_RAW) ? 1.0 : 1.0 / (s + 1e-6);
     if (slot == 0) {
         float4* o = reinterpret_cast<float4*>(F + (((size_t)b * n_kp + kp) * 32 + 4 * qd) * 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            o[c] = make_float4((float)(a0[c] / den), (float)(ax[c] / den), (float)(ay[c] / den),
-                               (float)(az[c] / den));
+            o[c] = make_float4((float)(a0[c] * inv_den), (float)(ax[c] * inv_den), (float)(ay[c] * inv_den),
+                               (float)(az[c] * inv_den));
     }
 }
 
