@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     int* cell_of = reinterpret_cast<int*>(wb + w.off_cell);
     int* counts = reinterpret_cast<int*>(wb + w.off_counts) + (size_t)blockIdx.x * kMaxCells;
-    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
+    const Grid g = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) hist[c] = 0;
     __syncthreads();
     const int j = blockIdx.x * kSortWG + threadIdx.x;
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, 
     const int* __restrict__ counts = reinterpret_cast<const int*>(wb + w.off_counts);
     int* __restrict__ bases = reinterpret_cast<int*>(wb + w.off_bases);
     int* __restrict__ start = reinterpret_cast<int*>(wb + w.off_start);
-    const Grid gg = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
+    const Grid gg = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
+    if (threadIdx.x == 0) store_grid(reinterpret_cast<unsigned int*>(wb + w.off_bbox), gg);     // for every later kernel
     const int n_cells = gg.nx * gg.ny * gg.nz;   // cells beyond this are never populated
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) {
         int run = 0;

@@ -60,7 +60,7 @@ __device__ __forceinline__ float dec_ord(unsigned int e)
 // radius < 0: kNN mode for K = -radius neighbours: the cell edge c is derived from the point density
 //   (surface-like clouds: rho = N / (product of the two largest extents)) such that a disc of radius
 //   2c holds ~2 K points, i.e. a ball of radius 2c covers the K nearest of nearly every query.
-__device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox, float radius, int N)
+__device__ __forceinline__ Grid load_grid_compute(const unsigned int* __restrict__ bbox, float radius, int N)
 {
     Grid g;
     const float mn[3] = {dec_ord(~bbox[0]), dec_ord(~bbox[1]), dec_ord(~bbox[2])};
@@ -102,6 +102,25 @@ __device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox,
     g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
     g.invx = inv[0]; g.invy = inv[1]; g.invz = inv[2];
     g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    return g;
+}
+
+// The geometry is computed once per built structure (grid_scan_kernel stores it in words 8..16 of the bounding-box record);
+// every later kernel reads the nine words instead of redoing the divisions (and, in kNN mode, the cell-edge search loop) in
+// every wavefront.  `radius` and `N` must be the ones the structure was built with (they are not re-checked).
+__device__ __forceinline__ void store_grid(unsigned int* __restrict__ bbox, const Grid& g)
+{
+    bbox[8] = __float_as_uint(g.minx); bbox[9] = __float_as_uint(g.miny); bbox[10] = __float_as_uint(g.minz);
+    bbox[11] = __float_as_uint(g.invx); bbox[12] = __float_as_uint(g.invy); bbox[13] = __float_as_uint(g.invz);
+    bbox[14] = (unsigned int)g.nx | ((unsigned int)g.ny << 8) | ((unsigned int)g.nz << 16);
+}
+__device__ __forceinline__ Grid load_grid(const unsigned int* __restrict__ bbox, float /*radius*/, int /*N*/)
+{
+    Grid g;
+    g.minx = __uint_as_float(bbox[8]); g.miny = __uint_as_float(bbox[9]); g.minz = __uint_as_float(bbox[10]);
+    g.invx = __uint_as_float(bbox[11]); g.invy = __uint_as_float(bbox[12]); g.invz = __uint_as_float(bbox[13]);
+    const unsigned int n = bbox[14];
+    g.nx = (int)(n & 255u); g.ny = (int)((n >> 8) & 255u); g.nz = (int)(n >> 16);
     return g;
 }
 
