@@ -248,30 +248,56 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                                                 const Grid& g, float qx, float qy, float qz, float r2, int K,
                                                 int n_eff, int nbits, int* lst, int cap, int lane)
 {
-    const int cx = cell_axis(qx, g.minx, g.invx, g.nx);
-    const int cy = cell_axis(qy, g.miny, g.invy, g.ny);
-    const int cz = cell_axis(qz, g.minz, g.invz, g.nz);
-    const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < g.nx - 1 ? cx + 1 : g.nx - 1;
-    const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy < g.ny - 1 ? cy + 1 : g.ny - 1;
-    const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz < g.nz - 1 ? cz + 1 : g.nz - 1;
+    // the rows (y, z) of cells that intersect the ball, each clipped to the ball's chord in that row.  A point with d2 < r2
+    // always lies in a visited cell: cell_axis is monotone, the ranges come from a radius inflated by 1e-4 (>> the rounding of
+    // the coordinates involved), and a row's chord is computed from the row's distance to the query -- a lower bound of the
+    // distance of every point in it (shrunk by 1e-4 for the same reason).
+    const float rq = sqrtf(r2) * 1.0001f + 1e-20f;
+    const int y0 = cell_axis(qy - rq, g.miny, g.invy, g.ny), y1 = cell_axis(qy + rq, g.miny, g.invy, g.ny);
+    const int z0 = cell_axis(qz - rq, g.minz, g.invz, g.nz), z1 = cell_axis(qz + rq, g.minz, g.invz, g.nz);
+    const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
+    const float rq2 = rq * rq;
     int cnt = 0;
     int thr = n_eff - 1;   // accept original indices <= thr (lengths2: only the first n_eff points exist)
-    for (int z = z0; z <= z1; ++z)
-        for (int y = y0; y <= y1; ++y) {
-            const int cbase = (z * g.ny + y) * g.nx;
-            const int beg = __builtin_amdgcn_readfirstlane(start[cbase + x0]);
-            const int end = __builtin_amdgcn_readfirstlane(start[cbase + x1 + 1]);
-            // kScanUnroll chunks per trip, loads issued together: a serial load -> test -> load chain
-            // left the wave waiting on L2 latency for half of its lifetime (SQ_WAIT_ANY 49 %)
-            for (int base = beg; base < end; base += kWave * kScanUnroll) {
-                float4 pv[kScanUnroll];
+    // every row's run [beg, end) of the sorted table is looked up by ONE LANE, all rows at once (two dependent table reads per
+    // row, one memory latency for all of them instead of one per row), then the rows are walked in order
+    const int ny_r = y1 - y0 + 1, n_rows = ny_r * (z1 - z0 + 1);
+    for (int r0 = 0; r0 < n_rows; r0 += kWave) {
+        int my_beg = 0, my_end = 0;
+        {
+            const int r = r0 + lane;
+            const int z = z0 + r / ny_r, y = y0 + r % ny_r;
+            const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
+            // (edge layers hold everything beyond them too: cell_axis clamps)
+            const float dzc = fmaxf(fmaxf(z > 0 ? z_a - qz : 0.f, z < g.nz - 1 ? qz - z_b : 0.f), 0.f) * 0.9999f;
+            const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
+            const float dyc = fmaxf(fmaxf(y > 0 ? y_a - qy : 0.f, y < g.ny - 1 ? qy - y_b : 0.f), 0.f) * 0.9999f;
+            const float rem = rq2 - dyc * dyc - dzc * dzc;
+            if (r < n_rows && rem > 0.f) {
+                const float sx = sqrtf(rem) * 1.0001f + 1e-20f;
+                const int cbase = (z * g.ny + y) * g.nx;
+                my_beg = start[cbase + cell_axis(qx - sx, g.minx, g.invx, g.nx)];
+                my_end = start[cbase + cell_axis(qx + sx, g.minx, g.invx, g.nx) + 1];
+            }
+        }
+        const int n_here = min(kWave, n_rows - r0);
+        for (int rr = 0; rr < n_here; ++rr) {
+            const int beg = __builtin_amdgcn_readlane(my_beg, rr);
+            const int end = __builtin_amdgcn_readlane(my_end, rr);
+            if (beg >= end) continue;                                     // (wave-uniform)
+            // up to kScanUnroll chunks per trip, loads issued together: a serial load -> test -> load chain left the wave
+            // waiting on L2 latency for half of its lifetime (SQ_WAIT_ANY 49 %); a row's tail of <= 2 chunks takes the 2-chunk
+            // form (rows are ~100-250 points with the half-radius cells)
+            auto scan = [&](int base, auto U_) __attribute__((always_inline)) {
+                constexpr int U = decltype(U_)::value;
+                float4 pv[U];
 #pragma unroll
-                for (int u = 0; u < kScanUnroll; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const int pos = base + u * kWave + lane;
                     pv[u] = P4s[pos < end ? pos : end - 1];
                 }
 #pragma unroll
-                for (int u = 0; u < kScanUnroll; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const int pos = base + u * kWave + lane;
                     const float4 p = pv[u];
                     const int oi = __float_as_int(p.w);
@@ -293,8 +319,12 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                         }
                     }
                 }
-            }
+            };
+            int base = beg;
+            for (; end - base > 2 * kWave; base += kWave * kScanUnroll) scan(base, std::integral_constant<int, kScanUnroll>{});
+            if (base < end) scan(base, std::integral_constant<int, 2>{});
         }
+    }
     __builtin_amdgcn_wave_barrier();
     if (cnt > K) {
         thr = select_kth(lst, cnt, K, nbits, lane);
