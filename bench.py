@@ -159,7 +159,7 @@ def main():
         return h
 
     def finish(h):
-        out = pipe.finish(h)                                    # host RNG draw + SE(3) hypotheses
+        out = pipe.finish(h, order_caller=False)                # host RNG draw + SE(3) hypotheses (consumed on the pair's own stream below)
         with torch.cuda.stream(pipe.stream_of(h)):              # a7 + recall gates, on the device
             ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, counts[h.slot])
 

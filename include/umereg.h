@@ -211,6 +211,14 @@ int umereg_pair_match_graph_create(const float* pts, const float* feat, const in
                                    float radius, float tau, float* F, int64_t* match_idx, float* match_dist, float* prob,
                                    void* workspace, size_t workspace_bytes, void* stream, void** graph_out);
 int umereg_pair_match_graph_launch(void* graph, void* stream);
+/* Replay + the device -> host copy of the match probabilities (the operand of the host draw, evaluate.py:238; prob_host:
+ * pinned host memory, n_kp floats, or NULL) in one call. */
+int umereg_pair_match_graph_launch_ex(void* graph, float* prob_host, void* stream);
+/* The continuation after the host draw (evaluate.py:238-254): upload the kept match indices (cond_host int64 [n_cond], pinned
+ * host memory; NULL = every match) and solve one SE(3) per kept match from the graph's own outputs:
+ * T_out[k] from (F_src[cond[k]], F_tgt[match[cond[k]]]).  cond_dev int64 [n_cond], T_out f32 [n_cond,4,4]: device buffers. */
+int umereg_pair_match_graph_solve(void* graph, const int64_t* cond_host, int n_cond, int64_t* cond_dev, float* T_out,
+                                  void* stream);
 int umereg_pair_match_graph_destroy(void* graph);
 
 /* ---------------------------------------------------------------------------------------------

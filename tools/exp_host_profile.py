@@ -1,4 +1,4 @@
-"""Where the host time of one pipelined pair goes (KT shape, depth 2, batched clouds)."""
+"""Where the host time of one pipelined pair goes (KT shape, batched clouds).  usage: exp_host_profile.py [depth] [graphs 0|1]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -17,8 +17,10 @@ for s in range(4):
     e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds)
     pool.append(e)
 rng = np.random.RandomState(0)
-pipe = evaluate.RegistrationPipeline(args, dev, depth=2, rng=rng)
-counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(2)]
+DEPTH = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+GRAPHS = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
+pipe = evaluate.RegistrationPipeline(args, dev, depth=DEPTH, rng=rng, use_graphs=GRAPHS)
+counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(DEPTH)]
 acc = {}
 def lap(name, t0):
     t1 = time.perf_counter(); acc[name] = acc.get(name, 0.0) + t1 - t0; return t1
@@ -30,7 +32,7 @@ def finish(h):
     t0 = time.perf_counter()
     h.ready.synchronize(); t0 = lap("wait for prob (GPU behind host)", t0)
     cond = choice_noreplace(rng, h.num_kpts, 2500, pipe.host_prob[h.slot].numpy()); t0 = lap("weighted draw", t0)
-    out = pipe.finish(h, cond=cond); t0 = lap("finish (H2D + phase B enqueue)", t0)
+    out = pipe.finish(h, cond=cond, order_caller=False); t0 = lap("finish (H2D + phase B enqueue)", t0)
     with torch.cuda.stream(pipe.stream_of(h)):
         ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, counts[h.slot])
     lap("gates enqueue", t0)
@@ -38,7 +40,7 @@ def run(n):
     pend = []
     for i in range(n):
         pend.append(submit(i))
-        if len(pend) >= 2: finish(pend.pop(0))
+        if len(pend) >= DEPTH: finish(pend.pop(0))
     while pend: finish(pend.pop(0))
 run(10); torch.cuda.synchronize(); acc.clear()
 t0 = time.perf_counter(); run(100); torch.cuda.synchronize(); tot = time.perf_counter() - t0

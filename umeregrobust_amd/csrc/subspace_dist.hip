@@ -1019,6 +1019,10 @@ UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const 
 struct PairMatchGraph {
     hipGraph_t graph;
     hipGraphExec_t exec;
+    const float* F;            // [2, n_kp, 32, 4]: the captured chain's outputs, for the fused continuation below
+    const int64_t* match_idx;
+    const float* prob;
+    int n_kp;
 };
 
 UMEREG_API int umereg_pair_match_graph_create(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
@@ -1053,7 +1057,7 @@ UMEREG_API int umereg_pair_match_graph_create(const float* pts, const float* fea
         set_error("pair_match_graph_create: hipGraphInstantiate failed (%s)", hipGetErrorString(e_inst));
         return UMEREG_ELAUNCH;
     }
-    PairMatchGraph* h = new PairMatchGraph{g, ex};
+    PairMatchGraph* h = new PairMatchGraph{g, ex, F, match_idx, prob, n_kp};
     *graph_out = h;
     return UMEREG_OK;
 }
@@ -1069,6 +1073,43 @@ UMEREG_API int umereg_pair_match_graph_launch(void* graph, void* stream)
         return UMEREG_ELAUNCH;
     }
     return UMEREG_OK;
+}
+
+// Replay + the device -> host copy of the match probabilities (the operand of the host draw, evaluate.py:238) in one call.
+UMEREG_API int umereg_pair_match_graph_launch_ex(void* graph, float* prob_host, void* stream)
+{
+    UMEREG_REQUIRE(graph, "pair_match_graph_launch_ex: null graph");
+    PairMatchGraph* h = (PairMatchGraph*)graph;
+    if (int rc = umereg_pair_match_graph_launch(graph, stream)) return rc;
+    if (prob_host && h->prob &&
+        hipMemcpyAsync(prob_host, h->prob, (size_t)h->n_kp * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pair_match_graph_launch_ex: hipMemcpyAsync(prob) failed");
+        return UMEREG_ELAUNCH;
+    }
+    return UMEREG_OK;
+}
+
+// The continuation after the host draw (evaluate.py:238-254): upload the kept match indices and solve one SE(3) per kept
+// match from the graph's own outputs -- T[k] from (F_src[cond[k]], F_tgt[match[cond[k]]]).  cond_host NULL: every match.
+//   cond_host int64 [n_cond] (pinned host memory for an asynchronous copy), cond_dev int64 [n_cond] and T_out f32
+//   [n_cond, 4, 4] device buffers of the caller.
+UMEREG_API int umereg_pair_match_graph_solve(void* graph, const int64_t* cond_host, int n_cond, int64_t* cond_dev, float* T_out,
+                                             void* stream)
+{
+    UMEREG_REQUIRE(graph && T_out, "pair_match_graph_solve: null pointer");
+    PairMatchGraph* h = (PairMatchGraph*)graph;
+    const float* Fs = h->F;
+    const float* Ft = h->F + (size_t)h->n_kp * 128;
+    if (!cond_host)
+        return umereg_rtume_solve_f32(Fs, Ft, nullptr, nullptr, h->match_idx, h->n_kp, h->n_kp, h->n_kp, T_out, nullptr, stream);
+    UMEREG_REQUIRE(cond_dev && n_cond > 0 && n_cond <= h->n_kp, "pair_match_graph_solve: bad cond buffers / count (%d)", n_cond);
+    if (hipMemcpyAsync(cond_dev, cond_host, (size_t)n_cond * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pair_match_graph_solve: hipMemcpyAsync(cond) failed");
+        return UMEREG_ELAUNCH;
+    }
+    return umereg_rtume_solve_f32(Fs, Ft, cond_dev, nullptr, h->match_idx, h->n_kp, h->n_kp, n_cond, T_out, nullptr, stream);
 }
 
 UMEREG_API int umereg_pair_match_graph_destroy(void* graph)

@@ -310,7 +310,8 @@ class RegistrationPipeline:
         self.args, self.rng, self.depth = args, rng, depth
         # use_graphs: replay phase A (12 launches) as one hipGraph per (slot, PairBatch): for loops that keep submitting
         # the same PairBatch objects (resident or double-buffered inputs).  The graph writes into buffers it owns, so the
-        # tensors of a pair are valid until the same (slot, PairBatch) is submitted again.
+        # tensors of a pair are valid until the same (slot, PairBatch) is submitted again, its rtume_tform / g_index (slot
+        # buffers) until the slot's next finish(): consume or clone them before submitting `depth` more pairs.
         self.use_graphs = use_graphs
         self.graphs = {}
         self.pool = None
@@ -324,6 +325,12 @@ class RegistrationPipeline:
         self.cond_uploaded = [None] * depth     # event: the H2D copy out of host_cond[k] has completed
         self.in_flight = [False] * depth        # slot k holds a submitted pair whose finish() has not run yet
         self.n_submitted = 0
+        # graph fast path: per-slot reusable event, pinned buffers with cached numpy views / addresses, device index buffer
+        self.ready_ev = [torch.cuda.Event() for _ in range(depth)]
+        self.host_cond_np = [None] * depth
+        self.cond_dev = [None] * depth
+        self.T_buf = [None] * depth
+        self.stream_ptrs = [s_.cuda_stream for s_ in self.streams]
 
     def submit(self, src_pts, tgt_pts, src_feat, tgt_feat, src_inds=None, tgt_inds=None, timing=None, pair=None, rng=None):
         """pair: optional PairBatch holding the same clouds/keypoints as a batch of 2 (then the per-cloud
@@ -355,6 +362,21 @@ class RegistrationPipeline:
                     self.graphs.clear()
                 graph = self.graphs[key] = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, self.args.ume_max_nn, self.args.ume_r_nn,
                                                               self.args.tau if self.args.filter_by_ume_dist_cond else None)
+        if graph is not None and self.pool is None and torch.cuda.current_device() == self.dev.index:
+            # graph fast path: replay + probability download in one native call on the slot's stream, no torch stream /
+            # device contexts, a per-slot event (the host side of a pair is as long as its GPU side: every 10 us count)
+            hp = None
+            if graph.prob is not None:
+                hp = self.host_prob[k]
+                if hp is None or hp.numel() != graph.prob.numel():
+                    hp = self.host_prob[k] = torch.empty(graph.prob.numel(), dtype=torch.float32, pin_memory=True)
+            graph.launch_ex(hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
+            ev = self.ready_ev[k]
+            ev.record(st)
+            a = SimpleNamespace(ume_src=graph.F[0:1], ume_tgt=graph.F[1:2], match=graph.m, match_d=graph.d, prob=graph.prob, D=None,
+                                src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=graph.F.shape[1], dev=self.dev, src_pts=src_pts,
+                                tgt_pts=tgt_pts, ready=ev, slot=k, rng=rng, draw=None, graph=graph)
+            return a
         with torch.cuda.stream(st):
             a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, graph)
             if a.prob is not None:
@@ -375,13 +397,61 @@ class RegistrationPipeline:
         num_matches = min(a.num_kpts, self.args.ume_n_samples)
         return choice_noreplace(a.rng, a.num_kpts, num_matches, self.host_prob[a.slot].numpy())
 
-    def finish(self, a, cond=None):
+    def finish(self, a, cond=None, order_caller=True):
+        """Host draw (or the injected `cond`) + phase B of pair `a` on its slot's stream.  The CALLER'S current stream is made
+        to wait for that stream (no host synchronisation), so the returned tensors can be consumed with ordinary torch
+        semantics.  A caller that consumes them under `with torch.cuda.stream(pipe.stream_of(a))` only -- bench.py's loop --
+        passes order_caller=False and saves the event record / wait and the allocator bookkeeping (~15 us of host time).
+        With use_graphs the phase-A outputs (ume_src/ume_tgt, match, match_d, prob) are buffers owned by the captured graph:
+        valid until the same (slot, pair) is submitted again."""
         st = self.streams[a.slot]
+        caller = torch.cuda.current_stream(self.dev)
+        out = self._finish_on_slot(a, cond, st)
+        if order_caller and caller != st:
+            caller.wait_stream(st)
+            for t_ in (out.rtume_tform, getattr(out, "g_index", None)):
+                if isinstance(t_, torch.Tensor):
+                    t_.record_stream(caller)          # allocated on the slot's stream, read on the caller's
+        return out
+
+    def _finish_on_slot(self, a, cond, st):
         if not self.in_flight[a.slot]:
             raise RuntimeError("RegistrationPipeline.finish: this pair was already finished")
         self.in_flight[a.slot] = False
+        injected = cond is not None
         if self.args.filter_by_ume_dist_cond and cond is None:
             cond = a.draw.result() if a.draw is not None else self._draw(a)
+        graph = getattr(a, "graph", None)
+        if graph is not None and not isinstance(cond, torch.Tensor):
+            # graph fast path: index upload + SE(3) solve from the graph's own outputs in one native call
+            k = a.slot
+            out = PairResult(**vars(a))
+            if self.args.filter_by_ume_dist_cond:
+                c = np.asarray(cond, dtype=np.int64)
+                n = c.size
+                if self.host_cond[k] is None or self.host_cond[k].numel() != n:
+                    self.host_cond[k] = torch.empty(n, dtype=torch.int64, pin_memory=True)
+                    self.host_cond_np[k] = self.host_cond[k].numpy()
+                    self.cond_dev[k] = torch.empty(n, dtype=torch.int64, device=self.dev)
+                if injected:
+                    a.ready.synchronize()     # (the draw path has waited already) the slot's previous upload out of the pinned buffer is done
+                self.host_cond_np[k][:] = c
+                # T and the index tensor are the slot's buffers (no per-pair allocation / cross-stream allocator bookkeeping):
+                # like the graph's own outputs they are valid until the slot's next finish
+                T = self.T_buf[k]
+                if T is None or T.shape[0] != n:
+                    T = self.T_buf[k] = torch.empty((n, 4, 4), dtype=torch.float32, device=self.dev)
+                graph.solve(self.host_cond[k].data_ptr(), n, self.cond_dev[k], T, self.stream_ptrs[k])
+                out.cond, out.g_index = c, self.cond_dev[k]
+            else:
+                n = a.num_kpts
+                T = self.T_buf[k]
+                if T is None or T.shape[0] != n:
+                    T = self.T_buf[k] = torch.empty((n, 4, 4), dtype=torch.float32, device=self.dev)
+                graph.solve(0, n, None, T, self.stream_ptrs[k])
+                out.cond, out.g_index = cond, torch.arange(n, device=self.dev)
+            out.rtume_tform = T.view(1, n, 4, 4)
+            return out
         with torch.cuda.stream(st):
             if self.args.filter_by_ume_dist_cond and not isinstance(cond, torch.Tensor):
                 # upload through pinned memory: a pageable-source copy blocks the host for tens of microseconds

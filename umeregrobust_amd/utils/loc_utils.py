@@ -206,13 +206,18 @@ class FeatureCorrelator:
                                      tgt_norm=None, timing=None):
         if self.P is not None:
             raise NotImplementedError("FeatureCorrelator: P is None on every reference call path")
-        src_feat_weight = feature_spatial_var(source_pc, source_feat, knn=50)           # :662
-        tgt_feat_weight = feature_spatial_var(target_pc, target_feat, knn=50)           # :663
+        if source_pc.shape == target_pc.shape and source_feat.shape == target_feat.shape:
+            # both clouds as one batch of two through the grid build and the search (same arithmetic per cloud, half the launches)
+            w = feature_spatial_var(torch.cat([source_pc, target_pc], 0), torch.cat([source_feat, target_feat], 0), knn=50)
+            src_feat_weight, tgt_feat_weight = w[0:1], w[1:2]                           # :662-663
+        else:
+            src_feat_weight = feature_spatial_var(source_pc, source_feat, knn=50)       # :662
+            tgt_feat_weight = feature_spatial_var(target_pc, target_feat, knn=50)       # :663
         wsf, wtf = ops.corr_weighted_features(source_feat[0], target_feat[0], src_feat_weight[0], tgt_feat_weight[0])
         mmf_score = ops.corr_scores(source_pc[0], target_pc[0], wsf, wtf, T_kp, K=self.corr_num_nn, sigma=self.sigma,
                                     timing=timing)                                          # :666-673
         self.last_scores = mmf_score
-        best_T_list_order = torch.argsort(mmf_score, descending=True)                      # :676
-        return_T_list = T_kp[best_T_list_order[:self.n_hypotheses]]                        # :677
-        return_mmf_score = mmf_score[best_T_list_order[:self.n_hypotheses]]                # :679
-        return return_T_list[torch.argmax(return_mmf_score)]                               # :680
+        # :676-680 -- the n_hypotheses best by score, then the best of those: a top-k instead of the full argsort
+        return_mmf_score, best_T_list_order = torch.topk(mmf_score, min(self.n_hypotheses, mmf_score.shape[0]), sorted=True)
+        return_T_list = T_kp[best_T_list_order]
+        return return_T_list[torch.argmax(return_mmf_score)]
