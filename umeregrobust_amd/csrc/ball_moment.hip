@@ -561,13 +561,14 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     // the end re-read the last neighbour) and, in the single ragged trip, their features are zeroed by selects;
     // the LDS reads and the gathers of a trip are all issued before the first use.  (Prefetching the next trip
     // while accumulating the current one was measured: 0.151 vs 0.125 ms -- the extra registers cost a wave per SIMD.)
-    auto trip = [&](int e0, bool ragged) __attribute__((always_inline)) {
-        unsigned int jj[kMomUnroll];
+    auto trip = [&](int e0, bool ragged, auto U_) __attribute__((always_inline)) {
+        constexpr int kU = decltype(U_)::value;
+        unsigned int jj[kU];
 #pragma unroll
-        for (int u = 0; u < kMomUnroll; ++u) jj[u] = (unsigned int)lst[min(e0 + u * 8 + slot, count - 1)];
-        float4 pp[kMomUnroll], ff[kMomUnroll];
+        for (int u = 0; u < kU; ++u) jj[u] = (unsigned int)lst[min(e0 + u * 8 + slot, count - 1)];
+        float4 pp[kU], ff[kU];
 #pragma unroll
-        for (int u = 0; u < kMomUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             // the 8 lanes of a slot need the SAME neighbour's coordinates: one of them loads (the gather returns 128 B per
             // wave instead of 1 KiB), the others get them by two DPP moves per word (lane 0 of the quad, then quad 0 -> quad 1)
             pp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -575,13 +576,13 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
             ff[u] = fb[(size_t)jj[u] * 8 + qd];
         }
 #pragma unroll
-        for (int u = 0; u < kMomUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             pp[u].x = bcast8(pp[u].x);
             pp[u].y = bcast8(pp[u].y);
             pp[u].z = bcast8(pp[u].z);
         }
 #pragma unroll
-        for (int u = 0; u < kMomUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             if (ragged) {
                 const bool v = e0 + u * 8 + slot < count;
                 ff[u].x = v ? ff[u].x : 0.f; ff[u].y = v ? ff[u].y : 0.f;
@@ -601,9 +602,12 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 #ifndef UMEREG_MOM_ABLATE
 #define UMEREG_MOM_ABLATE 0   // timing experiments only: 1 = no gather / accumulation (search cost alone)
 #endif
+    // full trips of 8 x kMomUnroll neighbours, then the tail in trips of 8 (a single ragged 32-neighbour trip wasted half a
+    // trip per keypoint on average)
     const int full = (UMEREG_MOM_ABLATE & 1) ? 0 : count & ~(8 * kMomUnroll - 1);
-    for (int e0 = 0; e0 < full; e0 += 8 * kMomUnroll) trip(e0, false);
-    if (!(UMEREG_MOM_ABLATE & 1) && full < count) trip(full, true);
+    for (int e0 = 0; e0 < full; e0 += 8 * kMomUnroll) trip(e0, false, std::integral_constant<int, kMomUnroll>{});
+    if (!(UMEREG_MOM_ABLATE & 1))
+        for (int e0 = full; e0 < count; e0 += 8) trip(e0, e0 + 8 > count, std::integral_constant<int, 1>{});
     // fold the 8 neighbour slots (lanes that share qd differ in bits 3..5)
 #pragma unroll
     for (int m = 8; m < 64; m <<= 1) {
