@@ -894,7 +894,6 @@ __global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict_
 }
 
 constexpr int kCoopCap = 256;       // cooperative key list (keys)
-constexpr int kCoopSamples = 16;    // table entries sampled per lane for the first bound
 
 // keep the K smallest of list[0 .. cnt) (cnt <= SLOTS * 64 <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
 // Rank counting: keys are unique, so ranks are a permutation.  cnt * SLOTS compare-and-adds per lane.
@@ -1121,11 +1120,9 @@ __device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const fl
     return cnt;
 }
 
-// images in empty parts of the target (partly overlapping clouds): served with D = d_K + margin (78 % -> 91 % of the queries of a
-// half-overlapping pair), but their steps are so much heavier that the pass gets slower than the lattice it relieves
-// (15 ms vs 7.5 ms): off, such source points are left to the lattice
-constexpr bool kConsSparse = false;
-constexpr float kConsSparseMargin = 1.6f; // D = d_K + this many grid cells
+// (Images in empty parts of the target -- partly overlapping clouds -- are not served here: with D = d_K + margin the coverage
+// of a half-overlapping pair went 78 % -> 91 %, but their stages are full and the pass got slower than the lattice it relieves,
+// 15 ms vs 7.5 ms.  Such source points give up below and are left to the lattice.)
 constexpr int kConsIdxBits = 9;          // low bits of a key's index word = position in the stage (kConsCap <= 512)
 
 // (the consensus pass's level-0 histogram has one more row than kBins: the overflow bin)
@@ -1179,7 +1176,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     float D = kConsRadiusCells * c.cs_min;
     int n_c = 0;
     const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
-    bool shrunk = false, sparse_done = false;
     for (int attempt = 0; attempt < 10; ++attempt) {
         const float D2 = D * D, rq = D * 1.0001f + 1e-20f;
         const int ylo = cell_axis(cy - rq, g.miny, g.invy, g.ny), yhi = cell_axis(cy + rq, g.miny, g.invy, g.ny);
@@ -1209,48 +1205,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 }
             }
         }
-        if (n_c > kConsCap) { D *= fminf(0.95f, sqrtf(0.85f * (float)kConsCap / (float)n_c)); shrunk = true; continue; }
-        if (kConsSparse && n_c < K + 4 && !shrunk && !sparse_done && Nt >= kWave * kCoopSamples) {
-            // the image lies in an empty part of the target (clouds that overlap partly: ~40 % of the source points): its
-            // neighbours are far, but all agreeing hypotheses still share them.  Exact d_K by one cooperative scan of the
-            // table (64 points per step, sampled bound, rank-counting cuts), then D = d_K + kConsSparseMargin cells.
-            // (Doubling D until the ball held 2 K points was tried first: it overshoots into the dense part of the cloud --
-            // full stages, 3x the kernel time.)
-            sparse_done = true;
-            unsigned long long* la = reinterpret_cast<unsigned long long*>(my);
-            unsigned long long* lb = la + kCoopCap;
-            auto d2c = [&](const float4& p) __attribute__((always_inline)) { const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z; return dx * dx + dy * dy + dz * dz; };
-            unsigned long long ukey = ~0ull;
-            {
-                const int step = Nt / (kWave * kCoopSamples);
-                float m = 3.0e38f;
-                for (int sm = 0; sm < kCoopSamples; ++sm) m = fminf(m, d2c(c.P4s[(sm * kWave + lane) * step]));
-                int rk = 0;
-                for (int f = 0; f < kWave; ++f) { const float o = __shfl(m, f, kWave); rk += (o < m || (o == m && f < lane)) ? 1 : 0; }
-                const unsigned long long kth = __ballot(rk == K - 1);
-                if (kth != 0ull) ukey = ((unsigned long long)__float_as_uint(__shfl(m, __ffsll((long long)kth) - 1, kWave)) << 32) | 0xffffffffull;
-            }
-            int kc = 0;
-            for (int base = 0; base < Nt; base += kWave) {
-                if (kc + kWave > kCoopCap) {
-                    kc = coop_cut(la, lb, kc, K, lane);
-                    unsigned long long* t_ = la; la = lb; lb = t_;
-                    if (kc == K) ukey = la[K - 1];
-                }
-                const int j = base + lane;
-                const float4 p = c.P4s[j];                          // (padded table: reading past Nt is safe)
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d2c(p)) << 32) | (unsigned int)__float_as_int(p.w);
-                const bool okk = j < Nt && key <= ukey;
-                const unsigned long long bb = __ballot(okk);
-                if (okk) la[kc + mbcnt(bb)] = key;
-                kc += __popcll(bb);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-            kc = coop_cut(la, lb, kc, K, lane);
-            const float dks = kc == K ? sqrtf(__uint_as_float((unsigned int)(lb[K - 1] >> 32))) : 0.f;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (kc == K) { D = dks + kConsSparseMargin * c.cs_min; continue; }
-        }
+        if (n_c > kConsCap) { D *= fminf(0.95f, sqrtf(0.85f * (float)kConsCap / (float)n_c)); continue; }
         break;
     }
     if (n_c < K || n_c > kConsCap) { give_up(); return; }
