@@ -68,6 +68,32 @@ for n in samp:
             served = np.count_nonzero(act & (dk + 2 * dl <= D))
             res[name] += (1, m_use, served, np.count_nonzero(act))
             hist[name].append(m_use)
+    # deferral: lanes whose delta would push the cut-off stage beyond m_target points are put off to extra, packed steps
+    for m_target in (40, 64, 96):
+        name = f"defer>{m_target}"
+        res.setdefault(name, np.zeros(4)); hist.setdefault(name, [])
+        r_t = st[min(m_target, st.size) - 1]
+        d_star = max((r_t - dk) / 2, 0.0)
+        deferred = []
+        for h0 in range(0, M, 64):
+            hs = order_g[h0:h0 + 64]
+            dl = delta[hs]
+            act = (dl < D) & (dk <= D)
+            reg = act & (dl <= d_star)
+            deferred += list(hs[act & ~reg])
+            if reg.any():
+                m_use = np.count_nonzero(st <= dk + 2 * dl[reg].max())
+                res[name] += (1, m_use, np.count_nonzero(reg & (dk + 2 * dl <= D)), np.count_nonzero(reg))
+                hist[name].append(m_use)
+            else:
+                res[name] += (0.15, 0, 0, 0)          # a step that only computes deltas
+        deferred = np.array(deferred, dtype=int)
+        for h0 in range(0, deferred.size, 64):
+            hs = deferred[h0:h0 + 64]
+            dl = delta[hs]
+            m_use = np.count_nonzero(st <= dk + 2 * dl.max())
+            res[name] += (1, m_use, np.count_nonzero(dk + 2 * dl <= D), hs.size)
+            hist[name].append(m_use)
 for k, v in res.items():
     h = np.array(hist[k])
     print(f"{k:14s} steps {int(v[0]):6d}  sum m_use {int(v[1]):8d} (avg {v[1] / max(v[0], 1):6.1f})  served(approx) {int(v[2]):7d}  act {int(v[3]):7d}"

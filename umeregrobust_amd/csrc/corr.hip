@@ -893,6 +893,87 @@ __global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict_
     }
 }
 
+// ---- per-neighbourhood hypothesis orders -----------------------------------------------------------------------------
+// How far a hypothesis moves a source point from its consensus image depends on where the point is (a rotation error of
+// 0.5 degrees is 4 cm at 5 m and 45 cm at 50 m), so ONE order of the hypotheses serves no neighbourhood well: 64-hypothesis
+// steps that mix small and large displacements pay the large cut-off stage for every lane (CPU simulation,
+// tools/sim_consensus_order.py: -22 % candidate visits with an order per neighbourhood, -27 % with one per point).  The
+// source cloud's processing order is cell-sorted, so a chunk of 64 slots is a neighbourhood: every chunk gets its own order,
+// by the displacement of its centroid, and the positions (served bits, val rows) of a source point are positions in the order
+// of ITS chunk.  perm[chunk][pos] = h, inv[chunk][h] = pos.
+constexpr int kChunkOrderMax = 8192;        // hypotheses a chunk order can sort in LDS (beyond: the global order for every chunk)
+
+// slot -> chunk map by source index, and the centroid of every chunk
+__global__ __launch_bounds__(256) void chunk_centroid_kernel(const char* __restrict__ ws_src, const float* __restrict__ src_pts, int Ns,
+                                                             int* __restrict__ chunk_of, float4* __restrict__ centroid)
+{
+    const int chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int slot = chunk * kWave + lane;
+    if (chunk * kWave >= Ns) return;
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s);
+    const bool valid = slot < Ns;
+    const int sidx = __float_as_int(S4s[valid ? slot : chunk * kWave].w);
+    if (valid) chunk_of[sidx] = chunk;
+    float x = valid ? src_pts[(size_t)sidx * 3] : 0.f, y = valid ? src_pts[(size_t)sidx * 3 + 1] : 0.f, z = valid ? src_pts[(size_t)sidx * 3 + 2] : 0.f;
+    x = wave_sum_f(x); y = wave_sum_f(y); z = wave_sum_f(z);
+    const float inv_n = 1.0f / (float)min(kWave, Ns - chunk * kWave);
+    if (lane == 0) centroid[chunk] = make_float4(x * inv_n, y * inv_n, z * inv_n, 0.f);
+}
+
+// one workgroup per chunk: key = (displacement of the centroid, hypothesis), bitonic sort in LDS.  (The sort key keeps the
+// displacement's upper 19 bits: an order only has to group similar displacements; ties resolve by hypothesis index.)
+__global__ __launch_bounds__(1024) void hyp_order_chunk_kernel(const float* __restrict__ T, int M, const float* __restrict__ Tmed,
+                                                               const float4* __restrict__ centroid, const int* __restrict__ gperm,
+                                                               int* __restrict__ perm, int* __restrict__ inv)
+{
+    __shared__ unsigned int key[kChunkOrderMax];
+    const int chunk = blockIdx.x;
+    int* pc = perm + (size_t)chunk * M;
+    int* ic = inv + (size_t)chunk * M;
+    if (M > kChunkOrderMax) {                           // too many for the LDS sort: the global order
+        for (int r = threadIdx.x; r < M; r += blockDim.x) { const int h = gperm[r]; pc[r] = h; ic[h] = r; }
+        return;
+    }
+    int n2 = 64;
+    while (n2 < M) n2 <<= 1;
+    const float4 c = centroid[chunk];
+    const float mx = fmaf(Tmed[2], c.z, fmaf(Tmed[1], c.y, Tmed[0] * c.x)) + Tmed[3];
+    const float my = fmaf(Tmed[6], c.z, fmaf(Tmed[5], c.y, Tmed[4] * c.x)) + Tmed[7];
+    const float mz = fmaf(Tmed[10], c.z, fmaf(Tmed[9], c.y, Tmed[8] * c.x)) + Tmed[11];
+    for (int h = threadIdx.x; h < n2; h += blockDim.x) {
+        unsigned int k = 0xffffffffu;
+        if (h < M) {
+            const float* Th = T + (size_t)h * 16;
+            const float ex = fmaf(Th[2], c.z, fmaf(Th[1], c.y, Th[0] * c.x)) + Th[3] - mx;
+            const float ey = fmaf(Th[6], c.z, fmaf(Th[5], c.y, Th[4] * c.x)) + Th[7] - my;
+            const float ez = fmaf(Th[10], c.z, fmaf(Th[9], c.y, Th[8] * c.x)) + Th[11] - mz;
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            // NaN / inf transforms last (before the padding): 0x7f800 in the upper 19 bits; finite d2 >= 0 orders as its bits
+            const unsigned int b = d2 == d2 && d2 < 3.0e38f ? __float_as_uint(d2) >> 13 : 0x3fc00u;
+            k = (b << 13) | (unsigned int)h;
+        }
+        key[h] = k;
+    }
+    for (int kk = 2; kk <= n2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (lo & kk) == 0;
+                const unsigned int a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+        }
+    __syncthreads();
+    for (int r = threadIdx.x; r < M; r += blockDim.x) {
+        const int h = (int)(key[r] & 0x1fffu);
+        pc[r] = h;
+        ic[h] = r;
+    }
+}
+
 constexpr int kCoopCap = 256;       // cooperative key list (keys)
 
 // keep the K smallest of list[0 .. cnt) (cnt <= SLOTS * 64 <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
@@ -1137,16 +1218,21 @@ __host__ __device__ constexpr size_t cons_lds_per_wave(int cap)
 }
 
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) void corr_consensus_kernel(
-    const char* __restrict__ ws_tgt, const float* __restrict__ src_pts, const float4* __restrict__ vp4, const float4* __restrict__ vq4,
-    const float* __restrict__ T, const float* __restrict__ Tmed, const int* __restrict__ perm, int Ns, int Nt, int M, int K, int cap,
+    const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+    const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed, const int* __restrict__ perm, int Ns, int Nt,
+    int M, int K, int cap,
     float sigma, float* __restrict__ val, unsigned long long* __restrict__ served, unsigned int* __restrict__ stats)
 {
     typedef unsigned int IdxT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
-    const int n = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (n >= Ns) return;
+    // wavefront <-> slot of the source cloud's cell-sorted processing order: neighbouring wavefronts work in one neighbourhood
+    // of the target, and a slot's chunk (64 slots) selects the hypothesis order (hyp_order_chunk_kernel)
+    const int slot_n = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (slot_n >= Ns) return;
+    const int n = __float_as_int(reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s)[slot_n].w);
+    perm += (size_t)(slot_n >> 6) * M;
     const GridWs wt = grid_ws(Nt);
     char* my = lds + (size_t)wave * cons_lds_per_wave(cap);
     KnnLds<IdxT> L;
@@ -1475,7 +1561,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
                                                            const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
                                                            char* __restrict__ lat, unsigned int c_max,
                                                            const unsigned long long* __restrict__ served, int n_words,
-                                                           const int* __restrict__ inv)
+                                                           const int* __restrict__ inv, const int* __restrict__ chunk_of)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
@@ -1492,7 +1578,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
         const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
         const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
         const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-        if (served) { const int ph = inv[h]; if ((served[(size_t)n * n_words + (ph >> 6)] >> (ph & 63)) & 1ull) continue; }   // done by the consensus pass
+        if (served) { const int ph = inv[(size_t)chunk_of[n] * M + h]; if ((served[(size_t)n * n_words + (ph >> 6)] >> (ph & 63)) & 1ull) continue; }   // done by the consensus pass
         const int cell = lattice_cell(L, qx, qy, qz);
         if (cell >= 0) marks[cell] = 1;
     }
@@ -1781,7 +1867,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
         int cnt;
         // queries the consensus pass has already scored are not this kernel's business
-        const int ph = served ? inv[h] : 0;       // position of the hypothesis in the consensus pass's processing order
+        const int ph = served ? inv[(size_t)chunk * M + h] : 0;       // position of the hypothesis in the order of this chunk (consensus pass)
         const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull));
         bool fb_lanes = false;
         const bool near_q = todo_q;
@@ -1917,7 +2003,7 @@ __global__ __launch_bounds__(256) void leftover_queue_kernel(const char* __restr
     if (lane == 0) base = atomicAdd(&header[4], (unsigned int)__popcll(recs));
     base = (unsigned int)__shfl((int)base, 0, kWave);
     if (rec) {
-        queue[base + (unsigned int)mbcnt(recs)] = make_uint4((unsigned int)perm[pos], (unsigned int)chunk, (unsigned int)mine, (unsigned int)(mine >> 32));
+        queue[base + (unsigned int)mbcnt(recs)] = make_uint4((unsigned int)perm[(size_t)chunk * M + pos], (unsigned int)chunk, (unsigned int)mine, (unsigned int)(mine >> 32));
         atomicAdd(&header[6], (unsigned int)__popcll(mine));
     }
 }
@@ -2050,14 +2136,18 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
 
 // sums of the consensus pass's terms over slices of kValSlice source points (fixed order inside a slice)
 constexpr int kValSlice = 64;
-__global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __restrict__ val, int M, int Ns, float* __restrict__ slices)
+__global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __restrict__ val, int M, int Ns, const char* __restrict__ ws_src,
+                                                              float* __restrict__ slices)
 {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= M) return;
-    const int n0 = blockIdx.y * kValSlice, n1 = min(n0 + kValSlice, Ns);
+    // slice = chunk of 64 slots of the processing order: its points share one hypothesis order, so position `pos` means the
+    // same hypothesis in every row summed here
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= M) return;
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s);
+    const int s0 = blockIdx.y * kValSlice, s1 = min(s0 + kValSlice, Ns);
     float s = 0.f;
-    for (int n = n0; n < n1; ++n) s += val[(size_t)n * M + h];                   // coalesced over h
-    slices[(size_t)blockIdx.y * M + h] = s;
+    for (int sl = s0; sl < s1; ++sl) s += val[(size_t)__float_as_int(S4s[sl].w) * M + pos];   // coalesced over pos; fixed order
+    slices[(size_t)blockIdx.y * M + pos] = s;
 }
 
 // one wavefront per hypothesis: lanes stride over the slices / chunks, then a fixed butterfly: deterministic
@@ -2069,8 +2159,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
     const int lane = lane_id();
     if (h >= M) return;
     float s = 0.f;
-    const int ph = n_slices ? inv[h] : 0;                                            // the consensus pass stores in its processing order
-    for (int k = lane; k < n_slices; k += kWave) s += slices[(size_t)k * M + ph];    // consensus pass
+    for (int k = lane; k < n_slices; k += kWave) s += slices[(size_t)k * M + inv[(size_t)k * M + h]];   // consensus pass: chunk k's order
     for (int k = lane; k < n_chunks; k += kWave) s += partial[(size_t)h * n_chunks + k];
     s = wave_sum_f(s);
     if (lane == 0) scores[h] = s / (float)Ns;                                        // utils/loc_utils.py:610
@@ -2187,8 +2276,10 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
     if (Ns <= 0 || Nt <= 0 || M <= 0) return 0;
     const size_t n_chunks = (Ns + kWave - 1) / kWave;
     const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
+    // val, served, Tmed, slices, global order (perm, inv, err), per-chunk orders (perm, inv), chunk_of, chunk centroids
     const size_t cons = consensus_on(c_max, M, flags) ? align_up((size_t)Ns * M * 4, 256) + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256) + 256 +
-                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) : 0;
+                                                        align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) +
+                                                        2 * align_up(n_chunks * M * 4, 256) + align_up((size_t)Ns * 4, 256) + align_up(n_chunks * 16, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
            (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
@@ -2272,6 +2363,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     float* slices = nullptr;
     int* perm = nullptr;
     int* inv = nullptr;
+    int* chunk_of = nullptr;
     unsigned long long* served = nullptr;
     if (c_max && hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
     if (consensus_on(c_max, M, flags, T)) {
@@ -2286,14 +2378,28 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         float* err = (float*)(inv + M);
         hipLaunchKernelGGL(hyp_median_kernel, dim3(12), dim3(1024), 0, st, T, M, Tmed);
         UMEREG_CHECK_LAUNCH("hyp_median_kernel");
-        hipLaunchKernelGGL(hyp_err_kernel, dim3((M + 255) / 256), dim3(256), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox),
-                           (const float*)Tmed, err);
-        UMEREG_CHECK_LAUNCH("hyp_err_kernel");
-        hipLaunchKernelGGL(hyp_order_kernel, dim3((M + kWave - 1) / kWave), dim3(256), 0, st, (const float*)err, M, perm, inv);
-        UMEREG_CHECK_LAUNCH("hyp_order_kernel");
+        if (M > kChunkOrderMax) {
+            hipLaunchKernelGGL(hyp_err_kernel, dim3((M + 255) / 256), dim3(256), 0, st, T, M, (const unsigned int*)(ws_src + grid_ws(Ns).off_bbox),
+                               (const float*)Tmed, err);
+            UMEREG_CHECK_LAUNCH("hyp_err_kernel");
+        }
+        int* gperm = perm;                                   // the global order: only the fallback of the chunk orders (M > kChunkOrderMax)
+        if (M > kChunkOrderMax) {
+            hipLaunchKernelGGL(hyp_order_kernel, dim3((M + kWave - 1) / kWave), dim3(256), 0, st, (const float*)err, M, perm, inv);
+            UMEREG_CHECK_LAUNCH("hyp_order_kernel");
+        }
+        perm = (int*)((char*)gperm + align_up((size_t)M * 12, 256));
+        inv = (int*)((char*)perm + align_up(n_chunks_sz * M * 4, 256));
+        chunk_of = (int*)((char*)inv + align_up(n_chunks_sz * M * 4, 256));
+        float4* centroid = (float4*)((char*)chunk_of + align_up((size_t)Ns * 4, 256));
+        hipLaunchKernelGGL(chunk_centroid_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, st, (const char*)ws_src, src_pts, Ns, chunk_of, centroid);
+        UMEREG_CHECK_LAUNCH("chunk_centroid_kernel");
+        hipLaunchKernelGGL(hyp_order_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, T, M, (const float*)Tmed, (const float4*)centroid,
+                           (const int*)gperm, perm, inv);
+        UMEREG_CHECK_LAUNCH("hyp_order_chunk_kernel");
         hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
-                           (const char*)ws_tgt, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed, (const int*)perm,
-                           Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
+                           (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
+                           (const int*)perm, Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
         UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
         hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns);
@@ -2310,7 +2416,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         if (hipMemsetAsync(lat + 256, 0, lw.off_wave_tot - 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice marks) failed"); return UMEREG_ELAUNCH; }
         const int hpt = 16;
         hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
-                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
+                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of);
         UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
         int bcap, bwaves;
         size_t blds;
@@ -2354,7 +2460,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     }
     const int n_slices = val ? (Ns + kValSlice - 1) / kValSlice : 0;
     if (val) {
-        hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, slices);
+        hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, (const char*)ws_src, slices);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
     }
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 3) / 4), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
