@@ -319,7 +319,18 @@ class RegistrationPipeline:
             from concurrent.futures import ThreadPoolExecutor
             self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="umereg-draw")
         self.dev = torch.device(device)
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(depth)]
+        # The HIP runtime deals its streams round-robin onto 4 hardware queues in creation order, and which slot streams share a
+        # queue decides how the pairs' kernels overlap: all four slots on one queue 2 820 pairs/s, four separate queues 3 280-3 610
+        # depending on which other stream of the process they fall beside, slots {0,2} and {1,3} sharing a queue each 3 480-3 555
+        # whatever the offset (measured, KT shape, depth 4).  So the slot streams are created HERE, each followed by a spacer
+        # stream: slot i and slot i+2 then share a queue, and nothing depends on when torch would have created them lazily.
+        self.streams, self._spacers = [], []
+        with torch.cuda.device(self.dev):
+            for _ in range(depth):
+                for keep in (self.streams, self._spacers):
+                    s_ = torch.cuda.Stream(self.dev)
+                    s_.cuda_stream                      # creates the HIP stream now
+                    keep.append(s_)
         self.host_prob = [None] * depth
         self.host_cond = [None] * depth
         self.cond_uploaded = [None] * depth     # event: the H2D copy out of host_cond[k] has completed
@@ -405,9 +416,11 @@ class RegistrationPipeline:
         With use_graphs the phase-A outputs (ume_src/ume_tgt, match, match_d, prob) are buffers owned by the captured graph:
         valid until the same (slot, pair) is submitted again."""
         st = self.streams[a.slot]
+        if not order_caller:
+            return self._finish_on_slot(a, cond, st)
         caller = torch.cuda.current_stream(self.dev)
         out = self._finish_on_slot(a, cond, st)
-        if order_caller and caller != st:
+        if caller != st:
             caller.wait_stream(st)
             for t_ in (out.rtume_tform, getattr(out, "g_index", None)):
                 if isinstance(t_, torch.Tensor):
