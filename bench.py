@@ -55,6 +55,9 @@ def parse():
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=4,
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
+    ap.add_argument("--stream-plan", default=None,
+                    help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
+                         "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false",
                     help="enqueue phase A (a1-a5) as 12 launches per pair instead of replaying one captured hipGraph")
     ap.add_argument("--threaded-draw", action="store_true", help="host RNG draw on a worker thread (off: slower, see DESIGN 3.5)")
@@ -138,7 +141,8 @@ def main():
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
     depth = max(1, a.depth)
-    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs)
+    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs,
+                                         stream_plan=a.stream_plan)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     # per-kernel HIP-event samples: `timing` from pairs that run ALONE (the kernel's own duration: what `roofline` prices),

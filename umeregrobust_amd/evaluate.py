@@ -302,7 +302,7 @@ class RegistrationPipeline:
     be called in order.
     """
 
-    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False, use_graphs=False):
+    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False, use_graphs=False, stream_plan=None):
         """threaded_draw: run the host draw (event wait + choice) on one worker thread, in submission
         order, so it also overlaps the main thread's kernel enqueues (the native draw releases the GIL).
         Use depth >= 3 with it.  The worker is then the only consumer of `rng` between submit and finish,
@@ -326,11 +326,13 @@ class RegistrationPipeline:
         # stream: slot i and slot i+2 then share a queue, and nothing depends on when torch would have created them lazily.
         self.streams, self._spacers = [], []
         with torch.cuda.device(self.dev):
-            for _ in range(depth):
-                for keep in (self.streams, self._spacers):
-                    s_ = torch.cuda.Stream(self.dev)
-                    s_.cuda_stream                      # creates the HIP stream now
-                    keep.append(s_)
+            plan = stream_plan if stream_plan else "sd" * depth          # 's' = the next slot's stream, 'd' = a spacer
+            for tok in plan + "s" * depth:
+                if tok == "s" and len(self.streams) >= depth:
+                    continue
+                s_ = torch.cuda.Stream(self.dev)
+                s_.cuda_stream                          # creates the HIP stream now
+                (self.streams if tok == "s" else self._spacers).append(s_)
         self.host_prob = [None] * depth
         self.host_cond = [None] * depth
         self.cond_uploaded = [None] * depth     # event: the H2D copy out of host_cond[k] has completed
