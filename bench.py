@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--stream-plan", default=None,
                     help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
                          "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
+    ap.add_argument("--match-tuning", default=None,
+                    help="(experiments) 'splits,share_mask' for umereg_ume_match_set_tuning, e.g. 0,0x80008009")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false",
                     help="enqueue phase A (a1-a5) as 12 launches per pair instead of replaying one captured hipGraph")
     ap.add_argument("--threaded-draw", action="store_true", help="host RNG draw on a worker thread (off: slower, see DESIGN 3.5)")
@@ -140,6 +142,10 @@ def main():
         e.mom_bytes = [sum(per_cloud)] if e.pair is not None else per_cloud
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
+    if a.match_tuning:
+        from umeregrobust_amd import _lib as _l
+        sp_, mk_ = a.match_tuning.split(",")
+        _l.load().umereg_ume_match_set_tuning(int(sp_), int(mk_, 0), 0)
     depth = max(1, a.depth)
     pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs,
                                          stream_plan=a.stream_plan)
