@@ -181,6 +181,32 @@ def soak_corr(rng):
     return f"corr {Ns}x{Nt} K={K} M={M} flags={flags}"
 
 
+def soak_voxel(rng):
+    """voxel thinning (evaluate.py:261-264 restated) vs numpy's unique on the same fp32 quotient: clouds with duplicates,
+    negative coordinates, clustered points (hash collisions) and voxel edges from 2 cm to 10 m"""
+    n = max(1, rand_size(rng, 200000))
+    kind = rng.randint(4)
+    if kind == 0:
+        pts = rng.uniform(-80, 80, (n, 3))
+    elif kind == 1:
+        pts = rng.standard_normal((n, 3)) * rng.choice([0.05, 1.0, 30.0])
+    elif kind == 2:
+        pts = np.round(rng.uniform(-20, 20, (n, 3)) / 0.3) * 0.3            # points on voxel boundaries
+    else:
+        pts = rng.uniform(-60, 60, (n, 3)) * np.array([1.0, 1.0, 0.02])    # a flat scan
+    pts = pts.astype(np.float32)
+    if n > 4:
+        dup = rng.randint(0, n, n // 4)
+        pts[rng.randint(0, n, n // 4)] = pts[dup]                          # exact duplicates, either order
+    voxel = float(rng.choice([0.02, 0.3, 0.3, 0.6, 1.7, 10.0]))
+    q = np.floor(pts / np.float32(voxel)).astype(np.int64)
+    _, first = np.unique(q, axis=0, return_index=True)
+    want = np.sort(first)
+    got = N_(ops.voxel_first_index(T_(pts), voxel))
+    assert got.dtype == np.int64 and np.array_equal(got, want), f"voxel thinning differs (n={n}, kind={kind}, voxel={voxel}: {len(got)} vs {len(want)})"
+    return f"voxel {n} kind={kind} voxel={voxel}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
@@ -190,7 +216,7 @@ def main():
     a = ap.parse_args()
     global BIG
     BIG = a.big
-    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr}
+    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr, "voxel": soak_voxel}
     if a.only:
         kinds = {k: v for k, v in kinds.items() if k in a.only.split(",")}
     t0 = time.time()
