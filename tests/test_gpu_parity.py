@@ -316,6 +316,17 @@ def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
     assert rc == 0 and np.array_equal(N_(m1[0]), mr) and np.array_equal(N_(d1[0]), dr)
 
 
+def test_ume_match_f16r_pform_variant_equals_the_default(gpu):
+    """The P-form coarse filter (UMEREG_MATCH_PFORM=1: one inner product per pair over the packed 32 x 32 projectors,
+    K = 528, no squares in the epilogue -- measured slower than the Q-form kernel on MI355X, kept for side-by-side runs):
+    every f16r matcher test passes on it too (own process: the switch is read once per process)."""
+    import os, subprocess, sys
+    env = dict(os.environ, UMEREG_MATCH_PFORM="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "f16r and not pform"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     """Candidate-list overflow (hundreds of identical targets), all-zero UMEs and a one-target set: the
     exhaustive fallback of the refine kernel must give the lowest index among exact ties."""

@@ -513,16 +513,265 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
     if (lane == 0) ms.cnt[(size_t)blk * ms.splits + sp] = (unsigned int)qn;
 }
 
+// ---- P-form coarse filter ---------------------------------------------------------------------------------------------
+// The Q-form kernel above is bound by its VALU epilogue (16 squares per (source, target) pair: ~13 VALU instructions
+// per MFMA, MFMA pipe 1/3 busy).  The same score as ONE inner product per pair needs no squares at all:
+//     s = |Qi^T Qj|_F^2 = <Pi, Pj>_F,   P = Q Q^T (32 x 32, symmetric)
+// packed as the 528 entries of the upper triangle, off-diagonals scaled by sqrt(2) -> K = 528 (33 k-steps of 16):
+// 1.03x the MFMA work of the Q-form, one accumulator per pair, and the epilogue is the three
+// limit instructions per pair.  Packing order: k = 32 d + u holds P[u][(u + d) & 31] for the wrapped diagonals
+// d = 0..15 (every unordered pair once), k = 512 + u (u < 16) holds P[u][u + 16].
+// Error of the coarse score: the packed entries are f16-rounded from fp32 (|dP|_F <= 2^-11 |P|_F + 1e-5, |P|_F = 2), so
+// |s~ - s| <= 2 |dP|_F |P|_F = 2^-8 (+ fp32 accumulation of 544 terms <= 2.6e-4): delta = 4.3e-3 against the Q-form's 2^-6.
+constexpr int kPK = 33;                      // MFMA k-steps per pair of keypoints (528 / 16)
+constexpr int kPWaves = 8;                   // waves per workgroup: two per SIMD
+constexpr int kPRows = 32;                   // source keypoints per wave = per A tile = per candidate region = per refine workgroup
+constexpr int kPWG = kPRows * kPWaves;       // source keypoints per workgroup
+constexpr int kPRegionCap = 1024;            // candidates per (32 rows, split)
+constexpr float kCoarseMarginP = 0.009765625f;   // 2 delta + slack
+constexpr int kPDepth = 4;                   // B fragments in flight LDS -> registers per wave
+constexpr int kQsStride = 33;                // float4 per keypoint in the packer's LDS (32 rows + 1)
+
+// Q (split-f16 fragment order, hi + lo) -> packed projector fragments.  One workgroup per tile of 32 keypoints;
+// fragment (tile, ks) = 64 lanes x 8 halfs: lane l = keypoint (l & 31), k = 16 ks + 8 (l >> 5) + e -- the A and the B
+// operand order of v_mfma_f32_32x32x16_f16 alike, so both sets use the same layout.
+__global__ __launch_bounds__(256) void pform_pack_kernel(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Bh, int n1,
+                                                         int n2, int tiles1, int tiles2, half8* __restrict__ PA,
+                                                         half8* __restrict__ PB)
+{
+    __shared__ float4 qs[32 * kQsStride];
+    const int side = blockIdx.y, tile = blockIdx.x;
+    if (tile >= (side ? tiles2 : tiles1)) return;
+    const int n = side ? n2 : n1;
+    const _Float16* const Q = side ? Bh : Ah;
+    half8* const P = (side ? PB : PA) + (size_t)tile * kPK * 64;
+    const int tid = threadIdx.x;
+    if (tile * 32 >= n) {   // padding tiles: zero fragments, nothing read
+        for (int o = tid; o < kPK * 64; o += 256) P[o] = half8{0};
+        return;
+    }
+    float* const qf = reinterpret_cast<float*>(qs);
+    for (int c = tid; c < 512; c += 256) {   // chunk = (keypoint, basis column, 8 channels)
+        const int kp = c & 31, a = (c >> 5) & 3, k8 = c >> 7;
+        const int i = tile * 32 + kp;
+        half8 vh = half8{0}, vl = half8{0};
+        if (i < n) {
+            const size_t off0 = side ? hoff_cols(i, a, k8 * 8, 0) : hoff_rows(i, a, k8 * 8, 0);
+            const size_t off1 = side ? hoff_cols(i, a, k8 * 8, 1) : hoff_rows(i, a, k8 * 8, 1);
+            vh = *reinterpret_cast<const half8*>(Q + off0);
+            vl = *reinterpret_cast<const half8*>(Q + off1);
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) qf[(kp * kQsStride + k8 * 8 + x) * 4 + a] = (float)vh[x] + (float)vl[x];   // as the refine pass reads it
+    }
+    __syncthreads();
+    for (int o = tid; o < kPK * 64; o += 256) {
+        const int ks = o >> 6, l = o & 63, kp = l & 31, c = ks * 2 + (l >> 5);
+        half8 out = half8{0};
+        if (c < 66) {
+            const int d = c < 64 ? c >> 2 : 16, u0 = c < 64 ? (c & 3) * 8 : (c - 64) * 8;
+            const float w = d == 0 ? 1.0f : 1.41421356237f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 qu = qs[kp * kQsStride + u0 + e], qv = qs[kp * kQsStride + ((u0 + e + d) & 31)];
+                out[e] = (_Float16)(w * fmaf(qu.x, qv.x, fmaf(qu.y, qv.y, fmaf(qu.z, qv.z, qu.w * qv.w))));
+            }
+        }
+        P[o] = out;
+    }
+}
+
+// Workgroup = 8 waves (two per SIMD) x 32 source keypoints: one stationary A tile of 33 fragments per wave, held in
+// AGPRs (the MFMA reads either register file) next to the accumulators; limits and the B ring live in VGPRs.  A panel =
+// 32 targets x 33 fragments (33 KiB) goes global -> LDS directly, once per workgroup, double-buffered, and is read by
+// all 8 waves.  A wave's MFMAs form ONE dependent accumulator chain (measured: ~47 cycles per dependent
+// v_mfma_f32_32x32x16_f16 against 32 of issue), so the SIMD's second wave is what fills the matrix pipe, and its MFMAs
+// are also what covers this wave's candidate bookkeeping after each panel.
+__global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const half8* __restrict__ PA, const half8* __restrict__ PB,
+                                                                        int n1, int n2, int n_ablk, int n_btiles,
+                                                                        int tiles_per_split, MatchScratch ms)
+{
+    __shared__ half8 ldsB[2][kPK * 64];   // 2 x 33 KiB
+    __shared__ __attribute__((aligned(16))) unsigned int seenL[kPWaves][32];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int ablk = blockIdx.x % n_ablk;
+    const int sp = blockIdx.x / n_ablk;
+    const int jt0 = sp * tiles_per_split;
+    const int jt1 = min(jt0 + tiles_per_split, n_btiles);
+    const int h = lane >> 5;
+    const int atile = ablk * kPWaves + wave;   // this wave's 32-row tile = its candidate region = its refine workgroup
+    const int i_base = atile * 32;
+
+    half8 a[kPK];
+#pragma unroll
+    for (int ks = 0; ks < kPK; ++ks) a[ks] = PA[((size_t)atile * kPK + ks) * 64 + lane];
+
+    // accumulator register r = source row (r >> 2) * 8 + h * 4 + (r & 3), target column lane & 31
+    int lim[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i_base + (r >> 2) * 8 + h * 4 + (r & 3);
+        lim[r] = __float_as_int(i < n1 ? 1.0e-30f : 3.0e38f);
+    }
+    int qn = 0;   // wave-uniform number of candidates appended so far
+    // What the other workgroups have published for this wave's 32 rows is fetched global -> LDS asynchronously (issued at
+    // one sharing point, consumed at the next; agent-coherent load), so the panel loop never waits for that round trip
+    // and the copy costs no registers.
+    auto fetch_seen = [&]() __attribute__((always_inline)) {
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ms.rowlim + min(i_base + lane, n1 - 1)),
+                                             (__attribute__((address_space(3))) void*)(&seenL[wave][0]), 4, 0, 16 /* sc1 */);
+    };
+    auto share = [&](bool reload) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 sv = *reinterpret_cast<const uint4*>(&seenL[wave][g * 8 + h * 4]);
+            const unsigned int seen[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = g * 4 + e;
+                const float v = group32_max(__int_as_float(lim[r]));
+                const int i = i_base + g * 8 + h * 4 + e;
+                if ((lane & 31) == 0 && i < n1 && __float_as_uint(v) > seen[e]) atomicMax(ms.rowlim + i, __float_as_uint(v));
+                lim[r] = max(__float_as_int(v), (int)seen[e]);
+            }
+        }
+        if (reload) fetch_seen();
+    };
+    // candidates of one 32 x 32 tile of scores whose limits are already updated (some lane hit)
+    unsigned int* const region = ms.cand + ((size_t)atile * ms.splits + sp) * kPRegionCap;
+    auto tile_candidates = [&](const f32x16& cc, const int jt) __attribute__((always_inline)) {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any |= __builtin_amdgcn_ballot_w64(cc[r] >= __int_as_float(lim[r]));
+        if (__builtin_popcountll(any) > 8) {   // a crowd: pool the limits of the 32 columns first (see the Q-form kernel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lim[r] = __float_as_int(group32_max(__int_as_float(lim[r])));
+        }
+        const unsigned int j = (unsigned int)(jt * 32 + (lane & 31));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(cc[r] >= __int_as_float(lim[r]));
+            if (mask) {
+                const int pos = qn + mbcnt(mask);
+                if (((mask >> lane) & 1ull) && pos < kPRegionCap)
+                    region[pos] = ((unsigned int)((r >> 2) * 8 + h * 4 + (r & 3)) << 27) | j;
+                qn += __builtin_popcountll(mask);
+            }
+        }
+    };
+
+    // staging: the panel's 33 fragments of 1 KiB go global -> LDS directly (global_load_lds_dwordx4: 16 B per lane, LDS
+    // address = wave-uniform base + 16 * lane), fragment f by wave f & 7 -- no staging registers, no ds_write.
+    auto stage = [&](int jt, int buf) __attribute__((always_inline)) {
+        const half8* const src = PB + (size_t)jt * kPK * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < (kPK + kPWaves - 1) / kPWaves; ++q) {
+            const int f = q * kPWaves + wave;
+            if (f < kPK)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 64),
+                                                 (__attribute__((address_space(3))) void*)(&ldsB[buf][f * 64]), 16, 0, 0);
+        }
+    };
+    // One panel: the 33 MFMAs of panel jt into `acc`, and -- one accumulator register per k-step, between the MFMAs --
+    // the limit updates and hit tests of panel jt - 1, whose scores are still in `prev`.  The rare part (a hit
+    // somewhere: append candidates) follows the loop.
+    auto panel = [&](const int jt, const int buf, f32x16& acc, f32x16& prev, const bool have_prev, const bool run)
+                     __attribute__((always_inline)) {
+        unsigned int fl = ~0u;   // sign bits of (score - limit), one per row: bit 15 - r clear = this lane's row r hit
+        if (run) {
+            if (jt + 1 < jt1) stage(jt + 1, buf ^ 1);   // free since the barrier that ended panel jt - 1
+            const half8* const lb = &ldsB[buf][lane];
+            half8 b[kPDepth];
+#pragma unroll
+            for (int q = 0; q < kPDepth; ++q) b[q] = lb[q * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < kPK; ++ks) {
+                // inline asm: the register file of every operand is ours to choose (A tile and accumulators in AGPRs)
+                if (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "a"(a[ks]), "v"(b[ks % kPDepth]));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(a[ks]), "v"(b[ks % kPDepth]));
+                if (ks + kPDepth < kPK) b[ks % kPDepth] = lb[(ks + kPDepth) * 64];
+                if (ks < 32 && (ks & 1) == 0) {   // row r = ks / 2 of the previous panel
+                    const int r = ks >> 1;
+                    lim[r] = max(lim[r], __float_as_int(prev[r] - kCoarseMarginP));
+                    // sign bit of (score - limit) shifted into the lane's row history: bit 15 - r clear = row r hit
+                    fl = __builtin_amdgcn_alignbit(fl, __float_as_int(prev[r] - __int_as_float(lim[r])), 31);
+                    asm volatile("" : "+v"(fl), "+v"(lim[r]));   // here, not after the loop
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads kPDepth steps ahead and the limit work between the MFMAs
+            }
+            // the last MFMA's results must not be read for 18 wait states (the compiler does not see inside the asm);
+            // the next panel has landed in LDS
+            asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                lim[r] = max(lim[r], __float_as_int(prev[r] - kCoarseMarginP));
+                fl = __builtin_amdgcn_alignbit(fl, __float_as_int(prev[r] - __int_as_float(lim[r])), 31);
+            }
+        }
+        if (have_prev) {
+            const int kt = jt - 1 - jt0;
+            if ((ms.share_mask >> (kt < 31 ? kt : 31)) & 1u) {
+                if (kt < 31 || (kt & 31) == 31) share(true);
+            }
+            unsigned int hits = ~fl & 0xffffu;
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(hits != 0);
+            if (__builtin_popcountll(mask) > 8) {
+                tile_candidates(prev, jt - 1);   // a crowd: pool the limits first
+            } else {
+                // a few lanes, usually one row each: every round appends the highest pending row of each such lane
+                const unsigned int j = (unsigned int)((jt - 1) * 32 + (lane & 31));
+                while (mask) {
+                    if (hits) {
+                        const int k = 31 - __builtin_clz(hits);
+                        hits &= ~(1u << k);
+                        const int r = 15 - k;
+                        const int pos = qn + mbcnt(mask);
+                        if (pos < kPRegionCap) region[pos] = ((unsigned int)((r >> 2) * 8 + h * 4 + (r & 3)) << 27) | j;
+                    }
+                    qn += __builtin_popcountll(mask);
+                    mask = __builtin_amdgcn_ballot_w64(hits != 0);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    if (jt0 < jt1) stage(jt0, 0);
+    fetch_seen();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 accA, accB;
+    accA = accB = f32x16{-1.0f};   // below every limit
+    int jt = jt0;
+    for (; jt + 1 < jt1; jt += 2) {
+        panel(jt, 0, accA, accB, jt > jt0, true);
+        panel(jt + 1, 1, accB, accA, true, true);
+    }
+    if (jt < jt1) {
+        panel(jt, 0, accA, accB, jt > jt0, true);
+        panel(jt + 1, 1, accB, accA, true, false);   // drain: limits and candidates of the last panel
+    } else if (jt0 < jt1) {
+        panel(jt, 0, accA, accB, true, false);
+    }
+    share(false);   // publish what this split learned
+    if (lane == 0) ms.cnt[(size_t)atile * ms.splits + sp] = (unsigned int)qn;
+}
+
 // refine: one workgroup per block of kCoarseRows source rows (= one wave of the coarse kernel), one
 // thread per candidate.  d2 = 4 - sum_ab (Qi[:,a] . Qj[:,b])^2 in fp64 from hi+lo; per-row arg-min through
 // an LDS atomicMin on (bits(float(d2)) << 32 | j): lowest index among candidates whose d2 agree to fp32.
 constexpr int kQiStride = 130;   // doubles per row in LDS: 128 + 2 (rows land on different banks)
 
+template <int kRows, int kCap>   // rows per block = rows per wave of the coarse kernel that filled the regions; region capacity
 __global__ __launch_bounds__(256, 4) void match_refine_kernel(const _Float16* __restrict__ Ah,
                                                            const _Float16* __restrict__ Bh, int n1, int n2,
                                                            MatchScratch ms, int64_t* __restrict__ idx,
                                                            float* __restrict__ dist)
 {
+    constexpr int kCoarseRows = kRows, kRegionCap = kCap;   // shadow the Q-form constants
     __shared__ double qi[kCoarseRows * kQiStride];
     __shared__ unsigned long long best[kCoarseRows];
     __shared__ unsigned int offs[kWave + 1];
@@ -684,13 +933,29 @@ static int g_tune_splits = 0;
 static long g_tune_share_mask = -1;
 static int g_tune_exhaustive = 0;
 
+// UMEREG_MATCH_PFORM=1 selects the P-form coarse kernel (one inner product per pair, no squares) instead of the Q-form
+// one.  It is bit-identical in its results and measured SLOWER on MI355X: kept for side-by-side runs.
+static bool use_pform()
+{
+    static const bool p = [] { const char* e = getenv("UMEREG_MATCH_PFORM"); return e && e[0] == '1'; }();
+    return p;
+}
+constexpr int kNumCU = 256;   // MI355X
+
 static CoarsePlan coarse_plan(int n1, int n2)
 {
     CoarsePlan p;
-    p.n_ablk = (n1 + kCoarseWG - 1) / kCoarseWG;
-    p.n_blocks = p.n_ablk * kDistWaves;
     p.n_btiles = (n2 + 31) / 32;
-    int splits = (2560 + p.n_ablk - 1) / p.n_ablk;   // ~10 workgroups per CU
+    int splits;
+    if (use_pform()) {
+        p.n_ablk = (n1 + kPWG - 1) / kPWG;
+        p.n_blocks = p.n_ablk * kPWaves;
+        splits = kNumCU / p.n_ablk;   // one workgroup per CU, one round
+    } else {
+        p.n_ablk = (n1 + kCoarseWG - 1) / kCoarseWG;
+        p.n_blocks = p.n_ablk * kDistWaves;
+        splits = (2560 + p.n_ablk - 1) / p.n_ablk;   // ~10 workgroups per CU
+    }
     if (g_tune_splits > 0) splits = g_tune_splits;   // umereg_ume_match_set_tuning
     if (splits > kMaxSplits) splits = kMaxSplits;
     if (splits > p.n_btiles) splits = p.n_btiles;
@@ -699,10 +964,20 @@ static CoarsePlan coarse_plan(int n1, int n2)
     p.splits = (p.n_btiles + p.tiles_per_split - 1) / p.tiles_per_split;
     return p;
 }
+static size_t region_cap() { return use_pform() ? (size_t)kPRegionCap : (size_t)kRegionCap; }
+static size_t cand_bytes(int n1, const CoarsePlan& p)
+{
+    return align_up(((size_t)n1 + (size_t)p.n_blocks * p.splits * (1 + region_cap())) * sizeof(unsigned int), 256);
+}
+// packed projector fragments of both sets (P-form only): [n_blocks][34][64] + [n_btiles][34][64] half8
+static size_t pfrag_bytes(const CoarsePlan& p)
+{
+    return use_pform() ? ((size_t)p.n_blocks + (size_t)p.n_btiles) * kPK * 64 * sizeof(half8) : 0;
+}
 static size_t match_scratch_bytes(int n1, int n2)
 {
     const CoarsePlan p = coarse_plan(n1, n2);
-    return align_up(((size_t)n1 + (size_t)p.n_blocks * p.splits * (1 + kRegionCap)) * sizeof(unsigned int), 256);
+    return cand_bytes(n1, p) + pfrag_bytes(p);
 }
 
 }  // namespace umereg
@@ -750,6 +1025,8 @@ static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
     if (g_tune_share_mask >= 0) ms.share_mask = (unsigned int)g_tune_share_mask;
     return ms;
 }
+static half8* pfrag_rows(void* scratch, int n1, const CoarsePlan& p) { return (half8*)((char*)scratch + cand_bytes(n1, p)); }
+static half8* pfrag_cols(void* scratch, int n1, const CoarsePlan& p) { return pfrag_rows(scratch, n1, p) + (size_t)p.n_blocks * kPK * 64; }
 
 UMEREG_API int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, int n1, int n2, void* stream)
 {
@@ -774,6 +1051,18 @@ UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2
     hipStream_t st = (hipStream_t)stream;
     const CoarsePlan p = coarse_plan(n1, n2);
     const MatchScratch ms = carve_scratch(scratch, n1, p);
+    if (use_pform()) {
+        half8* const PA = pfrag_rows(scratch, n1, p);
+        half8* const PB = pfrag_cols(scratch, n1, p);
+        const int tiles = p.n_blocks > p.n_btiles ? p.n_blocks : p.n_btiles;
+        hipLaunchKernelGGL(pform_pack_kernel, dim3(tiles, 2), dim3(256), 0, st, (const _Float16*)Q1_rows_h, (const _Float16*)Q2_cols_h,
+                           n1, n2, p.n_blocks, p.n_btiles, PA, PB);
+        UMEREG_CHECK_LAUNCH("pform_pack_kernel");
+        hipLaunchKernelGGL(ume_coarse_p_kernel, dim3(p.n_ablk * p.splits), dim3(kWave * kPWaves), 0, st, PA, PB, n1, n2, p.n_ablk,
+                           p.n_btiles, p.tiles_per_split, ms);
+        UMEREG_CHECK_LAUNCH("ume_coarse_p_kernel");
+        return UMEREG_OK;
+    }
     hipLaunchKernelGGL(ume_coarse_h_kernel, dim3(p.n_ablk * p.splits), dim3(kWave * kDistWaves), 0, st,
                        (const half8*)Q1_rows_h, (const half8*)Q2_cols_h, n1, n2, p.n_ablk, p.n_btiles, p.tiles_per_split, ms);
     UMEREG_CHECK_LAUNCH("ume_coarse_h_kernel");
@@ -788,8 +1077,12 @@ UMEREG_API int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2
     if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, (void*)scratch, scratch_bytes, "ume_match_refine_f16")) return rc;
     const CoarsePlan p = coarse_plan(n1, n2);
     const MatchScratch ms = carve_scratch((void*)scratch, n1, p);
-    hipLaunchKernelGGL(match_refine_kernel, dim3(p.n_blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)Q1_rows_h,
-                       (const _Float16*)Q2_cols_h, n1, n2, ms, match_idx, match_dist);
+    if (use_pform())
+        hipLaunchKernelGGL((match_refine_kernel<kPRows, kPRegionCap>), dim3(p.n_blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)Q1_rows_h, (const _Float16*)Q2_cols_h, n1, n2, ms, match_idx, match_dist);
+    else
+        hipLaunchKernelGGL((match_refine_kernel<kCoarseRows, kRegionCap>), dim3(p.n_blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)Q1_rows_h, (const _Float16*)Q2_cols_h, n1, n2, ms, match_idx, match_dist);
     UMEREG_CHECK_LAUNCH("match_refine_kernel");
     return UMEREG_OK;
 }
