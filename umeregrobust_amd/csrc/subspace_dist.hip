@@ -21,6 +21,8 @@
 // the L1/L2 do not already serve).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "grid.h"
 #include "qlayout.h"
@@ -529,7 +531,7 @@ constexpr int kPRows = 32;                   // source keypoints per wave = per 
 constexpr int kPWG = kPRows * kPWaves;       // source keypoints per workgroup
 constexpr int kPRegionCap = 1024;            // candidates per (32 rows, split)
 constexpr float kCoarseMarginP = 0.009765625f;   // 2 delta + slack
-constexpr int kPDepth = 4;                   // B fragments in flight LDS -> registers per wave
+constexpr int kPDepth = 5;                   // B fragments in flight LDS -> registers per wave
 constexpr int kQsStride = 33;                // float4 per keypoint in the packer's LDS (32 rows + 1)
 
 // Q (split-f16 fragment order, hi + lo) -> packed projector fragments.  One workgroup per tile of 32 keypoints;
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const h
                                                                         int n1, int n2, int n_ablk, int n_btiles,
                                                                         int tiles_per_split, MatchScratch ms)
 {
-    __shared__ half8 ldsB[2][kPK * 64];   // 2 x 33 KiB
+    __shared__ half8 ldsB[3][kPK * 64];   // 3 x 33 KiB: the panel in use, the next one, the one being staged
     __shared__ __attribute__((aligned(16))) unsigned int seenL[kPWaves][32];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -624,6 +626,7 @@ __global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const h
                                              (__attribute__((address_space(3))) void*)(&seenL[wave][0]), 4, 0, 16 /* sc1 */);
     };
     auto share = [&](bool reload) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fetch issued at the previous sharing point (long landed)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const uint4 sv = *reinterpret_cast<const uint4*>(&seenL[wave][g * 8 + h * 4]);
@@ -663,83 +666,110 @@ __global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const h
     };
 
     // staging: the panel's 33 fragments of 1 KiB go global -> LDS directly (global_load_lds_dwordx4: 16 B per lane, LDS
-    // address = wave-uniform base + 16 * lane), fragment f by wave f & 7 -- no staging registers, no ds_write.
+    // address = wave-uniform base + 16 * lane) -- no staging registers, no ds_write.  Issued by the four OLDER waves
+    // (fragment f by wave f & 3) in the slack they have before each barrier: the matrix pipe serves the older wave of a
+    // SIMD first, so it is the younger one that arrives last.
     auto stage = [&](int jt, int buf) __attribute__((always_inline)) {
         const half8* const src = PB + (size_t)jt * kPK * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < (kPK + kPWaves - 1) / kPWaves; ++q) {
-            const int f = q * kPWaves + wave;
+        for (int q = 0; q < (kPK + kPWaves / 2 - 1) / (kPWaves / 2); ++q) {
+            const int f = q * (kPWaves / 2) + wave;
             if (f < kPK)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 64),
                                                  (__attribute__((address_space(3))) void*)(&ldsB[buf][f * 64]), 16, 0, 0);
         }
     };
-    // One panel: the 33 MFMAs of panel jt into `acc`, and -- one accumulator register per k-step, between the MFMAs --
-    // the limit updates and hit tests of panel jt - 1, whose scores are still in `prev`.  The rare part (a hit
-    // somewhere: append candidates) follows the loop.
-    auto panel = [&](const int jt, const int buf, f32x16& acc, f32x16& prev, const bool have_prev, const bool run)
-                     __attribute__((always_inline)) {
-        unsigned int fl = ~0u;   // sign bits of (score - limit), one per row: bit 15 - r clear = this lane's row r hit
-        if (run) {
-            if (jt + 1 < jt1) stage(jt + 1, buf ^ 1);   // free since the barrier that ended panel jt - 1
-            const half8* const lb = &ldsB[buf][lane];
-            half8 b[kPDepth];
+    // limits and hit tests of one panel's scores, as straight code: the lane's row history in `fl`
+    auto limits = [&](const f32x16& cc, unsigned int& fl) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < kPDepth; ++q) b[q] = lb[q * 64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < kPK; ++ks) {
-                // inline asm: the register file of every operand is ours to choose (A tile and accumulators in AGPRs)
-                if (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "a"(a[ks]), "v"(b[ks % kPDepth]));
-                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(a[ks]), "v"(b[ks % kPDepth]));
-                if (ks + kPDepth < kPK) b[ks % kPDepth] = lb[(ks + kPDepth) * 64];
-                if (ks < 32 && (ks & 1) == 0) {   // row r = ks / 2 of the previous panel
-                    const int r = ks >> 1;
-                    lim[r] = max(lim[r], __float_as_int(prev[r] - kCoarseMarginP));
-                    // sign bit of (score - limit) shifted into the lane's row history: bit 15 - r clear = row r hit
-                    fl = __builtin_amdgcn_alignbit(fl, __float_as_int(prev[r] - __int_as_float(lim[r])), 31);
-                    asm volatile("" : "+v"(fl), "+v"(lim[r]));   // here, not after the loop
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep the reads kPDepth steps ahead and the limit work between the MFMAs
-            }
-            // the last MFMA's results must not be read for 18 wait states (the compiler does not see inside the asm);
-            // the next panel has landed in LDS
-            asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        for (int r = 0; r < 16; ++r) {
+            lim[r] = max(lim[r], __float_as_int(cc[r] - kCoarseMarginP));
+            fl = __builtin_amdgcn_alignbit(fl, __float_as_int(cc[r] - __int_as_float(lim[r])), 31);
+        }
+    };
+    // sharing point + candidates of panel jp, whose limits are updated and whose row history is `fl`
+    auto bookkeeping = [&](const f32x16& cc, const unsigned int fl, const int jp) __attribute__((always_inline)) {
+        const int kt = jp - jt0;
+        if ((ms.share_mask >> (kt < 31 ? kt : 31)) & 1u) {
+            if (kt < 31 || (kt & 31) == 31) share(true);
+        }
+        unsigned int hits = ~fl & 0xffffu;   // bit 15 - r set = this lane's row r hit
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(hits != 0);
+        if (__builtin_popcountll(mask) > 8) {
+            tile_candidates(cc, jp);   // a crowd: pool the limits first
         } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                lim[r] = max(lim[r], __float_as_int(prev[r] - kCoarseMarginP));
-                fl = __builtin_amdgcn_alignbit(fl, __float_as_int(prev[r] - __int_as_float(lim[r])), 31);
+            // a few lanes, usually one row each: every round appends the highest pending row of each such lane
+            const unsigned int j = (unsigned int)(jp * 32 + (lane & 31));
+            while (mask) {
+                if (hits) {
+                    const int k = 31 - __builtin_clz(hits);
+                    hits &= ~(1u << k);
+                    const int r = 15 - k;
+                    const int pos = qn + mbcnt(mask);
+                    if (pos < kPRegionCap) region[pos] = ((unsigned int)((r >> 2) * 8 + h * 4 + (r & 3)) << 27) | j;
+                }
+                qn += __builtin_popcountll(mask);
+                mask = __builtin_amdgcn_ballot_w64(hits != 0);
             }
         }
-        if (have_prev) {
-            const int kt = jt - 1 - jt0;
-            if ((ms.share_mask >> (kt < 31 ? kt : 31)) & 1u) {
-                if (kt < 31 || (kt & 31) == 31) share(true);
+    };
+    // The 33 MFMAs of panel jt from LDS buffer `buf` into `acc` (inline asm: the register file of every operand is ours
+    // to choose -- A tile and accumulators in AGPRs).  INTERLEAVE: the limit updates and hit tests of panel jt - 1
+    // (scores in `prev`) go between the MFMAs, one accumulator register per two k-steps.
+    auto mfma_panel = [&](const int buf, f32x16& acc, const f32x16& prev, unsigned int& fl, auto interleave) __attribute__((always_inline)) {
+        const half8* const lb = &ldsB[buf][lane];
+        half8 b[kPDepth];
+#pragma unroll
+        for (int q = 0; q < kPDepth; ++q) b[q] = lb[q * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < kPK; ++ks) {
+            // refill the ring slot the PREVIOUS MFMA consumed: a whole MFMA lies between an MFMA and the LDS read that
+            // overwrites its B operand (the compiler's hazard recogniser does not see inside the asm)
+            if (ks >= 1 && ks - 1 + kPDepth < kPK) b[(ks - 1) % kPDepth] = lb[(ks - 1 + kPDepth) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments 0..31 of the A tile fill the 128 AGPRs a wave of this kernel gets; the last one stays in VGPRs
+            // (asking for a 33rd AGPR quad makes the compiler copy into it right before the MFMA -- a VALU write ->
+            // MFMA read hazard it cannot see through the asm: wrong scores, now and then)
+            if (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(a[ks]), "v"(b[ks % kPDepth]));
+            else if (ks < 32) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a[ks]), "v"(b[ks % kPDepth]));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a[ks]), "v"(b[ks % kPDepth]));
+            if (decltype(interleave)::value && ks < 32 && (ks & 1) == 0) {
+                const int r = ks >> 1;
+                lim[r] = max(lim[r], __float_as_int(prev[r] - kCoarseMarginP));
+                fl = __builtin_amdgcn_alignbit(fl, __float_as_int(prev[r] - __int_as_float(lim[r])), 31);
+                asm volatile("" : "+v"(fl), "+v"(lim[r]));   // here, not after the loop
             }
-            unsigned int hits = ~fl & 0xffffu;
-            unsigned long long mask = __builtin_amdgcn_ballot_w64(hits != 0);
-            if (__builtin_popcountll(mask) > 8) {
-                tile_candidates(prev, jt - 1);   // a crowd: pool the limits first
-            } else {
-                // a few lanes, usually one row each: every round appends the highest pending row of each such lane
-                const unsigned int j = (unsigned int)((jt - 1) * 32 + (lane & 31));
-                while (mask) {
-                    if (hits) {
-                        const int k = 31 - __builtin_clz(hits);
-                        hits &= ~(1u << k);
-                        const int r = 15 - k;
-                        const int pos = qn + mbcnt(mask);
-                        if (pos < kPRegionCap) region[pos] = ((unsigned int)((r >> 2) * 8 + h * 4 + (r & 3)) << 27) | j;
-                    }
-                    qn += __builtin_popcountll(mask);
-                    mask = __builtin_amdgcn_ballot_w64(hits != 0);
-                }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads kPDepth steps ahead and the limit work between the MFMAs
+        }
+        // the last MFMA's results must not be read for 18 wait states (the compiler does not see inside the asm)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    };
+    const bool young = wave >= kPWaves / 2;   // wave-uniform
+    // One panel.  Older wave of a SIMD: MFMAs with the limit work of the previous panel in between, then that panel's
+    // candidates, then -- in the slack before the barrier -- the staging of panel jt + 2.  Younger wave: the previous
+    // panel's limits and candidates first (the matrix pipe is busy with the older wave anyway), then a bare MFMA loop.
+    auto panel = [&](const int jt, f32x16& acc, f32x16& prev) __attribute__((always_inline)) {
+        const int buf = (jt - jt0) % 3;
+        unsigned int fl = ~0u;
+        if (young) {
+            if (jt > jt0) {
+                limits(prev, fl);
+                bookkeeping(prev, fl, jt - 1);
             }
+            mfma_panel(buf, acc, prev, fl, std::false_type{});
+        } else {
+            mfma_panel(buf, acc, prev, fl, std::true_type{});
+            if (jt > jt0) bookkeeping(prev, fl, jt - 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // panel jt + 1 (issued one panel ago) has landed
+            if (jt + 2 < jt1) stage(jt + 2, (buf + 2) % 3);    // its buffer was last read in panel jt - 1
         }
         __syncthreads();
     };
-    if (jt0 < jt1) stage(jt0, 0);
+    if (!young) {
+        if (jt0 < jt1) stage(jt0, 0);
+        if (jt0 + 1 < jt1) stage(jt0 + 1, 1);
+    }
     fetch_seen();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -747,14 +777,17 @@ __global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const h
     accA = accB = f32x16{-1.0f};   // below every limit
     int jt = jt0;
     for (; jt + 1 < jt1; jt += 2) {
-        panel(jt, 0, accA, accB, jt > jt0, true);
-        panel(jt + 1, 1, accB, accA, true, true);
+        panel(jt, accA, accB);
+        panel(jt + 1, accB, accA);
     }
     if (jt < jt1) {
-        panel(jt, 0, accA, accB, jt > jt0, true);
-        panel(jt + 1, 1, accB, accA, true, false);   // drain: limits and candidates of the last panel
-    } else if (jt0 < jt1) {
-        panel(jt, 0, accA, accB, true, false);
+        panel(jt, accA, accB);
+        accB = accA;
+    }
+    if (jt0 < jt1) {   // drain: limits and candidates of the last panel (its scores are in accB either way)
+        unsigned int fl = ~0u;
+        limits(accB, fl);
+        bookkeeping(accB, fl, jt1 - 1);
     }
     share(false);   // publish what this split learned
     if (lane == 0) ms.cnt[(size_t)atile * ms.splits + sp] = (unsigned int)qn;
