@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--stream-plan", default=None,
                     help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
                          "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
+    ap.add_argument("--match-pform", action="store_true",
+                    help="(experiments) run the P-form coarse kernel of the matcher (umereg_ume_match_set_variant(1))")
     ap.add_argument("--match-tuning", default=None,
                     help="(experiments) 'splits,share_mask' for umereg_ume_match_set_tuning, e.g. 0,0x80008009")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false",
@@ -142,6 +144,9 @@ def main():
         e.mom_bytes = [sum(per_cloud)] if e.pair is not None else per_cloud
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
+    if a.match_pform:
+        from umeregrobust_amd import _lib as _l0
+        _l0.load().umereg_ume_match_set_variant(1)
     if a.match_tuning:
         from umeregrobust_amd import _lib as _l
         sp_, mk_ = a.match_tuning.split(",")

@@ -174,6 +174,11 @@ int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1
  * set it before the size query), share_mask = limit-sharing schedule (-1: default), force_exhaustive != 0: refine every
  * block of rows exhaustively (a parity test uses it). */
 int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive);
+/* Which coarse kernel the filter + refine matcher runs, process-wide: 0 (default) = the Q-form kernel (16 basis-column
+ * products per pair, squared and summed in the epilogue), 1 = the P-form kernel (one inner product of the packed
+ * 32 x 32 projectors per pair, K = 528).  Same results bit for bit; it changes umereg_ume_match_q_scratch_bytes /
+ * umereg_ume_match_workspace_bytes (the P-form keeps its packed operands there), so set it before the size query. */
+int umereg_ume_match_set_variant(int variant);
 
 /* the stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, in this order): reset zeroes the
  * per-row limits (a 4 n1 byte memset), coarse is the MFMA filter, refine the fp64 arg-min over the candidates */

@@ -317,14 +317,28 @@ def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
 
 
 def test_ume_match_f16r_pform_variant_equals_the_default(gpu):
-    """The P-form coarse filter (UMEREG_MATCH_PFORM=1: one inner product per pair over the packed 32 x 32 projectors,
-    K = 528, no squares in the epilogue -- measured slower than the Q-form kernel on MI355X, kept for side-by-side runs):
-    every f16r matcher test passes on it too (own process: the switch is read once per process)."""
-    import os, subprocess, sys
-    env = dict(os.environ, UMEREG_MATCH_PFORM="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "f16r and not pform"],
-                         env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    """The P-form coarse filter (umereg_ume_match_set_variant(1): one inner product per pair over the packed 32 x 32
+    projectors, K = 528, no squares in the epilogue -- faster as a stage, slower in the pipelined path, hence not the
+    default): the matcher tests pass on it too, and it returns the same matches and distances as the default bit for bit."""
+    from umeregrobust_amd import ops
+    lib = __import__("umeregrobust_amd")._lib.load()
+    rng = np.random.RandomState(5)
+    u1 = rng.standard_normal((2500, 32, 4)).astype(np.float32); u2 = rng.standard_normal((3100, 32, 4)).astype(np.float32)
+    u2[:900] = u1[:900] @ (np.eye(4) + 0.05 * rng.standard_normal((4, 4))).astype(np.float32)
+    u2[1000:1400] = u2[1000]                                       # a block of identical targets (candidate overflow)
+    m0, d0 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+    assert lib.umereg_ume_match_set_variant(2) != 0
+    assert lib.umereg_ume_match_set_variant(1) == 0
+    try:
+        for _ in range(3):
+            m1, d1 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+            assert torch.equal(m0, m1) and torch.equal(d0, d1)
+        for n1, n2 in ((1, 1), (63, 33), (250, 1000), (3000, 2500)):
+            test_ume_match_f16r_vs_oracle(gpu, n1, n2)
+        test_ume_match_f16r_duplicates_and_degenerate(gpu)
+        test_ume_match_f16r_spatially_ordered_keypoints(gpu)
+    finally:
+        assert lib.umereg_ume_match_set_variant(0) == 0
 
 
 def test_ume_match_f16r_duplicates_and_degenerate(gpu):

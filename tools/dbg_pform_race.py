@@ -12,6 +12,8 @@ n1, n2 = int(sys.argv[1]), int(sys.argv[2])
 splits = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 mask = int(sys.argv[4], 0) if len(sys.argv) > 4 else -1
 _lib.load().umereg_ume_match_set_tuning(splits, mask, 0)
+if os.environ.get('UMEREG_MATCH_PFORM') == '1':
+    _lib.load().umereg_ume_match_set_variant(1)
 dev = torch.device("cuda:0")
 rng = np.random.RandomState(n1 * 11 + n2)
 u1 = rng.standard_normal((n1, 32, 4)).astype(np.float32); u2 = rng.standard_normal((n2, 32, 4)).astype(np.float32)

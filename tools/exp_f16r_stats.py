@@ -7,6 +7,8 @@ if os.environ.get('ALTLIB'):       # time another build of the library
     import umeregrobust_amd._lib as _L
     _L.LIB_PATH = _b.LIB_PATH
 from umeregrobust_amd import ops, _lib
+if os.environ.get('UMEREG_MATCH_PFORM') == '1':
+    _lib.load().umereg_ume_match_set_variant(1)
 if os.environ.get('TUNE_SPLITS') or os.environ.get('TUNE_SHARE_MASK'):
     _lib.load().umereg_ume_match_set_tuning(int(os.environ.get('TUNE_SPLITS', '0')), int(os.environ.get('TUNE_SHARE_MASK', '-1'), 0), 0)
 from umeregrobust_amd.synth import synth_pair_cfg

@@ -760,11 +760,14 @@ __global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const h
             mfma_panel(buf, acc, prev, fl, std::false_type{});
         } else {
             mfma_panel(buf, acc, prev, fl, std::true_type{});
-            if (jt > jt0) bookkeeping(prev, fl, jt - 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // panel jt + 1 (issued one panel ago) has landed
+            if (jt > jt0) bookkeeping(prev, fl, jt - 1);
             if (jt + 2 < jt1) stage(jt + 2, (buf + 2) % 3);    // its buffer was last read in panel jt - 1
         }
-        __syncthreads();
+        // a bare barrier: __syncthreads() would drain the staging just issued (its fence waits for vmcnt(0)).  LDS reads
+        // of this panel are complete (every fragment went through an MFMA), the staged data is covered by the explicit
+        // vmcnt(0) above, one barrier before its first read.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     if (!young) {
         if (jt0 < jt1) stage(jt0, 0);
@@ -966,13 +969,11 @@ static int g_tune_splits = 0;
 static long g_tune_share_mask = -1;
 static int g_tune_exhaustive = 0;
 
-// UMEREG_MATCH_PFORM=1 selects the P-form coarse kernel (one inner product per pair, no squares) instead of the Q-form
-// one.  It is bit-identical in its results and measured SLOWER on MI355X: kept for side-by-side runs.
-static bool use_pform()
-{
-    static const bool p = [] { const char* e = getenv("UMEREG_MATCH_PFORM"); return e && e[0] == '1'; }();
-    return p;
-}
+// umereg_ume_match_set_variant(1) selects the P-form coarse kernel (one inner product per pair, no squares) instead of
+// the Q-form one.  Bit-identical results; 11 % faster as a stage on MI355X but 4 % slower in the pipelined path, where it
+// leaves no room on the CUs for the kernels of the other pairs in flight: kept as a variant.
+static int g_match_variant = 0;
+static bool use_pform() { return g_match_variant == 1; }
 constexpr int kNumCU = 256;   // MI355X
 
 static CoarsePlan coarse_plan(int n1, int n2)
@@ -1445,6 +1446,13 @@ UMEREG_API int umereg_pair_match_graph_destroy(void* graph)
     (void)hipGraphExecDestroy(h->exec);
     (void)hipGraphDestroy(h->graph);
     delete h;
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_ume_match_set_variant(int variant)
+{
+    if (variant != 0 && variant != 1) { set_error("ume_match_set_variant: unknown variant %d (0 = Q-form, 1 = P-form)", variant); return UMEREG_EINVAL; }
+    g_match_variant = variant;
     return UMEREG_OK;
 }
 
