@@ -250,13 +250,16 @@ def main():
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
         # timed separately.  Algorithmic flops = 2*512 per (source, target) pair, as for the scans.
         ref_ms = [s.elapsed_time(e_) for s, e_ in timing["dist"].refine]
-        roof_dist = {"kernel": "ume_coarse_h_kernel", "bound": "mfma", "achieved": round(dist_tfs, 2),
+        roof_dist = {"kernel": "pform_pack_kernel + ume_coarse_p_kernel" if a.match_pform else "ume_coarse_h_kernel",
+                     "bound": "mfma", "achieved": round(dist_tfs, 2),
                      "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dist_tfs / MFMA_F16_PEAK_TFLOPS, 4),
                      "traffic": None, "avg_launch_ms": round(float(np.mean(dist_ms)), 4), "launches": len(dist_ms),
                      "in_situ_avg_launch_ms": situ(timing_situ["dist"]),
                      "algorithmic_flops_per_launch": dist_flops,
                      "refine_avg_launch_ms": round(float(np.mean(ref_ms)), 4) if ref_ms else None,
-                     "d_used": "512-equivalent (Q-form), single f16 MFMA product (hi planes) + fp64 refine of the candidates"}
+                     "d_used": ("528 (P-form: one inner product of the packed 32 x 32 projectors per pair) + fp64 refine of the candidates"
+                                if a.match_pform else
+                                "512-equivalent (Q-form), single f16 MFMA product (hi planes) + fp64 refine of the candidates")}
     elif a.precision == "f16x2":
         # 3 f16 MFMA products per algorithmic product (hi*hi, hi*lo, lo*hi): the flops the MFMA pipe
         # executes are 3x the algorithmic count; `achieved` stays ALGORITHMIC, `issued` is reported too
