@@ -181,6 +181,22 @@ def soak_corr(rng):
     return f"corr {Ns}x{Nt} K={K} M={M} flags={flags}"
 
 
+def soak_match_pform(rng):
+    """the same trial on the P-form coarse kernel (umereg_ume_match_set_variant(1)), plus: identical to the default's result"""
+    from umeregrobust_amd import _lib
+    lib = _lib.load()
+    st = rng.get_state()
+    ref = soak_match(rng)
+    rng.set_state(st)
+    assert lib.umereg_ume_match_set_variant(1) == 0
+    try:
+        out = soak_match(rng)
+    finally:
+        lib.umereg_ume_match_set_variant(0)
+    assert out == ref
+    return out + " (P-form)"
+
+
 def soak_voxel(rng):
     """voxel thinning (evaluate.py:261-264 restated) vs numpy's unique on the same fp32 quotient: clouds with duplicates,
     negative coordinates, clustered points (hash collisions) and voxel edges from 2 cm to 10 m"""
@@ -216,7 +232,7 @@ def main():
     a = ap.parse_args()
     global BIG
     BIG = a.big
-    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr, "voxel": soak_voxel}
+    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr, "voxel": soak_voxel, "matchp": soak_match_pform}
     if a.only:
         kinds = {k: v for k, v in kinds.items() if k in a.only.split(",")}
     t0 = time.time()
