@@ -743,7 +743,8 @@ __global__ __launch_bounds__(kWave* kPWaves, 2) void ume_coarse_p_kernel(const h
             __builtin_amdgcn_sched_barrier(0);   // keep the reads kPDepth steps ahead and the limit work between the MFMAs
         }
         // the last MFMA's results must not be read for 18 wait states (the compiler does not see inside the asm)
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // (`acc` is an operand so that no compiler-generated read of it can be scheduled between the last MFMA and the nops)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc) : : "memory");
     };
     const bool young = wave >= kPWaves / 2;   // wave-uniform
     // One panel.  Older wave of a SIMD: MFMAs with the limit work of the previous panel in between, then that panel's
