@@ -264,16 +264,22 @@ def _phase_b(a, args, cond):
     return out
 
 
-def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):
-    """Keypoint draws (:195-204): host numpy RNG unless injected."""
+def _draw_keypoints_host(n_src, n_tgt, args, rng, src_inds=None, tgt_inds=None):
+    """Keypoint draws (:195-204) on the host numpy RNG (unless injected) -> index arrays, nothing touches the device."""
     if args.filter_by_ume_dist_cond:
-        num_init_sel = min(10000, min(src_pts.shape[1], tgt_pts.shape[1]))
+        num_init_sel = min(10000, min(n_src, n_tgt))
     else:
-        num_init_sel = min(min(src_pts.shape[1], tgt_pts.shape[1]), args.ume_n_samples)
+        num_init_sel = min(min(n_src, n_tgt), args.ume_n_samples)
     if src_inds is None:
-        src_inds = choice_uniform_noreplace(rng, src_pts.shape[1], num_init_sel)
+        src_inds = choice_uniform_noreplace(rng, n_src, num_init_sel)
     if tgt_inds is None:
-        tgt_inds = choice_uniform_noreplace(rng, tgt_pts.shape[1], num_init_sel)
+        tgt_inds = choice_uniform_noreplace(rng, n_tgt, num_init_sel)
+    return src_inds, tgt_inds
+
+
+def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):
+    """Keypoint draws (:195-204): host numpy RNG unless injected; -> device index tensors."""
+    src_inds, tgt_inds = _draw_keypoints_host(src_pts.shape[1], tgt_pts.shape[1], args, rng, src_inds, tgt_inds)
     return _index_tensor(src_inds, src_pts.device), _index_tensor(tgt_inds, src_pts.device)
 
 
@@ -506,15 +512,25 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False):
     where the last four are the numbers the reference prints (:304-309).  Datasets and the feature network are the
     caller's business (out of scope); everything between them and the printed metrics is here."""
     R_sel, t_sel, raw = [], [], []
-    for pair in pairs:
-        out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng)   # :195-254
+    it = iter(pairs)
+    pair = next(it, None)
+    draw = lambda p: _draw_keypoints_host(p["src_pts"].shape[1], p["tgt_pts"].shape[1], args, rng)   # noqa: E731  (:199-200)
+    kp = draw(pair) if pair is not None else None
+    while pair is not None:
+        out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng,
+                            src_inds=kp[0], tgt_inds=kp[1])                                                         # :195-254
         src_raw = pair.get("src_pts_raw", pair["src_pts"][0])
         tgt_raw = pair.get("tgt_pts_raw", pair["tgt_pts"][0])
         _, _, R_hat, t_hat = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
                                                pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng)  # :258-296
+        raw.append((src_raw, tgt_raw, pair["gt_tform"]))
+        # The correlation scores of this pair are still being computed (nothing above waits for them): fetch the next pair
+        # and make its keypoint draws now.  The host RNG is consumed in the reference's order -- this pair's draws are all
+        # done, the next pair's loader / keypoint draws are the next ones in the stream (evaluate.py:175-200).
+        pair = next(it, None)
+        kp = draw(pair) if pair is not None else None
         R_sel.append(R_hat.cpu())
         t_sel.append(t_hat.cpu())
-        raw.append((src_raw, tgt_raw, pair["gt_tform"]))
     R_sel, t_sel = torch.cat(R_sel, dim=0), torch.cat(t_sel, dim=0)
     if refine:
         T_est, rre, rte = refine_registration(R_sel, t_sel, args, raw)                                             # :301

@@ -220,4 +220,6 @@ class FeatureCorrelator:
         # :676-680 -- the n_hypotheses best by score, then the best of those: a top-k instead of the full argsort
         return_mmf_score, best_T_list_order = torch.topk(mmf_score, min(self.n_hypotheses, mmf_score.shape[0]), sorted=True)
         return_T_list = T_kp[best_T_list_order]
-        return return_T_list[torch.argmax(return_mmf_score)]
+        # (index_select with a device index: `return_T_list[argmax]` would read the index back to the host and stall it
+        # until the scores are done -- the caller can use that time, see evaluate.evaluate_pairs)
+        return return_T_list.index_select(0, torch.argmax(return_mmf_score).reshape(1))[0]
