@@ -444,11 +444,38 @@ def main():
                 "note": "the same pairs and seeds with several pairs in flight (one host thread + one HIP stream each): the host round "
                         "trips of one pair (tau-weighted draw, voxel counts, ICP stop test) are filled by another pair's kernels"}
 
+    def api_loop(entries, n_pairs, seed):
+        """the library's own loop, `evaluate.evaluate_pairs` (= the reference's: ONE host RNG across the pairs, hypothesis
+        selection pair by pair, ICP for all pairs at the end), which overlaps consecutive pairs on two HIP streams"""
+        def gen(n):
+            for i in range(n):
+                e = entries[(rank + world * i) % len(entries)]
+                yield dict(src_pts=e.src_pts, tgt_pts=e.tgt_pts, src_feat=e.src_feat, tgt_feat=e.tgt_feat, gt_tform=e.gt)
+        with torch.no_grad():
+            evaluate.evaluate_pairs(gen(4), args, rng=np.random.RandomState(seed), refine=True)
+            fence()
+            t_0 = time.perf_counter()
+            r = evaluate.evaluate_pairs(gen(n_pairs), args, rng=np.random.RandomState(seed + 1), refine=True)
+            fence()
+            el = time.perf_counter() - t_0
+        if collective:
+            tm = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        return {"pairs_per_s": round(world * n_pairs / el, 2), "ms_per_pair_per_gpu": round(1e3 * el / n_pairs, 3),
+                "rank0_N.P_percent": round(100.0 * r["rr_np"], 3), "rank0_S.P_percent": round(100.0 * r["rr_sp"], 3),
+                "note": "evaluate.evaluate_pairs over the same pairs on ONE host thread and ONE host RNG stream consumed in the "
+                        "reference's order (keypoint draws, weighted draw, two sub-sampling draws, pair after pair), ICP of all "
+                        "pairs after the loop as at evaluate.py:301; pair i + 1 is prepared on a second HIP stream while the "
+                        "correlation scores of pair i are computed -- results identical to one pair at a time "
+                        "(test_evaluate_pairs_overlapped_equals_one_pair_at_a_time)"}
+
     if not a.no_e2e and a.e2e_pairs > 0:
         result["end_to_end"] = e2e_leg(pool, a.e2e_pairs, 500000, f"{a.config} pairs of the named-path leg (exact rigid copies, kind={a.kind})",
                                        a.e2e_in_flight)
         if a.e2e_side_by_side > a.e2e_in_flight:
             result["end_to_end"]["side_by_side"] = side_by_side(e2e_leg(pool, a.e2e_pairs, 500000, "", a.e2e_side_by_side))
+        result["end_to_end"]["evaluate_pairs_loop"] = api_loop(pool, a.e2e_pairs, 510000)
     hard_pool = None
     if not a.no_e2e and a.e2e_hard_pairs > 0:
         hard_pool = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))

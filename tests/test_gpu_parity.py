@@ -1414,6 +1414,32 @@ def test_voxel_first_index_vs_numpy(gpu):
         ops.voxel_first_index(T_(pts, gpu), 0.0)
 
 
+def test_evaluate_pairs_overlapped_equals_one_pair_at_a_time(gpu):
+    """evaluate.evaluate_pairs overlaps consecutive pairs on two HIP streams (pair i + 1 is prepared while the correlation
+    scores of pair i are computed): same selections, same refined registrations, same host-RNG position afterwards as one
+    pair at a time on the caller's stream -- bit for bit, from a lazily generating iterator too."""
+    from types import SimpleNamespace
+    from umeregrobust_amd import evaluate
+    from umeregrobust_amd.synth import synth_pair_hard
+    from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
+    args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("kitti_test"))
+    args.batch_size, args.ume_n_samples, args.pc_corr_max_size = 1, 256, 3000
+
+    def gen():
+        for i in range(5):
+            p = synth_pair_hard(seed=300 + i, N=6000 + 500 * i, n_kp=4000, sector_deg=220.0, sector_shift_deg=90.0, noise_sigma=0.02, feat_corrupt=0.3)
+            yield dict(src_pts=T_(p.src_pts, gpu)[None], tgt_pts=T_(p.tgt_pts, gpu)[None], src_feat=T_(p.src_feat, gpu)[None],
+                       tgt_feat=T_(p.tgt_feat, gpu)[None], gt_tform=T_(p.gt_tform, gpu))
+    r1, r2 = np.random.RandomState(77), np.random.RandomState(77)
+    a = evaluate.evaluate_pairs(gen(), args, rng=r1, refine=True, overlap=False)
+    for _ in range(3):
+        r2 = np.random.RandomState(77)
+        b = evaluate.evaluate_pairs(gen(), args, rng=r2, refine=True, overlap=True)
+        for k in ("R_sel", "t_sel", "T_est", "rre", "rte"):
+            assert torch.equal(a[k], b[k]), k
+    assert r1.rand() == r2.rand()
+
+
 def test_full_pipeline_equals_the_oracle_on_replayed_draws(gpu):
     """The whole loop iteration (evaluate.py:195-309: a1-a7, raw-cloud prep, f1, f2) through this library with the oracle's five
     host draws replayed: the same selected hypothesis, the same refined registration -- pair by pair, on hard pairs (partial

@@ -6,6 +6,8 @@ as a function, with the host RNG made explicit so a caller can replay or inject 
 """
 from types import SimpleNamespace
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -501,7 +503,10 @@ class RegistrationPipeline:
         return self.streams[a.slot]
 
 
-def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False):
+_OVERLAP_STREAMS = {}
+
+
+def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overlap=True):
     """The reference's evaluation loop (evaluate.py:175-309) over an iterable of registration pairs, with the
     reference's RNG consumption order per pair (keypoint draws, weighted match draw, correlation sub-sampling):
 
@@ -509,28 +514,51 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False):
                     src_pts_raw [n,3], tgt_pts_raw [m,3]  (raw clouds; default: the network points), gt_tform [4,4])
 
     -> dict(R_sel, t_sel [P,...] (selected hypotheses), T_est [P,4,4], rre [P], rte [P], rr_np, rr_sp, mrre, mrte)
-    where the last four are the numbers the reference prints (:304-309).  Datasets and the feature network are the
+    where the last four are the numbers the reference prints (:304-309).  overlap (default): consecutive pairs overlap on
+    two HIP streams (same results, same RNG consumption; see the loop).  Datasets and the feature network are the
     caller's business (out of scope); everything between them and the printed metrics is here."""
     R_sel, t_sel, raw = [], [], []
-    it = iter(pairs)
-    pair = next(it, None)
-    draw = lambda p: _draw_keypoints_host(p["src_pts"].shape[1], p["tgt_pts"].shape[1], args, rng)   # noqa: E731  (:199-200)
-    kp = draw(pair) if pair is not None else None
-    while pair is not None:
-        out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng,
-                            src_inds=kp[0], tgt_inds=kp[1])                                                         # :195-254
-        src_raw = pair.get("src_pts_raw", pair["src_pts"][0])
-        tgt_raw = pair.get("tgt_pts_raw", pair["tgt_pts"][0])
-        _, _, R_hat, t_hat = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
-                                               pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng)  # :258-296
+    # Two pairs overlap on two HIP streams: while the correlation scores of pair i are computed (two thirds of a pair's GPU
+    # time, and nothing on the host needs them before the read-back below), pair i + 1 goes through its keypoint draws,
+    # a1-a7, the weighted draw, the raw-cloud prep and the enqueue of its own scores.  The host RNG is consumed exactly in
+    # the reference's order (pair i completely, then pair i + 1): every host read inside a pair waits for that pair's
+    # stream only.  overlap=False: one pair at a time on the caller's stream.
+    streams, pending, k = None, None, 0
+
+    def read_back(p):
+        R_hat, t_hat, st, _keep = p     # _keep: the pair's input tensors stay alive until its last kernel is done
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            R_sel.append(R_hat.cpu())
+            t_sel.append(t_hat.cpu())
+
+    for pair in pairs:
+        dev = pair["src_pts"].device
+        st = None
+        if overlap and dev.type == "cuda":
+            if streams is None:
+                # (kept per device: the native workspaces are per stream, a fresh pair of streams per call would allocate anew)
+                streams = _OVERLAP_STREAMS.setdefault(dev, [torch.cuda.Stream(dev), torch.cuda.Stream(dev)])
+            st = streams[k % 2]
+            st.wait_stream(torch.cuda.current_stream(dev))      # the pair's tensors were made on the caller's stream
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng)   # :195-254
+            src_raw = pair.get("src_pts_raw", pair["src_pts"][0])
+            tgt_raw = pair.get("tgt_pts_raw", pair["tgt_pts"][0])
+            _, _, R_hat, t_hat = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
+                                                   pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng)  # :258-296
         raw.append((src_raw, tgt_raw, pair["gt_tform"]))
-        # The correlation scores of this pair are still being computed (nothing above waits for them): fetch the next pair
-        # and make its keypoint draws now.  The host RNG is consumed in the reference's order -- this pair's draws are all
-        # done, the next pair's loader / keypoint draws are the next ones in the stream (evaluate.py:175-200).
-        pair = next(it, None)
-        kp = draw(pair) if pair is not None else None
-        R_sel.append(R_hat.cpu())
-        t_sel.append(t_hat.cpu())
+        if pending is not None:
+            read_back(pending)        # the previous pair's result: its scores ran beside everything above
+        pending = (R_hat, t_hat, st, pair)
+        if st is None:
+            read_back(pending)
+            pending = None
+        k += 1
+    if pending is not None:
+        read_back(pending)
+    if streams is not None:
+        for st in streams:
+            torch.cuda.current_stream(streams[0].device).wait_stream(st)
     R_sel, t_sel = torch.cat(R_sel, dim=0), torch.cat(t_sel, dim=0)
     if refine:
         T_est, rre, rte = refine_registration(R_sel, t_sel, args, raw)                                             # :301
