@@ -351,11 +351,14 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
  *   UMEREG_CORR_NO_CONSENSUS   skip the consensus pass (by default, with the lattice on and M >= 256, every source
  *                              point first scores all hypotheses whose image of it lies near the image under the
  *                              median hypothesis from ONE staged set of target points; the rest goes to the lattice)
- *   UMEREG_CORR_FORCE_CONSENSUS  run it whatever M (needs the lattice: combine with FORCE_LATTICE on small jobs) */
+ *   UMEREG_CORR_FORCE_CONSENSUS  run it whatever M (needs the lattice: combine with FORCE_LATTICE on small jobs)
+ *   UMEREG_CORR_NO_FLAT        serve the queries neither pass could (one wavefront per query) record by record instead of
+ *                              as a flat list (the round-2 start form; bit-identical sums) */
 #define UMEREG_CORR_NO_LATTICE 1
 #define UMEREG_CORR_FORCE_LATTICE 2
 #define UMEREG_CORR_NO_CONSENSUS 4
 #define UMEREG_CORR_FORCE_CONSENSUS 8
+#define UMEREG_CORR_NO_FLAT 16
 size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
 int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
                               const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,

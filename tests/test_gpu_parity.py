@@ -1414,6 +1414,29 @@ def test_voxel_first_index_vs_numpy(gpu):
         ops.voxel_first_index(T_(pts, gpu), 0.0)
 
 
+def test_corr_scores_flat_leftovers_equal_the_record_form(gpu):
+    """The queries neither the consensus pass nor the lattice serves go to the one-wavefront-per-query search as a flat list
+    (corr_score_flat_kernel) or record by record (UMEREG_CORR_NO_FLAT): the same additions in the same order, so the scores
+    are bit-identical -- on a pair with garbage hypotheses (many far-off queries), for the consensus and the lattice path."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(12)
+    Nt, Ns, M = 6000, 5000, 300
+    tgt = (rng.uniform(-30, 30, (Nt, 3)) * np.array([1, 1, 0.1])).astype(np.float32)
+    src = (tgt[rng.randint(0, Nt, Ns)] + rng.standard_normal((Ns, 3)) * 0.1).astype(np.float32)
+    sf = rng.standard_normal((Ns, 32)).astype(np.float32); tf = rng.standard_normal((Nt, 32)).astype(np.float32)
+    Ts = np.tile(np.eye(4, dtype=np.float32), (M, 1, 1))
+    for m in range(M):
+        th = np.deg2rad(rng.choice([0.2, 3.0, 60.0])) * rng.randn()
+        Ts[m, :2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+        Ts[m, :3, 3] = rng.standard_normal(3) * rng.choice([0.05, 2.0, 40.0])
+    for base in (ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS, ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS):
+        a = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu), K=20, sigma=1.5, flags=base)
+        b = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu), K=20, sigma=1.5, flags=base | ops.CORR_NO_FLAT)
+        assert torch.equal(a, b), base
+    ref = orc.pc_corr_cost(Ts[:8, :3, :3], Ts[:8, :3, 3], src, tgt, 20, sf, tf, 1.5)
+    assert np.abs(N_(a)[:8] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
+
+
 def test_evaluate_pairs_overlapped_equals_one_pair_at_a_time(gpu):
     """evaluate.evaluate_pairs overlaps consecutive pairs on two HIP streams (pair i + 1 is prepared while the correlation
     scores of pair i are computed): same selections, same refined registrations, same host-RNG position afterwards as one

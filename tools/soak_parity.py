@@ -172,7 +172,7 @@ def soak_corr(rng):
     sigma = float(rng.choice([0.05, 1.5]))
     ref = orc.pc_corr_cost(Ts[:, :3, :3], Ts[:, :3, 3], src, tgt, K, sf, tf, sigma)
     flags = int(rng.choice([0, ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS, ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS,
-                            ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS, ops.CORR_NO_LATTICE]))   # every search structure
+                            ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS | ops.CORR_NO_FLAT, ops.CORR_NO_LATTICE]))   # every search structure
     out = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma, flags=flags))
     scale = np.abs(ref).max() + 1e-6
     assert np.abs(out - ref).max() <= 2e-4 * scale + 1e-6, f"corr scores differ {np.abs(out - ref).max():.3g} of {scale:.3g} (Ns={Ns}, Nt={Nt}, K={K}, M={M})"

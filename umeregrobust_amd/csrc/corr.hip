@@ -2083,6 +2083,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
     const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
     unsigned long long* la = lists[wave][0];
     unsigned long long* lb = lists[wave][1];
+    if (header[11] == 0u && header[12] != 0u) return;                  // served as a flat list (corr_score_flat_kernel)
     const unsigned int n_rec = header[4];
     const int grp = lane >> 3, sub = lane & 7;
     for (unsigned int r = blockIdx.x; r < n_rec; r += gridDim.x) {      // (static assignment: see DESIGN on the atomic-counter hang)
@@ -2131,6 +2132,126 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
             if (lane == 0) partial[(size_t)h * n_chunks + chunk] += total;
         }
         __syncthreads();
+    }
+}
+
+// ---- the same queries as a FLAT list ---------------------------------------------------------------------------------
+// A record holds a dozen queries on average, and the eight wavefronts of corr_score_fallback_kernel meet at two barriers
+// per record: with 1 or 2 queries each they wait for the slowest (SQ counters: 63 % of the wavefronts' time is waiting).
+// Flattened, every wavefront takes queries of its own: leftover_flatten_kernel gives each record a contiguous range of
+// query slots (entry = record << 6 | lane, lanes ascending), corr_score_flat_kernel writes one value per slot, and
+// leftover_sum_kernel adds a record's values in lane order to its (hypothesis, chunk) partial sum -- the same additions
+// in the same order as the record kernel's, so the result is bit-identical.  More than kFlatMaxQ queries (header word 11
+// set): the flat kernels return and the record kernel runs as before.
+constexpr unsigned int kFlatMaxQ = 1u << 21;
+constexpr int kFlatBlocks = 6144;   // workgroups of corr_score_flat_kernel (8 wavefronts each, queries dealt round-robin; 768 .. 16 384 measured: 1.17 .. 1.10 ms)
+struct FlatWs {
+    unsigned int* rbase;   // [records] first query slot of the record
+    unsigned int* qlist;   // [slots] record << 6 | lane
+    float* qval;           // [slots]
+};
+__host__ __device__ inline size_t flat_slots(long n_queries) { return (size_t)(n_queries < (long)kFlatMaxQ ? n_queries : (long)kFlatMaxQ); }
+__host__ __device__ inline size_t flat_bytes(size_t n_records, long n_queries)
+{
+    return align_up(n_records * 4, 256) + 2 * align_up(flat_slots(n_queries) * 4, 256);
+}
+__host__ __device__ inline FlatWs flat_ws(char* base, size_t n_records, long n_queries)
+{
+    FlatWs f;
+    f.rbase = reinterpret_cast<unsigned int*>(base);
+    f.qlist = reinterpret_cast<unsigned int*>(base + align_up(n_records * 4, 256));
+    f.qval = reinterpret_cast<float*>(base + align_up(n_records * 4, 256) + align_up(flat_slots(n_queries) * 4, 256));
+    return f;
+}
+
+__global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict__ lat, unsigned int c_max, FlatWs f)
+{
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lat_ws(c_max).off_header);
+    const uint4* queue = reinterpret_cast<const uint4*>(lat + lat_ws(c_max).total);
+    const unsigned int n_rec = header[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) header[12] = 1u;          // the flat path ran (unless word 11 says it overflowed)
+    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
+        const uint4 rec = queue[r];
+        unsigned long long mask = ((unsigned long long)rec.w << 32) | rec.z;
+        const unsigned int cnt = (unsigned int)__popcll(mask);
+        const unsigned int base = atomicAdd(&header[10], cnt);
+        f.rbase[r] = base;
+        if (base + cnt > kFlatMaxQ || base + cnt < base) { header[11] = 1u; continue; }
+        for (unsigned int j = 0; mask != 0ull; mask &= mask - 1ull, ++j)
+            f.qlist[base + j] = (r << 6) | (unsigned int)(__ffsll((long long)mask) - 1);
+    }
+}
+
+__global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+                                                                       const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+                                                                       const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
+                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f)
+{
+    __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
+    __shared__ unsigned int chist[kCoopWaves][kWave];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const LatWs lw = lat_ws(c_max);
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    if (header[11] != 0u) return;                      // too many queries: the record kernel serves them
+    const unsigned int n_q = header[10];
+    const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
+    unsigned long long* la = lists[wave][0];
+    unsigned long long* lb = lists[wave][1];
+    const int grp = lane >> 3, sub = lane & 7;
+    const unsigned int n_waves = gridDim.x * kCoopWaves;
+    for (unsigned int q = blockIdx.x * kCoopWaves + wave; q < n_q; q += n_waves) {
+        const unsigned int ent = f.qlist[q];
+        const uint4 rec = queue[ent >> 6];
+        const int h = (int)rec.x, slot = (int)rec.y * kWave + (int)(ent & 63u);
+        if (slot >= Ns) {
+            if (lane == 0) f.qval[q] = 0.f;
+            continue;
+        }
+        const int qs = __float_as_int(S4s[slot].w);
+        const float sx = src_pts[(size_t)qs * 3], sy = src_pts[(size_t)qs * 3 + 1], sz = src_pts[(size_t)qs * 3 + 2];
+        const float* Th = T + (size_t)h * 16;
+        // (the same arithmetic as the record kernel and corr_score_kernel)
+        const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
+        const float4 a = vp4[(size_t)qs * 8 + sub];
+        float part = 0.f;
+        for (int e0 = 0; e0 < cnt; e0 += 8) {
+            const int e = e0 + grp;
+            const unsigned long long k = la[e < cnt ? e : 0];
+            const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));                 // torch.linalg.norm (:593)
+            const float rr = dist / sigma;
+            const float wgt = 1.0f / (1.0f + rr * rr);                                          // cauchy_kernel (:588-589)
+            const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
+            float d = a.x * o.x;
+            d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+            part += e < cnt ? wgt * d : 0.f;
+        }
+        part = wave_sum_f(part);
+        if (lane == 0) f.qval[q] = part;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+__global__ __launch_bounds__(256) void leftover_sum_kernel(const char* __restrict__ lat, unsigned int c_max, FlatWs f, int n_chunks,
+                                                           float* __restrict__ partial)
+{
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lat_ws(c_max).off_header);
+    if (header[11] != 0u) return;
+    const uint4* queue = reinterpret_cast<const uint4*>(lat + lat_ws(c_max).total);
+    const unsigned int n_rec = header[4];
+    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
+        const uint4 rec = queue[r];
+        const unsigned int cnt = (unsigned int)(__popc(rec.z) + __popc(rec.w)), base = f.rbase[r];
+        float total = 0.f;                                               // the record's queries in lane order
+        for (unsigned int j = 0; j < cnt; ++j) total += f.qval[base + j];
+        partial[(size_t)rec.x * n_chunks + rec.y] += total;              // every record has one writer
     }
 }
 
@@ -2282,7 +2403,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
                                                         2 * align_up(n_chunks * M * 4, 256) + align_up((size_t)Ns * 4, 256) + align_up(n_chunks * 16, 256) : 0;
     return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
-           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) : 0) + cons;
+           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + flat_bytes((size_t)M * n_chunks, (long)M * Ns) : 0) + cons;
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -2443,6 +2564,18 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
+        // ... as a flat list of queries when they fit (header word 12 marks that the flat path ran), record by record otherwise
+        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
+        const FlatWs fw = flat_ws(flat_base, (size_t)M * n_chunks_sz, (long)M * Ns);
+        if (!(flags & UMEREG_CORR_NO_FLAT)) {
+            hipLaunchKernelGGL(leftover_flatten_kernel, dim3(256), dim3(256), 0, st, lat, c_max, fw);
+            UMEREG_CHECK_LAUNCH("leftover_flatten_kernel");
+            hipLaunchKernelGGL(corr_score_flat_kernel, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt, (const char*)ws_src,
+                               src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
+            UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
+            hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial);
+            UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
+        }
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);

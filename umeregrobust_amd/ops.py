@@ -488,7 +488,7 @@ def corr_weighted_features(src_feat, tgt_feat, src_w, tgt_w):
     return so, to
 
 
-CORR_NO_LATTICE, CORR_FORCE_LATTICE, CORR_NO_CONSENSUS, CORR_FORCE_CONSENSUS = 1, 2, 4, 8
+CORR_NO_LATTICE, CORR_FORCE_LATTICE, CORR_NO_CONSENSUS, CORR_FORCE_CONSENSUS, CORR_NO_FLAT = 1, 2, 4, 8, 16
 
 
 def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None, flags=0):
