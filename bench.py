@@ -446,7 +446,7 @@ def main():
 
     def api_loop(entries, n_pairs, seed):
         """the library's own loop, `evaluate.evaluate_pairs` (= the reference's: ONE host RNG across the pairs, hypothesis
-        selection pair by pair, ICP for all pairs at the end), which overlaps consecutive pairs on two HIP streams"""
+        selection pair by pair, ICP), which overlaps consecutive pairs on two HIP streams"""
         def gen(n):
             for i in range(n):
                 e = entries[(rank + world * i) % len(entries)]
@@ -465,9 +465,10 @@ def main():
         return {"pairs_per_s": round(world * n_pairs / el, 2), "ms_per_pair_per_gpu": round(1e3 * el / n_pairs, 3),
                 "rank0_N.P_percent": round(100.0 * r["rr_np"], 3), "rank0_S.P_percent": round(100.0 * r["rr_sp"], 3),
                 "note": "evaluate.evaluate_pairs over the same pairs on ONE host thread and ONE host RNG stream consumed in the "
-                        "reference's order (keypoint draws, weighted draw, two sub-sampling draws, pair after pair), ICP of all "
-                        "pairs after the loop as at evaluate.py:301; pair i + 1 is prepared on a second HIP stream while the "
-                        "correlation scores of pair i are computed -- results identical to one pair at a time "
+                        "reference's order (keypoint draws, weighted draw, two sub-sampling draws, pair after pair); pair i + 1 is "
+                        "prepared on a second HIP stream while the correlation scores of pair i are computed, and the ICP of a pair "
+                        "(evaluate.py:301 runs it after the loop; it draws nothing) runs when its hypothesis is read back, beside "
+                        "the next pair's scores -- results identical to one pair at a time "
                         "(test_evaluate_pairs_overlapped_equals_one_pair_at_a_time)"}
 
     if not a.no_e2e and a.e2e_pairs > 0:

@@ -525,11 +525,18 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
     # stream only.  overlap=False: one pair at a time on the caller's stream.
     streams, pending, k = None, None, 0
 
+    refined = []      # per pair (T_est [1,4,4], rre [1], rte [1]) when the ICP runs inside the loop
+
     def read_back(p):
         R_hat, t_hat, st, _keep = p     # _keep: the pair's input tensors stay alive until its last kernel is done
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
             R_sel.append(R_hat.cpu())
             t_sel.append(t_hat.cpu())
+            if refine and st is not None:
+                # The reference refines all pairs after the loop (:301).  The ICP consumes no random numbers and touches
+                # nothing but its own pair, so running it here -- on the pair's stream, while the NEXT pair's correlation
+                # scores keep the GPU busy on the other one -- gives the same registrations with its host round trips hidden.
+                refined.append(refine_registration(R_sel[-1], t_sel[-1], args, [raw[len(R_sel) - 1]]))
 
     for pair in pairs:
         dev = pair["src_pts"].device
@@ -560,7 +567,9 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
         for st in streams:
             torch.cuda.current_stream(streams[0].device).wait_stream(st)
     R_sel, t_sel = torch.cat(R_sel, dim=0), torch.cat(t_sel, dim=0)
-    if refine:
+    if refine and len(refined) == R_sel.shape[0]:
+        T_est, rre, rte = (torch.cat([r[i] for r in refined]) for i in range(3))
+    elif refine:
         T_est, rre, rte = refine_registration(R_sel, t_sel, args, raw)                                             # :301
     else:
         T_est = torch.eye(4)[None].repeat(R_sel.shape[0], 1, 1)
