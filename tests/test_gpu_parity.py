@@ -1435,6 +1435,15 @@ def test_corr_scores_flat_leftovers_equal_the_record_form(gpu):
         assert torch.equal(a, b), base
     ref = orc.pc_corr_cost(Ts[:8, :3, :3], Ts[:8, :3, 3], src, tgt, 20, sf, tf, 1.5)
     assert np.abs(N_(a)[:8] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
+    # more such queries than the flat list holds (2^21): every image 300 m outside the target, 450 x 5000 = 2.25 M queries --
+    # the flat kernels stand back and the record kernel serves them; same scores as with the flat path switched off
+    far = Ts.copy(); far = np.concatenate([far, far[:150]]); far[:, 0, 3] += 300.0
+    base = ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS
+    a = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(far, gpu), K=20, sigma=1.5, flags=base)
+    b = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(far, gpu), K=20, sigma=1.5, flags=base | ops.CORR_NO_FLAT)
+    assert torch.equal(a, b)
+    ref = orc.pc_corr_cost(far[:4, :3, :3], far[:4, :3, 3], src, tgt, 20, sf, tf, 1.5)
+    assert np.abs(N_(a)[:4] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
 
 
 def test_evaluate_pairs_overlapped_equals_one_pair_at_a_time(gpu):
