@@ -91,7 +91,18 @@ def gate_counts(rre, rte):
 
 def main():
     a = parse()
+    # one process per GPU: N ranks share the host's cores.  Every rank runs numpy draws, the ICP's stop-test polling and torch's
+    # intra-op pool; left alone each would start one thread per core (8 x 256 threads on an 8-GPU node).  Pin the pools before
+    # torch / numpy create them (the CPU-baseline leg, world 1 only, keeps all cores).
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    host_threads = os.cpu_count() or 1
+    if world_env > 1:
+        host_threads = max(1, min(8, host_threads // world_env))
+        for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+            os.environ.setdefault(var, str(host_threads))
     import torch
+    if world_env > 1:
+        torch.set_num_threads(host_threads)
     import torch.distributed as dist
 
     import umeregrobust_amd
@@ -302,6 +313,10 @@ def main():
         "metric": "registration_pairs_per_s", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "world": {"ranks": world, "backend": (dist.get_backend() if collective else None), "device": torch.cuda.get_device_name(dev),
+                  "devices_visible": torch.cuda.device_count(), "host_threads_per_rank": host_threads,
+                  "note": "one process per GPU; the named path has no data-path collective, the counters below are summed with one "
+                          "all-reduce (RCCL over xGMI when backend = nccl)"},
         "config": {"workload": f"{a.config}: named hot path a1-a7 on synthetic KITTI-shaped pairs "
                                f"(N={cfg['N']} pts/cloud, {n_kp} keypoints/cloud, K={args.ume_max_nn}, r={args.ume_r_nn} m, "
                                f"d=32, M={args.ume_n_samples} hypotheses, tau={args.tau}, kind={a.kind})",
@@ -391,10 +406,12 @@ def main():
 
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream(dev))
-        run_all(0, 2 * n_fl, False)
+        # the timed pairs are local indices 0 .. n_pairs - 1 (global g = rank + world * i: an N-GPU run over n pairs per GPU covers
+        # the same pairs, with the same seeds, as a 1-GPU run over N * n); the warm-up takes indices beyond them
+        run_all(n_pairs, 2 * n_fl, False)
         fence()
         t_0 = time.perf_counter()
-        run_all(2 * n_fl, n_pairs, True)
+        run_all(0, n_pairs, True)
         fence()
         el = time.perf_counter() - t_0
         sel_timing = [x for l_ in sel_timing for x in l_]

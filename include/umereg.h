@@ -359,6 +359,14 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
 #define UMEREG_CORR_NO_CONSENSUS 4
 #define UMEREG_CORR_FORCE_CONSENSUS 8
 #define UMEREG_CORR_NO_FLAT 16
+#define UMEREG_CORR_CONSENSUS_V1 32 /* the consensus pass in its first form (round 2: K + 6 entry lists, images in empty regions give up) */
+#define UMEREG_CORR_DEBUG_STATS 64  /* the consensus pass counts its steps into workspace header words 16..23 (tools/exp_f1_prod.py) */
+#define UMEREG_CORR_FAR_MARGIN_SHIFT 8 /* bits 8..15: margin of the stage of an image in an empty region, in eighths of a grid cell
+                                          (0 = default, 255 = such source points are left to the lattice) */
+#define UMEREG_CORR_SRC_ROWS 128 /* source points processed in row-major cell order (round 2) instead of Hilbert-curve order */
+#define UMEREG_CORR_RECORD_STAGE 256 /* (experimental) the queries neither pass serves first go one wavefront per RECORD over a staged candidate set; what that cannot serve goes one wavefront per query as before */
+#define UMEREG_CORR_LEFT_COOP (1 << 16)    /* what the consensus pass leaves goes to the one-wavefront-per-query search whatever its size */
+#define UMEREG_CORR_LEFT_LATTICE (1 << 17) /* ... to the candidate lattice whatever its size (by default the count decides) */
 size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
 int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
                               const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,

@@ -817,6 +817,39 @@ def test_bench_collectives_on_rccl(gpu, tmp_path):
     assert j1["end_to_end"]["rr_1deg_0.1m"] == j2["end_to_end"]["rr_1deg_0.1m"]
 
 
+def test_bench_two_ranks_equal_one_rank_over_the_same_pairs(gpu):
+    """The N > 1 path of bench.py with TWO ranks on this 1-GPU box: `torch.distributed.run --nproc-per-node 2`, both ranks on
+    device 0 (--force-device), collectives on gloo (RCCL refuses two ranks on one device).  Rank r takes the global pairs
+    r, r + 2, ...; pool entry and RNG seed of a pair depend on its global index only, so the summed integer counts -- RTUME
+    hypotheses inside every gate on the named path, selected / refined registrations inside every gate end to end -- must
+    EQUAL those of a single-process run over the same number of pairs (bench.py:129-130's claim)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    common = ["--config", "K1", "--warmup", "1", "--steps", "2", "--no-cpu-baseline", "--e2e-hard-pairs", "0", "--e2e-side-by-side", "0"]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                         "--force-device", "0", "--pairs-per-step", "4", "--e2e-pairs", "3"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["world"]["ranks"] == 2 and j2["world"]["backend"] == "gloo" and j2["scaling"] == "weak"
+    assert j2["world"]["host_threads_per_rank"] <= 8                      # the ranks share the host: pools are pinned
+    r1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--pairs-per-step", "8", "--e2e-pairs", "6"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["hypothesis_quality"]["counts"] == j2["hypothesis_quality"]["counts"]      # 2 ranks x 2 steps x 4 pairs == 1 x 2 x 8
+    e1, e2 = j1["end_to_end"], j2["end_to_end"]
+    assert e1["pairs"] == e2["pairs"] == 6
+    for key in ("rr_1.5deg_0.6m", "rr_1.5deg_0.3m", "rr_1deg_0.1m"):
+        assert e1[key] == e2[key] and e1["selected_before_icp"][key] == e2["selected_before_icp"][key]
+    assert abs(e1["mRRE_deg"] - e2["mRRE_deg"]) < 1e-4 and abs(e1["mRTE_m"] - e2["mRTE_m"]) < 1e-4
+
+
 @pytest.mark.parametrize("case", ["kitti", "lattice_ties", "sparse_far", "tiny"])
 def test_corr_scores_lattice_vs_grid_vs_oracle(gpu, case):
     """f1: the per-cell candidate lattice must deliver the same K nearest as the grid walk (and as the brute-force
@@ -1433,6 +1466,12 @@ def test_corr_scores_flat_leftovers_equal_the_record_form(gpu):
         a = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu), K=20, sigma=1.5, flags=base)
         b = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu), K=20, sigma=1.5, flags=base | ops.CORR_NO_FLAT)
         assert torch.equal(a, b), base
+        # round 3, opt-in: first one wavefront per RECORD (a staged set of the record's neighbours, one lane per query; what it
+        # cannot prove exact stays for the flat list) -- the same neighbour sets, the terms added in another order
+        c = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu), K=20, sigma=1.5, flags=base | ops.CORR_RECORD_STAGE)
+        c2 = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu), K=20, sigma=1.5, flags=base | ops.CORR_RECORD_STAGE)
+        assert torch.equal(c, c2), base
+        assert float((c - a).abs().max()) <= 1e-5 * float(a.abs().max()), base
     ref = orc.pc_corr_cost(Ts[:8, :3, :3], Ts[:8, :3, 3], src, tgt, 20, sf, tf, 1.5)
     assert np.abs(N_(a)[:8] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
     # more such queries than the flat list holds (2^21): every image 300 m outside the target, 450 x 5000 = 2.25 M queries --
@@ -1442,6 +1481,8 @@ def test_corr_scores_flat_leftovers_equal_the_record_form(gpu):
     a = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(far, gpu), K=20, sigma=1.5, flags=base)
     b = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(far, gpu), K=20, sigma=1.5, flags=base | ops.CORR_NO_FLAT)
     assert torch.equal(a, b)
+    c = ops.corr_scores(T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(far, gpu), K=20, sigma=1.5, flags=base | ops.CORR_RECORD_STAGE)
+    assert float((c - a).abs().max()) <= 1e-5 * float(a.abs().max())
     ref = orc.pc_corr_cost(far[:4, :3, :3], far[:4, :3, 3], src, tgt, 20, sf, tf, 1.5)
     assert np.abs(N_(a)[:4] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
 

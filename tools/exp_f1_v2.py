@@ -1,0 +1,81 @@
+"""f1 A/B probe of the consensus pass: first form (round 2) vs second form (round 3) with several margins of the far-point stage,
+on the plain / half-overlapping / large-rotation KT pair: ms per call, agreement of the scores, served / leftover counts and the
+pass's step statistics (UMEREG_CORR_DEBUG_STATS).
+usage: python tools/exp_f1_v2.py [reps] [plain,hard,rot] [variants: v1,off,4,8,16 (eighths of a cell)]"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from umeregrobust_amd import _lib, evaluate, ops  # noqa: E402
+from umeregrobust_amd.synth import synth_pair, synth_pair_hard  # noqa: E402
+from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+kinds = (sys.argv[2] if len(sys.argv) > 2 else "plain,hard").split(",")
+variants = (sys.argv[3] if len(sys.argv) > 3 else "v1,off,4,8,16").split(",")
+dev = torch.device("cuda:0")
+lib = _lib.load()
+args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("kitti_test"))
+t = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
+
+
+def flags_of(v):
+    extra = 0
+    if v.endswith("R"):
+        return ops.CORR_SRC_ROWS | flags_of(v[:-1])
+    if v.endswith("S"):
+        return ops.CORR_RECORD_STAGE | flags_of(v[:-1])
+    if v.endswith("L"):
+        extra, v = ops.CORR_LEFT_LATTICE, v[:-1]
+    elif v.endswith("C"):
+        extra, v = ops.CORR_LEFT_COOP, v[:-1]
+    return extra | flags_of0(v)
+
+
+def flags_of0(v):
+    if v == "v1":
+        return ops.CORR_CONSENSUS_V1
+    if v == "off":
+        return 255 << ops.CORR_FAR_MARGIN_SHIFT
+    if v == "def":
+        return 0
+    return int(v) << ops.CORR_FAR_MARGIN_SHIFT
+
+
+for which in kinds:
+    gen = {"plain": synth_pair, "hard": synth_pair_hard, "rot": lambda **k: synth_pair(kind="rot", **k)}[which]
+    p = gen(seed=3, N=50000, n_kp=10000)
+    sp, tp, sf, tf = t(p.src_pts)[None], t(p.tgt_pts)[None], t(p.src_feat)[None], t(p.tgt_feat)[None]
+    out = evaluate.register_pair(sp, tp, sf, tf, args, rng=np.random.RandomState(0))
+    T = out.rtume_tform[0].contiguous()
+    rs = np.random.RandomState(1)
+    si, ti = t(rs.choice(50000, 10000, replace=False)), t(rs.choice(50000, 10000, replace=False))
+    a, b, fa, fb = sp[0, si].contiguous(), tp[0, ti].contiguous(), sf[0, si].contiguous(), tf[0, ti].contiguous()
+    M, Ns, Nt = T.shape[0], a.shape[0], b.shape[0]
+    off = lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, ops.CORR_NO_LATTICE)
+    ref = None
+    for v in variants:
+        fl = flags_of(v)
+        sc = ops.corr_scores(a, b, fa, fb, T, K=20, sigma=1.5, flags=fl | ops.CORR_DEBUG_STATS)
+        torch.cuda.synchronize()
+        ws = ops._workspace(dev, lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, fl | ops.CORR_DEBUG_STATS), "corr")
+        hdr = ws[off:off + 128].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            sc = ops.corr_scores(a, b, fa, fb, T, K=20, sigma=1.5, flags=fl)
+        ev[1].record()
+        torch.cuda.synchronize()
+        s = sc.cpu().numpy()
+        if ref is None:
+            ref = s
+        steps_a, u_a, steps_b, u_b = int(hdr[19]), int(hdr[20]), int(hdr[21]), int(hdr[22])
+        print(f"{which:5s} {v:5s}: {ev[0].elapsed_time(ev[1]) / reps:7.3f} ms  max|d| {np.abs(s - ref).max():.2e} of {np.abs(ref).max():.3f} "
+              f"argmax {int(s.argmax())}  served {int(hdr[7])} left {int(hdr[9])} path {'coop' if hdr[8] else 'lattice'} marked {int(hdr[3])} "
+              f"fb records {int(hdr[4])} queries {int(hdr[6])} | staged near {int(hdr[16])} far {int(hdr[17])} avg n_c {hdr[18] / max(hdr[16] + hdr[17], 1):.1f} | "
+              f"A steps {steps_a} avg u {u_a / max(steps_a, 1):.1f}  B steps {steps_b} avg u {u_b / max(steps_b, 1):.1f}  zoom steps {int(hdr[23])} | records {int(hdr[24])} avg stage {hdr[25] / max(hdr[24], 1):.0f} pts, queries of staged records {int(hdr[26])} left {int(hdr[27])}",
+              flush=True)

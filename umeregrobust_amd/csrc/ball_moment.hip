@@ -78,8 +78,30 @@ __global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __res
 }
 
 // ---- K1: cell ids + per-workgroup histograms --------------------------------------------------
+// order_only != 0: the structure will only be used as a PROCESSING ORDER (corr.hip: the source cloud of the correlation
+// scores), never searched.  Single-layer grids then sort by the cell's position along the Hilbert curve instead of the
+// row-major cell id: 64 consecutive points of the sorted table form a compact blob (~8 m x 8 m on a KITTI cloud) instead of a
+// strip one cell wide and ~40 m long, which is what makes "a chunk of 64 slots" a neighbourhood (per-chunk hypothesis orders,
+// per-record candidate sets).  The start[] table of such a structure is indexed by curve position and of no use to a search.
+__device__ __forceinline__ int hilbert64(int x, int y)
+{
+    // position of cell (x, y), 0 <= x, y < 64, along the Hilbert curve of the 64 x 64 grid: consecutive positions are always
+    // edge-adjacent cells (a Morton code jumps across the grid at every quadrant boundary)
+    int d = 0;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const int rx = (x & s) ? 1 : 0, ry = (y & s) ? 1 : 0;
+        d += s * s * ((3 * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 63 - x; y = 63 - y; }
+            const int t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
 __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ ws, size_t ws_stride, int N,
-                                                            float radius)
+                                                            float radius, int order_only)
 {
     __shared__ int hist[kMaxCells];
     const GridWs w = grid_ws(N);
@@ -93,8 +115,10 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
     const int j = blockIdx.x * kSortWG + threadIdx.x;
     if (j < N) {
         const float4 p = P4o[j];
-        const int c = (cell_axis(p.z, g.minz, g.invz, g.nz) * g.ny + cell_axis(p.y, g.miny, g.invy, g.ny)) * g.nx +
-                      cell_axis(p.x, g.minx, g.invx, g.nx);
+        int c = (cell_axis(p.z, g.minz, g.invz, g.nz) * g.ny + cell_axis(p.y, g.miny, g.invy, g.ny)) * g.nx +
+                cell_axis(p.x, g.minx, g.invx, g.nx);
+        if (order_only && g.nz == 1 && g.nx <= 64 && g.ny <= 64)          // (positions < 64 * 64 = kMaxCells)
+            c = hilbert64(cell_axis(p.x, g.minx, g.invx, g.nx), cell_axis(p.y, g.miny, g.invy, g.ny));
         cell_of[j] = c;
         atomicAdd(&hist[c], 1);   // integer counts: order-independent
     }
@@ -105,7 +129,7 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
 // ---- K2: exclusive scan over (cell, workgroup): bases[wg][c] = first slot of (wg, c) within cell c --
 // One workgroup; reads and writes go to different arrays so the per-cell loop over workgroups is a
 // stream of independent loads (a read-modify-write in place serialised ~50 dependent round trips).
-__global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius)
+__global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius, int order_only)
 {
     __shared__ int tot[kMaxCells];
     __shared__ int part[1024 / 64];
@@ -116,7 +140,8 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, 
     int* __restrict__ start = reinterpret_cast<int*>(wb + w.off_start);
     const Grid gg = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     if (threadIdx.x == 0) store_grid(reinterpret_cast<unsigned int*>(wb + w.off_bbox), gg);     // for every later kernel
-    const int n_cells = gg.nx * gg.ny * gg.nz;   // cells beyond this are never populated
+    // cells beyond this are never populated (curve positions of an order-only structure: any of the 4096)
+    const int n_cells = order_only ? kMaxCells : gg.nx * gg.ny * gg.nz;
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) {
         int run = 0;
         if (c >= n_cells) { tot[c] = 0; continue; }
@@ -637,7 +662,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st)
+int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only)
 {
     const GridWs w = grid_ws(N);
     // the B bounding-box records (64 B each, one per cloud's workspace slice) in one call
@@ -651,9 +676,9 @@ int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStrea
         hipLaunchKernelGGL(pack_points_kernel, dim3(nb, B), dim3(kPackWG), 0, st, pts, ws, w.total, N);
     }
     UMEREG_CHECK_LAUNCH("pack_points_kernel");
-    hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius);
+    hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius, order_only);
     UMEREG_CHECK_LAUNCH("grid_hist_kernel");
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1, B), dim3(1024), 0, st, ws, w.total, N, radius);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1, B), dim3(1024), 0, st, ws, w.total, N, radius, order_only);
     UMEREG_CHECK_LAUNCH("grid_scan_kernel");
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N);
     UMEREG_CHECK_LAUNCH("grid_scatter_kernel");

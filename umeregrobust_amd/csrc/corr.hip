@@ -26,6 +26,8 @@
 //     chunk) partial sums are written and reduced in a fixed order => deterministic scores.
 // Squared distances use the reference's arithmetic: sum_d (p1-p2)^2 left to right in fp32, no FMA
 // contraction (-ffp-contract=off), ties resolved towards the lower index.
+#include <type_traits>
+
 #include "grid.h"
 
 namespace umereg {
@@ -62,6 +64,35 @@ __device__ __forceinline__ int wave_max_i(int v)
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(v, m, kWave); v = o > v ? o : v; }
     return v;
+}
+// max over the wavefront of a NON-NEGATIVE int (0 = identity; also the bit pattern of a non-negative float), as a uniform
+// value: four DPP row shifts, two row broadcasts, one readlane -- instead of six ds_bpermute round trips
+__device__ __forceinline__ int wave_max_nonneg(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8: lane 15 of every row holds the row's max
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true));   // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true));   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_nonneg_f(float v) { return __int_as_float(wave_max_nonneg(__float_as_int(v))); }
+// min / max of a float over the wavefront (uniform result), same DPP ladder with the operation's identity for lanes
+// without a source
+template <bool kMax>
+__device__ __forceinline__ float wave_minmax_f(float v)
+{
+    const int ident = __float_as_int(kMax ? -3.0e38f : 3.0e38f);
+#define UMEREG_MM_STEP(ctrl, rm)                                                                                                    \
+    {                                                                                                                               \
+        const float o_ = __int_as_float(__builtin_amdgcn_update_dpp(ident, __float_as_int(v), ctrl, rm, 0xf, false));              \
+        v = kMax ? fmaxf(v, o_) : fminf(v, o_);                                                                                     \
+    }
+    UMEREG_MM_STEP(0x111, 0xf) UMEREG_MM_STEP(0x112, 0xf) UMEREG_MM_STEP(0x114, 0xf) UMEREG_MM_STEP(0x118, 0xf)
+    UMEREG_MM_STEP(0x142, 0xa) UMEREG_MM_STEP(0x143, 0xc)
+#undef UMEREG_MM_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_sum_f(float v)
 {
@@ -1535,16 +1566,553 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     if (lane == 0 && stats) atomicAdd(stats, n_served);
 }
 
+// ---- consensus pass, second form (round 3) ----------------------------------------------------------------------------
+// Same contract as corr_consensus_kernel (val / served / stats, exact or left to the other structures), rebuilt around three
+// observations about where that kernel's ~2 900 VALU instructions per 64-hypothesis step went:
+//   (1) the K + 6 entry lists were trimmed to K by repeated arg-max sweeps (~1 000 instructions per step).  But the stage is
+//       sorted by distance from the consensus image, and |d_j(q) - d_j(q~)| <= delta, so for a whole step (delta <= dmax)
+//         * staged points with  d_j(q~) < d_K(q~) - 2 dmax  are among the K nearest of EVERY lane (there are < K of them and each
+//           is closer to q than d_K(q) >= d_K(q~) - delta):  "sure-in", summed without any selection;
+//         * staged points with  d_j(q~) > d_K(q~) + 2 dmax  are among the K nearest of NO lane;
+//       what is left to select from is a ZONE of u = m_use - s_min points around stage position K, of which every lane needs
+//       the same number  need = K - s_min.  Agreeing hypotheses (delta of centimetres) leave u <= 12: their d2 stay in
+//       registers and the `need` smallest are found by rank counting (66 key comparisons), no LDS list, no histogram;
+//   (2) wider steps (u > 12) histogram only the range the K-th distance can lie in, [(d_K(q~) - delta)^2, (d_K(q~) + delta)^2)
+//       (everything below it is sure-in by the query's own distance: the underflow bin), in 32 bins of BYTE counters (the
+//       stage holds <= 252 points, so a counter cannot wrap): 2.3 KiB per wavefront instead of 8.4.  Everything below the bin
+//       of the K-th neighbour is summed on the fly in the second sweep; only the candidates IN that bin go to a list
+//       (kCons2Tie entries) and are trimmed there.  A fuller bin is zoomed into once (x32); a lane whose finest bin still
+//       overflows the list (exact distance ties by the dozen) is left to the other structures, like any lane that fails
+//       the a-posteriori test;
+//   (3) with the 13.3 KiB list gone a wavefront needs 12.25 KiB of LDS: three wavefronts per SIMD instead of two.
+// And, new: source points whose consensus image lies in an EMPTY part of the target (partly overlapping clouds: 38 % of the
+// points of a half-overlapping pair) used to give up (< K targets within D); they now stage the points within
+// d_K(q~) + margin of the image, found through the chunk boxes of the sorted table (coop_knn for d_K, then one pruned sweep)
+// -- the fine range of (2) is what makes the thin shell their neighbours live in selectable in one histogram.
+constexpr float kConsFarMarginCells = 2.0f;   // default margin of the far-point stage (see corr_consensus2_kernel), in grid cells
+constexpr int kCons2Cap = 252;           // staged target points per source point (byte counters: see above)
+constexpr int kCons2Tie = 8;             // list entries per lane for the candidates of the K-th neighbour's bin
+constexpr int kCons2Zone = 12;           // zone size up to which the rank-counting path is taken
+constexpr int kCons2HistWords = 9;       // 36 byte counters per lane: bin t = 0 below the range, 1..32, 33 at or beyond it
+constexpr size_t kCons2WorkBytes = (size_t)kCons2HistWords * kWave * 4 + (size_t)kCons2Tie * kWave * 8;   // 6 400: >= 252 raw points, >= coop_knn's lists
+__host__ __device__ constexpr size_t cons2_lds_per_wave() { return kCons2WorkBytes + 256 * 16 + 256 * 4 * 2; }
+
+__device__ __forceinline__ int cons2_bin(float d2, float lo, float sc)
+{
+    // (d2 - lo) * sc + 1 truncated: 0 <=> below lo (then certainly d2 < lo), 1..32 the bins, >= 33 at or beyond the range
+    const int t = (int)fmaf(d2 - lo, sc, 1.0f);
+    return min(max(t, 0), 33);
+}
+__device__ __forceinline__ void cons2_hist_add(unsigned int* hist, int lane, int t)
+{
+    atomicAdd(&hist[(t >> 2) * kWave + lane], 1u << ((t & 3) * 8));       // lane-private byte counter (ds_add_u32)
+}
+// first bin t (0..33) with  base + h[0] + .. + h[t] >= K:  bstar = t, before = base + h[0..t-1], inbin = h[t]; bstar = -1 if none
+__device__ __forceinline__ void cons2_scan(const unsigned int* hist, int lane, int base, int K, int& bstar, int& before, int& inbin)
+{
+    unsigned int w[kCons2HistWords];
+    int cw[kCons2HistWords];
+    int run = base;
+#pragma unroll
+    for (int i = 0; i < kCons2HistWords; ++i) {
+        w[i] = hist[i * kWave + lane];
+        run = (int)__builtin_amdgcn_sad_u8(w[i], 0u, (unsigned int)run);      // + the word's four byte counters
+        cw[i] = run;
+    }
+    int ws = 0;
+#pragma unroll
+    for (int i = 0; i < kCons2HistWords; ++i) ws += cw[i] < K ? 1 : 0;         // cw ascends: the first word that reaches K
+    int cb = base;
+    unsigned int ww = 0u;
+#pragma unroll
+    for (int i = 0; i < kCons2HistWords; ++i) {
+        cb = (i + 1 == ws) ? cw[i] : cb;
+        ww = (i == ws) ? w[i] : ww;
+    }
+    int b = -1, bef = cb, inb = 0, c = cb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = (int)((ww >> (8 * k)) & 255u);
+        const bool hit = b < 0 && c + h >= K;
+        b = hit ? ws * 4 + k : b;
+        bef = hit ? c : bef;
+        inb = hit ? h : inb;
+        c += h;
+    }
+    const bool any = ws < kCons2HistWords && b >= 0 && b <= 33;
+    bstar = any ? b : -1;
+    before = bef;
+    inbin = any ? inb : 0;
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void corr_consensus2_kernel(
+    const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+    const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed, const int* __restrict__ perm, int Ns, int Nt,
+    int M, int K, float sigma, float far_margin_cells, float* __restrict__ val, unsigned long long* __restrict__ served,
+    unsigned int* __restrict__ stats, int dbg)
+{
+    typedef unsigned int IdxT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int slot_n = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (slot_n >= Ns) return;
+    const int n = __float_as_int(reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s)[slot_n].w);
+    perm += (size_t)(slot_n >> 6) * M;
+    const GridWs wt = grid_ws(Nt);
+    char* my = lds + (size_t)wave * cons2_lds_per_wave();
+    unsigned int* hist = reinterpret_cast<unsigned int*>(my);
+    KeyList<IdxT> tie;
+    tie.d2 = reinterpret_cast<unsigned int*>(my + (size_t)kCons2HistWords * kWave * 4);
+    tie.ix = tie.d2 + kCons2Tie * kWave;
+    float4* raw = reinterpret_cast<float4*>(my);                                   // setup only: collected, unsorted
+    // the stage: sorted by (distance from the centre, index), quad-padded, one 64-byte record per quad of points:
+    // x[4] y[4] z[4] w[4] (w = original index << kConsIdxBits | stage position)
+    float* stage = reinterpret_cast<float*>(my + kCons2WorkBytes);
+    float* dots = stage + 256 * 4;
+    float* dc2 = dots + 256;                                                       // squared distance from the centre (ascending)
+    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
+    const Grid& g = c.g;
+    const int n_words = (M + 63) >> 6;
+    const float px = src_pts[(size_t)n * 3], py = src_pts[(size_t)n * 3 + 1], pz = src_pts[(size_t)n * 3 + 2];
+    const float cx = fmaf(Tmed[2], pz, fmaf(Tmed[1], py, Tmed[0] * px)) + Tmed[3];
+    const float cy = fmaf(Tmed[6], pz, fmaf(Tmed[5], py, Tmed[4] * px)) + Tmed[7];
+    const float cz = fmaf(Tmed[10], pz, fmaf(Tmed[9], py, Tmed[8] * px)) + Tmed[11];
+    auto give_up = [&]() __attribute__((always_inline)) {
+        for (int h = lane; h < M; h += kWave) val[(size_t)n * M + h] = 0.f;
+        for (int w = lane; w < n_words; w += kWave) served[(size_t)n * n_words + w] = 0ull;
+    };
+    if (!(cx == cx) || !(cy == cy) || !(cz == cz)) { give_up(); return; }
+    // ---- setup (a): the target points within D of the consensus image: as many as the stage holds ----
+    float D = kConsRadiusCells * c.cs_min;
+    int n_c = 0;
+    const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        const float D2 = D * D, rq = D * 1.0001f + 1e-20f;
+        const int ylo = cell_axis(cy - rq, g.miny, g.invy, g.ny), yhi = cell_axis(cy + rq, g.miny, g.invy, g.ny);
+        const int zlo = cell_axis(cz - rq, g.minz, g.invz, g.nz), zhi = cell_axis(cz + rq, g.minz, g.invz, g.nz);
+        n_c = 0;
+        for (int z = zlo; z <= zhi; ++z) {
+            const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
+            const float dzc = fmaxf(fmaxf(z_a - cz, cz - z_b), 0.f) * 0.9999f;
+            for (int y = ylo; y <= yhi; ++y) {
+                const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
+                const float dyc = fmaxf(fmaxf(y_a - cy, cy - y_b), 0.f) * 0.9999f;
+                const float rem = D2 - dyc * dyc - dzc * dzc;
+                if (!(rem > 0.f)) continue;
+                const float sx = sqrtf(rem) * 1.0001f + 1e-20f;
+                const int cb = (z * g.ny + y) * g.nx;
+                const int a = c.start[cb + cell_axis(cx - sx, g.minx, g.invx, g.nx)];
+                const int b = c.start[cb + cell_axis(cx + sx, g.minx, g.invx, g.nx) + 1];
+                for (int pos0 = a; pos0 < b; pos0 += kWave) {
+                    const int pos = pos0 + lane;
+                    const float4 p = c.P4s[pos < b ? pos : a];
+                    const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+                    const bool in = pos < b && dx * dx + dy * dy + dz * dz <= D2;
+                    const unsigned long long bal = __ballot(in);
+                    const int at = n_c + mbcnt(bal);
+                    if (in && at < kCons2Cap) raw[at] = p;
+                    n_c += __popcll(bal);
+                }
+            }
+        }
+        if (n_c > kCons2Cap) { D *= fminf(0.95f, sqrtf(0.85f * (float)kCons2Cap / (float)n_c)); continue; }
+        break;
+    }
+    if (n_c > kCons2Cap) { give_up(); return; }
+    bool far_pt = false;
+    if (n_c < K) {
+        // ---- setup (a'): an image in an empty part of the target.  d_K of the image by the chunk-pruned cooperative search,
+        // then every target point within d_K + margin of it through the same chunk boxes (margin shrinks while they overflow
+        // the stage).  A box distance is formed with the operation sequence of a point's d2, each step monotone, so it never
+        // exceeds the d2 of a point inside the box: pruning cannot lose a point of the ball.
+        if (!(far_margin_cells > 0.f) || Nt < K) { give_up(); return; }
+        far_pt = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned long long* la = reinterpret_cast<unsigned long long*>(my);
+        unsigned long long* lb = la + kCoopCap;
+        unsigned int* chist = reinterpret_cast<unsigned int*>(lb + kCoopCap);
+        const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
+        const int cntk = coop_knn(c.P4s, box, Nt, K, cx, cy, cz, la, lb, chist, lane);
+        if (cntk < K) { give_up(); return; }
+        const float dkf = sqrtf(__uint_as_float((unsigned int)(la[K - 1] >> 32)));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (!(dkf < 1.0e18f)) { give_up(); return; }
+        const int n_tch = (Nt + kWave - 1) / kWave;
+        float margin = far_margin_cells * c.cs_min;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            D = dkf * 1.0001f + margin;
+            const float D2 = D * D;
+            n_c = 0;
+            for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+                const int ch = c0 + lane;
+                float t = 3.0e38f;
+                if (ch < n_tch) {
+                    const float4 blo = box[2 * ch], bhi = box[2 * ch + 1];
+                    const float dx = fmaxf(fmaxf(blo.x - cx, cx - bhi.x), 0.f);
+                    const float dy = fmaxf(fmaxf(blo.y - cy, cy - bhi.y), 0.f);
+                    const float dz = fmaxf(fmaxf(blo.z - cz, cz - bhi.z), 0.f);
+                    t = dx * dx + dy * dy + dz * dz;
+                }
+                unsigned long long pend = __ballot(t <= D2);
+                while (pend != 0ull) {
+                    const int l = __ffsll((long long)pend) - 1;
+                    pend &= pend - 1ull;
+                    const int j = (c0 + l) * kWave + lane;
+                    const float4 p = c.P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
+                    const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+                    const bool in = j < Nt && dx * dx + dy * dy + dz * dz <= D2;
+                    const unsigned long long bal = __ballot(in);
+                    const int at = n_c + mbcnt(bal);
+                    if (in && at < kCons2Cap) raw[at] = p;
+                    n_c += __popcll(bal);
+                }
+            }
+            if (n_c > kCons2Cap) { margin *= 0.6f; continue; }
+            break;
+        }
+        if (n_c < K || n_c > kCons2Cap) { give_up(); return; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- setup (b): sort by (distance from the centre, original index) by rank counting; (c) d_K of the centre ----
+    constexpr int kPer = 4;
+    {
+        float4 mine[kPer];
+        int rank_d[kPer];
+        unsigned long long dkey[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int e = u * kWave + lane;
+            mine[u] = raw[e < n_c ? e : 0];
+            const float dx = cx - mine[u].x, dy = cy - mine[u].y, dz = cz - mine[u].z;
+            dkey[u] = e < n_c ? (((unsigned long long)__float_as_uint(dx * dx + dy * dy + dz * dz) << 32) | (unsigned int)__float_as_int(mine[u].w)) : ~0ull;
+            rank_d[u] = 0;
+        }
+        for (int f = 0; f < n_c; ++f) {
+            const float4 o = raw[f];                                     // broadcast read
+            const float dx = cx - o.x, dy = cy - o.y, dz = cz - o.z;
+            const unsigned long long ok = ((unsigned long long)__float_as_uint(dx * dx + dy * dy + dz * dz) << 32) | (unsigned int)__float_as_int(o.w);
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) rank_d[u] += ok < dkey[u] ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int e = u * kWave + lane;
+            if (e < n_c) {
+                const int r = rank_d[u];
+                float* q4 = stage + (r >> 2) * 16 + (r & 3);
+                q4[0] = mine[u].x; q4[4] = mine[u].y; q4[8] = mine[u].z;
+                q4[12] = __int_as_float((__float_as_int(mine[u].w) << kConsIdxBits) | r);
+                dc2[r] = __uint_as_float((unsigned int)(dkey[u] >> 32));
+            }
+        }
+        if (lane < 4) {
+            const int r = n_c + lane;
+            float* q4 = stage + (r >> 2) * 16 + (r & 3);
+            q4[0] = kFar; q4[4] = kFar; q4[8] = kFar; q4[12] = __int_as_float(r);
+            dc2[r] = 3.0e38f;
+            dots[r] = 0.f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float dk = sqrtf(dc2[K - 1]);
+    // ---- setup (d): <vp_n, vq_j> of the staged points, 8 lanes per feature row ----
+    {
+        const int grp = lane >> 3, sub = lane & 7;
+        const float4 a = vp4[(size_t)n * 8 + sub];
+        for (int j0 = 0; j0 < n_c; j0 += 8) {
+            const int j = j0 + grp;
+            const int jj = j < n_c ? j : 0;
+            const int oi = __float_as_int(stage[(jj >> 2) * 16 + 12 + (jj & 3)]) >> kConsIdxBits;
+            const float4 o = vq4[(size_t)oi * 8 + sub];
+            float d = a.x * o.x;
+            d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+            d += __shfl_xor(d, 1, kWave);
+            d += __shfl_xor(d, 2, kWave);
+            d += __shfl_xor(d, 4, kWave);
+            if (sub == 0 && j < n_c) dots[j] = d;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (dbg && lane == 0) {
+        atomicAdd(stats + 9 + (far_pt ? 1 : 0), 1u);                       // header words 16 / 17: staged near / far source points
+        atomicAdd(stats + 11, (unsigned int)n_c);                          // word 18: staged points
+    }
+    // ---- the hypotheses, 64 per step, in the order of their displacement of this point's chunk ----
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    unsigned int n_served = 0u;
+    const float inv_sigma = 1.0f / sigma;
+    // weight 1 / (1 + (|d| / sigma)^2) (cauchy_kernel :588-589 on torch.linalg.norm :593): hardware square root and reciprocal,
+    // each within 1 ulp of the IEEE forms the other structures use (see corr_consensus_kernel)
+    auto wgt = [&](float d2) __attribute__((always_inline)) {
+        const float r = __builtin_amdgcn_sqrtf(d2) * inv_sigma;
+        return __builtin_amdgcn_rcpf(1.0f + r * r);
+    };
+    for (int h0 = 0; h0 < M; h0 += kWave) {
+        const int pos_h = h0 + lane;
+        const int h = perm[pos_h < M ? pos_h : 0];
+        const float4* Th = reinterpret_cast<const float4*>(T + (size_t)h * 16);    // (T is 16-byte aligned: checked by the host)
+        const float4 r0 = Th[0], r1 = Th[1], r2 = Th[2];
+        const float qx = fmaf(r0.z, pz, fmaf(r0.y, py, r0.x * px)) + r0.w;               // the arithmetic of corr_score_kernel
+        const float qy = fmaf(r1.z, pz, fmaf(r1.y, py, r1.x * px)) + r1.w;
+        const float qz = fmaf(r2.z, pz, fmaf(r2.y, py, r2.x * px)) + r2.w;
+        const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
+        const float delta = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f;   // (1 ulp: inside the slack)
+        // a lane can only pass the exactness test if d_K(q) + delta <= D, and d_K(q) >= d_K(q~) - delta
+        const bool act = pos_h < M && delta < D && dk <= D;                                 // (NaN transforms: false)
+        if (!__any(act)) {
+            if (pos_h < M) val[(size_t)n * M + pos_h] = 0.f;
+            if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = 0ull;
+            continue;
+        }
+        const float dmax = wave_max_nonneg_f(act ? delta : 0.f);
+        // the zone of the step: stage positions [s_min, m_use)
+        int m_use, s_min;
+        {
+            const float rc = (dk + 2.f * dmax) * 1.0001f + 1e-5f, rc2 = rc * rc;
+            const float rs = (dk - 2.f * dmax) * 0.9999f - 1e-5f, rs2 = rs > 0.f ? rs * rs : 0.f;
+            int cnt_in = 0, cnt_s = 0;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const float v = dc2[u * kWave + lane];
+                const bool in_stage = u * kWave + lane < n_c;
+                cnt_in += __popcll(__ballot(in_stage && v <= rc2));
+                cnt_s += __popcll(__ballot(in_stage && v < rs2));
+            }
+            m_use = (cnt_in + 3) & ~3;                                                       // (the stage is quad-padded with far points)
+            s_min = min(cnt_s, K - 1) & ~3;                                                  // (cnt_s <= K - 1 by construction)
+        }
+        const int u_zone = m_use - s_min;
+        const int need = K - s_min;
+        const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        auto quad_d2 = [&](int u0, f2& t01, f2& t23) __attribute__((always_inline)) {
+            const f4* q4 = reinterpret_cast<const f4*>(stage + u0 * 4);
+            const f4 X = q4[0], Y = q4[1], Z = q4[2];
+            const f2 dx01 = qx2 - X.xy, dx23 = qx2 - X.zw;
+            const f2 dy01 = qy2 - Y.xy, dy23 = qy2 - Y.zw;
+            const f2 dz01 = qz2 - Z.xy, dz23 = qz2 - Z.zw;
+            t01 = dx01 * dx01; t23 = dx23 * dx23;
+            t01 = t01 + dy01 * dy01; t23 = t23 + dy23 * dy23;
+            t01 = t01 + dz01 * dz01; t23 = t23 + dz23 * dz23;
+        };
+        float acc = 0.f, d2m = 0.f;
+        // the sure-in prefix: among the K nearest of every lane of the step
+        for (int u0 = 0; u0 < s_min; u0 += 4) {
+            f2 t01, t23;
+            quad_d2(u0, t01, t23);
+            const f4 dt = *reinterpret_cast<const f4*>(dots + u0);
+            acc = fmaf(wgt(t01.x), dt.x, acc); acc = fmaf(wgt(t01.y), dt.y, acc);
+            acc = fmaf(wgt(t23.x), dt.z, acc); acc = fmaf(wgt(t23.y), dt.w, acc);
+            d2m = fmaxf(fmaxf(d2m, fmaxf(t01.x, t01.y)), fmaxf(t23.x, t23.y));
+        }
+        bool sel_ok;
+        if (u_zone <= kCons2Zone) {
+            // ---- (A) the zone in registers, the `need` smallest keys by rank counting ----
+            float z[kCons2Zone];
+            unsigned int zi[kCons2Zone];
+            float zd[kCons2Zone];
+#pragma unroll
+            for (int qd = 0; qd < kCons2Zone / 4; ++qd) {
+                const int b0 = s_min + 4 * qd;
+                if (b0 < m_use) {
+                    f2 t01, t23;
+                    quad_d2(b0, t01, t23);
+                    const f4 W = reinterpret_cast<const f4*>(stage + b0 * 4)[3];
+                    const f4 dt = *reinterpret_cast<const f4*>(dots + b0);
+                    z[4 * qd] = t01.x; z[4 * qd + 1] = t01.y; z[4 * qd + 2] = t23.x; z[4 * qd + 3] = t23.y;
+                    zi[4 * qd] = __float_as_uint(W.x); zi[4 * qd + 1] = __float_as_uint(W.y);
+                    zi[4 * qd + 2] = __float_as_uint(W.z); zi[4 * qd + 3] = __float_as_uint(W.w);
+                    zd[4 * qd] = dt.x; zd[4 * qd + 1] = dt.y; zd[4 * qd + 2] = dt.z; zd[4 * qd + 3] = dt.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { z[4 * qd + k] = 3.0e38f; zi[4 * qd + k] = 0xffffffffu; zd[4 * qd + k] = 0.f; }
+                }
+            }
+            // rank of key i = (earlier keys below it) + (later keys below it): one comparison per pair; keys are unique (the
+            // index word holds the stage position), so "not below" is "above"
+            int below[kCons2Zone], above[kCons2Zone];
+#pragma unroll
+            for (int i = 0; i < kCons2Zone; ++i) { below[i] = 0; above[i] = 0; }
+#pragma unroll
+            for (int i = 0; i < kCons2Zone; ++i)
+#pragma unroll
+                for (int j = i + 1; j < kCons2Zone; ++j) {
+                    const unsigned long long ki = ((unsigned long long)__float_as_uint(z[i]) << 32) | zi[i];
+                    const unsigned long long kj = ((unsigned long long)__float_as_uint(z[j]) << 32) | zi[j];
+                    const int lt = ki < kj ? 1 : 0;
+                    below[j] += lt;                              // key i, earlier, is below key j
+                    above[i] += lt;                              // key j, later, is above key i
+                }
+#pragma unroll
+            for (int i = 0; i < kCons2Zone; ++i) {
+                const bool inc = below[i] + (kCons2Zone - 1 - i) - above[i] < need;
+                const float term = wgt(z[i]) * zd[i];
+                acc += inc ? term : 0.f;
+                d2m = inc ? fmaxf(d2m, z[i]) : d2m;
+            }
+            sel_ok = true;                                       // the zone holds the K nearest of q~: at least `need` real points
+            if (dbg && lane == 0) { atomicAdd(stats + 12, 1u); atomicAdd(stats + 13, (unsigned int)u_zone); }
+        } else {
+            // ---- (B) byte histogram over the range the K-th distance can lie in; list only for the K-th neighbour's bin ----
+            const float rl = fmaxf((dk - delta) * 0.9999f - 1e-5f, 0.f);
+            const float rb = (dk + delta) * 1.0001f + 1e-5f;
+            const float lo = act ? rl * rl : 0.f;
+            const float width = ((act ? rb * rb : 1.0f) - lo) * (1.0f / (float)kBins);   // bin width; sc ~ 1 / width (the same sc everywhere)
+            const float sc = __builtin_amdgcn_rcpf(width);
+#pragma unroll
+            for (int i = 0; i < kCons2HistWords; ++i) hist[i * kWave + lane] = 0u;
+            for (int u0 = s_min; u0 < m_use; u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                cons2_hist_add(hist, lane, cons2_bin(t01.x, lo, sc));
+                cons2_hist_add(hist, lane, cons2_bin(t01.y, lo, sc));
+                cons2_hist_add(hist, lane, cons2_bin(t23.x, lo, sc));
+                cons2_hist_add(hist, lane, cons2_bin(t23.y, lo, sc));
+            }
+            int b0, before, inbin;
+            cons2_scan(hist, lane, s_min, K, b0, before, inbin);
+            // (bin 0 holds < K candidates of an active lane, bin 33 = at or beyond the range cannot hold its K-th: see (2) above)
+            if (!act || b0 < 1 || b0 > 32) b0 = -1;
+            // The list keeps the kCons2Tie SMALLEST keys of the K-th neighbour's bin (a full list replaces its largest key), so
+            // a bin fuller than the list is fine as long as no more than kCons2Tie of its candidates are needed.  Otherwise
+            // zoom into the bin once (x32); a lane that still needs more than the list holds is left to the other structures.
+            int b1 = -1;
+            float lo1 = 0.f, sc1 = 0.f;
+            const bool zoom = b0 >= 0 && K - before > kCons2Tie;
+            if (__any(zoom)) {
+                lo1 = lo + (float)(b0 - 1) * width;
+                sc1 = sc * (float)kBins;
+                if (zoom) {
+#pragma unroll
+                    for (int i = 0; i < kCons2HistWords; ++i) hist[i * kWave + lane] = 0u;
+                }
+                for (int u0 = s_min; u0 < m_use; u0 += 4) {
+                    f2 t01, t23;
+                    quad_d2(u0, t01, t23);
+                    const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (zoom && cons2_bin(d2v[k], lo, sc) == b0) cons2_hist_add(hist, lane, cons2_bin(d2v[k], lo1, sc1));
+                }
+                if (zoom) {
+                    int bb, bef1, inb1;
+                    cons2_scan(hist, lane, before, K, bb, bef1, inb1);
+                    b1 = bb;
+                    before = bef1;
+                    if (bb < 0 || K - bef1 > kCons2Tie) { b0 = -1; b1 = -1; }     // exact ties by the dozen: not this pass's business
+                }
+                if (dbg && lane == 0) atomicAdd(stats + 16, 1u);
+            }
+            const int need_t = K - before;                        // how many of the K-th neighbour's bin are kept
+            // candidates at or below a lane's bin b0 have d2 < lo + b0 * width, i.e. lie within sqrt(that) + delta of the centre:
+            // the second sweep stops at the last stage position any lane can still need
+            int m2 = m_use;
+            {
+                const float reach = wave_max_nonneg_f(b0 >= 0 ? __builtin_amdgcn_sqrtf(lo + (float)b0 * width) * 1.0002f + delta + 1e-5f : 0.f);
+                const float reach2 = reach * reach;
+                int cnt2 = 0;
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) cnt2 += __popcll(__ballot(u * kWave + lane < n_c && dc2[u * kWave + lane] <= reach2));
+                m2 = min(m_use, (cnt2 + 3) & ~3);
+            }
+            int ntie = 0;
+            auto sweep2 = [&](auto zoomed_tag) __attribute__((always_inline)) {
+                constexpr bool kZoomed = decltype(zoomed_tag)::value;
+                for (int u0 = s_min; u0 < m2; u0 += 4) {
+                    f2 t01, t23;
+                    quad_d2(u0, t01, t23);
+                    const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
+                    int cls[4];                                       // 1 = below the K-th neighbour's bin, 2 = in it, 0 = beyond
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int t0 = cons2_bin(d2v[k], lo, sc);
+                        int c = t0 < b0 ? 1 : (t0 == b0 ? 2 : 0);
+                        if (kZoomed) {                                // (zoomed lanes: the second level decides inside bin b0)
+                            const int t1 = cons2_bin(d2v[k], lo1, sc1);
+                            const int c1 = t1 < b1 ? 1 : (t1 == b1 ? 2 : 0);
+                            c = (b1 >= 0 && c == 2) ? c1 : c;
+                        }
+                        cls[k] = c;
+                    }
+                    const int any_cls = cls[0] | cls[1] | cls[2] | cls[3];
+                    if (__any((any_cls & 1) != 0)) {
+                        const f4 dt = *reinterpret_cast<const f4*>(dots + u0);
+                        const float dv[4] = {dt.x, dt.y, dt.z, dt.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float term = wgt(d2v[k]) * dv[k];
+                            acc += cls[k] == 1 ? term : 0.f;
+                        }
+                    }
+                    if (__any((any_cls & 2) != 0)) {
+                        const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
+                        const float wv[4] = {W.x, W.y, W.z, W.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
+                            const bool is_tie = cls[k] == 2;
+                            const bool put = is_tie && ntie < kCons2Tie;
+                            if (put) tie.set(ntie, lane, key);
+                            ntie += put ? 1 : 0;
+                            if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
+                                unsigned long long mk = 0ull;
+                                int mp = 0;
+#pragma unroll
+                                for (int e = 0; e < kCons2Tie; ++e) {
+                                    const unsigned long long ke = tie.get(e, lane);
+                                    if (ke >= mk) { mk = ke; mp = e; }
+                                }
+                                if (is_tie && !put && key < mk) tie.set(mp, lane, key);
+                            }
+                        }
+                    }
+                }
+            };
+            if (__any(b1 >= 0)) sweep2(std::true_type()); else sweep2(std::false_type());
+            {
+                // (the bin function is monotone in d2, so every key of the K-th neighbour's bin is at or above everything the second
+                // sweep summed on the fly: the K-th distance found is the largest key kept here or one of the sure-in prefix, whose
+                // maximum d2m already holds; the count is K iff need_t keys are kept)
+                const int bound = wave_max_nonneg(ntie);
+                while (__any(ntie > need_t)) drop_max(tie, ntie, ntie > need_t, bound, lane);
+#pragma unroll
+                for (int e = 0; e < kCons2Tie; ++e) {
+                    if (e < bound) {
+                        const bool on = e < ntie;
+                        const float d2 = __uint_as_float(tie.d2[e * kWave + lane]);
+                        const float dv = dots[tie.ix[e * kWave + lane] & ((1u << kConsIdxBits) - 1u)];
+                        const float term = wgt(d2) * dv;
+                        acc += on ? term : 0.f;
+                        d2m = on ? fmaxf(d2m, d2) : d2m;
+                    }
+                }
+            }
+            sel_ok = b0 >= 0 && ntie == need_t;
+            if (dbg && lane == 0) { atomicAdd(stats + 14, 1u); atomicAdd(stats + 15, (unsigned int)u_zone); }
+        }
+        // the exactness test: the K-th distance found plus delta must stay inside the staged ball
+        const bool ok = act && sel_ok && __builtin_amdgcn_sqrtf(d2m) * 1.0001f + delta <= D * 0.9999f - 1e-6f;
+        if (pos_h < M) val[(size_t)n * M + pos_h] = ok ? acc : 0.f;                     // (in processing order: see corr_reduce_kernel)
+        const unsigned long long sb = __ballot(ok);
+        if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = sb;
+        n_served += (unsigned int)__popcll(sb);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0 && stats) atomicAdd(stats, n_served);
+}
+
 // who takes what the consensus pass left (header word 8): 1 = the grid kernel (few leftovers: they sit in a few
 // thousand (hypothesis, chunk) wavefronts), 0 = the candidate lattice (many: hypotheses that do not agree, clouds that
 // barely overlap -- queries in empty parts of the target, where lists pay off).  Both sets of kernels are enqueued;
 // the ones not chosen return at once.
-constexpr unsigned int kLeftMax = 1u << 21;
-__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries)
+constexpr unsigned int kLeftMax = 1u << 20;   // (measured round 3: 0.26 M leftovers 2.84 ms through the queue against 3.80 through the lattice, 1.6 M 9.1 against 8.9)
+__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force)
 {
     const long left = n_queries - (long)header[7];
     header[9] = (unsigned int)(left < 0xffffffffl ? left : 0xffffffffl);
-    header[8] = left <= (long)kLeftMax ? 1u : 0u;
+    header[8] = force == 1 ? 1u : (force == 2 ? 0u : (left <= (long)kLeftMax ? 1u : 0u));   // force: UMEREG_CORR_LEFT_COOP / _LATTICE (tuning)
 }
 
 // ---- lattice build ---------------------------------------------------------------------------------------------------
@@ -2239,6 +2807,190 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
     }
 }
 
+// ---- the same queries, first one wavefront per RECORD (round 3) --------------------------------------------------------
+// A record = the queries of one 64-slot chunk of the source order under one hypothesis that nothing else served.  With the
+// source in Hilbert-curve order a chunk is a compact blob, and a rigid transform keeps it one: its queries lie in a box B of a few
+// metres and share their neighbours.  One cooperative search (coop_knn at the centre c of B) gives d_K(c); the target points
+// within R of ANY of the record's queries are staged in LDS (one sweep over the target's chunk boxes pruned against B, then
+// point against query), and every lane selects ITS K nearest from the stage with the histogram / append machinery of the
+// other structures (broadcast LDS reads).
+//   R = d_K(c) + min(hd, max(d_K(c) / 2, half a grid cell)),   hd = half diagonal of B.
+// Exactness is per lane and a posteriori, as in the consensus pass: a point that is not staged is farther than R from every
+// query of the record, so a lane whose K-th distance stays below R has its true K nearest.  (R = d_K(c) + hd and "within R of
+// the box" would be a superset for every query of B a priori -- the lattice's argument -- but for a rotated blob of 8 m in a
+// dense part of the target that is a thousand points; the union of balls stages ~250 and loses the few queries in sparser spots.)
+// Lanes that pass are summed into the record's partial sum here; the record's mask is REWRITTEN to the lanes that did not
+// (sparser spot, stage overflow, degenerate image) and the flat one-wavefront-per-query path that follows serves exactly
+// those -- one search per record instead of one per query for the rest (the flat kernel alone: 4 ns per query, 1.1 ms per pair).
+constexpr int kRecStage = 768;           // staged target points per record
+
+template <class IdxT>
+__host__ __device__ constexpr size_t rec_lds_per_wave(int cap)
+{
+    // list / histogram region (also coop_knn's two key lists + its histogram: 4 352 B) + the record's queries + the stage
+    return (knn_lds_per_wave(cap, sizeof(IdxT)) > (size_t)(2 * kCoopCap * 8 + kWave * 4) ? knn_lds_per_wave(cap, sizeof(IdxT)) : (size_t)(2 * kCoopCap * 8 + kWave * 4)) +
+           (size_t)kWave * 16 + (size_t)(kRecStage + 4) * 16;
+}
+
+template <class IdxT>
+__global__ __launch_bounds__(128) void corr_score_record2_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+                                                                 const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+                                                                 const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
+                                                                 int K, int cap, float sigma, int n_chunks, float* __restrict__ partial,
+                                                                 char* __restrict__ lat, unsigned int c_max, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const LatWs lw = lat_ws(c_max);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    uint4* queue = reinterpret_cast<uint4*>(lat + lw.total);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
+    char* my = lds + (size_t)wave * rec_lds_per_wave<IdxT>(cap);
+    const KnnLds<IdxT> L = carve_lds<IdxT>(my, 0, cap);
+    float4* stage = reinterpret_cast<float4*>(my + rec_lds_per_wave<IdxT>(cap) - (size_t)(kRecStage + 4) * 16);
+    float4* qs = stage - kWave;                                  // the record's queries (lane order)
+    const unsigned int n_rec = header[4];
+    const int n_tch = (Nt + kWave - 1) / kWave;
+    const float half_cell = 0.5f * fminf(1.0f / __uint_as_float(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox)[11]),
+                                         1.0f / __uint_as_float(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox)[12]));
+    const unsigned int n_wf = gridDim.x * (blockDim.x >> 6);
+    for (unsigned int r = blockIdx.x * (blockDim.x >> 6) + wave; r < n_rec; r += n_wf) {      // (static assignment: see DESIGN on the atomic-counter hang)
+        const uint4 rec = queue[r];
+        const int h = (int)rec.x, chunk = (int)rec.y;
+        const unsigned long long mask = ((unsigned long long)rec.w << 32) | rec.z;
+        const int slot = chunk * kWave + lane;
+        const bool live = ((mask >> lane) & 1ull) != 0ull && slot < Ns;
+        const unsigned long long live_m = __ballot(live);
+        if (live_m == 0ull || Nt < K) continue;
+        const int sidx = __float_as_int(S4s[slot < Ns ? slot : 0].w);
+        const float sx = src_pts[(size_t)sidx * 3], sy = src_pts[(size_t)sidx * 3 + 1], sz = src_pts[(size_t)sidx * 3 + 2];
+        const float* Th = T + (size_t)h * 16;
+        // (the same arithmetic as the other structures)
+        const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        const bool fin = live && fabsf(qx) < 1.0e18f && fabsf(qy) < 1.0e18f && fabsf(qz) < 1.0e18f;     // (NaN / inf images: not boxed)
+        if (!__any(fin)) continue;
+        // the box of the record's (finite) queries
+        const float bx0 = wave_minmax_f<false>(fin ? qx : 3.0e38f), bx1 = wave_minmax_f<true>(fin ? qx : -3.0e38f);
+        const float by0 = wave_minmax_f<false>(fin ? qy : 3.0e38f), by1 = wave_minmax_f<true>(fin ? qy : -3.0e38f);
+        const float bz0 = wave_minmax_f<false>(fin ? qz : 3.0e38f), bz1 = wave_minmax_f<true>(fin ? qz : -3.0e38f);
+        const float ccx = 0.5f * (bx0 + bx1), ccy = 0.5f * (by0 + by1), ccz = 0.5f * (bz0 + bz1);
+        const float hx = 0.5f * (bx1 - bx0), hy = 0.5f * (by1 - by0), hz = 0.5f * (bz1 - bz0);
+        const float hd = sqrtf(hx * hx + hy * hy + hz * hz);
+        float dkc;
+        {
+            unsigned long long* la = reinterpret_cast<unsigned long long*>(my);
+            unsigned long long* lb = la + kCoopCap;
+            unsigned int* chist = reinterpret_cast<unsigned int*>(lb + kCoopCap);
+            const int cntk = coop_knn(P4s, box, Nt, K, ccx, ccy, ccz, la, lb, chist, lane);
+            dkc = cntk >= K ? sqrtf(__uint_as_float((unsigned int)(la[K - 1] >> 32))) : 3.0e18f;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        if (!(dkc < 1.0e17f)) continue;
+        const float R = dkc + fminf(hd, fmaxf(0.5f * dkc, half_cell));
+        const float R2 = R * R;
+        const unsigned long long fin_m = __ballot(fin);
+        qs[lane] = make_float4(qx, qy, qz, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int n_s = 0;
+        for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+            const int ch = c0 + lane;
+            float t = 3.0e38f;
+            if (ch < n_tch) {
+                const float4 tlo = box[2 * ch], thi = box[2 * ch + 1];
+                const float dx = fmaxf(fmaxf(tlo.x - bx1, bx0 - thi.x), 0.f);
+                const float dy = fmaxf(fmaxf(tlo.y - by1, by0 - thi.y), 0.f);
+                const float dz = fmaxf(fmaxf(tlo.z - bz1, bz0 - thi.z), 0.f);
+                t = (dx * dx + dy * dy + dz * dz) * 0.9999f;          // (a chunk is skipped only if it is clearly out of reach)
+            }
+            unsigned long long pend = __ballot(t <= R2);
+            while (pend != 0ull) {
+                const int l = __ffsll((long long)pend) - 1;
+                pend &= pend - 1ull;
+                const int j = (c0 + l) * kWave + lane;
+                const float4 pt = P4s[j];                    // (the padded table makes reads up to Nt + 63 safe)
+                const float dx = fmaxf(fmaxf(bx0 - pt.x, pt.x - bx1), 0.f);
+                const float dy = fmaxf(fmaxf(by0 - pt.y, pt.y - by1), 0.f);
+                const float dz = fmaxf(fmaxf(bz0 - pt.z, pt.z - bz1), 0.f);
+                bool in = j < Nt && (dx * dx + dy * dy + dz * dz) * 0.9999f <= R2;
+                if (__any(in)) {
+                    // within R of some query of the record?  (queries broadcast from LDS)
+                    float best = 3.0e38f;
+                    for (unsigned long long todo = fin_m; todo != 0ull; todo &= todo - 1ull) {
+                        const float4 qq = qs[__ffsll((long long)todo) - 1];
+                        const float ex = qq.x - pt.x, ey = qq.y - pt.y, ez = qq.z - pt.z;
+                        best = fminf(best, ex * ex + ey * ey + ez * ez);
+                    }
+                    in = in && best * 0.9999f <= R2;
+                }
+                const unsigned long long bal = __ballot(in);
+                const int at = n_s + mbcnt(bal);
+                if (in && at < kRecStage) stage[at] = pt;
+                n_s += __popcll(bal);
+            }
+        }
+        if (dbg && lane == 0) { atomicAdd(&header[24], 1u); atomicAdd(&header[25], (unsigned int)(n_s < 100000 ? n_s : 100000)); }
+        if (n_s > kRecStage || n_s < K) continue;            // (overflow: the record stays as it is, for the query-by-query path)
+        if (lane < 4) stage[n_s + lane] = make_float4(kFar, kFar, kFar, __int_as_float(0x7fffffff));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int n_s4 = (n_s + 3) & ~3;
+        auto walk_s = [&](bool on, float, auto&& body) __attribute__((always_inline)) {
+            for (int u0 = 0; u0 < n_s4; u0 += 4) {
+                float d2[4];
+                float4 pt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 pp = stage[u0 + u];              // same address in every lane: broadcast reads
+                    const float dx = qx - pp.x;
+                    const float dy = qy - pp.y;
+                    const float dz = qz - pp.z;
+                    float t = dx * dx;
+                    t = t + dy * dy;
+                    t = t + dz * dz;
+                    d2[u] = t;
+                    pt[u].w = pp.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(d2[u], pt[u], u0 + u, on);   // padding = far points: never admitted
+            }
+        };
+        LaneSel S;
+        S.nlev = 1;
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l) { S.lo[l] = 0.f; S.sc[l] = 0.f; S.bs[l] = kBins - 1; }
+        {
+            // the K nearest of the centre lie within d_K(c) + |q - c| of q; beyond R the stage is not complete anyway
+            const float ex = qx - ccx, ey = qy - ccy, ez = qz - ccz;
+            const float rq = fminf(R, (dkc + sqrtf(ex * ex + ey * ey + ez * ez)) * 1.0001f + 1e-5f);
+            S.hi0 = fin ? rq * rq : 1.0f;
+        }
+        S.sc[0] = (float)kBins / S.hi0;
+        bool done = !fin, starved;
+        int found;
+        refine_loop(walk_s, S, done, true, K, cap, L.hist, lane, starved, found);
+        int cnt = append_pass(walk_s, S, fin, K, cap, L.list, lane);
+        // a posteriori: K neighbours, the farthest of them clearly inside R (whatever is not staged is farther than R)
+        float d2k = 0.f;
+        for (int e = 0; e < K; ++e)
+            if (e < cnt) d2k = fmaxf(d2k, __uint_as_float(L.list.d2[e * kWave + lane]));
+        const bool pass = fin && cnt == K && sqrtf(d2k) * 1.0001f + 1e-5f <= R;
+        cnt = pass ? cnt : 0;
+        const float total = score_epilogue(L.list, cnt, pass, sidx, vp4, vq4, K, sigma, lane);
+        const unsigned long long left = live_m & ~__ballot(pass);
+        if (lane == 0) {
+            partial[(size_t)h * n_chunks + chunk] += total;       // every record has one writer at a time (stream order)
+            queue[r] = make_uint4(rec.x, rec.y, (unsigned int)left, (unsigned int)(left >> 32));
+            if (dbg) { atomicAdd(&header[26], (unsigned int)__popcll(live_m)); atomicAdd(&header[27], (unsigned int)__popcll(left)); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 __global__ __launch_bounds__(256) void leftover_sum_kernel(const char* __restrict__ lat, unsigned int c_max, FlatWs f, int n_chunks,
                                                            float* __restrict__ partial)
 {
@@ -2469,7 +3221,9 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     UMEREG_CHECK_LAUNCH("mean_rotation_kernel");
     hipLaunchKernelGGL(rotate_points_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, src_pts, Ns, (const float*)Rbar, rotated);
     UMEREG_CHECK_LAUNCH("rotate_points_kernel");
-    if (int rc = launch_prep(rotated, ws_src, 1, Ns, -(float)K, st)) return rc;
+    // (compact 64-point chunks where the consensus pass runs; the per-lane grid walk of small jobs keeps the row-aligned strips)
+    const bool curve_src = consensus_on(lattice_cells_for((long)M * Ns, Nt, flags), M, flags, T) && !(flags & UMEREG_CORR_SRC_ROWS);
+    if (int rc = launch_prep(rotated, ws_src, 1, Ns, -(float)K, st, curve_src ? 1 : 0)) return rc;
     int cap, waves;
     size_t lds;
     bool idx16;
@@ -2518,12 +3272,27 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(hyp_order_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, T, M, (const float*)Tmed, (const float4*)centroid,
                            (const int*)gperm, perm, inv);
         UMEREG_CHECK_LAUNCH("hyp_order_chunk_kernel");
-        hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
-                           (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
-                           (const int*)perm, Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
-        UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
+        if (flags & UMEREG_CORR_CONSENSUS_V1) {
+            hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
+                               (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
+                               (const int*)perm, Ns, Nt, M, K, cap, sigma, val, served, (unsigned int*)lat + 7);
+            UMEREG_CHECK_LAUNCH("corr_consensus_kernel");
+        } else {
+            // images in empty parts of the target stage the ball of radius d_K + margin (in grid cells; flags bits 8..15 in
+            // eighths of a cell, 0 = default, 255 = such points give up as in the first form)
+            const int mf = (flags >> UMEREG_CORR_FAR_MARGIN_SHIFT) & 0xff;
+            const float far_margin = mf == 0 ? kConsFarMarginCells : (mf == 0xff ? 0.f : (float)mf * 0.125f);
+            hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
+            UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+            hipLaunchKernelGGL(corr_consensus2_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons2_lds_per_wave(), st,
+                               (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
+                               (const int*)perm, Ns, Nt, M, K, sigma, far_margin, val, served, (unsigned int*)lat + 7,
+                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0);
+            UMEREG_CHECK_LAUNCH("corr_consensus2_kernel");
+        }
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
-        hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns);
+        hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns,
+                           (flags & UMEREG_CORR_LEFT_COOP) ? 1 : ((flags & UMEREG_CORR_LEFT_LATTICE) ? 2 : 0));
         UMEREG_CHECK_LAUNCH("leftover_decide_kernel");
         if (hipMemsetAsync(partial, 0, (size_t)M * n_chunks_sz * 4, st) != hipSuccess) { set_error("hipMemsetAsync(partial) failed"); return UMEREG_ELAUNCH; }
         hipLaunchKernelGGL(leftover_queue_kernel, dim3((unsigned)(((long)n_chunks * n_words + 3) / 4)), dim3(256), 0, st, (const char*)ws_src, Ns, M,
@@ -2567,6 +3336,23 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // ... as a flat list of queries when they fit (header word 12 marks that the flat path ran), record by record otherwise
         char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
         const FlatWs fw = flat_ws(flat_base, (size_t)M * n_chunks_sz, (long)M * Ns);
+        if ((flags & UMEREG_CORR_RECORD_STAGE) && !(flags & UMEREG_CORR_NO_FLAT)) {
+            // first one wavefront per record (a staged set of the record's neighbours, one lane per query); the records keep the lanes it could not serve
+            int rcap, rwaves;
+            size_t rlds;
+            bool r16;
+            knn_lds_plan(K, Nt, &rcap, &rwaves, &rlds, 2, &r16);
+            const int dbg = (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0;
+            if (r16)
+                hipLaunchKernelGGL(corr_score_record2_kernel<unsigned short>, dim3(4096), dim3(2 * kWave), 2 * rec_lds_per_wave<unsigned short>(rcap), st,
+                                   (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, rcap,
+                                   sigma, n_chunks, partial, lat, c_max, dbg);
+            else
+                hipLaunchKernelGGL(corr_score_record2_kernel<unsigned int>, dim3(4096), dim3(2 * kWave), 2 * rec_lds_per_wave<unsigned int>(rcap), st,
+                                   (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, rcap,
+                                   sigma, n_chunks, partial, lat, c_max, dbg);
+            UMEREG_CHECK_LAUNCH("corr_score_record2_kernel");
+        }
         if (!(flags & UMEREG_CORR_NO_FLAT)) {
             hipLaunchKernelGGL(leftover_flatten_kernel, dim3(256), dim3(256), 0, st, lat, c_max, fw);
             UMEREG_CHECK_LAUNCH("leftover_flatten_kernel");

@@ -29,7 +29,8 @@ FEATURE_KEYS = ("src_feat", "tgt_feat")
 
 
 def load_pickle(filename):
-    """reference utils/general_utils.py:16-19"""
+    """reference utils/general_utils.py:16-19.  The cache format IS a pickle (kitti_dataset.py:647-657), and unpickling
+    executes what the file says: read cache files only from a source you trust (your own preprocessing run)."""
     with open(filename, "rb") as f:
         return pickle.load(f)
 
@@ -103,60 +104,88 @@ def sparse_collate(coords, feats):
     return torch.cat(bcoords, dim=0), torch.cat(bfeats, dim=0)
 
 
+class _Dilution:
+    """One cloud of one batch element thinned to `size` points: the draw (`rng.choice(n, size, replace=False)`, the call the
+    reference makes at kitti_dataset.py:571 / :579) and the inverse map original index -> position in the thinned cloud
+    (-1: dropped), which is what the match bookkeeping below needs."""
+
+    def __init__(self, n, size, rng):
+        self.keep = rng.choice(n, size, replace=False)
+        self.position = np.full(n, -1, dtype=np.int64)
+        self.position[self.keep] = np.arange(size, dtype=np.int64)
+
+    def __call__(self, *fields):
+        return tuple(f[self.keep] for f in fields)
+
+
+def surviving_matches(matches, src, tgt):
+    """The correspondences (source index, target index) whose two end points both survive the dilutions `src` / `tgt`,
+    re-indexed into the thinned clouds -- the result of the reference's two `np.intersect1d(..., return_indices=True)` calls
+    (kitti_dataset.py:585-589), expressed through the inverse maps:
+      * a source point keeps only its first correspondence (in file order); candidates are visited in ascending source index;
+      * a target point keeps only the first of those candidates; rows come out in ascending target index."""
+    matches = np.asarray(matches)
+    _, first_of_src = np.unique(matches[:, 0], return_index=True)              # ascending source index, first occurrence
+    rows = first_of_src[src.position[matches[first_of_src, 0]] >= 0]
+    _, first_of_tgt = np.unique(matches[rows, 1], return_index=True)           # ascending target index, first candidate
+    rows = rows[first_of_tgt]
+    rows = rows[tgt.position[matches[rows, 1]] >= 0]
+    return np.stack([src.position[matches[rows, 0]], tgt.position[matches[rows, 1]]], axis=1)
+
+
 def batch_collate_fn_dset(data, num_matches, max_pc_size=100000, rng=np.random):
-    """reference datasets/kitti/kitti_dataset.py:546-616.
+    """The loader output contract of reference datasets/kitti/kitti_dataset.py:546-616 (what evaluate.py:175-178 unpacks).
     data: list of items (src_pts, src_sem, src_coords, tgt_pts, tgt_sem, tgt_coords, src_pts_tform, gt_tform, matches
-    [, src_feat, tgt_feat]).  Every cloud of the batch is diluted to the batch-minimum size (at most max_pc_size) by
-    `rng.choice(n, size, replace=False)` -- source then target, element by element, then one draw per element for the
-    matches: the reference's order on the reference's (global numpy) stream.
+    [, src_feat, tgt_feat]).  Every cloud of the batch is thinned to the batch-minimum size (at most max_pc_size).  The
+    host RNG is consumed in the reference's order, on the reference's (global numpy) stream by default: per element the
+    source draw, then the target draw; after the loop one draw per element for the matches.
     -> (src_pts [bs,n,3], src_seg [bs,n], src_coords [bs*n,4], src_feat [bs*n,1] (ones: the network's input),
         tgt_pts, tgt_seg, tgt_coords, tgt_feat, src_pts_tform [bs,n,3], gt_tform [bs,4,4], matches [bs,k,2])
        + (src_net_feat [bs,n,d], tgt_net_feat [bs,m,d]) when the items carry features."""
-    bs = len(data)
     with_feat = len(data[0]) > 9
-    src_pts, src_seg, src_coords, src_feat, tgt_pts, tgt_seg, tgt_coords, tgt_feat = [], [], [], [], [], [], [], []
-    src_pts_tform, matches, src_net, tgt_net = [], [], [], []
-    src_num_pts = min(min(len(d[0]) for d in data), max_pc_size)               # :565-566
-    tgt_num_pts = min(min(len(d[3]) for d in data), max_pc_size)
-    for b_idx in range(bs):
-        d = data[b_idx]
-        src_rand_idx = rng.choice(len(d[0]), src_num_pts, replace=False)        # :571
-        src_pts.append(d[0][src_rand_idx])
-        src_seg.append(d[1][src_rand_idx])
-        src_coords.append(d[2][src_rand_idx])
-        src_feat.append(torch.ones_like(d[0][src_rand_idx, :1]).float())
-        src_pts_tform.append(d[6][src_rand_idx])
-        tgt_rand_idx = rng.choice(len(d[3]), tgt_num_pts, replace=False)        # :579
-        tgt_pts.append(d[3][tgt_rand_idx])
-        tgt_seg.append(d[4][tgt_rand_idx])
-        tgt_coords.append(d[5][tgt_rand_idx])
-        tgt_feat.append(torch.ones_like(d[3][tgt_rand_idx, :1]).float())
-        if with_feat:
-            src_net.append(d[9][src_rand_idx])
-            tgt_net.append(d[10][tgt_rand_idx])
-        # matches that survive the dilution, re-indexed into the diluted clouds (:585-589)
-        m = np.asarray(d[8])
-        _, m1, idxs1 = np.intersect1d(src_rand_idx, m[:, 0], return_indices=True)
-        _, m2, idxs2 = np.intersect1d(tgt_rand_idx, m[idxs1, 1], return_indices=True)
-        matches.append(np.concatenate([m1[idxs2, None], m2[:, None]], axis=1))
-    src_coords, src_feat = sparse_collate(src_coords, src_feat)                 # :593
-    tgt_coords, tgt_feat = sparse_collate(tgt_coords, tgt_feat)                 # :599
-    gt_tform = torch.stack([d[7] for d in data], dim=0)
-    num_matches = min(min(len(m) for m in matches), num_matches)                 # :606-607
-    matches = torch.stack([torch.from_numpy(m[rng.choice(len(m), num_matches, replace=False)]) for m in matches], dim=0)
-    out = (torch.stack(src_pts, dim=0), torch.stack(src_seg, dim=0), src_coords, src_feat,
-           torch.stack(tgt_pts, dim=0), torch.stack(tgt_seg, dim=0), tgt_coords, tgt_feat,
-           torch.stack(src_pts_tform, dim=0), gt_tform, matches)
+    n_src = min(min(len(d[0]) for d in data), max_pc_size)                     # :565-566
+    n_tgt = min(min(len(d[3]) for d in data), max_pc_size)
+    sides = {"src": [], "tgt": []}                                             # per element: (pts, seg, coords, ones[, net feature])
+    moved, kept_matches = [], []
+    for d in data:
+        src = _Dilution(len(d[0]), n_src, rng)                                 # :571
+        tgt = _Dilution(len(d[3]), n_tgt, rng)                                 # :579
+        for name, dil, first, feat_at in (("src", src, 0, 9), ("tgt", tgt, 3, 10)):
+            pts, seg, coords = dil(d[first], d[first + 1], d[first + 2])
+            fields = (pts, seg, coords, torch.ones_like(pts[:, :1]).float())
+            sides[name].append(fields + (dil(d[feat_at]) if with_feat else ()))
+        moved.append(src(d[6])[0])
+        kept_matches.append(surviving_matches(d[8], src, tgt))                 # :585-589
+
+    def batched(name):
+        pts, seg, coords, ones = (list(col) for col in list(zip(*sides[name]))[:4])
+        coords, ones = sparse_collate(coords, ones)                            # :593, :599
+        return torch.stack(pts, dim=0), torch.stack(seg, dim=0), coords, ones
+
+    k = min(min(len(m) for m in kept_matches), num_matches)                    # :606-607
+    matches = torch.stack([torch.from_numpy(m[rng.choice(len(m), k, replace=False)]) for m in kept_matches], dim=0)
+    out = batched("src") + batched("tgt") + (torch.stack(moved, dim=0), torch.stack([d[7] for d in data], dim=0), matches)
     if with_feat:
-        out = out + (torch.stack(src_net, dim=0), torch.stack(tgt_net, dim=0))
+        out = out + tuple(torch.stack([e[4] for e in sides[name]], dim=0) for name in ("src", "tgt"))
     return out
 
 
-def checkpoint_state_dict(path_or_obj):
+def checkpoint_state_dict(path_or_obj, allow_pickle=False):
     """The weight-file schema of reference train_coloring.py:214-222 as `evaluate.py:164` consumes it: a dict with
     'epoch', 'model_state_dict', 'optimizer_state_dict', 'total_loss'.  -> the model state dict (name -> tensor); raises
-    with the offending keys otherwise.  (Bare state dicts, `save_model` :209-211, are accepted as they are.)"""
-    ck = torch.load(path_or_obj, map_location="cpu", weights_only=False) if isinstance(path_or_obj, (str, os.PathLike)) else path_or_obj
+    with the offending keys otherwise.  (Bare state dicts, `save_model` :209-211, are accepted as they are.)
+    Files are read with torch's restricted unpickler (`weights_only=True`); a checkpoint that needs the full one (arbitrary
+    pickled objects = arbitrary code at load time) is refused unless `allow_pickle=True`: only for files you trust."""
+    if isinstance(path_or_obj, (str, os.PathLike)):
+        try:
+            # tensors, containers and scalars only: nothing in the file is executed
+            ck = torch.load(path_or_obj, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError:
+            if not allow_pickle:
+                raise
+            ck = torch.load(path_or_obj, map_location="cpu", weights_only=False)     # full unpickler: trusted files only
+    else:
+        ck = path_or_obj
     if not isinstance(ck, dict):
         raise TypeError(f"checkpoint: expected a dict, got {type(ck).__name__}")
     if "model_state_dict" in ck:

@@ -327,7 +327,8 @@ class RegistrationPipeline:
         # tensors of a pair are valid until the same (slot, PairBatch) is submitted again, its rtume_tform / g_index (slot
         # buffers) until the slot's next finish(): consume or clone them before submitting `depth` more pairs.
         self.use_graphs = use_graphs
-        self.graphs = {}
+        self.graphs = {}                 # (slot, id(pair)) -> (PairMatchGraph, pair), least recently used first
+        self.max_graphs = 64
         self.pool = None
         if threaded_draw:
             from concurrent.futures import ThreadPoolExecutor
@@ -367,8 +368,48 @@ class RegistrationPipeline:
         if self.in_flight[k]:
             raise RuntimeError(f"RegistrationPipeline: slot {k} still holds an unfinished pair -- at most depth={self.depth} "
                                "pairs may be submitted before their finish() (its pinned buffers would be overwritten)")
+        a = self._submit_slot(k, src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds, timing, pair, rng)
+        # the slot is taken only once the pair is really enqueued: a submit that raised (graph capture, a bad argument, the
+        # host-side Hungarian step) leaves the pipeline usable
         self.in_flight[k] = True
         self.n_submitted += 1
+        return a
+
+    def _graph_for(self, k, pair):
+        """The captured phase A of `pair` on slot k.  A cached graph is replayed only if every buffer it was captured over
+        (address, shape, dtype of pts / feat / inds) and every baked-in parameter (K, radius, tau) is the one asked for now:
+        `id(pair)` alone is not an identity (CPython reuses ids, and a PairBatch's tensors can be reassigned)."""
+        args = self.args
+        tau = args.tau if args.filter_by_ume_dist_cond else None
+        key = (k, id(pair))
+        entry = self.graphs.get(key)
+        if entry is not None:
+            graph, owner = entry
+            if owner is pair and graph.matches(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau):
+                self.graphs[key] = self.graphs.pop(key)                 # most recently used last
+                return graph
+            self._retire(key)
+        if len(self.graphs) >= self.max_graphs:
+            # least recently used first; a graph whose slot has a pair in flight is still referenced by that pair's handle
+            # and may be running: only idle slots' graphs go, after their stream has drained
+            for old in list(self.graphs):
+                if len(self.graphs) < self.max_graphs:
+                    break
+                if not self.in_flight[old[0]]:
+                    self._retire(old)
+        with torch.cuda.stream(self.streams[k]):
+            # buffers owned by the graph are allocated under the slot's stream: that is the stream its kernels run on, so
+            # the caching allocator cannot hand them to somebody else while a replay is in flight
+            graph = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau)
+        self.graphs[key] = (graph, pair)          # the strong reference keeps id(pair) from being reused while the entry lives
+        return graph
+
+    def _retire(self, key):
+        entry = self.graphs.pop(key, None)
+        if entry is not None:
+            self.streams[key[0]].synchronize()    # the exec may still be running on its slot's stream
+
+    def _submit_slot(self, k, src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds, timing, pair, rng):
         st = self.streams[k]
         rng = rng if rng is not None else self.rng
         if pair is not None:
@@ -382,13 +423,7 @@ class RegistrationPipeline:
         graph = None
         if self.use_graphs and pair is not None and timing is None and ops.DEFAULT_MATCH_PRECISION == "f16r" \
                 and not getattr(self.args, "hungarian_matching_flag", False):
-            key = (k, id(pair))
-            graph = self.graphs.get(key)
-            if graph is None or graph.pts is not pair.pts:
-                if len(self.graphs) > 64:
-                    self.graphs.clear()
-                graph = self.graphs[key] = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, self.args.ume_max_nn, self.args.ume_r_nn,
-                                                              self.args.tau if self.args.filter_by_ume_dist_cond else None)
+            graph = self._graph_for(k, pair)
         if graph is not None and self.pool is None and torch.cuda.current_device() == self.dev.index:
             # graph fast path: replay + probability download in one native call on the slot's stream, no torch stream /
             # device contexts, a per-slot event (the host side of a pair is as long as its GPU side: every 10 us count)
@@ -544,7 +579,9 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
         if overlap and dev.type == "cuda":
             if streams is None:
                 # (kept per device: the native workspaces are per stream, a fresh pair of streams per call would allocate anew)
-                streams = _OVERLAP_STREAMS.setdefault(dev, [torch.cuda.Stream(dev), torch.cuda.Stream(dev)])
+                streams = _OVERLAP_STREAMS.get(dev)
+                if streams is None:
+                    streams = _OVERLAP_STREAMS[dev] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
             st = streams[k % 2]
             st.wait_stream(torch.cuda.current_stream(dev))      # the pair's tensors were made on the caller's stream
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):

@@ -489,6 +489,9 @@ def corr_weighted_features(src_feat, tgt_feat, src_w, tgt_w):
 
 
 CORR_NO_LATTICE, CORR_FORCE_LATTICE, CORR_NO_CONSENSUS, CORR_FORCE_CONSENSUS, CORR_NO_FLAT = 1, 2, 4, 8, 16
+CORR_CONSENSUS_V1, CORR_DEBUG_STATS, CORR_FAR_MARGIN_SHIFT = 32, 64, 8      # include/umereg.h
+CORR_SRC_ROWS, CORR_RECORD_STAGE = 128, 256
+CORR_LEFT_COOP, CORR_LEFT_LATTICE = 1 << 16, 1 << 17
 
 
 def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None, flags=0):
@@ -603,6 +606,9 @@ class PairMatchGraph:
         N, n = self.pts.shape[1], self.kp_index.shape[1]
         dev = self.pts.device
         self.dev = dev
+        # what the captured kernels were recorded against: replaying the graph for anything else would silently compute
+        # from the old buffers / parameters (see `matches`)
+        self.signature = self.signature_of(self.pts, self.feat, self.kp_index, K, radius, tau)
         self.F = torch.empty((2, n, 32, 4), dtype=torch.float32, device=dev)
         self.m = torch.empty((1, n), dtype=torch.int64, device=dev)
         self.d = torch.empty((1, n), dtype=torch.float32, device=dev)
@@ -619,6 +625,16 @@ class PairMatchGraph:
                                                     ctypes.byref(handle))
         _lib.check(rc, "umereg_pair_match_graph_create")
         self.handle = handle
+
+    @staticmethod
+    def signature_of(pts, feat, kp_index, K, radius, tau):
+        """(address, shape, dtype) of every captured input buffer + the scalar parameters baked into the graph."""
+        return tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in (pts, feat, kp_index)) + \
+            (int(K), float(radius), None if tau is None else float(tau))
+
+    def matches(self, pts, feat, kp_index, K, radius, tau):
+        """True if replaying this graph computes a1..a5 of exactly these buffers with these parameters."""
+        return self.handle is not None and self.signature == self.signature_of(pts, feat, kp_index, K, radius, tau)
 
     def launch(self):
         with torch.cuda.device(self.dev):
