@@ -12,8 +12,9 @@
  *     tensors are dense, row-major, batch-first, fp32 values / int64 indices, exactly the
  *     layouts the reference's torch tensors have;
  *   - the library never allocates or frees device memory: outputs and workspaces are caller
- *     owned (size queries: *_workspace_bytes); no global mutable state except the
- *     thread-local last-error string;
+ *     owned (size queries: *_workspace_bytes); the only mutable state is the thread-local
+ *     last-error string and the four process-wide matcher knobs of umereg_ume_match_set_tuning /
+ *     umereg_ume_match_set_variant (atomics; experiments and tests only, defaults otherwise);
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous
  *     with respect to the host and re-entrant;
  *   - return value: UMEREG_OK (0) or a negative UMEREG_E* code; umereg_last_error() gives the
@@ -54,6 +55,9 @@ enum {
 };
 
 int umereg_abi_version(void);
+/* sha256 (64 hex digits) of the HIP sources, headers and compiler flags this library was compiled from; the build
+ * recipe (umeregrobust_amd/_build.py) rebuilds an in-tree library whose hash differs from the tree's */
+const char* umereg_build_source_hash(void);
 const char* umereg_last_error(void);
 /* number of visible HIP devices; fills name (may be NULL) with device 0's gcnArchName */
 int umereg_device_count(char* arch_name, size_t arch_name_len);
@@ -169,8 +173,8 @@ size_t umereg_ume_match_q_scratch_bytes(int n1, int n2);
 int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
                             int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
                             void* stream);
-/* Tuning / test knobs of the filter + refine matcher, process-wide (no environment variables are read by this
- * library): splits = target splits of the coarse pass (0: automatic; it changes umereg_ume_match_q_scratch_bytes, so
+/* Tuning / test knobs of the filter + refine matcher, process-wide atomics (no environment variables are read by this
+ * library; a matcher call reads each knob once, so a concurrent change is seen whole or not at all): splits = target splits of the coarse pass (0: automatic; it changes umereg_ume_match_q_scratch_bytes, so
  * set it before the size query), share_mask = limit-sharing schedule (-1: default), force_exhaustive != 0: refine every
  * block of rows exhaustively (a parity test uses it). */
 int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive);
@@ -364,7 +368,7 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
 #define UMEREG_CORR_FAR_MARGIN_SHIFT 8 /* bits 8..15: margin of the stage of an image in an empty region, in eighths of a grid cell
                                           (0 = default, 255 = such source points are left to the lattice) */
 #define UMEREG_CORR_SRC_ROWS 128 /* source points processed in row-major cell order (round 2) instead of Hilbert-curve order */
-#define UMEREG_CORR_RECORD_STAGE 256 /* (experimental) the queries neither pass serves first go one wavefront per RECORD over a staged candidate set; what that cannot serve goes one wavefront per query as before */
+#define UMEREG_CORR_RECORD_STAGE (1 << 18) /* (experimental) the queries neither pass serves first go one wavefront per RECORD over a staged candidate set; what that cannot serve goes one wavefront per query as before */
 #define UMEREG_CORR_LEFT_COOP (1 << 16)    /* what the consensus pass leaves goes to the one-wavefront-per-query search whatever its size */
 #define UMEREG_CORR_LEFT_LATTICE (1 << 17) /* ... to the candidate lattice whatever its size (by default the count decides) */
 size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);

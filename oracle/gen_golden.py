@@ -390,6 +390,7 @@ def main():
 
     gen_g8(loc_utils, eval_utils)
     gen_g9(loc_utils, evaluate)
+    gen_g10()                       # (the default run rebuilds EVERY fixture; `--only g9|g10`, `g8` rebuild one)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -21,6 +21,7 @@ c_double = ctypes.c_double
 # name -> (restype, argtypes); mirrors include/umereg.h one to one
 SIGNATURES = {
     "umereg_abi_version": (c_int, []),
+    "umereg_build_source_hash": (ctypes.c_char_p, []),
     "umereg_last_error": (ctypes.c_char_p, []),
     "umereg_device_count": (c_int, [ctypes.c_char_p, c_size_t]),
     "umereg_ball_query_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -33,6 +33,14 @@ int check_device()
 
 UMEREG_API int umereg_abi_version(void) { return UMEREG_ABI_VERSION; }
 
+#ifndef UMEREG_SOURCE_HASH
+#define UMEREG_SOURCE_HASH "0000000000000000000000000000000000000000000000000000000000000000"   /* built outside _build.py */
+#endif
+// "UMEREG_SRC_HASH=<sha256 of the sources, headers and flags this library was compiled from>": findable in the file
+// without loading it (umeregrobust_amd/_build.py: embedded_hash)
+extern "C" __attribute__((visibility("default"), used)) const char umereg_src_hash_record[] = "UMEREG_SRC_HASH=" UMEREG_SOURCE_HASH;
+UMEREG_API const char* umereg_build_source_hash(void) { return umereg_src_hash_record + 16; }
+
 UMEREG_API const char* umereg_last_error(void) { return umereg::g_err; }
 
 UMEREG_API int umereg_device_count(char* arch_name, size_t arch_name_len)

@@ -19,6 +19,7 @@
 // tiles; operands arrive in fragment order (ortho.hip), i.e. as coalesced 1 KiB dwordx4 loads,
 // with no LDS staging (K = 32 is a single MFMA k-sweep, nothing to re-use across waves that
 // the L1/L2 do not already serve).
+#include <atomic>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -965,16 +966,18 @@ struct CoarsePlan {
     int n_ablk, n_blocks, n_btiles, splits, tiles_per_split;
 };
 // explicit tuning knobs of the filter + refine matcher (umereg_ume_match_set_tuning; process-wide, set them before the
-// scratch-size query of the calls they should affect).  0 / -1 = automatic.
-static int g_tune_splits = 0;
-static long g_tune_share_mask = -1;
-static int g_tune_exhaustive = 0;
+// scratch-size query of the calls they should affect).  0 / -1 = automatic.  Atomics: a setter may race with matcher calls
+// on other host threads without tearing (each call reads every knob once, in coarse_plan / carve_scratch); a call that
+// overlaps a change sees the old or the new value -- change them only between calls if the scratch size depends on them.
+static std::atomic<int> g_tune_splits{0};
+static std::atomic<long> g_tune_share_mask{-1};
+static std::atomic<int> g_tune_exhaustive{0};
 
 // umereg_ume_match_set_variant(1) selects the P-form coarse kernel (one inner product per pair, no squares) instead of
 // the Q-form one.  Bit-identical results; 11 % faster as a stage on MI355X but 4 % slower in the pipelined path, where it
 // leaves no room on the CUs for the kernels of the other pairs in flight: kept as a variant.
-static int g_match_variant = 0;
-static bool use_pform() { return g_match_variant == 1; }
+static std::atomic<int> g_match_variant{0};
+static bool use_pform() { return g_match_variant.load(std::memory_order_relaxed) == 1; }
 constexpr int kNumCU = 256;   // MI355X
 
 static CoarsePlan coarse_plan(int n1, int n2)
@@ -991,7 +994,7 @@ static CoarsePlan coarse_plan(int n1, int n2)
         p.n_blocks = p.n_ablk * kDistWaves;
         splits = (2560 + p.n_ablk - 1) / p.n_ablk;   // ~10 workgroups per CU
     }
-    if (g_tune_splits > 0) splits = g_tune_splits;   // umereg_ume_match_set_tuning
+    if (const int ts = g_tune_splits.load(std::memory_order_relaxed); ts > 0) splits = ts;   // umereg_ume_match_set_tuning
     if (splits > kMaxSplits) splits = kMaxSplits;
     if (splits > p.n_btiles) splits = p.n_btiles;
     if (splits < 1) splits = 1;
@@ -1056,8 +1059,8 @@ static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
     ms.cand = ms.cnt + (size_t)p.n_blocks * p.splits;
     ms.splits = p.splits;
     ms.share_mask = kShareMask;
-    ms.force_exhaustive = g_tune_exhaustive ? 1 : 0;
-    if (g_tune_share_mask >= 0) ms.share_mask = (unsigned int)g_tune_share_mask;
+    ms.force_exhaustive = g_tune_exhaustive.load(std::memory_order_relaxed) ? 1 : 0;
+    if (const long sm = g_tune_share_mask.load(std::memory_order_relaxed); sm >= 0) ms.share_mask = (unsigned int)sm;
     return ms;
 }
 static half8* pfrag_rows(void* scratch, int n1, const CoarsePlan& p) { return (half8*)((char*)scratch + cand_bytes(n1, p)); }
@@ -1453,15 +1456,15 @@ UMEREG_API int umereg_pair_match_graph_destroy(void* graph)
 UMEREG_API int umereg_ume_match_set_variant(int variant)
 {
     if (variant != 0 && variant != 1) { set_error("ume_match_set_variant: unknown variant %d (0 = Q-form, 1 = P-form)", variant); return UMEREG_EINVAL; }
-    g_match_variant = variant;
+    g_match_variant.store(variant, std::memory_order_relaxed);
     return UMEREG_OK;
 }
 
 UMEREG_API int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive)
 {
     if (splits < 0 || force_exhaustive < 0) { set_error("ume_match_set_tuning: negative argument"); return UMEREG_EINVAL; }
-    g_tune_splits = splits;
-    g_tune_share_mask = share_mask;
-    g_tune_exhaustive = force_exhaustive;
+    g_tune_splits.store(splits, std::memory_order_relaxed);
+    g_tune_share_mask.store(share_mask, std::memory_order_relaxed);
+    g_tune_exhaustive.store(force_exhaustive, std::memory_order_relaxed);
     return UMEREG_OK;
 }

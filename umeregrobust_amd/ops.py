@@ -490,7 +490,7 @@ def corr_weighted_features(src_feat, tgt_feat, src_w, tgt_w):
 
 CORR_NO_LATTICE, CORR_FORCE_LATTICE, CORR_NO_CONSENSUS, CORR_FORCE_CONSENSUS, CORR_NO_FLAT = 1, 2, 4, 8, 16
 CORR_CONSENSUS_V1, CORR_DEBUG_STATS, CORR_FAR_MARGIN_SHIFT = 32, 64, 8      # include/umereg.h
-CORR_SRC_ROWS, CORR_RECORD_STAGE = 128, 256
+CORR_SRC_ROWS, CORR_RECORD_STAGE = 128, 1 << 18
 CORR_LEFT_COOP, CORR_LEFT_LATTICE = 1 << 16, 1 << 17
 
 
