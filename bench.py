@@ -494,7 +494,7 @@ def main():
         if a.e2e_side_by_side > a.e2e_in_flight:
             result["end_to_end"]["side_by_side"] = side_by_side(e2e_leg(pool, a.e2e_pairs, 500000, "", a.e2e_side_by_side))
         result["end_to_end"]["evaluate_pairs_loop"] = api_loop(pool, a.e2e_pairs, 510000)
-    hard_pool = None
+    hard_pool = hard_pool_first = None
     if not a.no_e2e and a.e2e_hard_pairs > 0:
         hard_pool = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))
                      for i in range(min(4, a.e2e_hard_pairs))]
@@ -503,7 +503,16 @@ def main():
                                             "sigma = 2 cm point noise, 20 % corrupted features", a.e2e_in_flight)
         if a.e2e_side_by_side > a.e2e_in_flight:
             result["end_to_end_hard"]["side_by_side"] = side_by_side(e2e_leg(hard_pool, a.e2e_hard_pairs, 600000, "", a.e2e_side_by_side))
+        hard_pool_first = hard_pool[0]
         del hard_pool
+
+    # ---- f1 (hypothesis selection) on its own: stage times by HIP events inside the native call, the consensus pass's step
+    # statistics, and the counters of the tracked rocprofv3 passes -- what DESIGN 3.6 quotes, recomputable from profiles/ ----
+    if rank == 0 and not a.no_e2e and a.e2e_pairs > 0:
+        f1 = {"plain": f1_profile(evaluate, ops, torch, pool[0], args, dev)}
+        if hard_pool_first is not None:
+            f1["hard"] = f1_profile(evaluate, ops, torch, hard_pool_first, args, dev)
+        result["f1_selection"] = f1
 
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -546,6 +555,62 @@ def main():
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+
+
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0     # wave64 VALU instructions per ns the chip can issue: 1024 SIMDs x 2.4 GHz / 4 cycles each
+
+
+def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
+    """reference utils/loc_utils.py:656-681 on one resident pair, the way evaluate.select_hypothesis feeds it (network points
+    as raw clouds, pc_corr_max_size sub-sample, weighted features): per-stage HIP-event times of the native call, the
+    consensus pass's statistics (one extra, untimed call with UMEREG_CORR_DEBUG_STATS) and the tracked SQ counters."""
+    from umeregrobust_amd.utils.loc_utils import feature_spatial_var
+    with torch.no_grad():
+        out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=np.random.RandomState(0),
+                                     src_inds=e.src_inds, tgt_inds=e.tgt_inds)
+        T = out.rtume_tform[0].contiguous()
+        rs = np.random.RandomState(1)
+        n = min(args.pc_corr_max_size, e.src_pts.shape[1])
+        si = torch.from_numpy(rs.choice(e.src_pts.shape[1], n, replace=False)).to(dev)
+        ti = torch.from_numpy(rs.choice(e.tgt_pts.shape[1], n, replace=False)).to(dev)
+        sp, tp = e.src_pts[0, si].contiguous(), e.tgt_pts[0, ti].contiguous()
+        sf, tf = e.src_feat[0, si].contiguous(), e.tgt_feat[0, ti].contiguous()
+        w = feature_spatial_var(torch.stack([sp, tp]), torch.stack([sf, tf]), knn=50)
+        wsf, wtf = ops.corr_weighted_features(sf, tf, w[0], w[1])
+        kw = dict(K=20, sigma=float(args.corr_kernel_sigma))
+        ops.corr_scores_profile(sp, tp, wsf, wtf, T, **kw)
+        acc = None
+        for _ in range(reps):
+            _, st, hdr = ops.corr_scores_profile(sp, tp, wsf, wtf, T, **kw)
+            acc = st if acc is None else {k: acc[k] + v for k, v in st.items()}
+        stages = {k: round(v / reps, 4) for k, v in acc.items()}
+        _, _, h = ops.corr_scores_profile(sp, tp, wsf, wtf, T, flags=ops.CORR_DEBUG_STATS, **kw)
+    M, Ns = int(T.shape[0]), int(sp.shape[0])
+    queries = M * Ns
+    steps_a, zone_a, steps_b, zone_b, zoomed = int(h[19]), int(h[20]), int(h[21]), int(h[22]), int(h[23])
+    visits = 64.0 * (float(h[28]) + float(h[29]))
+    res = {"queries": queries, "hypotheses": M, "points_per_cloud": Ns, "stage_ms": stages,
+           "served_by_the_consensus_pass": int(h[7]), "served_frac": round(int(h[7]) / queries, 5),
+           "left_to": ("one_wavefront_per_query" if int(h[8]) else "candidate_lattice"), "left_queries": int(h[9]),
+           "consensus_pass": {"source_points_staged_near": int(h[16]), "source_points_staged_in_empty_regions": int(h[17]),
+                              "avg_staged_target_points": round(float(h[18]) / max(int(h[16]) + int(h[17]), 1), 1),
+                              "steps_rank_counting": steps_a, "avg_zone_rank_counting": round(zone_a / max(steps_a, 1), 2),
+                              "steps_histogram": steps_b, "avg_zone_histogram": round(zone_b / max(steps_b, 1), 2), "steps_zoomed": zoomed,
+                              "candidate_slot_visits": visits, "visits_per_query": round(visits / queries, 2),
+                              "minimum_visits_K_per_query": 20.0 * queries,
+                              "reference_brute_force_distance_tests": float(queries) * float(tp.shape[0])},
+           "note": "stage_ms: HIP events recorded inside umereg_corr_scores_profile_f32 on the launch stream, mean of "
+                   f"{reps} calls; the statistics come from one more call with UMEREG_CORR_DEBUG_STATS (not timed)"}
+    sq = os.path.join(REPO, "profiles", "f1_sq_summary.json")
+    if os.path.exists(sq):
+        res["kernels"] = {}
+        which = "hard" if int(h[17]) > 0 else "plain"
+        tracked = json.load(open(sq)).get(which, {})
+        for k, v in tracked.items():
+            res["kernels"][k] = dict(v, bound="valu_issue", peak_valu_ginst_per_s=round(VALU_ISSUE_PEAK_GINST, 1),
+                                     counters_source="profiles/f1_sq_summary.json (rocprofv3 --pmc SQ passes of tools/exp_f1_prod.py, "
+                                                     "an earlier run of the same kernels; tools/f1_pmc.sh)")
+    return res
 
 
 def cpu_pair(orc, p, args, rs):

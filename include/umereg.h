@@ -110,6 +110,10 @@ int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const i
  *   generate_ume_from_keypoints2(normalized_ume=False), utils/loc_utils.py:160-162. */
 #define UMEREG_MOMENTS_ORDERED 1
 #define UMEREG_MOMENTS_RAW 2
+/*   flags & UMEREG_MOMENTS_ACC_F32 (opt-in, measurement): neighbour sums in packed fp32 on keypoint-centred coordinates, the
+ *   centre, slot fold, normaliser and division in fp64.  9 % faster on MI355X, but 2.6e-5 (row-relative maximum) from the fp64
+ *   evaluation instead of correctly rounded (see ume_moments_kernel); the default accumulates every term in fp64. */
+#define UMEREG_MOMENTS_ACC_F32 4
 int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
                               int n_kp, float radius, void* stream);
 /*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers
@@ -364,7 +368,9 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
 #define UMEREG_CORR_FORCE_CONSENSUS 8
 #define UMEREG_CORR_NO_FLAT 16
 #define UMEREG_CORR_CONSENSUS_V1 32 /* the consensus pass in its first form (round 2: K + 6 entry lists, images in empty regions give up) */
-#define UMEREG_CORR_DEBUG_STATS 64  /* the consensus pass counts its steps into workspace header words 16..23 (tools/exp_f1_prod.py) */
+#define UMEREG_CORR_DEBUG_STATS 64  /* the consensus pass counts into workspace header words 16..23, 28, 29: staged near / far source points,
+                                       staged target points, rank-counting steps and their zone sizes, histogram steps and their zone sizes,
+                                       zoomed steps, candidate slots visited per lane by either kind of step (ops.corr_scores_profile) */
 #define UMEREG_CORR_FAR_MARGIN_SHIFT 8 /* bits 8..15: margin of the stage of an image in an empty region, in eighths of a grid cell
                                           (0 = default, 255 = such source points are left to the lattice) */
 #define UMEREG_CORR_SRC_ROWS 128 /* source points processed in row-major cell order (round 2) instead of Hilbert-curve order */
@@ -375,6 +381,20 @@ size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
 int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
                               const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
                               int flags, float* scores, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same call with its stages timed by HIP events on the launch stream (measurement; it synchronises the stream):
+ * stage_ms_host[0..5] = milliseconds of  structures + hypothesis orders | consensus pass (+ leftover queue) | lattice build |
+ * list kernel | one-wavefront-per-query / per-record leftovers | reduction,   stage_ms_host[6] = the whole call.
+ * A stage the configuration skips reads 0. */
+int umereg_corr_scores_profile_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
+                                   const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
+                                   int flags, float* scores, void* workspace, size_t workspace_bytes, void* stream,
+                                   float* stage_ms_host);
+
+/* FeatureCorrelator's pick (utils/loc_utils.py:676-680: argsort by score, the n_hypotheses best, the best of those =
+ * the arg-max): T_best f32 [4,4] = T[argmax scores] (lowest index among equal scores; a NaN score never wins),
+ * best_index int64 [1] (optional).  Everything stays on the device: no host read of the index. */
+int umereg_corr_select_best_f32(const float* scores, const float* T, int M, float* T_best, int64_t* best_index, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3  torch.linalg.svdvals(ume)                                       utils/eval_utils.py:31-32

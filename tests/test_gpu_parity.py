@@ -146,6 +146,29 @@ def test_moments_kitti_shape_vs_oracle(gpu):
     assert torch.equal(F, F2)
 
 
+def test_moments_packed_f32_option(gpu):
+    """acc="f32" (UMEREG_MOMENTS_ACC_F32, opt-in): packed fp32 sums of keypoint-centred terms.  Same neighbourhoods; the matrix
+    is no longer correctly rounded but stays inside the reference's own fp32 summation noise (measured: 2.6e-5 row-relative
+    maximum on a KITTI-shaped cloud, median 1e-7; the reference's own sums: 1.6e-4)."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_pair
+    p = synth_pair(21, N=50000, n_kp=10000)
+    kp = p.src_pts[p.src_inds[:1500]]
+    a = (T_(p.src_pts, gpu)[None], T_(kp, gpu)[None], T_(p.src_feat, gpu)[None], 750, 5.0)
+    F64g, c64 = ops.ume_moments(*a, return_count=True)
+    F32g, c32 = ops.ume_moments(*a, return_count=True, acc="f32")
+    assert torch.equal(c64, c32)
+    F64 = orc.ume_moments(p.src_pts, kp, p.src_feat, 750, 5.0, accum="f64")
+    Fref = orc.ume_moments(p.src_pts, kp, p.src_feat, 750, 5.0, accum="f32")           # the reference's summation
+    scale = np.abs(F64).max(axis=(1, 2), keepdims=True) + 1e-30
+    e32 = (np.abs(N_(F32g[0]) - F64) / scale).max(axis=(1, 2))
+    eref = (np.abs(Fref - F64) / scale).max(axis=(1, 2))
+    assert (np.abs(N_(F64g[0]) - F64) / scale).max() < 3e-7
+    assert e32.max() < 2e-4 and np.median(e32) < 1e-6 and e32.max() <= 1.5 * eref.max() + 1e-6
+    with pytest.raises(ValueError, match="acc"):
+        ops.ume_moments(*a, acc="f16")
+
+
 def test_moments_saturated_ball(gpu):
     """Dense cloud: every ball holds > K points -> first-K-by-index truncation must match."""
     from umeregrobust_amd import ops

@@ -96,6 +96,9 @@ SIGNATURES = {
     "umereg_corr_scores_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                           c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_rre_deg_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "umereg_corr_scores_profile_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                               c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "umereg_corr_select_best_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

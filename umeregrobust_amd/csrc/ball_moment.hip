@@ -519,6 +519,16 @@ __device__ __forceinline__ float bcast8(float v)
 
 constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 measured no faster, and costs 2 waves/SIMD)
 
+// kF64 = true (default): every neighbour term accumulated in fp64 (order-independent to 1e-16, the correctly rounded fp32 matrix).
+// kF64 = false (UMEREG_MOMENTS_ACC_F32, opt-in): the neighbour sums in packed fp32 on KEYPOINT-CENTRED coordinates -- sum f (p - c)^T
+// with |p - c| <= radius instead of |p| <= 50 m, the term  c (sum f)^T  added back once, in fp64, together with the fold of the 8
+// neighbour slots, the normaliser and the division: 8 v_pk_add / v_pk_fma + 3 subtractions per lane and neighbour instead of 16 fp64
+// operations + 7 conversions.  Measured on MI355X (tools/exp_mom_acc.py, KT pair): 101 us against 111 us -- 9 %, not the 40 % the
+// instruction count suggests: v_pk_fma_f32 issues at half rate here, so 8 packed FMAs cost what 16 fp64 FMAs do and only the
+// conversions are saved -- for a result 2.6e-5 (row-relative maximum; median 1e-7) from the fp64 evaluation instead of 0, 4.6e-4 on
+// saturated balls of random features, where the normaliser sum_c sum f cancels (the reference's own fp32 sums: 1.6e-4 / 8.7e-4).
+// Three per cent of a pair for two orders of magnitude of accuracy: it stays an option, not the default.
+template <bool kF64>
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
@@ -582,6 +592,8 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const int slot = lane >> 3;  // neighbour slot 0..7
     const int qd = lane & 7;     // channel quad: channels 4*qd .. 4*qd+3
     double a0[4] = {0, 0, 0, 0}, ax[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0}, az[4] = {0, 0, 0, 0};
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v b0[2] = {{0.f, 0.f}, {0.f, 0.f}}, bx[2] = {{0.f, 0.f}, {0.f, 0.f}}, by[2] = {{0.f, 0.f}, {0.f, 0.f}}, bz[2] = {{0.f, 0.f}, {0.f, 0.f}};
     // One trip = 8 slots x kMomUnroll neighbours.  No per-element branches: the list index is clamped (slots past
     // the end re-read the last neighbour) and, in the single ragged trip, their features are zeroed by selects;
     // the LDS reads and the gathers of a trip are all issued before the first use.  (Prefetching the next trip
@@ -613,14 +625,28 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
                 ff[u].x = v ? ff[u].x : 0.f; ff[u].y = v ? ff[u].y : 0.f;
                 ff[u].z = v ? ff[u].z : 0.f; ff[u].w = v ? ff[u].w : 0.f;
             }
-            const double x = pp[u].x, y = pp[u].y, z = pp[u].z;
-            const double f[4] = {ff[u].x, ff[u].y, ff[u].z, ff[u].w};
+            if (kF64) {
+                const double x = pp[u].x, y = pp[u].y, z = pp[u].z;
+                const double f[4] = {ff[u].x, ff[u].y, ff[u].z, ff[u].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                a0[c] += f[c];
-                ax[c] = fma(f[c], x, ax[c]);
-                ay[c] = fma(f[c], y, ay[c]);
-                az[c] = fma(f[c], z, az[c]);
+                for (int c = 0; c < 4; ++c) {
+                    a0[c] += f[c];
+                    ax[c] = fma(f[c], x, ax[c]);
+                    ay[c] = fma(f[c], y, ay[c]);
+                    az[c] = fma(f[c], z, az[c]);
+                }
+            } else {
+                const float dx = pp[u].x - qx, dy = pp[u].y - qy, dz = pp[u].z - qz;
+                const f2v f01 = {ff[u].x, ff[u].y}, f23 = {ff[u].z, ff[u].w};
+                const f2v dx2 = {dx, dx}, dy2 = {dy, dy}, dz2 = {dz, dz};
+                b0[0] += f01;
+                b0[1] += f23;
+                bx[0] = __builtin_elementwise_fma(f01, dx2, bx[0]);
+                bx[1] = __builtin_elementwise_fma(f23, dx2, bx[1]);
+                by[0] = __builtin_elementwise_fma(f01, dy2, by[0]);
+                by[1] = __builtin_elementwise_fma(f23, dy2, by[1]);
+                bz[0] = __builtin_elementwise_fma(f01, dz2, bz[0]);
+                bz[1] = __builtin_elementwise_fma(f23, dz2, bz[1]);
             }
         }
     };
@@ -633,6 +659,12 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     for (int e0 = 0; e0 < full; e0 += 8 * kMomUnroll) trip(e0, false, std::integral_constant<int, kMomUnroll>{});
     if (!(UMEREG_MOM_ABLATE & 1))
         for (int e0 = full; e0 < count; e0 += 8) trip(e0, e0 + 8 > count, std::integral_constant<int, 1>{});
+    if (!kF64) {
+        a0[0] = b0[0].x; a0[1] = b0[0].y; a0[2] = b0[1].x; a0[3] = b0[1].y;
+        ax[0] = bx[0].x; ax[1] = bx[0].y; ax[2] = bx[1].x; ax[3] = bx[1].y;
+        ay[0] = by[0].x; ay[1] = by[0].y; ay[2] = by[1].x; ay[3] = by[1].y;
+        az[0] = bz[0].x; az[1] = bz[0].y; az[2] = bz[1].x; az[3] = bz[1].y;
+    }
     // fold the 8 neighbour slots (lanes that share qd differ in bits 3..5)
 #pragma unroll
     for (int m = 8; m < 64; m <<= 1) {
@@ -642,6 +674,15 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
             ax[c] += shfl_xor_f64(ax[c], m);
             ay[c] += shfl_xor_f64(ay[c], m);
             az[c] += shfl_xor_f64(az[c], m);
+        }
+    }
+    if (!kF64) {
+        // back from keypoint-centred to absolute coordinates: sum f p^T = sum f (p - c)^T + (sum f) c^T
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ax[c] = fma(a0[c], (double)qx, ax[c]);
+            ay[c] = fma(a0[c], (double)qy, ay[c]);
+            az[c] = fma(a0[c], (double)qz, az[c]);
         }
     }
     // normaliser: sum over the 32 channels of F0 (evaluate.py:59), + 1e-6
@@ -788,9 +829,14 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     int cap, waves;
     lds_plan(K, &cap, &waves);
     dim3 grid((n_kp + waves - 1) / waves, B);
-    hipLaunchKernelGGL(ume_moments_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                       (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                       n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
+    if (!(flags & UMEREG_MOMENTS_ACC_F32))
+        hipLaunchKernelGGL(ume_moments_kernel<true>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
+    else
+        hipLaunchKernelGGL(ume_moments_kernel<false>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
     return UMEREG_OK;
 }

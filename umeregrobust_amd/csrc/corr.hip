@@ -1646,10 +1646,10 @@ __device__ __forceinline__ void cons2_scan(const unsigned int* hist, int lane, i
 }
 
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void corr_consensus2_kernel(
-    const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float4* __restrict__ vp4,
-    const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed, const int* __restrict__ perm, int Ns, int Nt,
-    int M, int K, float sigma, float far_margin_cells, float* __restrict__ val, unsigned long long* __restrict__ served,
-    unsigned int* __restrict__ stats, int dbg)
+    const char* __restrict__ ws_tgt, const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
+    const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed,
+    const int* __restrict__ perm, int Ns, int Nt, int M, int K, float sigma, float far_margin_cells, float* __restrict__ val,
+    unsigned long long* __restrict__ served, unsigned int* __restrict__ stats, int dbg)
 {
     typedef unsigned int IdxT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1732,8 +1732,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         unsigned long long* la = reinterpret_cast<unsigned long long*>(my);
         unsigned long long* lb = la + kCoopCap;
         unsigned int* chist = reinterpret_cast<unsigned int*>(lb + kCoopCap);
-        const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
-        const int cntk = coop_knn(c.P4s, box, Nt, K, cx, cy, cz, la, lb, chist, lane);
+        // (the table and chunk boxes of the cooperative searches: the target in Hilbert-curve order where that copy exists)
+        const float4* P4c = reinterpret_cast<const float4*>(ws_coop + wt.off_p4s);
+        const float4* box = reinterpret_cast<const float4*>(ws_coop + wt.off_box);
+        const int cntk = coop_knn(P4c, box, Nt, K, cx, cy, cz, la, lb, chist, lane);
         if (cntk < K) { give_up(); return; }
         const float dkf = sqrtf(__uint_as_float((unsigned int)(la[K - 1] >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1759,7 +1761,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const int l = __ffsll((long long)pend) - 1;
                     pend &= pend - 1ull;
                     const int j = (c0 + l) * kWave + lane;
-                    const float4 p = c.P4s[j];                       // (the padded table makes reads up to Nt + 63 safe)
+                    const float4 p = P4c[j];                         // (the padded table makes reads up to Nt + 63 safe)
                     const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
                     const bool in = j < Nt && dx * dx + dy * dy + dz * dz <= D2;
                     const unsigned long long bal = __ballot(in);
@@ -1953,7 +1955,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 d2m = inc ? fmaxf(d2m, z[i]) : d2m;
             }
             sel_ok = true;                                       // the zone holds the K nearest of q~: at least `need` real points
-            if (dbg && lane == 0) { atomicAdd(stats + 12, 1u); atomicAdd(stats + 13, (unsigned int)u_zone); }
+            if (dbg && lane == 0) { atomicAdd(stats + 12, 1u); atomicAdd(stats + 13, (unsigned int)u_zone); atomicAdd(stats + 21, (unsigned int)m_use); }
         } else {
             // ---- (B) byte histogram over the range the K-th distance can lie in; list only for the K-th neighbour's bin ----
             const float rl = fmaxf((dk - delta) * 0.9999f - 1e-5f, 0.f);
@@ -2090,7 +2092,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
             }
             sel_ok = b0 >= 0 && ntie == need_t;
-            if (dbg && lane == 0) { atomicAdd(stats + 14, 1u); atomicAdd(stats + 15, (unsigned int)u_zone); }
+            if (dbg && lane == 0) { atomicAdd(stats + 14, 1u); atomicAdd(stats + 15, (unsigned int)u_zone); atomicAdd(stats + 22, (unsigned int)(s_min + u_zone + (m2 - s_min))); }
         }
         // the exactness test: the K-th distance found plus delta must stay inside the staged ball
         const bool ok = act && sel_ok && __builtin_amdgcn_sqrtf(d2m) * 1.0001f + delta <= D * 0.9999f - 1e-6f;
@@ -3038,6 +3040,39 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
     if (lane == 0) scores[h] = s / (float)Ns;                                        // utils/loc_utils.py:610
 }
 
+// ---- FeatureCorrelator's pick (utils/loc_utils.py:676-680): the hypothesis with the highest score -------------------------
+// The reference sorts all scores, keeps the n_hypotheses best and returns the best of those: the arg-max.  One workgroup:
+// arg-max over the M scores (lowest index among equal scores; NaN scores never win unless every score is NaN, then index 0),
+// and the winning 4 x 4 transform copied out -- instead of a top-k, an arg-max and an index_select launch with their sorts.
+__global__ __launch_bounds__(1024) void corr_select_best_kernel(const float* __restrict__ scores, const float* __restrict__ T, int M,
+                                                                float* __restrict__ T_best, int64_t* __restrict__ best_index)
+{
+    __shared__ unsigned long long red[1024 / kWave];
+    // key = (ordered score bits << 32) | (~index): the maximum key is the highest score, lowest index on ties
+    unsigned long long best = 0ull;
+    for (int h = threadIdx.x; h < M; h += blockDim.x) {
+        const float v = scores[h];
+        const unsigned int e = v == v ? enc_ord(v) : 0u;                  // NaN: below every number
+        const unsigned long long k = ((unsigned long long)e << 32) | (unsigned int)(~(unsigned int)h);
+        best = k > best ? k : best;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long o = ((unsigned long long)(unsigned int)__shfl_xor((int)(best >> 32), m, kWave) << 32) |
+                                     (unsigned int)__shfl_xor((int)(best & 0xffffffffull), m, kWave);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        unsigned long long b = 0ull;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) b = red[w] > b ? red[w] : b;
+        const int idx = (int)(~(unsigned int)(b & 0xffffffffull));
+        T_best[threadIdx.x] = T[(size_t)idx * 16 + threadIdx.x];
+        if (threadIdx.x == 0 && best_index) *best_index = (int64_t)idx;
+    }
+}
+
 static void knn_lds_plan(int K, int n2, int* cap, int* waves, size_t* bytes, int max_waves, bool* idx16)
 {
     // K + 6 list entries: the threshold bin typically holds 2-3 candidates (a fuller one is zoomed into); K + 4 and
@@ -3135,6 +3170,27 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
 
 static const int kColsumBlocks = 64;
 
+// ---- stage timing of one corr_scores call (umereg_corr_scores_profile_f32) --------------------------------------------------
+// The stages are enqueued by ONE native call, so a caller cannot bracket them with events of its own.  The profile entry
+// point hands this thread a row of HIP events; umereg_corr_scores_ex_f32 records event i when it has enqueued stage i's
+// last kernel (on the launch stream), and the profile entry reads the differences after a stream synchronise.
+constexpr int kCorrStages = 7;      // start | structures + orders | consensus pass | lattice build | list kernel | rest of the leftovers | reduction
+static thread_local hipEvent_t* t_corr_marks = nullptr;
+static inline void corr_mark(int i, hipStream_t st)
+{
+    if (t_corr_marks) (void)hipEventRecord(t_corr_marks[i], st);
+}
+
+UMEREG_API int umereg_corr_select_best_f32(const float* scores, const float* T, int M, float* T_best, int64_t* best_index, void* stream)
+{
+    UMEREG_REQUIRE(scores && T && T_best, "corr_select_best: null pointer");
+    UMEREG_REQUIRE(M > 0, "corr_select_best: M must be positive (got %d)", M);
+    if (int rc = check_device()) return rc;
+    hipLaunchKernelGGL(corr_select_best_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, T, M, T_best, best_index);
+    UMEREG_CHECK_LAUNCH("corr_select_best_kernel");
+    return UMEREG_OK;
+}
+
 UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M) { return umereg_corr_workspace_bytes_ex(Ns, Nt, M, 0); }
 
 // the consensus pass rides on the lattice (it leaves the queries it cannot prove exact to it)
@@ -3153,7 +3209,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
     const size_t cons = consensus_on(c_max, M, flags) ? align_up((size_t)Ns * M * 4, 256) + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256) + 256 +
                                                         align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) +
                                                         2 * align_up(n_chunks * M * 4, 256) + align_up((size_t)Ns * 4, 256) + align_up(n_chunks * 16, 256) : 0;
-    return grid_ws(Ns).total + grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
+    return grid_ws(Ns).total + 2 * grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
            (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + flat_bytes((size_t)M * n_chunks, (long)M * Ns) : 0) + cons;
 }
@@ -3206,9 +3262,14 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         return UMEREG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    corr_mark(0, st);
     char* ws_src = (char*)workspace;
     char* ws_tgt = ws_src + grid_ws(Ns).total;
-    float* partial = (float*)(ws_tgt + grid_ws(Nt).total);
+    // a second copy of the target table in Hilbert-curve order, with the bounding boxes of ITS 64-point chunks: what the
+    // one-wavefront-per-query searches (coop_knn) prune with.  Chunks of the row-major table are strips one cell wide and
+    // ~40 m long; a far query's bound lets dozens of them through, compact blobs a handful.
+    char* ws_tgth = ws_tgt + grid_ws(Nt).total;
+    float* partial = (float*)(ws_tgth + grid_ws(Nt).total);
     const size_t n_chunks_sz = (size_t)((Ns + kWave - 1) / kWave);
     float* rotated = (float*)((char*)partial + align_up((size_t)M * n_chunks_sz * 4, 256) + align_up((size_t)kColsumBlocks * 32 * 8, 256));
     float* Rbar = (float*)((char*)rotated + align_up((size_t)Ns * 12, 256));
@@ -3217,6 +3278,13 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     // target: the search structure; source: only a processing order (wavefronts of queries that stay row-aligned
     // with the target grid under the consensus rotation)
     if (int rc = launch_prep(tgt_pts, ws_tgt, 1, Nt, -(float)K, st)) return rc;
+    const bool coop_copy = lattice_cells_for((long)M * Ns, Nt, flags) != 0 && !(flags & UMEREG_CORR_SRC_ROWS);
+    const char* ws_coop = coop_copy ? ws_tgth : ws_tgt;
+    if (coop_copy) {
+        if (int rc = launch_prep(tgt_pts, ws_tgth, 1, Nt, -(float)K, st, 1)) return rc;
+        hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgth, (size_t)0, Nt);
+        UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+    }
     hipLaunchKernelGGL(mean_rotation_kernel, dim3(1), dim3(256), 0, st, T, M, Rbar);
     UMEREG_CHECK_LAUNCH("mean_rotation_kernel");
     hipLaunchKernelGGL(rotate_points_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, src_pts, Ns, (const float*)Rbar, rotated);
@@ -3272,6 +3340,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(hyp_order_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, T, M, (const float*)Tmed, (const float4*)centroid,
                            (const int*)gperm, perm, inv);
         UMEREG_CHECK_LAUNCH("hyp_order_chunk_kernel");
+        corr_mark(1, st);
         if (flags & UMEREG_CORR_CONSENSUS_V1) {
             hipLaunchKernelGGL(corr_consensus_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons_lds_per_wave(cap), st,
                                (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
@@ -3282,10 +3351,12 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             // eighths of a cell, 0 = default, 255 = such points give up as in the first form)
             const int mf = (flags >> UMEREG_CORR_FAR_MARGIN_SHIFT) & 0xff;
             const float far_margin = mf == 0 ? kConsFarMarginCells : (mf == 0xff ? 0.f : (float)mf * 0.125f);
-            hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
-            UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+            if (!coop_copy) {
+                hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
+                UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+            }
             hipLaunchKernelGGL(corr_consensus2_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons2_lds_per_wave(), st,
-                               (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
+                               (const char*)ws_tgt, ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
                                (const int*)perm, Ns, Nt, M, K, sigma, far_margin, val, served, (unsigned int*)lat + 7,
                                (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0);
             UMEREG_CHECK_LAUNCH("corr_consensus2_kernel");
@@ -3298,6 +3369,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(leftover_queue_kernel, dim3((unsigned)(((long)n_chunks * n_words + 3) / 4)), dim3(256), 0, st, (const char*)ws_src, Ns, M,
                            n_chunks, (const unsigned long long*)served, n_words, (const int*)perm, lat, c_max);
         UMEREG_CHECK_LAUNCH("leftover_queue_kernel");
+        corr_mark(2, st);
     }
     if (c_max) {
         // candidate lattice on the target (built once per call, used by all M hypotheses): mark -> compact -> count -> scan -> fill
@@ -3316,9 +3388,11 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(lattice_compact_kernel, dim3(1), dim3(1024), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
         UMEREG_CHECK_LAUNCH("lattice_compact_kernel");
         const unsigned int build_blocks = (c_max / kLatLanes + (unsigned int)bwaves - 1) / (unsigned int)bwaves;
-        hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
-        UMEREG_CHECK_LAUNCH("chunk_box_kernel");
-        hipLaunchKernelGGL(lattice_dk_kernel, dim3(1024), dim3(8 * kWave), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
+        if (!coop_copy) {
+            hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
+            UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+        }
+        hipLaunchKernelGGL(lattice_dk_kernel, dim3(1024), dim3(8 * kWave), 0, st, ws_coop, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_dk_kernel");
         hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), (size_t)(kMaxCells + 64) * 4, st,
                            (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
@@ -3327,11 +3401,13 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
         hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
+        corr_mark(3, st);
         const dim3 lat_grid(score_grid.x < 16384u ? score_grid.x : 16384u);
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), lat_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
+        corr_mark(4, st);
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
         // ... as a flat list of queries when they fit (header word 12 marks that the flat path ran), record by record otherwise
         char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
@@ -3345,27 +3421,28 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             const int dbg = (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0;
             if (r16)
                 hipLaunchKernelGGL(corr_score_record2_kernel<unsigned short>, dim3(4096), dim3(2 * kWave), 2 * rec_lds_per_wave<unsigned short>(rcap), st,
-                                   (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, rcap,
+                                   ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, rcap,
                                    sigma, n_chunks, partial, lat, c_max, dbg);
             else
                 hipLaunchKernelGGL(corr_score_record2_kernel<unsigned int>, dim3(4096), dim3(2 * kWave), 2 * rec_lds_per_wave<unsigned int>(rcap), st,
-                                   (const char*)ws_tgt, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, rcap,
+                                   ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, rcap,
                                    sigma, n_chunks, partial, lat, c_max, dbg);
             UMEREG_CHECK_LAUNCH("corr_score_record2_kernel");
         }
         if (!(flags & UMEREG_CORR_NO_FLAT)) {
             hipLaunchKernelGGL(leftover_flatten_kernel, dim3(256), dim3(256), 0, st, lat, c_max, fw);
             UMEREG_CHECK_LAUNCH("leftover_flatten_kernel");
-            hipLaunchKernelGGL(corr_score_flat_kernel, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt, (const char*)ws_src,
+            hipLaunchKernelGGL(corr_score_flat_kernel, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
                                src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
             UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
             hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial);
             UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
         }
-        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, (const char*)ws_tgt,
+        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, ws_coop,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);
         UMEREG_CHECK_LAUNCH("corr_score_fallback_kernel");
+        corr_mark(5, st);
     } else if (idx16) {
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, false>), score_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
@@ -3385,7 +3462,45 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 3) / 4), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
                        scores);
     UMEREG_CHECK_LAUNCH("corr_reduce_kernel");
+    corr_mark(6, st);
     return UMEREG_OK;
+}
+
+UMEREG_API int umereg_corr_scores_profile_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
+                                              const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
+                                              int flags, float* scores, void* workspace, size_t workspace_bytes, void* stream,
+                                              float* stage_ms_host)
+{
+    UMEREG_REQUIRE(stage_ms_host, "corr_scores_profile: null pointer");
+    if (int rc = check_device()) return rc;
+    hipEvent_t ev[kCorrStages + 1];                 // [kCorrStages] = the base, recorded before everything
+    for (int i = 0; i <= kCorrStages; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("corr_scores_profile: hipEventCreate failed"); return UMEREG_ELAUNCH; }
+    hipStream_t st = (hipStream_t)stream;
+    // a stage that a configuration skips (no consensus pass, no lattice) never records its mark: every mark is recorded once
+    // up front, right after the base, so that a skipped stage reads as "no later than the stage before it"
+    (void)hipEventRecord(ev[kCorrStages], st);
+    for (int i = 0; i < kCorrStages; ++i) (void)hipEventRecord(ev[i], st);
+    t_corr_marks = ev;
+    const int rc = umereg_corr_scores_ex_f32(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, Ns, Nt, M, K, sigma, flags, scores, workspace,
+                                             workspace_bytes, stream);
+    t_corr_marks = nullptr;
+    int out = rc;
+    if (rc == UMEREG_OK) {
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error("corr_scores_profile: hipStreamSynchronize failed"); out = UMEREG_ELAUNCH; }
+        float at[kCorrStages];                      // time of mark i since the base, made monotone
+        for (int i = 0; i < kCorrStages && out == UMEREG_OK; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[kCorrStages], ev[i]) != hipSuccess) ms = 0.f;
+            at[i] = i > 0 && ms < at[i - 1] ? at[i - 1] : ms;
+        }
+        if (out == UMEREG_OK) {
+            for (int i = 0; i + 1 < kCorrStages; ++i) stage_ms_host[i] = at[i + 1] - at[i];
+            stage_ms_host[kCorrStages - 1] = at[kCorrStages - 1] - at[0];
+        }
+    }
+    for (int i = 0; i <= kCorrStages; ++i) (void)hipEventDestroy(ev[i]);
+    return out;
 }
 
 #ifdef UMEREG_KNN_DEBUG

@@ -217,9 +217,8 @@ class FeatureCorrelator:
         mmf_score = ops.corr_scores(source_pc[0], target_pc[0], wsf, wtf, T_kp, K=self.corr_num_nn, sigma=self.sigma,
                                     timing=timing)                                          # :666-673
         self.last_scores = mmf_score
-        # :676-680 -- the n_hypotheses best by score, then the best of those: a top-k instead of the full argsort
-        return_mmf_score, best_T_list_order = torch.topk(mmf_score, min(self.n_hypotheses, mmf_score.shape[0]), sorted=True)
-        return_T_list = T_kp[best_T_list_order]
-        # (index_select with a device index: `return_T_list[argmax]` would read the index back to the host and stall it
-        # until the scores are done -- the caller can use that time, see evaluate.evaluate_pairs)
-        return return_T_list.index_select(0, torch.argmax(return_mmf_score).reshape(1))[0]
+        # :676-680 -- argsort by score, the n_hypotheses best, the best of those: whatever n_hypotheses >= 1 is, that is the
+        # arg-max.  One native launch, everything stays on the device (`T_kp[argmax]` would read the index back to the host
+        # and stall it until the scores are done -- the caller can use that time, see evaluate.evaluate_pairs)
+        best_T, self.last_best_index = ops.corr_select_best(mmf_score, T_kp)
+        return best_T
