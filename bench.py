@@ -651,9 +651,11 @@ def cpu_f1_leg(orc, e, args, cfg, n_hyp=8):
                                                f"(oracle pc_corr_cost, C/OpenMP), scaled to M={cfg['M']}"}
 
 
-def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M=256, budget_s=25.0):
+def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M=256, budget_s=20.0):
     """Registration recall of the WHOLE pipeline (a1-a7 + raw prep + f1 + f2) on hard pairs at reduced size: the CPU oracle
-    (a restatement of the reference's loop iteration, evaluate.py:195-309) vs this library on the same pairs and RNG seeds."""
+    (a restatement of the reference's loop iteration, evaluate.py:195-309) vs this library with the oracle's five host draws per
+    pair REPLAYED, so the comparison is pair by pair.  Bounded by `budget_s` of CPU time; the long form (128 pairs at this size and
+    8 at KITTI size) is tools/rr_replay.py -> profiles/r03/rr_replay.json."""
     small = SimpleNamespace(**vars(args))
     small.ume_n_samples = M
     small.pc_corr_max_size = N
@@ -674,37 +676,45 @@ def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M
         t = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
         pair = dict(src_pts=t(p.src_pts)[None], tgt_pts=t(p.tgt_pts)[None], src_feat=t(p.src_feat)[None],
                     tgt_feat=t(p.tgt_feat)[None], gt_tform=t(p.gt_tform))
-        rg = evaluate.evaluate_pairs([pair], small, rng=np.random.RandomState(31 + i), refine=True)       # its own draws on the same seed
         try:
             rp = evaluate.evaluate_pairs([pair], small, rng=Replay(rec.log), refine=True)                  # the oracle's draws, replayed
             same = (float(rp["rre"][0]), float(rp["rte"][0]))
         except ValueError:
             same = (float("nan"), float("nan"))
-        rows.append((rc["rre"], rc["rte"], float(rg["rre"][0]), float(rg["rte"][0])) + same)
+        rows.append((rc["rre"], rc["rte"]) + same)
     r = np.array(rows, np.float64)
     n = r.shape[0]
     cpu_ok = np.stack([(r[:, 0] <= g0) & (r[:, 1] <= g1) for g0, g1 in GATES], 1)
-    gpu_ok = np.stack([(r[:, 2] <= g0) & (r[:, 3] <= g1) for g0, g1 in GATES], 1)
-    rep_ok = np.stack([(r[:, 4] <= g0) & (r[:, 5] <= g1) for g0, g1 in GATES], 1)
+    rep_ok = np.stack([(r[:, 2] <= g0) & (r[:, 3] <= g1) for g0, g1 in GATES], 1)
+
+    def wilson(k, z=1.96):
+        ph = k / max(n, 1)
+        d_ = 1 + z * z / max(n, 1)
+        c_ = (ph + z * z / (2 * max(n, 1))) / d_
+        h_ = z * np.sqrt(ph * (1 - ph) / max(n, 1) + z * z / (4 * max(n, 1) ** 2)) / d_
+        return [round(100 * max(0.0, c_ - h_), 1), round(100 * min(1.0, c_ + h_), 1)]
+
     differing = [{"pair": int(i), "cpu_rre_rte": [round(r[i, 0], 4), round(r[i, 1], 4)], "hip_rre_rte": [round(r[i, 2], 4), round(r[i, 3], 4)]}
-                 for i in np.flatnonzero((cpu_ok != gpu_ok).any(1))]
-    differing_rep = [{"pair": int(i), "cpu_rre_rte": [round(r[i, 0], 4), round(r[i, 1], 4)], "hip_rre_rte": [round(r[i, 4], 4), round(r[i, 5], 4)]}
-                     for i in np.flatnonzero((cpu_ok != rep_ok).any(1))]
+                 for i in np.flatnonzero((cpu_ok != rep_ok).any(1))]
+    both = cpu_ok[:, 0] & rep_ok[:, 0]
     return {"pairs": int(n), "size": f"N={N} pts/cloud, {N} keypoints, M={M} hypotheses; hard pairs: {RR_CHECK_HARD}",
             "gates": ["1.5deg,0.6m", "1.5deg,0.3m", "1deg,0.1m"],
             "cpu_rr_percent": [round(100.0 * float(v), 3) for v in cpu_ok.mean(0)],
-            "hip_rr_percent": [round(100.0 * float(v), 3) for v in gpu_ok.mean(0)],
             "hip_same_draws_rr_percent": [round(100.0 * float(v), 3) for v in rep_ok.mean(0)],
+            "rr_ci95_percent": [wilson(int(k)) for k in rep_ok.sum(0)],
             "cpu_mRRE_mRTE": [round(float(r[:, 0].mean()), 4), round(float(r[:, 1].mean()), 4)],
-            "hip_mRRE_mRTE": [round(float(r[:, 2].mean()), 4), round(float(r[:, 3].mean()), 4)],
-            "hip_same_draws_mRRE_mRTE": [round(float(np.nanmean(r[:, 4])), 4), round(float(np.nanmean(r[:, 5])), 4)],
-            "max_abs_diff_same_draws": {"rre_deg": round(float(np.nanmax(np.abs(r[:, 4] - r[:, 0]))), 5),
-                                        "rte_m": round(float(np.nanmax(np.abs(r[:, 5] - r[:, 1]))), 5)},
-            "pairs_with_a_different_gate_outcome": differing,
-            "pairs_with_a_different_gate_outcome_same_draws": differing_rep,
-            "note": "`hip_rr_percent`: this library drawing from its own generator on the same seed (the two paths' match distances "
-                    "differ in the last bits, so the weighted draws part after the first sub-sample: agreement is statistical). "
-                    "`hip_same_draws_*`: the oracle's five host draws per pair replayed into this library: agreement pair by pair",
+            "hip_same_draws_mRRE_mRTE": [round(float(np.nanmean(r[:, 2])), 4), round(float(np.nanmean(r[:, 3])), 4)],
+            "max_abs_diff_same_draws": {"rre_deg": round(float(np.nanmax(np.abs(r[:, 2] - r[:, 0]))), 5),
+                                        "rte_m": round(float(np.nanmax(np.abs(r[:, 3] - r[:, 1]))), 5)},
+            "max_abs_diff_where_both_pass_the_first_gate": {
+                "rre_deg": round(float(np.nanmax(np.abs(r[both, 2] - r[both, 0]))) if both.any() else 0.0, 5),
+                "rte_m": round(float(np.nanmax(np.abs(r[both, 3] - r[both, 1]))) if both.any() else 0.0, 5), "pairs": int(both.sum())},
+            "pairs_with_a_different_gate_outcome_same_draws": differing,
+            "note": "the oracle's five host draws per pair (keypoints x 2, weighted match draw, correlation sub-samples x 2) replayed into "
+                    "this library: agreement pair by pair.  (With its own generator on the same seed the two paths' match distances differ "
+                    "in the last bits, the weighted draws part after the first sub-sample and agreement is only statistical: that leg "
+                    "was dropped in round 3.)  With this many pairs the recall itself is known to the interval given; the tracked long "
+                    "run is profiles/r03/rr_replay.json (tools/rr_replay.py).",
             "cpu_s": round(t_cpu, 1), "cpu_pairs_per_s": round(n / max(t_cpu, 1e-9), 3)}
 
 

@@ -1056,11 +1056,8 @@ __device__ __forceinline__ int coop_hist_cut(const unsigned long long* list, uns
         const float d = __uint_as_float((unsigned int)(mine[u] >> 32));
         if (valid) { lo = fminf(lo, d); hi = fmaxf(hi, d); }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o, kWave));
-        hi = fmaxf(hi, __shfl_xor(hi, o, kWave));
-    }
+    lo = wave_minmax_f<false>(lo);           // (DPP ladders: no ds_bpermute round trips)
+    hi = wave_minmax_f<true>(hi);
     if (!(hi > lo) || cnt <= K) {            // nothing to split (or NaN keys): exact cut
         const int n = coop_cut(list, out, cnt, K, lane);
         if (n == K) bound = out[K - 1];
@@ -1104,8 +1101,7 @@ __device__ __forceinline__ int coop_hist_cut(const unsigned long long* list, uns
         }
         n += __popcll(b);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, kWave));
+    mx = wave_minmax_f<true>(mx);
     bound = ((unsigned long long)__float_as_uint(mx) << 32) | 0xffffffffull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     return n;
@@ -1184,38 +1180,58 @@ __device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const fl
         return cnt + __popcll(b);
     };
     // (1) seed: the nearest chunk with at least K points (a NaN query fails every comparison: chunk 0, nothing pruned,
-    //     NaN keys -- its terms come out NaN as on the other paths)
+    //     NaN keys -- its terms come out NaN as on the other paths).  The box distances of the first 256 chunks stay in
+    //     registers for step (2).
+    constexpr int kKeepT = 4;
+    float tk[kKeepT];
     float best = 3.0e38f;
     int best_c = 0;
-    for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+#pragma unroll
+    for (int r = 0; r < kKeepT; ++r) {
+        const int c = r * kWave + lane;
+        tk[r] = c < n_tch ? box2(c) : 3.0e38f;
+        if (c < n_tch && min(kWave, Nt - c * kWave) >= K && tk[r] < best) { best = tk[r]; best_c = c; }
+    }
+    for (int c0 = kKeepT * kWave; c0 < n_tch; c0 += kWave) {
         const int c = c0 + lane;
         if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
             const float t = box2(c);
             if (t < best) { best = t; best_c = c; }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, kWave);
-        const int oc = __shfl_xor(best_c, o, kWave);
-        if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    int seed;
+    {
+        // the lowest lane among those holding the smallest box distance (any fixed rule will do: the seed only supplies a bound)
+        const float bmin = wave_minmax_f<false>(best);
+        const unsigned long long who = __ballot(best == bmin);
+        seed = who != 0ull ? __builtin_amdgcn_readlane(best_c, __ffsll((long long)who) - 1) : 0;
     }
-    const int seed = __builtin_amdgcn_readfirstlane(best_c);
     int cnt = scan_chunk(seed, ~0ull, 0);
-    cnt = coop_cut(la, lb, cnt, K, lane);
-    { unsigned long long* t_ = la; la = lb; lb = t_; }
-    unsigned long long ukey = cnt == K ? la[K - 1] : ~0ull;
+    // a bound on the K-th smallest key: the largest key the histogram cut keeps (it keeps at least K; an exact cut of the
+    // seed's 64 keys by rank counting cost 2.5x as much and the bound only has to be valid)
+    unsigned long long ukey = ~0ull;
+    if (cnt >= K) {
+        cnt = coop_hist_cut<1>(la, lb, cnt, K, lane, hist, ukey);      // (exactly K keys: its exact branch, bound = the largest)
+        unsigned long long* t_ = la; la = lb; lb = t_;
+    }
     // (2) the chunks whose box reaches inside the bound
     for (int c0 = 0; c0 < n_tch; c0 += kWave) {
         const int c = c0 + lane;
-        const float t = c < n_tch ? box2(c) : 3.0e38f;
+        float t;
+        if (c0 < kKeepT * kWave) {
+            t = tk[0];
+#pragma unroll
+            for (int r = 1; r < kKeepT; ++r) t = c0 == r * kWave ? tk[r] : t;
+        } else {
+            t = c < n_tch ? box2(c) : 3.0e38f;
+        }
         const float bd = __uint_as_float((unsigned int)(ukey >> 32));
         unsigned long long pend = __ballot(c < n_tch && c != seed && (ukey == ~0ull || !(t > bd)));
         while (pend != 0ull) {
             const int l = __ffsll((long long)pend) - 1;
             pend &= pend - 1ull;
             // the bound may have dropped since the ballot
-            if (ukey != ~0ull && __shfl(t, l, kWave) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
+            if (ukey != ~0ull && __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), l)) > __uint_as_float((unsigned int)(ukey >> 32))) continue;
             if (cnt > 2 * kWave) {                      // (<= 3 * 64 keys: every scan adds at most 64)
                 cnt = coop_hist_cut<3>(la, lb, cnt, K, lane, hist, ukey);
                 unsigned long long* t_ = la; la = lb; lb = t_;
@@ -2109,7 +2125,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // thousand (hypothesis, chunk) wavefronts), 0 = the candidate lattice (many: hypotheses that do not agree, clouds that
 // barely overlap -- queries in empty parts of the target, where lists pay off).  Both sets of kernels are enqueued;
 // the ones not chosen return at once.
-constexpr unsigned int kLeftMax = 1u << 20;   // (measured round 3: 0.26 M leftovers 2.84 ms through the queue against 3.80 through the lattice, 1.6 M 9.1 against 8.9)
+constexpr unsigned int kLeftMax = 1u << 21;   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
 __global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force)
 {
     const long left = n_queries - (long)header[7];
