@@ -3157,7 +3157,10 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
         return UMEREG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = launch_prep(pts, (char*)workspace, B, N, -(float)knn, st)) return rc;
+    // small clouds go one wavefront per query through coop_knn, which never walks the grid: the table is then sorted along the
+    // Hilbert curve, so that its 64-point chunks -- what that search prunes with -- are compact blobs instead of 40 m strips
+    // (same neighbours, same ascending key order, same sums: the table's order only decides how many chunks get scanned)
+    if (int rc = launch_prep(pts, (char*)workspace, B, N, -(float)knn, st, N <= 32768 ? 1 : 0)) return rc;
     int cap, waves;
     size_t lds;
     bool idx16;

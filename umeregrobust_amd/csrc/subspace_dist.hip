@@ -340,6 +340,9 @@ __device__ __forceinline__ float group32_max(float v)
 // 32-target tile (8 KiB of hi fragments) is staged once per workgroup through a double-buffered LDS
 // stage.  The tile body is software-pipelined by hand in units of "groups" (one basis column b x two A
 // tiles = 4 MFMAs): the squares of group k run in the shadow of the MFMAs of group k+1.
+#ifndef UMEREG_COARSE_ABLATE
+#define UMEREG_COARSE_ABLATE 0   // timing experiments only (tools/exp_coarse_ablate.sh; results are wrong by construction): 1 no squares, 2 no filter, 4 no MFMAs, 8 no LDS reads
+#endif
 constexpr int kCoarseTA = 2;                         // A tiles (8 source keypoints each) per wave
 constexpr int kCoarseRows = kCoarseTA * 8;           // source keypoints per wave
 constexpr int kCoarseWG = kCoarseRows * kDistWaves;  // source keypoints per workgroup (<= ROWS_F16X2 padding)
@@ -434,23 +437,48 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
         float sc[kCoarseTA][4];    // coarse scores of this lane's 4*TA (source, target) pairs
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const half8 b0 = ldsB[cur][(b * 2 + 0) * 64 + lane];
-            const half8 b1 = ldsB[cur][(b * 2 + 1) * 64 + lane];
+            const half8 b0 = (UMEREG_COARSE_ABLATE & 8) ? a[0][0] : ldsB[cur][(b * 2 + 0) * 64 + lane];
+            const half8 b1 = (UMEREG_COARSE_ABLATE & 8) ? a[0][1] : ldsB[cur][(b * 2 + 1) * 64 + lane];
             f32x16 cc[kCoarseTA];
+            if (UMEREG_COARSE_ABLATE & 4) {
 #pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, f32x16{0}, 0, 0, 0);
+                for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
+                    for (int e = 0; e < 16; ++e) cc[t][e] = (float)b0[e & 7] + (float)b1[(e + t) & 7];
+            } else {
+#pragma unroll
+                for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, f32x16{0}, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    if (UMEREG_COARSE_ABLATE & 1) {
+                        sc[t][g] = b == 0 ? cc[t][4 * g] : sc[t][g] + cc[t][4 * g + 1];
+                        continue;
+                    }
                     // scalar FMAs on purpose: packed f32 VALU beside MFMAs is slower on gfx950
                     float acc = b == 0 ? cc[t][4 * g] * cc[t][4 * g] : fmaf(cc[t][4 * g], cc[t][4 * g], sc[t][g]);
                     acc = fmaf(cc[t][4 * g + 1], cc[t][4 * g + 1], acc);
                     acc = fmaf(cc[t][4 * g + 2], cc[t][4 * g + 2], acc);
                     sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
                 }
+        }
+        if (UMEREG_COARSE_ABLATE & 2) {
+            // no limits, no ballots, no candidates: the scores are folded into one register that is stored once at the end
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) lim[t][g] = max(lim[t][g], __float_as_int(sc[t][g]));
+            if (jt + 1 < jt1) {
+                ldsB[cur ^ 1][c0] = stWrite[0];
+                ldsB[cur ^ 1][c1] = stWrite[1];
+            }
+            __syncthreads();
+            cur ^= 1;
+            return;
         }
 #pragma unroll
         for (int t = 0; t < kCoarseTA; ++t)
