@@ -344,6 +344,13 @@ __device__ __forceinline__ float group32_max(float v)
 #define UMEREG_COARSE_ABLATE 0   // timing experiments only (tools/exp_coarse_ablate.sh; results are wrong by construction): 1 no squares, 2 no filter, 4 no MFMAs, 8 no LDS reads
 #endif
 constexpr int kCoarseTA = 2;                         // A tiles (8 source keypoints each) per wave
+#ifndef UMEREG_COARSE_LATE_FILTER
+#define UMEREG_COARSE_LATE_FILTER 0   // 1: a tile's filter runs one tile late, behind the first MFMAs of the next tile (measured round 3: 168 us against 143 -- worse)
+#endif
+#ifndef UMEREG_COARSE_TPS
+#define UMEREG_COARSE_TPS 1   // (2: 140-146 us against 138-147, 4: 162 -- round-3 measurement: the barrier is not the bound either)
+#endif
+constexpr int kCoarseTPS = UMEREG_COARSE_TPS;        // target tiles staged (and consumed) per workgroup barrier
 constexpr int kCoarseRows = kCoarseTA * 8;           // source keypoints per wave
 constexpr int kCoarseWG = kCoarseRows * kDistWaves;  // source keypoints per workgroup (<= ROWS_F16X2 padding)
 
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
     const half8* __restrict__ Afrag, const half8* __restrict__ Bfrag, int n1, int n2, int n_ablk, int n_btiles,
     int tiles_per_split, MatchScratch ms)
 {
-    __shared__ half8 ldsB[2][512];                          // 2 x 8 KiB: hi planes of one 32-target tile
+    __shared__ half8 ldsB[2][kCoarseTPS * 512];             // 2 x (kCoarseTPS x 8 KiB): hi planes of kCoarseTPS 32-target tiles per barrier
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int ablk = blockIdx.x % n_ablk;
@@ -417,67 +424,49 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
 
     // Staging: chunk c = r*256 + tid of the tile's 512 hi chunks; hi chunk (q = c>>6, l = c&63) sits at
     // fragment index (q*2 + 0)*64 + l.  A tile's loads are issued two tile-times before its LDS store.
-    half8 stA[2], stB[2];
+    // A GROUP of kCoarseTPS tiles is staged and consumed per barrier.  (Round 3 asked whether one barrier per tile is what
+    // the kernel waits for -- tools/exp_coarse_ablate.sh: 150 us as it is, 155 without its squares, 123 without its filter,
+    // 100 without both, 105 without its MFMAs -- and the answer is no: two tiles per barrier measure the same, four are slower.)
+    half8 st[kCoarseTPS][2];
     const int c0 = threadIdx.x, c1 = 256 + threadIdx.x;
     const int src0 = ((c0 >> 6) * 2) * 64 + (c0 & 63), src1 = ((c1 >> 6) * 2) * 64 + (c1 & 63);
-    auto gload = [&](half8 (&st)[2], int jt) __attribute__((always_inline)) {
-        st[0] = Bfrag[(size_t)jt * 1024 + src0];
-        st[1] = Bfrag[(size_t)jt * 1024 + src1];
+    auto gload = [&](int jg) __attribute__((always_inline)) {          // the tiles jg .. jg + kCoarseTPS - 1 -> registers
+#pragma unroll
+        for (int q = 0; q < kCoarseTPS; ++q) {
+            const int jt = min(jg + q, jt1 - 1);
+            st[q][0] = Bfrag[(size_t)jt * 1024 + src0];
+            st[q][1] = Bfrag[(size_t)jt * 1024 + src1];
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < kCoarseTPS; ++q) {
+            ldsB[buf][q * 512 + c0] = st[q][0];
+            ldsB[buf][q * 512 + c1] = st[q][1];
+        }
     };
     if (jt0 < jt1) {
-        gload(stA, jt0);
-        ldsB[0][c0] = stA[0];
-        ldsB[0][c1] = stA[1];
+        gload(jt0);
+        lstore(0);
     }
-    if (jt0 + 1 < jt1) gload(stB, jt0 + 1);
+    if (jt0 + kCoarseTPS < jt1) gload(jt0 + kCoarseTPS);
     __syncthreads();
     int cur = 0;
-    auto tile = [&](const int jt, half8 (&stLoad)[2], half8 (&stWrite)[2]) __attribute__((always_inline)) {
-        if (jt + 2 < jt1) gload(stLoad, jt + 2);
-        float sc[kCoarseTA][4];    // coarse scores of this lane's 4*TA (source, target) pairs
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const half8 b0 = (UMEREG_COARSE_ABLATE & 8) ? a[0][0] : ldsB[cur][(b * 2 + 0) * 64 + lane];
-            const half8 b1 = (UMEREG_COARSE_ABLATE & 8) ? a[0][1] : ldsB[cur][(b * 2 + 1) * 64 + lane];
-            f32x16 cc[kCoarseTA];
-            if (UMEREG_COARSE_ABLATE & 4) {
-#pragma unroll
-                for (int t = 0; t < kCoarseTA; ++t)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) cc[t][e] = (float)b0[e & 7] + (float)b1[(e + t) & 7];
-            } else {
-#pragma unroll
-                for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, f32x16{0}, 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (UMEREG_COARSE_ABLATE & 1) {
-                        sc[t][g] = b == 0 ? cc[t][4 * g] : sc[t][g] + cc[t][4 * g + 1];
-                        continue;
-                    }
-                    // scalar FMAs on purpose: packed f32 VALU beside MFMAs is slower on gfx950
-                    float acc = b == 0 ? cc[t][4 * g] * cc[t][4 * g] : fmaf(cc[t][4 * g], cc[t][4 * g], sc[t][g]);
-                    acc = fmaf(cc[t][4 * g + 1], cc[t][4 * g + 1], acc);
-                    acc = fmaf(cc[t][4 * g + 2], cc[t][4 * g + 2], acc);
-                    sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
-                }
-        }
+    // The filter of a tile -- limit updates, hit tests, candidate appends: a dependent chain of compares, ballots and scalar
+    // branches.  The ablations of tools/exp_coarse_ablate.sh say the squares overlap with the MFMAs completely and the filter
+    // not at all, so round 3 tried to run it ONE TILE LATE, right after the first MFMAs of the next tile have been issued
+    // (UMEREG_COARSE_LATE_FILTER=1; a limit that is one tile staler is still "some coarse score of that row - margin", the
+    // proof obligation is untouched): 168 us against 143 -- the scheduling fences and the eight score registers carried
+    // across the tile cost more than the shadow returns.  Kept as a compile-time variant, off.
+    float scp[kCoarseTA][4];   // scores of the tile whose filter is pending
+    int jprev = -1;
+    auto filter = [&](const int jt, const float (&sc)[kCoarseTA][4]) __attribute__((always_inline)) {
         if (UMEREG_COARSE_ABLATE & 2) {
             // no limits, no ballots, no candidates: the scores are folded into one register that is stored once at the end
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) lim[t][g] = max(lim[t][g], __float_as_int(sc[t][g]));
-            if (jt + 1 < jt1) {
-                ldsB[cur ^ 1][c0] = stWrite[0];
-                ldsB[cur ^ 1][c1] = stWrite[1];
-            }
-            __syncthreads();
-            cur ^= 1;
             return;
         }
 #pragma unroll
@@ -528,17 +517,68 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
                     }
                 }
         }
-        if (jt + 1 < jt1) {
-            ldsB[cur ^ 1][c0] = stWrite[0];
-            ldsB[cur ^ 1][c1] = stWrite[1];
+    };
+    auto tile = [&](const int jt, const int q) __attribute__((always_inline)) {
+        const half8* const lB = &ldsB[cur][q * 512];
+        float sc[kCoarseTA][4];    // coarse scores of this lane's 4*TA (source, target) pairs
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const half8 b0 = (UMEREG_COARSE_ABLATE & 8) ? a[0][0] : lB[(b * 2 + 0) * 64 + lane];
+            const half8 b1 = (UMEREG_COARSE_ABLATE & 8) ? a[0][1] : lB[(b * 2 + 1) * 64 + lane];
+            f32x16 cc[kCoarseTA];
+            if (UMEREG_COARSE_ABLATE & 4) {
+#pragma unroll
+                for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) cc[t][e] = (float)b0[e & 7] + (float)b1[(e + t) & 7];
+            } else {
+#pragma unroll
+                for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][0], b0, f32x16{0}, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
+            }
+            if (UMEREG_COARSE_LATE_FILTER && b == 0 && jprev >= 0) {
+                // (scheduling fence on both sides: the four MFMAs above stay above, the filter's code stays here)
+                __builtin_amdgcn_sched_barrier(0);
+                filter(jprev, scp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (UMEREG_COARSE_ABLATE & 1) {
+                        sc[t][g] = b == 0 ? cc[t][4 * g] : sc[t][g] + cc[t][4 * g + 1];
+                        continue;
+                    }
+                    // scalar FMAs on purpose: packed f32 VALU beside MFMAs is slower on gfx950
+                    float acc = b == 0 ? cc[t][4 * g] * cc[t][4 * g] : fmaf(cc[t][4 * g], cc[t][4 * g], sc[t][g]);
+                    acc = fmaf(cc[t][4 * g + 1], cc[t][4 * g + 1], acc);
+                    acc = fmaf(cc[t][4 * g + 2], cc[t][4 * g + 2], acc);
+                    sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
+                }
         }
+        if (UMEREG_COARSE_LATE_FILTER) {
+#pragma unroll
+            for (int t = 0; t < kCoarseTA; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) scp[t][g] = sc[t][g];
+            jprev = jt;
+        } else {
+            filter(jt, sc);
+        }
+    };
+    for (int jg = jt0; jg < jt1; jg += kCoarseTPS) {
+#pragma unroll
+        for (int q = 0; q < kCoarseTPS; ++q)
+            if (jg + q < jt1) tile(jg + q, q);
+        // the next group (loaded one group ago) into the other buffer, the one after it into the registers
+        if (jg + kCoarseTPS < jt1) lstore(cur ^ 1);
+        if (jg + 2 * kCoarseTPS < jt1) gload(jg + 2 * kCoarseTPS);
         __syncthreads();
         cur ^= 1;
-    };
-    for (int jt = jt0; jt < jt1; jt += 2) {
-        tile(jt, stA, stB);
-        if (jt + 1 < jt1) tile(jt + 1, stB, stA);
     }
+    if (UMEREG_COARSE_LATE_FILTER && jprev >= 0) filter(jprev, scp);      // the last tile's
     // publish what this split learned for the workgroups that start later
     share(false);
     if (lane == 0) ms.cnt[(size_t)blk * ms.splits + sp] = (unsigned int)qn;
