@@ -5,7 +5,8 @@
 #   kernel_stats.csv       rocprofv3 --kernel-trace --stats of the same command (without the CPU leg)
 #   pmc_{FETCH,WRITE}_SIZE.csv   separate --pmc passes of the named-path leg (kernel-trace only, as gpurun requires)
 #   sq/                    SQ / TCC counter passes of the named-path leg (tools/make_sq_summary.py turns them into sq_summary.json)
-#   f1_kernel_stats.txt    per-kernel times of the hypothesis-selection probe (tools/exp_f1_lattice.py)
+#   f1_kernel_stats.txt    per-kernel times of the hypothesis-selection probes (tools/exp_f1_lattice.py, exp_f1_prod.py, exp_f1_v2.py)
+#   e2e_kernel_stats.txt   kernel time and launches per end-to-end pair (tools/e2e_stats.sh); f1 SQ passes land in gpurun_out/f1pmc
 TAG=${1:-profiles_run}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -32,8 +33,15 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   f=$(ls $OUT/sq/p$i/*/pmc_counter_collection.csv $OUT/sq/p$i/pmc_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/sq/pass$i.csv
   rm -rf $OUT/sq/p$i
 done
+cd $ROOT
 timeout -s KILL 300 $ROOT/tools/f1_stats.sh 3 > $OUT/f1_kernel_stats.txt 2>&1
 echo "---- production path alone (tools/f1_prod_stats.sh): plain KT pair, then the half-overlapping one" >> $OUT/f1_kernel_stats.txt
 timeout -s KILL 300 $ROOT/tools/f1_prod_stats.sh 10 plain >> $OUT/f1_kernel_stats.txt 2>&1
 timeout -s KILL 300 $ROOT/tools/f1_prod_stats.sh 5 hard >> $OUT/f1_kernel_stats.txt 2>&1
+echo "---- first vs second form of the consensus pass, leftover routing (tools/exp_f1_v2.py)" >> $OUT/f1_kernel_stats.txt
+timeout -s KILL 300 python $ROOT/tools/exp_f1_v2.py 5 plain,hard,rot v1,def,defR,defC,defL 2>&1 | grep "^plain\|^hard\|^rot" >> $OUT/f1_kernel_stats.txt
+# SQ counter passes of the f1 kernels (plain and half-overlapping pair) -> gpurun_out/f1pmc (tools/make_f1_sq_summary.py)
+timeout -s KILL 900 $ROOT/tools/f1_pmc.sh 3 > $OUT/f1_pmc.log 2>&1
+# launches and kernel time per end-to-end pair
+timeout -s KILL 600 $ROOT/tools/e2e_stats.sh > $OUT/e2e_kernel_stats.txt 2>&1
 ls -la $OUT $OUT/sq

@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if short in k:
                 raw[short][c] = {"mean": round(sum(v) / len(v), 1), "launches": len(v)}
 out = {"_comment": "HBM-side bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
-                   "`bench.py --steps 6 --warmup 2 --depth 1`, KT workload; the moment kernel launch covers both clouds of a "
+                   "`bench.py --steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e` (tools/collect_profiles.sh: the named-path leg of the default command, shortened and with one pair in flight so that a launch is not time-shared), KT workload; the moment kernel launch covers both clouds of a "
                    "pair). Counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide (16 B/lane) "
                    "reads, so reads are DOUBLED per guides/MI355X_MICROARCH.md section HBM; WRITE_SIZE is used as reported. "
                    "Infinity-Cache hits are included in these counters, so this is an upper bound on DRAM traffic."}
@@ -34,6 +34,6 @@ print(json.dumps({k: v for k, v in out.items() if k not in ("_comment", "raw_kib
 if dst:
     os.makedirs(dst, exist_ok=True)
     for f in ("bench_default.json", "kernel_stats.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv", "bench_with_selection.json",
-              "bench_end_to_end.json", "kernel_stats_end_to_end.csv"):
+              "bench_end_to_end.json", "kernel_stats_end_to_end.csv", "f1_kernel_stats.txt", "e2e_kernel_stats.txt"):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, f))
