@@ -156,7 +156,7 @@ def soak_corr(rng):
     """per-hypothesis correlation scores (f1) vs the brute-force oracle: random clouds, random and degenerate transforms"""
     Ns, Nt = max(2, rand_size(rng, 3000)), max(2, rand_size(rng, 3000))
     K = int(min(Nt, rng.choice([1, 5, 20, 20, 20])))
-    M = int(rng.randint(1, 12))
+    M = int(rng.randint(1, 12)) if rng.rand() < 0.7 else int(rng.randint(64, 400))   # (many hypotheses: full 64-lane steps of the consensus pass)
     tgt = cloud(rng, Nt)
     src = cloud(rng, Ns) if rng.rand() < 0.3 else (tgt[rng.randint(0, Nt, Ns)] + rng.standard_normal((Ns, 3)).astype(np.float32) * np.float32(0.3))
     Ts = []
@@ -171,8 +171,13 @@ def soak_corr(rng):
     sf = rng.standard_normal((Ns, 32)).astype(np.float32); tf = rng.standard_normal((Nt, 32)).astype(np.float32)
     sigma = float(rng.choice([0.05, 1.5]))
     ref = orc.pc_corr_cost(Ts[:, :3, :3], Ts[:, :3, 3], src, tgt, K, sf, tf, sigma)
-    flags = int(rng.choice([0, ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS, ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS,
-                            ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS | ops.CORR_NO_FLAT, ops.CORR_NO_LATTICE]))   # every search structure
+    fc = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS
+    flags = int(rng.choice([0, ops.CORR_FORCE_LATTICE | ops.CORR_NO_CONSENSUS, fc, fc | ops.CORR_NO_FLAT, ops.CORR_NO_LATTICE,
+                            # round 3: first form of the consensus pass, row-major source order, leftovers forced either way, the
+                            # record-staged kernel, far-point margins (off / half a cell / four cells)
+                            fc | ops.CORR_CONSENSUS_V1, fc | ops.CORR_SRC_ROWS, fc | ops.CORR_LEFT_COOP, fc | ops.CORR_LEFT_LATTICE,
+                            fc | ops.CORR_RECORD_STAGE, fc | (255 << ops.CORR_FAR_MARGIN_SHIFT), fc | (4 << ops.CORR_FAR_MARGIN_SHIFT),
+                            fc | (32 << ops.CORR_FAR_MARGIN_SHIFT)]))   # every search structure
     out = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma, flags=flags))
     scale = np.abs(ref).max() + 1e-6
     assert np.abs(out - ref).max() <= 2e-4 * scale + 1e-6, f"corr scores differ {np.abs(out - ref).max():.3g} of {scale:.3g} (Ns={Ns}, Nt={Nt}, K={K}, M={M})"

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __res
 }
 
 // ---- K1: cell ids + per-workgroup histograms --------------------------------------------------
-// order_only != 0: the structure will only be used as a PROCESSING ORDER (corr.hip: the source cloud of the correlation
+// order_only (a bit per batch element; -1 = all) set: the structure will only be used as a PROCESSING ORDER (corr.hip: the source cloud of the correlation
 // scores), never searched.  Single-layer grids then sort by the cell's position along the Hilbert curve instead of the
 // row-major cell id: 64 consecutive points of the sorted table form a compact blob (~8 m x 8 m on a KITTI cloud) instead of a
 // strip one cell wide and ~40 m long, which is what makes "a chunk of 64 slots" a neighbourhood (per-chunk hypothesis orders,
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
         const float4 p = P4o[j];
         int c = (cell_axis(p.z, g.minz, g.invz, g.nz) * g.ny + cell_axis(p.y, g.miny, g.invy, g.ny)) * g.nx +
                 cell_axis(p.x, g.minx, g.invx, g.nx);
-        if (order_only && g.nz == 1 && g.nx <= 64 && g.ny <= 64)          // (positions < 64 * 64 = kMaxCells)
+        if (((order_only >> blockIdx.y) & 1) && g.nz == 1 && g.nx <= 64 && g.ny <= 64)          // (positions < 64 * 64 = kMaxCells)
             c = hilbert64(cell_axis(p.x, g.minx, g.invx, g.nx), cell_axis(p.y, g.miny, g.invy, g.ny));
         cell_of[j] = c;
         atomicAdd(&hist[c], 1);   // integer counts: order-independent
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, 
     const Grid gg = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     if (threadIdx.x == 0) store_grid(reinterpret_cast<unsigned int*>(wb + w.off_bbox), gg);     // for every later kernel
     // cells beyond this are never populated (curve positions of an order-only structure: any of the 4096)
-    const int n_cells = order_only ? kMaxCells : gg.nx * gg.ny * gg.nz;
+    const int n_cells = ((order_only >> blockIdx.y) & 1) ? kMaxCells : gg.nx * gg.ny * gg.nz;
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) {
         int run = 0;
         if (c >= n_cells) { tot[c] = 0; continue; }

@@ -78,6 +78,18 @@ __device__ __forceinline__ int wave_max_nonneg(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ float wave_max_nonneg_f(float v) { return __int_as_float(wave_max_nonneg(__float_as_int(v))); }
+// inclusive prefix sum over the wavefront's lanes: Hillis-Steele inside each row of 16 by DPP row shifts (invalid sources
+// read 0), then the row totals by the two row broadcasts -- six adds instead of six ds_bpermute round trips
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
 // min / max of a float over the wavefront (uniform result), same DPP ladder with the operation's identity for lanes
 // without a source
 template <bool kMax>
@@ -761,16 +773,30 @@ __global__ __launch_bounds__(256) void mean_rotation_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void rotate_points_kernel(const float* __restrict__ pts, int N, const float* __restrict__ Rbar,
-                                                            float* __restrict__ out)
+                                                            float* __restrict__ out, const float* __restrict__ tgt, int n_tgt_copies)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    // (equal-sized clouds: two copies of the target behind the rotated source, so that the three structures of a call --
+    // source order, target grid, Hilbert-ordered target copy -- are built as ONE batch of three: a third of the launches)
+    for (int c = 0; c < n_tgt_copies; ++c)
+        for (int r = 0; r < 3; ++r) out[((size_t)(c + 1) * N + i) * 3 + r] = tgt[(size_t)i * 3 + r];
     const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const float v = fmaf(Rbar[r * 3 + 2], z, fmaf(Rbar[r * 3 + 1], y, Rbar[r * 3] * x));
         out[(size_t)i * 3 + r] = v == v && fabsf(v) < 1e30f ? v : 0.f;
     }
+}
+
+// weight 1 / (1 + (|d| / sigma)^2) (cauchy_kernel :588-589 on torch.linalg.norm :593) from the hardware square root and
+// reciprocal and a multiplication by 1 / sigma: each within 1 ulp of the IEEE form (two IEEE divisions and a square root per
+// neighbour are ~35 instructions); the difference per term, <= 2e-7 relative, is below the summation-order differences between
+// the structures.  Used by the consensus pass (round 2) and, since round 3, by the one-wavefront-per-query kernels.
+__device__ __forceinline__ float cauchy_weight_hw(float d2, float inv_sigma)
+{
+    const float r = __builtin_amdgcn_sqrtf(d2) * inv_sigma;
+    return __builtin_amdgcn_rcpf(1.0f + r * r);
 }
 
 // ---- score epilogue ---------------------------------------------------------------------------------------------
@@ -1075,12 +1101,7 @@ __device__ __forceinline__ int coop_hist_cut(const unsigned long long* list, uns
         if (u * kWave + lane < cnt) atomicAdd(&hist[bin[u]], 1u);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int incl = (int)hist[lane];
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const int v = __shfl_up(incl, o, kWave);
-        incl += lane >= o ? v : 0;
-    }
+    const int incl = wave_incl_scan((int)hist[lane]);
     const unsigned long long reach = __ballot(incl >= K);      // non-empty: cnt > K
     const int tb = __ffsll((long long)reach) - 1;
     const int kept = __shfl(incl, tb, kWave);
@@ -1605,7 +1626,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 // points of a half-overlapping pair) used to give up (< K targets within D); they now stage the points within
 // d_K(q~) + margin of the image, found through the chunk boxes of the sorted table (coop_knn for d_K, then one pruned sweep)
 // -- the fine range of (2) is what makes the thin shell their neighbours live in selectable in one histogram.
-constexpr float kConsFarMarginCells = 2.0f;   // default margin of the far-point stage (see corr_consensus2_kernel), in grid cells
+constexpr float kConsFarMarginCells = 2.5f;   // default margin of the far-point stage (see corr_consensus2_kernel), in grid cells
 constexpr int kCons2Cap = 252;           // staged target points per source point (byte counters: see above)
 constexpr int kCons2Tie = 8;             // list entries per lane for the candidates of the K-th neighbour's bin
 constexpr int kCons2Zone = 12;           // zone size up to which the rank-counting path is taken
@@ -1758,7 +1779,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (!(dkf < 1.0e18f)) { give_up(); return; }
         const int n_tch = (Nt + kWave - 1) / kWave;
         float margin = far_margin_cells * c.cs_min;
-        for (int attempt = 0; attempt < 8; ++attempt) {
+        for (int attempt = 0; attempt < 12; ++attempt) {
             D = dkf * 1.0001f + margin;
             const float D2 = D * D;
             n_c = 0;
@@ -1786,7 +1807,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     n_c += __popcll(bal);
                 }
             }
-            if (n_c > kCons2Cap) { margin *= 0.6f; continue; }
+            if (n_c > kCons2Cap) { margin *= 0.8f; continue; }
             break;
         }
         if (n_c < K || n_c > kCons2Cap) { give_up(); return; }
@@ -2672,6 +2693,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
     if (header[11] == 0u && header[12] != 0u) return;                  // served as a flat list (corr_score_flat_kernel)
     const unsigned int n_rec = header[4];
     const int grp = lane >> 3, sub = lane & 7;
+    const float inv_sigma = 1.0f / sigma;
     for (unsigned int r = blockIdx.x; r < n_rec; r += gridDim.x) {      // (static assignment: see DESIGN on the atomic-counter hang)
         const uint4 rec = queue[r];
         const int h = (int)rec.x, chunk = (int)rec.y;
@@ -2699,9 +2721,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
             for (int e0 = 0; e0 < cnt; e0 += 8) {
                 const int e = e0 + grp;
                 const unsigned long long k = la[e < cnt ? e : 0];
-                const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));                 // torch.linalg.norm (:593)
-                const float rr = dist / sigma;
-                const float wgt = 1.0f / (1.0f + rr * rr);                                          // cauchy_kernel (:588-589)
+                const float wgt = cauchy_weight_hw(__uint_as_float((unsigned int)(k >> 32)), inv_sigma);   // :593, :588-589
                 const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
                 float d = a.x * o.x;
                 d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
@@ -2789,6 +2809,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
     unsigned long long* la = lists[wave][0];
     unsigned long long* lb = lists[wave][1];
     const int grp = lane >> 3, sub = lane & 7;
+    const float inv_sigma = 1.0f / sigma;
     const unsigned int n_waves = gridDim.x * kCoopWaves;
     for (unsigned int q = blockIdx.x * kCoopWaves + wave; q < n_q; q += n_waves) {
         const unsigned int ent = f.qlist[q];
@@ -2811,9 +2832,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
         for (int e0 = 0; e0 < cnt; e0 += 8) {
             const int e = e0 + grp;
             const unsigned long long k = la[e < cnt ? e : 0];
-            const float dist = sqrtf(__uint_as_float((unsigned int)(k >> 32)));                 // torch.linalg.norm (:593)
-            const float rr = dist / sigma;
-            const float wgt = 1.0f / (1.0f + rr * rr);                                          // cauchy_kernel (:588-589)
+            const float wgt = cauchy_weight_hw(__uint_as_float((unsigned int)(k >> 32)), inv_sigma);   // :593, :588-589
             const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
             float d = a.x * o.x;
             d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
@@ -3160,7 +3179,7 @@ UMEREG_API int umereg_feature_spatial_var_f32(const float* pts, const float* fea
     // small clouds go one wavefront per query through coop_knn, which never walks the grid: the table is then sorted along the
     // Hilbert curve, so that its 64-point chunks -- what that search prunes with -- are compact blobs instead of 40 m strips
     // (same neighbours, same ascending key order, same sums: the table's order only decides how many chunks get scanned)
-    if (int rc = launch_prep(pts, (char*)workspace, B, N, -(float)knn, st, N <= 32768 ? 1 : 0)) return rc;
+    if (int rc = launch_prep(pts, (char*)workspace, B, N, -(float)knn, st, N <= 32768 ? -1 : 0)) return rc;
     int cap, waves;
     size_t lds;
     bool idx16;
@@ -3229,7 +3248,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
                                                         align_up((size_t)((Ns + kValSlice - 1) / kValSlice) * M * 4, 256) + align_up((size_t)M * 12, 256) +
                                                         2 * align_up(n_chunks * M * 4, 256) + align_up((size_t)Ns * 4, 256) + align_up(n_chunks * 16, 256) : 0;
     return grid_ws(Ns).total + 2 * grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
-           align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)Ns * 12, 256) + 256 +
+           align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)(Ns + 2 * (size_t)Nt) * 12, 256) + 256 +
            (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + flat_bytes((size_t)M * n_chunks, (long)M * Ns) : 0) + cons;
 }
 
@@ -3291,26 +3310,35 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     float* partial = (float*)(ws_tgth + grid_ws(Nt).total);
     const size_t n_chunks_sz = (size_t)((Ns + kWave - 1) / kWave);
     float* rotated = (float*)((char*)partial + align_up((size_t)M * n_chunks_sz * 4, 256) + align_up((size_t)kColsumBlocks * 32 * 8, 256));
-    float* Rbar = (float*)((char*)rotated + align_up((size_t)Ns * 12, 256));
+    float* Rbar = (float*)((char*)rotated + align_up((size_t)(Ns + 2 * (size_t)Nt) * 12, 256));
     char* lat = (char*)Rbar + 256;
     const unsigned int c_max = lattice_cells_for((long)M * Ns, Nt, flags);
     // target: the search structure; source: only a processing order (wavefronts of queries that stay row-aligned
     // with the target grid under the consensus rotation)
-    if (int rc = launch_prep(tgt_pts, ws_tgt, 1, Nt, -(float)K, st)) return rc;
     const bool coop_copy = lattice_cells_for((long)M * Ns, Nt, flags) != 0 && !(flags & UMEREG_CORR_SRC_ROWS);
     const char* ws_coop = coop_copy ? ws_tgth : ws_tgt;
+    // (compact 64-point chunks where the consensus pass runs; the per-lane grid walk of small jobs keeps the row-aligned strips)
+    const bool curve_src = consensus_on(lattice_cells_for((long)M * Ns, Nt, flags), M, flags, T) && !(flags & UMEREG_CORR_SRC_ROWS);
+    hipLaunchKernelGGL(mean_rotation_kernel, dim3(1), dim3(256), 0, st, T, M, Rbar);
+    UMEREG_CHECK_LAUNCH("mean_rotation_kernel");
+    if (coop_copy && Ns == Nt) {
+        // the three structures as one batch of three (their workspaces are consecutive and, the clouds being equally large, equally
+        // long): [rotated source | target | target], Hilbert-curve order for the first (if the consensus pass runs) and the third
+        hipLaunchKernelGGL(rotate_points_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, src_pts, Ns, (const float*)Rbar, rotated, tgt_pts, 2);
+        UMEREG_CHECK_LAUNCH("rotate_points_kernel");
+        if (int rc = launch_prep(rotated, ws_src, 3, Ns, -(float)K, st, (curve_src ? 1 : 0) | 4)) return rc;
+    } else {
+        if (int rc = launch_prep(tgt_pts, ws_tgt, 1, Nt, -(float)K, st)) return rc;
+        if (coop_copy)
+            if (int rc = launch_prep(tgt_pts, ws_tgth, 1, Nt, -(float)K, st, 1)) return rc;
+        hipLaunchKernelGGL(rotate_points_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, src_pts, Ns, (const float*)Rbar, rotated, (const float*)nullptr, 0);
+        UMEREG_CHECK_LAUNCH("rotate_points_kernel");
+        if (int rc = launch_prep(rotated, ws_src, 1, Ns, -(float)K, st, curve_src ? 1 : 0)) return rc;
+    }
     if (coop_copy) {
-        if (int rc = launch_prep(tgt_pts, ws_tgth, 1, Nt, -(float)K, st, 1)) return rc;
         hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgth, (size_t)0, Nt);
         UMEREG_CHECK_LAUNCH("chunk_box_kernel");
     }
-    hipLaunchKernelGGL(mean_rotation_kernel, dim3(1), dim3(256), 0, st, T, M, Rbar);
-    UMEREG_CHECK_LAUNCH("mean_rotation_kernel");
-    hipLaunchKernelGGL(rotate_points_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, src_pts, Ns, (const float*)Rbar, rotated);
-    UMEREG_CHECK_LAUNCH("rotate_points_kernel");
-    // (compact 64-point chunks where the consensus pass runs; the per-lane grid walk of small jobs keeps the row-aligned strips)
-    const bool curve_src = consensus_on(lattice_cells_for((long)M * Ns, Nt, flags), M, flags, T) && !(flags & UMEREG_CORR_SRC_ROWS);
-    if (int rc = launch_prep(rotated, ws_src, 1, Ns, -(float)K, st, curve_src ? 1 : 0)) return rc;
     int cap, waves;
     size_t lds;
     bool idx16;
@@ -3411,7 +3439,9 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
             UMEREG_CHECK_LAUNCH("chunk_box_kernel");
         }
-        hipLaunchKernelGGL(lattice_dk_kernel, dim3(1024), dim3(8 * kWave), 0, st, ws_coop, lat, c_max, Nt, K);
+        // (grids of the kernels that usually find nothing to do -- the leftovers go to the queue up to 2 M -- are kept small: a
+        // workgroup that returns at once still costs its launch, 50 us for 1 024 x 512 threads with 33 KiB of LDS each)
+        hipLaunchKernelGGL(lattice_dk_kernel, dim3(512), dim3(8 * kWave), 0, st, ws_coop, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_dk_kernel");
         hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), (size_t)(kMaxCells + 64) * 4, st,
                            (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
@@ -3421,7 +3451,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
         corr_mark(3, st);
-        const dim3 lat_grid(score_grid.x < 16384u ? score_grid.x : 16384u);
+        const dim3 lat_grid(score_grid.x < 4096u ? score_grid.x : 4096u);
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), lat_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
                            lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
@@ -3457,7 +3487,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial);
             UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
         }
-        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3(4096), dim3(kCoopWaves * kWave), 0, st, ws_coop,
+        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3((flags & UMEREG_CORR_NO_FLAT) ? 4096 : 512), dim3(kCoopWaves * kWave), 0, st, ws_coop,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);
         UMEREG_CHECK_LAUNCH("corr_score_fallback_kernel");

@@ -154,8 +154,8 @@ __device__ __forceinline__ int cell_axis(float p, float mn, float inv, int n)
 }
 
 // build the structure for `pts` [B,N,3] with cell edge >= 1.0001 * radius (pack, bbox, stable counting sort)
-// order_only: the structure only supplies a processing order (Hilbert-curve order of the cells where the grid has one layer); it
-// must not be searched (see grid_hist_kernel)
+// order_only: bit b set (-1: every bit) = the structure of batch element b only supplies a processing order (Hilbert-curve order of
+// the cells where the grid has one layer); it must not be searched (see grid_hist_kernel)
 int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only = 0);
 // cell-sorted processing order of n_q query points (kpts [B,n_q,3] or indices into pts) -> ws.off_kperm
 int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,

@@ -177,6 +177,20 @@ __global__ __launch_bounds__(kIcpWG) void icp_step_kernel(const double* __restri
     state->iters += 1;
 }
 
+// the initial state, handed over by value as a kernel argument: no host staging buffer whose lifetime the stream would
+// have to be synchronised for
+struct IcpInit {
+    double T[16];
+};
+__global__ void icp_init_kernel(IcpState* __restrict__ state, IcpInit init)
+{
+    if (threadIdx.x < 16) state->T[threadIdx.x] = init.T[threadIdx.x];
+    if (threadIdx.x == 0) {
+        state->fitness = 0.0; state->rmse = 0.0; state->prev_fitness = 0.0; state->prev_rmse = 0.0;
+        state->iters = 0; state->done = 0; state->have_prev = 0; state->pad = 0;
+    }
+}
+
 static size_t icp_extra_bytes(int n_src)
 {
     const size_t n_blocks = ((size_t)n_src + kIcpWG - 1) / kIcpWG;
@@ -195,7 +209,7 @@ UMEREG_API size_t umereg_icp_workspace_bytes(int n_src, int n_tgt)
 
 // src f32 [n_src,3], tgt f32 [n_tgt,3] (device); T_init / T_out: HOST double [16] row major; fitness,
 // inlier_rmse, iterations: HOST outputs (may be NULL).  Synchronous with respect to `stream`: the loop's stop
-// test lives on the device, the host polls it once per batch of 8 iterations.
+// test lives on the device, the host polls it once per batch of iterations (4, then 8 at a time).
 UMEREG_API int umereg_icp_point_to_point_f32(const float* src, const float* tgt, int n_src, int n_tgt,
                                              const double* T_init_host, float max_correspondence_distance,
                                              int max_iteration, double relative_fitness, double relative_rmse,
@@ -219,26 +233,26 @@ UMEREG_API int umereg_icp_point_to_point_f32(const float* src, const float* tgt,
     if (int rc = launch_prep(tgt, ws, 1, n_tgt, -1.0f, st)) return rc;   // kNN-mode grid for K = 1
     IcpState h;
     memset(&h, 0, sizeof(h));
-    for (int k = 0; k < 16; ++k) h.T[k] = T_init_host[k];
-    if (hipMemcpyAsync(state, &h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) {
-        set_error("icp_point_to_point: state upload failed");
-        return UMEREG_ELAUNCH;
-    }
-    if (hipStreamSynchronize(st) != hipSuccess) {   // `h` is a stack object
-        set_error("icp_point_to_point: stream synchronize failed");
-        return UMEREG_ELAUNCH;
+    {
+        IcpInit init;
+        for (int k = 0; k < 16; ++k) init.T[k] = T_init_host[k];
+        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, st, state, init);
+        UMEREG_CHECK_LAUNCH("icp_init_kernel");
     }
     const int n_blocks = (n_src + kIcpWG - 1) / kIcpWG;
     int launched = 0;
     while (true) {
-        for (int b = 0; b < 8; ++b) {
+        // the first batch is short: most registrations that start from a selected hypothesis converge in 2-3 updates, and every
+        // iteration enqueued beyond the stop is a pair of launches that only finds the flag set
+        const int batch = launched == 0 ? 4 : 8;
+        for (int b = 0; b < batch; ++b) {
             hipLaunchKernelGGL(icp_eval_kernel, dim3(n_blocks), dim3(kIcpWG), 0, st, src, n_src, ws, n_tgt,
                                max_correspondence_distance, state, partial);
             hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(kIcpWG), 0, st, partial, n_blocks, n_src, max_iteration,
                                relative_fitness, relative_rmse, state);
         }
         UMEREG_CHECK_LAUNCH("icp kernels");
-        launched += 8;
+        launched += batch;
         if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
             set_error("icp_point_to_point: state download failed");
