@@ -296,7 +296,14 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src
     """
     assert src_pts.shape[0] == 1, "the reference evaluates with batch_size: 1"
     src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds)
-    a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D, timing)
+    pair = None
+    if timing is None and not materialize_D and src_pts.is_cuda and ops.DEFAULT_MATCH_PRECISION == "f16r" \
+            and not getattr(args, "hungarian_matching_flag", False):
+        # equally large clouds (what the reference's collate produces): both through every kernel as ONE batch of two and a1..a5
+        # as one native call (the same kernels; one device copy of the clouds, 14 MB at KITTI size, instead of a second set of
+        # grid-build and keypoint-order launches)
+        pair = PairBatch.from_clouds(src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds)
+    a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D, timing, pair=pair)
     if args.filter_by_ume_dist_cond and cond is None:
         # tau-weighted sub-sampling of matches (:233-245): the draw consumes the HOST numpy RNG
         num_matches = min(a.num_kpts, args.ume_n_samples)
