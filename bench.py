@@ -606,7 +606,11 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
         res["kernels"] = {}
         which = "hard" if int(h[17]) > 0 else "plain"
         tracked = json.load(open(sq)).get(which, {})
+        total_clk = sum(float(v.get("duration_shader_clocks") or 0.0) for v in tracked.values())
         for k, v in tracked.items():
+            if float(v.get("duration_shader_clocks") or 0.0) < 0.02 * total_clk:
+                continue      # (the lattice's four idle early-outs and the like: their rows stay in the summary file)
+            v = {kk: vv for kk, vv in v.items() if kk != "counters"}
             res["kernels"][k] = dict(v, bound="valu_issue", peak_valu_ginst_per_s=round(VALU_ISSUE_PEAK_GINST, 1),
                                      counters_source="profiles/f1_sq_summary.json (rocprofv3 --pmc SQ passes of tools/exp_f1_prod.py, "
                                                      "an earlier run of the same kernels; tools/f1_pmc.sh)")

@@ -1,0 +1,62 @@
+"""f1 probe: what would bounding the FAR queries buy?  (arg-max by branch and bound: a query whose image lies at least L0 from
+every target point contributes at most K * w(L) * |vp_i| * max|vq| in magnitude, so it can be skipped, its bound added to the
+hypothesis' slack E_h, and only the hypotheses whose interval [S_h - E_h, S_h + E_h] reaches the best lower bound need their skipped
+queries evaluated exactly.)  This measures, on the KT pairs of the bench, with exact nearest distances from torch.cdist:
+  skipped queries (and how many of them a second pass has to evaluate after all), surviving hypotheses, for several (L0, cell) choices.
+usage: python tools/exp_f1_bound.py [plain,hard,rot]"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from umeregrobust_amd import evaluate, ops  # noqa: E402
+from umeregrobust_amd.synth import synth_pair, synth_pair_hard  # noqa: E402
+from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml  # noqa: E402
+from umeregrobust_amd.utils.loc_utils import feature_spatial_var  # noqa: E402
+
+kinds = (sys.argv[1] if len(sys.argv) > 1 else "plain,hard").split(",")
+dev = torch.device("cuda:0")
+args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("kitti_test"))
+t = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
+K, sigma = 20, float(args.corr_kernel_sigma)
+
+for which in kinds:
+    gen = {"plain": synth_pair, "hard": synth_pair_hard, "rot": lambda **k: synth_pair(kind="rot", **k)}[which]
+    p = gen(seed=3, N=50000, n_kp=10000)
+    sp, tp, sf, tf = t(p.src_pts)[None], t(p.tgt_pts)[None], t(p.src_feat)[None], t(p.tgt_feat)[None]
+    with torch.no_grad():
+        out = evaluate.register_pair(sp, tp, sf, tf, args, rng=np.random.RandomState(0))
+        T = out.rtume_tform[0].contiguous()
+        rs = np.random.RandomState(1)
+        si, ti = t(rs.choice(50000, 10000, replace=False)), t(rs.choice(50000, 10000, replace=False))
+        a, b, fa, fb = sp[0, si].contiguous(), tp[0, ti].contiguous(), sf[0, si].contiguous(), tf[0, ti].contiguous()
+        w = feature_spatial_var(torch.stack([a, b]), torch.stack([fa, fb]), knn=50)
+        wsf, wtf = ops.corr_weighted_features(fa, fb, w[0], w[1])
+        s = ops.corr_scores(a, b, wsf, wtf, T, K=K, sigma=sigma).double()
+        M, Ns = T.shape[0], a.shape[0]
+        vn = wsf.norm(dim=1).double()                    # |vp_i|
+        vmax = float(wtf.norm(dim=1).max())
+        d1 = torch.empty((M, Ns), device=dev)
+        for h in range(M):
+            y = a @ T[h, :3, :3].T + T[h, :3, 3]
+            d1[h] = torch.cdist(y[None], b[None])[0].min(dim=1).values
+    best = float(s.max())
+    print(f"{which}: best score {best:.4f}, median {float(s.median()):.4f}; |vp| mean {float(vn.mean()):.3f} max|vq| {vmax:.3f}; "
+          f"d1 quantiles (m) {[round(float(q), 2) for q in torch.quantile(d1.flatten()[::97].float(), torch.tensor([.5, .9, .99], device=dev))]}",
+          flush=True)
+    for cell in (2.0, 4.0):
+        for L0 in (6.0, 10.0, 16.0, 24.0):
+            lb = (d1 - cell * 1.7320508).clamp_min(0.0).double()
+            skip = lb >= L0
+            eps = K / (1.0 + (lb / sigma) ** 2) * vn[None, :] * vmax
+            E = (eps * skip).sum(1) / Ns
+            thr = float((s - 2 * E).max())
+            surv = (s + 2 * E) >= thr
+            n_skip = int(skip.sum())
+            redo = int(skip[surv].sum())
+            print(f"   cell {cell:3.0f} L0 {L0:4.0f}: skipped {n_skip:9d} ({100.0 * n_skip / (M * Ns):5.1f} % of the queries), E_h max {float(E.max()):.4f} "
+                  f"median {float(E.median()):.4f}, survivors {int(surv.sum()):5d} of {M}, second pass {redo:8d} queries "
+                  f"({100.0 * redo / max(n_skip, 1):5.1f} % of the skipped)", flush=True)
