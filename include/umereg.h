@@ -377,6 +377,13 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
 #define UMEREG_CORR_RECORD_STAGE (1 << 18) /* (experimental) the queries neither pass serves first go one wavefront per RECORD over a staged candidate set; what that cannot serve goes one wavefront per query as before */
 #define UMEREG_CORR_LEFT_COOP (1 << 16)    /* what the consensus pass leaves goes to the one-wavefront-per-query search whatever its size */
 #define UMEREG_CORR_LEFT_LATTICE (1 << 17) /* ... to the candidate lattice whatever its size (by default the count decides) */
+#define UMEREG_CORR_CELL_PASS (1 << 19)    /* the cell pass (leftovers sorted by lattice cell, one wavefront per cell) also on jobs below 2^25 queries (tests, tuning) */
+#define UMEREG_CORR_NO_CELL_PASS (1 << 20) /* never (the round-3-start path: list kernel + one wavefront per query) */
+#define UMEREG_CORR_BOUND_OUTSIDE (1 << 21) /* arg-max mode: a listed query whose image lies outside the candidate lattice (>= 20 % of the target's extent away from its
+                                               bounding box) is BOUNDED (K w(dist to the box) |vp| max|vq|) instead of searched; hypotheses whose score + bound reaches the best
+                                               score - bound get those queries computed exactly in a second pass.  scores[h] is then exact for every hypothesis that can be the
+                                               arg-max; for the others it lacks the bounded terms (it is within the bound of the exact score, and the exact score is below the
+                                               arg-max's): umereg_corr_select_best_f32 returns the same hypothesis */
 size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
 int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
                               const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,

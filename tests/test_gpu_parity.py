@@ -1510,6 +1510,77 @@ def test_corr_scores_flat_leftovers_equal_the_record_form(gpu):
     assert np.abs(N_(a)[:4] - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
 
 
+def _garbage_hypotheses_case(seed=21, Nt=6000, Ns=5000, M=320):
+    rng = np.random.RandomState(seed)
+    tgt = (rng.uniform(-30, 30, (Nt, 3)) * np.array([1, 1, 0.1])).astype(np.float32)
+    src = (tgt[rng.randint(0, Nt, Ns)] + rng.standard_normal((Ns, 3)) * 0.1).astype(np.float32)
+    sf = rng.standard_normal((Ns, 32)).astype(np.float32); tf = rng.standard_normal((Nt, 32)).astype(np.float32)
+    Ts = np.tile(np.eye(4, dtype=np.float32), (M, 1, 1))
+    for m in range(M):
+        th = np.deg2rad(rng.choice([0.2, 3.0, 60.0])) * rng.randn()
+        Ts[m, :2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+        Ts[m, :3, 3] = rng.standard_normal(3) * rng.choice([0.05, 2.0, 40.0])
+    return src, tgt, sf, tf, Ts
+
+
+def test_corr_scores_cell_pass_equals_the_list_path(gpu):
+    """Round 3: when the consensus pass leaves MANY queries (nuScenes-size jobs, outlier hypotheses) they are sorted by the lattice cell
+    they land in and served one wavefront per cell from the cell's staged list (corr_cell_kernel) instead of lane by lane through
+    gathers.  Same neighbour sets, the terms of a query added in another order: scores within 1e-5 of the list path's, the same
+    arg-max, repeatable bit for bit, and equal to the oracle's brute force."""
+    from umeregrobust_amd import ops
+    src, tgt, sf, tf, Ts = _garbage_hypotheses_case()
+    a_ = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    base = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS | ops.CORR_LEFT_LATTICE
+    ref = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base | ops.CORR_NO_CELL_PASS)
+    got, _, hdr = ops.corr_scores_profile(*a_, K=20, sigma=1.5, flags=base | ops.CORR_CELL_PASS)
+    assert int(hdr[34]) > 10000 and int(hdr[35]) == 0, (int(hdr[32]), int(hdr[34]), int(hdr[35]))    # the pass did serve queries, none unselected
+    assert int(hdr[32]) == int(hdr[34])
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert int(got.argmax()) == int(ref.argmax())
+    assert torch.equal(got, ops.corr_scores(*a_, K=20, sigma=1.5, flags=base | ops.CORR_CELL_PASS))
+    want = orc.pc_corr_cost(Ts[:8, :3, :3], Ts[:8, :3, 3], src, tgt, 20, sf, tf, 1.5)
+    assert np.abs(N_(got)[:8] - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
+    # exact duplicates in the target (distance ties by the dozen: what the pass cannot select for stays with the other structures)
+    tgt2 = tgt.copy(); tgt2[:40] = tgt2[0]
+    b_ = (T_(src, gpu), T_(tgt2, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    r2 = ops.corr_scores(*b_, K=20, sigma=1.5, flags=base | ops.CORR_NO_CELL_PASS)
+    g2 = ops.corr_scores(*b_, K=20, sigma=1.5, flags=base | ops.CORR_CELL_PASS)
+    assert float((g2 - r2).abs().max()) <= 1e-5 * float(r2.abs().max())
+
+
+def test_corr_scores_bound_outside_keeps_the_arg_max(gpu):
+    """UMEREG_CORR_BOUND_OUTSIDE: listed queries whose image lies outside the candidate lattice are bounded instead of searched, and
+    only hypotheses whose score + bound reaches the best score - bound get them computed after all.  The arg-max and its score are
+    those of the exact run; every score is within its bound of the exact one.  Second case: the BEST hypothesis itself throws a
+    third of the source outside (it must be recomputed: header word 40), and still comes out exact."""
+    from umeregrobust_amd import ops
+    src, tgt, sf, tf, Ts = _garbage_hypotheses_case(seed=22)
+    Ts[::3, 0, 3] += 150.0                                       # every third hypothesis: everything 150 m outside
+    for base in (ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS, ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS | ops.CORR_LEFT_LATTICE | ops.CORR_CELL_PASS):
+        a_ = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+        ref = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base)
+        got, _, hdr = ops.corr_scores_profile(*a_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE)
+        assert int(hdr[41]) >= len(Ts) // 3, int(hdr[41])          # hypotheses with bounded queries
+        am = int(ref.argmax())
+        assert int(got.argmax()) == am and abs(float(got[am] - ref[am])) <= 1e-6 * abs(float(ref[am]))
+        assert torch.equal(got, ops.corr_scores(*a_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE))
+        Tb, ib = ops.corr_select_best(got, a_[4])
+        Tr, ir = ops.corr_select_best(ref, a_[4])
+        assert int(ib) == int(ir) and torch.equal(Tb, Tr)
+    # the winner needs its bounded queries: a third of the source sits 200 m away under EVERY hypothesis
+    src2 = src.copy(); src2[::3, 1] += 200.0
+    a_ = (T_(src2, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    base = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS
+    ref = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base)
+    got, _, hdr = ops.corr_scores_profile(*a_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE)
+    assert int(hdr[40]) >= 1, int(hdr[40])
+    am = int(ref.argmax())
+    assert int(got.argmax()) == am and abs(float(got[am] - ref[am])) <= 2e-6 * abs(float(ref[am])) + 1e-7
+    want = orc.pc_corr_cost(Ts[am:am + 1, :3, :3], Ts[am:am + 1, :3, 3], src2, tgt, 20, sf, tf, 1.5)
+    assert abs(float(got[am]) - float(want[0])) <= 2e-4 * abs(float(want[0])) + 1e-6
+
+
 def test_evaluate_pairs_overlapped_equals_one_pair_at_a_time(gpu):
     """evaluate.evaluate_pairs overlaps consecutive pairs on two HIP streams (pair i + 1 is prepared while the correlation
     scores of pair i are computed): same selections, same refined registrations, same host-RNG position afterwards as one

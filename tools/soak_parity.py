@@ -177,9 +177,23 @@ def soak_corr(rng):
                             # record-staged kernel, far-point margins (off / half a cell / four cells)
                             fc | ops.CORR_CONSENSUS_V1, fc | ops.CORR_SRC_ROWS, fc | ops.CORR_LEFT_COOP, fc | ops.CORR_LEFT_LATTICE,
                             fc | ops.CORR_RECORD_STAGE, fc | (255 << ops.CORR_FAR_MARGIN_SHIFT), fc | (4 << ops.CORR_FAR_MARGIN_SHIFT),
-                            fc | (32 << ops.CORR_FAR_MARGIN_SHIFT)]))   # every search structure
+                            fc | (32 << ops.CORR_FAR_MARGIN_SHIFT),
+                            # the cell pass (leftovers sorted by lattice cell), with the leftovers forced to the lattice and as the count decides
+                            fc | ops.CORR_LEFT_LATTICE | ops.CORR_CELL_PASS, fc | ops.CORR_LEFT_LATTICE | ops.CORR_CELL_PASS, fc | ops.CORR_CELL_PASS]))   # every search structure
+    bound = rng.rand() < 0.25 and not (flags & (ops.CORR_NO_LATTICE | ops.CORR_NO_FLAT))
+    if bound:
+        # arg-max mode: queries outside the lattice bounded; the winner and its score are the exact run's, every score within reach of it is exact
+        flags |= ops.CORR_BOUND_OUTSIDE
     out = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma, flags=flags))
     scale = np.abs(ref).max() + 1e-6
+    if bound:
+        am = int(np.argmax(ref))
+        tie = np.abs(ref - ref[am]) <= 4e-4 * scale + 2e-6          # (the oracle's own sums differ from the library's in the last bits)
+        assert tie[int(np.argmax(out))], f"bounded arg-max {int(np.argmax(out))} vs {am} (Ns={Ns}, Nt={Nt}, K={K}, M={M}, flags={flags})"
+        assert np.abs(out[tie] - ref[tie]).max() <= 2e-4 * scale + 1e-6, f"bounded run: score of a possible winner differs (Ns={Ns}, Nt={Nt}, K={K}, M={M})"
+        out2 = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma, flags=flags))
+        assert np.array_equal(out, out2), "bounded corr scores not deterministic"
+        return f"corr {Ns}x{Nt} K={K} M={M} flags={flags} (bounded)"
     assert np.abs(out - ref).max() <= 2e-4 * scale + 1e-6, f"corr scores differ {np.abs(out - ref).max():.3g} of {scale:.3g} (Ns={Ns}, Nt={Nt}, K={K}, M={M})"
     out2 = N_(ops.corr_scores(T_(src), T_(tgt), T_(sf), T_(tf), T_(Ts), K=K, sigma=sigma, flags=flags))
     assert np.array_equal(out, out2), "corr scores not deterministic"

@@ -540,8 +540,15 @@ __device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int 
 // position of a padding point (d2 ~ 3e36: never admitted).  Cells whose list would exceed kLatMaxQuads, cells that
 // do not fit the pool, and queries outside the lattice take the grid walk -- same result, by construction.
 constexpr int kLatMaxQuads = 128;                 // longest list (in quads of 4 entries)
-constexpr unsigned int kLatMinCells = 4096, kLatMaxCells = 1u << 20;
-constexpr size_t kLatPoolQuadsPerCell = 16;       // pool size = cells x this (quads): mean list <= 64 entries
+#ifndef UMEREG_LAT_MAXCELLS
+#define UMEREG_LAT_MAXCELLS (1u << 20)
+#endif
+#ifndef UMEREG_LAT_POOLQ
+#define UMEREG_LAT_POOLQ 32
+#endif
+constexpr unsigned int kLatMinCells = 4096, kLatMaxCells = UMEREG_LAT_MAXCELLS;
+constexpr size_t kLatPoolQuadsPerCell = UMEREG_LAT_POOLQ;       // pool size = cells x this (quads): mean list <= 128 entries (16 ran out on a half-overlapping
+                                                                // nuScenes-size job: 26 M quads for 0.96 M marked cells, 40 % of them left without a list)
 constexpr int kLatLanes = 16;                     // cells per wavefront in the build kernels: their walks are chains of dependent
                                                   // loads, so more, thinner wavefronts (and the slowest of 16 cells instead of 64) win
 
@@ -552,13 +559,14 @@ struct Lattice {
 };
 
 struct LatWs {
-    size_t off_header, off_marks, off_wave_tot, off_cids, off_cells, off_pool, total;
+    size_t off_header, off_marks, off_wave_tot, off_cids, off_cells, off_dk2, off_pool, total;
     unsigned int c_max;
     size_t pool_quads;
 };
 
 // header words: [0] pool quads handed out, [1] cells, [2] marked cells without a list, [3] marked cells,
-//               [4] fallback records, [6] fallback queries
+//               [4] fallback records, [6] fallback queries; cell pass: [32] queries listed, [33] next marked cell to take,
+//               [34] queries served, [35] queries it listed and could not select for, [36] batches
 __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
 {
     LatWs w;
@@ -571,6 +579,7 @@ __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
     o = (o + 255) / 256 * 256;
     w.off_cids = o;     o += (size_t)c_max * 4 + 256;                    // marked cells, ascending
     w.off_cells = o;    o += (size_t)c_max * 16;
+    w.off_dk2 = o;      o += (size_t)c_max * 4;                          // d_K^2 of the cell centres (float bits), for the cell pass
     w.off_pool = o;     o += w.pool_quads * 8 + 256;
     w.total = (o + 255) / 256 * 256;
     return w;
@@ -2168,7 +2177,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
                                                            const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
                                                            char* __restrict__ lat, unsigned int c_max,
                                                            const unsigned long long* __restrict__ served, int n_words,
-                                                           const int* __restrict__ inv, const int* __restrict__ chunk_of)
+                                                           const int* __restrict__ inv, const int* __restrict__ chunk_of, unsigned int* __restrict__ cell_cnt)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
@@ -2187,7 +2196,10 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
         const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
         if (served) { const int ph = inv[(size_t)chunk_of[n] * M + h]; if ((served[(size_t)n * n_words + (ph >> 6)] >> (ph & 63)) & 1ull) continue; }   // done by the consensus pass
         const int cell = lattice_cell(L, qx, qy, qz);
-        if (cell >= 0) marks[cell] = 1;
+        if (cell >= 0) {
+            marks[cell] = 1;
+            if (cell_cnt) atomicAdd(&cell_cnt[cell], 1u);       // (the cell pass's counting sort: see corr_cell_kernel)
+        }
     }
 }
 
@@ -2315,6 +2327,9 @@ __global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restri
     const uint4 pre = cells[id];
     const int cnt = valid ? (int)pre.y : 0;
     const unsigned int d2k_bits = pre.z;
+    if (valid) {
+        reinterpret_cast<unsigned int*>(lat + lw.off_dk2)[id] = d2k_bits;
+    }
     const float r = (sqrtf(__uint_as_float(d2k_bits)) + L.hd) * 1.0001f + 1e-6f;
     const float r2 = r * r;
     const float rw = r + L.hd;                       // ball around the centre that contains {dist(p, box) <= r}
@@ -2413,6 +2428,394 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(const char* __restric
     if (has) cells[id] = make_uint4((unsigned int)first, (unsigned int)quads, ce.z, 0u);
 }
 
+// ---- cell pass: the consensus pass's leftovers, when they are MANY, grouped by the lattice cell they land in ---------------------
+// The list kernel below works (hypothesis, chunk) record by record: 64 lanes with 64 different cells, every lane streaming ITS cell's
+// list through gathers -- chains of dependent loads, ~110 k clocks per record on a nuScenes-size job (5 000 hypotheses x 30 000
+// points, 25-90 M leftovers), and its selection pays for a coarse range [0, r^2).  But the queries of ONE cell share everything the
+// consensus pass's lanes share: a staged candidate set (the cell's list, a superset of the K nearest of every query in the cell) and a
+// tight bracket of the K-th distance, [d_K(c) - delta, d_K(c) + delta] with delta = |q - c| <= half a cell diagonal.  So:
+//   a counting sort of the unserved queries by cell: lattice_mark_kernel counts them per cell while it marks, cell_apply_kernel<0> /
+//     cell_blockscan_kernel / cell_apply_kernel<1> turn the counts of the cells with a list of <= kCellCap entries into first-entry
+//     offsets (three short launches over the marked list) and write one record per marked cell, cell_scatter_kernel writes the entries
+//     (source point x M + position of the hypothesis in the chunk's order -- where the consensus pass would have put the result --, and
+//     the hypothesis; the order inside a cell is whatever the atomics give: every query is computed on its own and written to its own slot);
+//   corr_cell_kernel: one wavefront per cell (kCellFetch cells per visit of a counter, marked cells in ascending = brick order), the list
+//     staged once in LDS (broadcast reads, no gathers in the loop), then 64 queries per step, one per lane, through the consensus pass's
+//     histogram form (B) on the unsorted stage: byte histogram over the bracket, the bin of the K-th neighbour, second sweep that appends
+//     everything below it to the lane's key list and keeps the <= kCons2Tie smallest of the bin itself; then the usual epilogue (8 lanes
+//     per feature row), branch-free so that ten row reads are in flight.
+// No a-posteriori test is needed -- the list is a superset by construction -- only lanes whose selection does not close (distance ties
+// by the dozen) stay unserved.  Results go where the consensus pass's go (val + served bit), so everything downstream is unchanged and
+// whatever this pass does not take (cells without a list or with a longer one, outside the lattice, more queries than the entry buffer
+// holds) is still there for the list kernel and the one-wavefront-per-query search.
+// Measured (MI355X, 5 000 hypotheses x 30 000 points, sigma 1): list kernel 27.7 -> 2.2 ms + this pass 10.6 + 3.2 (scatter) on a plain
+// pair (24.8 M leftovers, 22.2 M of them served here); on a half-overlapping one 68 -> 21 + 19.7 + 4.9.
+constexpr int kCellCap = 252;                       // list entries (byte counters: see corr_consensus2_kernel)
+constexpr size_t kCellMaxEntries = (size_t)1 << 26; // queries the pass can list (512 MiB of entries)
+constexpr long kCellMinQueries = 1l << 25;          // jobs below this never enqueue the pass (a KITTI-test pair: 2.5e7 queries, leftovers <= 2 M go to the queue)
+constexpr int kCellFetch = 4;                       // marked cells a wavefront takes per visit of the work counter
+struct CellWs {
+    unsigned int* cnt;     // [c_max] unserved queries per cell (lattice_mark_kernel), then (cell_apply_kernel) the cell's first entry
+    unsigned int* cur;     // [c_max] scatter cursor
+    unsigned int* bsum;    // [1024 + 64] per-block sums / offsets of the scan
+    uint4* rec;            // [2 c_max] per MARKED cell, in the order of the marked list: (cell, first entry, entries, d_K^2 bits), (list first, list quads, -, -)
+    uint2* ent;            // [cap] (source point x M + position of the hypothesis in the chunk's order, hypothesis)
+    unsigned int cap;
+};
+__host__ __device__ inline size_t cell_cap(long queries) { return (size_t)(queries < (long)kCellMaxEntries ? queries : (long)kCellMaxEntries); }
+__host__ inline size_t cell_bytes(unsigned int c_max, long queries)
+{
+    return 2 * align_up(((size_t)c_max + 64) * 4, 256) + align_up((1024 + 64) * 4, 256) + align_up((size_t)c_max * 32, 256) + align_up(cell_cap(queries) * 8, 256);
+}
+__host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
+{
+    CellWs w;
+    size_t o = 0;
+    w.cnt = reinterpret_cast<unsigned int*>(base + o);  o += align_up(((size_t)c_max + 64) * 4, 256);
+    w.cur = reinterpret_cast<unsigned int*>(base + o);  o += align_up(((size_t)c_max + 64) * 4, 256);
+    w.bsum = reinterpret_cast<unsigned int*>(base + o); o += align_up((1024 + 64) * 4, 256);
+    w.rec = reinterpret_cast<uint4*>(base + o);         o += align_up((size_t)c_max * 32, 256);
+    w.ent = reinterpret_cast<uint2*>(base + o);
+    w.cap = (unsigned int)cell_cap(queries);
+    return w;
+}
+__device__ __forceinline__ bool cell_usable(const uint4& ce) { return ce.w == 0u && ce.y != 0u && ce.y * 4u <= (unsigned int)kCellCap; }
+
+// exclusive prefix sums of the marked cells' counts (cells without a usable list count as empty), in the order of the marked list:
+// phase 0: per-block sums; cell_blockscan_kernel: their offsets; phase 1: cnt[cell] = first entry, cur[cell] = 0, the cell's record
+template <int kPhase>
+__global__ __launch_bounds__(1024) void cell_apply_kernel(char* __restrict__ lat, unsigned int c_max, CellWs cw)
+{
+    __shared__ unsigned int part[1024 / 64];
+    const LatWs lw = lat_ws(c_max);
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    if (header[8] != 0u) return;
+    const unsigned int n = header[3];
+    if (blockIdx.x * 1024u >= n) return;
+    const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
+    const uint4* cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
+    const unsigned int i = blockIdx.x * 1024u + threadIdx.x;
+    const unsigned int id = cids[i < n ? i : 0u];
+    const uint4 ce = cells[id];
+    const unsigned int v = i < n && cell_usable(ce) ? cw.cnt[id] : 0u;
+    const int lane = lane_id();
+    int incl = wave_incl_scan((int)v);
+    if (lane == 63) part[threadIdx.x >> 6] = (unsigned int)incl;
+    __syncthreads();
+    unsigned int base = 0u, tot = 0u;
+    for (int k = 0; k < 1024 / 64; ++k) { const unsigned int pk = part[k]; base += k < (int)(threadIdx.x >> 6) ? pk : 0u; tot += pk; }
+    if (kPhase == 0) {
+        if (threadIdx.x == 0) cw.bsum[blockIdx.x] = tot;
+        return;
+    }
+    const unsigned int first = cw.bsum[blockIdx.x] + base + (unsigned int)incl - v;
+    if (i < n) {
+        cw.cnt[id] = first;
+        cw.cur[id] = 0u;
+        const unsigned int n_e = first >= cw.cap ? 0u : min(v, cw.cap - first);
+        cw.rec[2 * (size_t)i] = make_uint4(id, first, n_e, reinterpret_cast<const unsigned int*>(lat + lw.off_dk2)[id]);
+        cw.rec[2 * (size_t)i + 1] = make_uint4(ce.x, ce.y, 0u, 0u);
+    }
+}
+__global__ __launch_bounds__(1024) void cell_blockscan_kernel(char* __restrict__ lat, unsigned int c_max, CellWs cw)
+{
+    __shared__ unsigned int part[1024 / 64];
+    const LatWs lw = lat_ws(c_max);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    if (header[8] != 0u) return;
+    const unsigned int nb = (header[3] + 1023u) / 1024u;               // <= 1024 (c_max <= 2^20)
+    const unsigned int v = threadIdx.x < nb ? cw.bsum[threadIdx.x] : 0u;
+    int incl = wave_incl_scan((int)v);
+    if (lane_id() == 63) part[threadIdx.x >> 6] = (unsigned int)incl;
+    __syncthreads();
+    unsigned int base = 0u, tot = 0u;
+    for (int k = 0; k < 1024 / 64; ++k) { const unsigned int pk = part[k]; base += k < (int)(threadIdx.x >> 6) ? pk : 0u; tot += pk; }
+    __syncthreads();
+    if (threadIdx.x < nb) cw.bsum[threadIdx.x] = base + (unsigned int)incl - v;
+    if (threadIdx.x == 0) header[32] = tot;
+}
+
+// the entries: every unserved query whose cell has a usable list, at cnt[cell] (= first) + cur[cell]++
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
+                                                           const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
+                                                           const char* __restrict__ lat, unsigned int c_max,
+                                                           const unsigned long long* __restrict__ served, int n_words,
+                                                           const int* __restrict__ inv, const int* __restrict__ chunk_of, CellWs cw)
+{
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // few leftovers: the queue takes them
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const uint4* cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
+    const int n_hg = (M + hyp_per_thread - 1) / hyp_per_thread;
+    const int n_pb = (Ns + 255) / 256;
+    for (long item = blockIdx.x; item < (long)n_pb * n_hg; item += gridDim.x) {
+        const int n = (int)(item % n_pb) * 256 + threadIdx.x;
+        const int h0 = (int)(item / n_pb) * hyp_per_thread, h1 = min(h0 + hyp_per_thread, M);
+        if (n >= Ns) continue;
+        const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
+        const int* inv_n = inv + (size_t)chunk_of[n] * M;
+        for (int h = h0; h < h1; ++h) {
+            const float* Th = T + (size_t)h * 16;     // uniform: scalar loads
+            const int ph = inv_n[h];
+            if ((served[(size_t)n * n_words + (ph >> 6)] >> (ph & 63)) & 1ull) continue;
+            // (the arithmetic of corr_score_kernel and lattice_mark_kernel: the cell is the one that was marked and counted)
+            const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+            const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+            const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+            const int cell = lattice_cell(L, qx, qy, qz);
+            if (cell < 0 || !cell_usable(cells[cell])) continue;
+            const unsigned int pos = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
+            if (pos < cw.cap) cw.ent[pos] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)ph, (unsigned int)h);
+        }
+    }
+}
+
+__host__ __device__ inline size_t cell_lds_per_wave(int K)
+{
+    // tie list (16-bit index plane) | stage (256 slots x 16 B) | the lane's K keys (d2 plane -- the byte histogram lives there until
+    // the second sweep starts --, 16-bit index plane)
+    const size_t d2_plane = (size_t)K * kWave * 4 > (size_t)kCons2HistWords * kWave * 4 ? (size_t)K * kWave * 4 : (size_t)kCons2HistWords * kWave * 4;
+    return (size_t)kCons2Tie * kWave * 6 + 256 * 16 + d2_plane + ((size_t)K * kWave * 2 + 255) / 256 * 256;
+}
+
+__global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
+                                                       const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T,
+                                                       int Ns, int Nt, int M, int K, float sigma, char* __restrict__ lat, unsigned int c_max, CellWs cw,
+                                                       float* __restrict__ val, unsigned long long* __restrict__ served, int dbg)
+{
+    typedef unsigned short IdxT;                     // (the lattice exists for targets of < 65 472 points only)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
+    if (header[8] != 0u) return;
+    const unsigned int n_marked = header[3];
+    const unsigned long long* pool = reinterpret_cast<const unsigned long long*>(lat + lw.off_pool);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    KeyList<IdxT> tie;
+    tie.d2 = reinterpret_cast<unsigned int*>(lds);
+    tie.ix = reinterpret_cast<IdxT*>(tie.d2 + kCons2Tie * kWave);
+    float* stage = reinterpret_cast<float*>(lds + (size_t)kCons2Tie * kWave * 6);
+    KeyList<IdxT> list;
+    list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + 256 * 16);
+    unsigned int* hist = list.d2;                    // (dead before the first key is written: see cell_lds_per_wave)
+    const size_t d2_plane = (size_t)K * kWave * 4 > (size_t)kCons2HistWords * kWave * 4 ? (size_t)K * kWave * 4 : (size_t)kCons2HistWords * kWave * 4;
+    list.ix = reinterpret_cast<IdxT*>(reinterpret_cast<char*>(list.d2) + d2_plane);
+    const int n_words = (M + 63) >> 6;
+    const float inv_sigma = 1.0f / sigma;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    unsigned int n_ok = 0u, n_fail = 0u, n_batches = 0u;
+    for (;;) {
+        unsigned int i0 = 0u;
+        if (lane == 0) i0 = atomicAdd(&header[33], (unsigned int)kCellFetch);
+        i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
+        if (i0 >= n_marked) break;
+        // the records of the kCellFetch cells of this visit: lanes 0 .. 2 kCellFetch - 1 hold one 16-byte half each
+        uint4 rl = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < 2 * kCellFetch && i0 + (unsigned int)(lane >> 1) < n_marked) rl = cw.rec[2 * (size_t)i0 + lane];
+        for (int ci = 0; ci < kCellFetch; ++ci) {
+        const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
+        const unsigned int first_e = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
+        const unsigned int n_e = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
+        const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
+        const unsigned int lfirst = (unsigned int)__builtin_amdgcn_readlane((int)rl.x, 2 * ci + 1);
+        const int quads = __builtin_amdgcn_readlane((int)rl.y, 2 * ci + 1);
+        if (n_e == 0u) continue;
+        // ---- the cell's list into the stage: quad q of the stage = the four positions of list word q (padding = a far point) ----
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int q = lane; q < quads; q += kWave) {
+            const unsigned long long w = pool[(size_t)lfirst + q];
+            float* q4 = stage + q * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 p = P4s[(unsigned int)(w >> (16 * k)) & 0xffffu];
+                q4[k] = p.x; q4[4 + k] = p.y; q4[8 + k] = p.z; q4[12 + k] = p.w;      // w = the point's original index (bits)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int m_use = quads * 4;
+        float ccx, ccy, ccz;
+        lattice_cell_centre(L, id, ccx, ccy, ccz);
+        const float dk = sqrtf(__uint_as_float(dk2b));
+        for (unsigned int b0e = 0u; b0e < n_e; b0e += kWave) {
+            const bool valid = b0e + (unsigned int)lane < n_e;
+            const uint2 eh = cw.ent[first_e + (valid ? b0e + (unsigned int)lane : 0u)];
+            const unsigned int e = eh.x;
+            const int n = (int)(e / (unsigned int)M), ph = (int)(e % (unsigned int)M);
+            const float px = src_pts[(size_t)n * 3], py = src_pts[(size_t)n * 3 + 1], pz = src_pts[(size_t)n * 3 + 2];
+            const float4* Th = reinterpret_cast<const float4*>(T + (size_t)eh.y * 16);
+            const float4 r0 = Th[0], r1 = Th[1], r2 = Th[2];
+            const float qx = fmaf(r0.z, pz, fmaf(r0.y, py, r0.x * px)) + r0.w;               // the arithmetic of corr_score_kernel
+            const float qy = fmaf(r1.z, pz, fmaf(r1.y, py, r1.x * px)) + r1.w;
+            const float qz = fmaf(r2.z, pz, fmaf(r2.y, py, r2.x * px)) + r2.w;
+            const float ex = qx - ccx, ey = qy - ccy, ez = qz - ccz;
+            const float delta = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f;
+            const bool act = valid && delta <= L.hd * 1.01f + 1e-5f;                        // (in its cell: always; a guard for the bracket)
+            // the K-th distance of q lies within delta of the centre's: bins over that bracket only (form (B) of the consensus pass)
+            const float rl_ = fmaxf((dk - delta) * 0.9999f - 1e-5f, 0.f);
+            const float rb = (dk + delta) * 1.0001f + 1e-5f;
+            const float lo = act ? rl_ * rl_ : 0.f;
+            const float width = ((act ? rb * rb : 1.0f) - lo) * (1.0f / (float)kBins);
+            const float sc = __builtin_amdgcn_rcpf(width);
+            const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+            auto quad_d2 = [&](int u0, f2& t01, f2& t23) __attribute__((always_inline)) {
+                const f4* q4 = reinterpret_cast<const f4*>(stage + u0 * 4);
+                const f4 X = q4[0], Y = q4[1], Z = q4[2];
+                const f2 dx01 = qx2 - X.xy, dx23 = qx2 - X.zw;
+                const f2 dy01 = qy2 - Y.xy, dy23 = qy2 - Y.zw;
+                const f2 dz01 = qz2 - Z.xy, dz23 = qz2 - Z.zw;
+                t01 = dx01 * dx01; t23 = dx23 * dx23;
+                t01 = t01 + dy01 * dy01; t23 = t23 + dy23 * dy23;
+                t01 = t01 + dz01 * dz01; t23 = t23 + dz23 * dz23;
+            };
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the previous step's epilogue read the plane the histogram shares)
+#pragma unroll
+            for (int w = 0; w < kCons2HistWords; ++w) hist[w * kWave + lane] = 0u;
+            for (int u0 = 0; u0 < ((UMEREG_F1_ABLATE & 0x400000) ? 4 : m_use); u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                cons2_hist_add(hist, lane, cons2_bin(t01.x, lo, sc));
+                cons2_hist_add(hist, lane, cons2_bin(t01.y, lo, sc));
+                cons2_hist_add(hist, lane, cons2_bin(t23.x, lo, sc));
+                cons2_hist_add(hist, lane, cons2_bin(t23.y, lo, sc));
+            }
+            int b0, before, inbin;
+            cons2_scan(hist, lane, 0, K, b0, before, inbin);
+            if (!act || b0 < 1 || b0 > 32) b0 = -1;
+            int b1 = -1;
+            float lo1 = 0.f, sc1 = 0.f;
+            const bool zoom = b0 >= 0 && K - before > kCons2Tie;
+            if (__any(zoom)) {
+                lo1 = lo + (float)(b0 - 1) * width;
+                sc1 = sc * (float)kBins;
+                if (zoom) {
+#pragma unroll
+                    for (int w = 0; w < kCons2HistWords; ++w) hist[w * kWave + lane] = 0u;
+                }
+                for (int u0 = 0; u0 < m_use; u0 += 4) {
+                    f2 t01, t23;
+                    quad_d2(u0, t01, t23);
+                    const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (zoom && cons2_bin(d2v[k], lo, sc) == b0) cons2_hist_add(hist, lane, cons2_bin(d2v[k], lo1, sc1));
+                }
+                if (zoom) {
+                    int bb, bef1, inb1;
+                    cons2_scan(hist, lane, before, K, bb, bef1, inb1);
+                    b1 = bb;
+                    before = bef1;
+                    if (bb < 0 || K - bef1 > kCons2Tie) { b0 = -1; b1 = -1; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the histogram is dead: its plane takes the keys now)
+            const int need_t = K - before;
+            int ntie = 0, cnt_l = 0;
+            auto sweep2 = [&](auto zoomed_tag) __attribute__((always_inline)) {
+                constexpr bool kZoomed = decltype(zoomed_tag)::value;
+                for (int u0 = 0; u0 < ((UMEREG_F1_ABLATE & 0x400000) ? 4 : m_use); u0 += 4) {
+                    f2 t01, t23;
+                    quad_d2(u0, t01, t23);
+                    const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
+                    int cls[4];                                       // 1 = below the K-th neighbour's bin, 2 = in it, 0 = beyond
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int t0 = cons2_bin(d2v[k], lo, sc);
+                        int c = t0 < b0 ? 1 : (t0 == b0 ? 2 : 0);
+                        if (kZoomed) {
+                            const int t1 = cons2_bin(d2v[k], lo1, sc1);
+                            const int c1 = t1 < b1 ? 1 : (t1 == b1 ? 2 : 0);
+                            c = (b1 >= 0 && c == 2) ? c1 : c;
+                        }
+                        cls[k] = c;
+                    }
+                    const int any_cls = cls[0] | cls[1] | cls[2] | cls[3];
+                    if (__any(any_cls != 0)) {
+                        const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
+                        const float wv[4] = {W.x, W.y, W.z, W.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
+                            if (cls[k] == 1 && cnt_l < K) { list.set(cnt_l, lane, key); ++cnt_l; }       // (at most `before` < K of them)
+                            const bool is_tie = cls[k] == 2;
+                            const bool put = is_tie && ntie < kCons2Tie;
+                            if (put) tie.set(ntie, lane, key);
+                            ntie += put ? 1 : 0;
+                            if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
+                                unsigned long long mk = 0ull;
+                                int mp = 0;
+#pragma unroll
+                                for (int t = 0; t < kCons2Tie; ++t) {
+                                    const unsigned long long ke = tie.get(t, lane);
+                                    if (ke >= mk) { mk = ke; mp = t; }
+                                }
+                                if (is_tie && !put && key < mk) tie.set(mp, lane, key);
+                            }
+                        }
+                    }
+                }
+            };
+            if (__any(b1 >= 0)) sweep2(std::true_type()); else sweep2(std::false_type());
+            {
+                const int bound = wave_max_nonneg(ntie);
+                while (__any(ntie > need_t)) drop_max(tie, ntie, ntie > need_t, bound, lane);
+            }
+            const bool ok = b0 >= 0 && ntie == need_t && cnt_l == before;
+            if (ok) {
+                for (int t = 0; t < need_t; ++t) list.set(cnt_l + t, lane, tie.get(t, lane));
+            }
+            // ---- epilogue: the K keys of every lane -> weights in place (lanes without a selection: weight 0 on point 0, so that the
+            // loop below has no branch and its row reads can be in flight ten at a time); 8 lanes share a feature row ----
+            for (int t = 0; t < K; ++t) {
+                const float w = cauchy_weight_hw(__uint_as_float(list.d2[t * kWave + lane]), inv_sigma);
+                list.d2[t * kWave + lane] = ok ? __float_as_uint(w) : 0u;
+                if (!ok) list.ix[KeyList<IdxT>::ix_at(t, lane)] = (IdxT)0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float acc = 0.f;
+            if (!(UMEREG_F1_ABLATE & 0x200000)) {
+                const int grp8 = lane & ~7, sub = lane & 7;
+                for (int it = 0; it < 8; ++it) {
+                    const int q = grp8 + it;
+                    const int sq = __shfl(n, q, kWave);
+                    const float4 a = vp4[(size_t)sq * 8 + sub];
+                    float part = 0.f;
+#pragma unroll 10
+                    for (int t = 0; t < K; ++t) {
+                        const float wg = __uint_as_float(list.d2[t * kWave + q]);
+                        const int j = (int)list.index(t, q);
+                        const float4 o = vq4[(size_t)j * 8 + sub];
+                        float d = a.x * o.x;
+                        d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                        part = fmaf(wg, d, part);
+                    }
+                    part += __shfl_xor(part, 1, kWave);
+                    part += __shfl_xor(part, 2, kWave);
+                    part += __shfl_xor(part, 4, kWave);
+                    acc = sub == it ? part : acc;                 // lane q keeps its query's sum
+                }
+            }
+            if (ok) {
+                val[e] = acc;
+                atomicOr(&served[(size_t)n * n_words + (ph >> 6)], 1ull << (ph & 63));
+            }
+            n_ok += (unsigned int)__popcll(__ballot(ok));
+            n_fail += (unsigned int)__popcll(__ballot(valid && !ok));
+            ++n_batches;
+        }
+        }   // the cells of this visit
+    }
+    if (lane == 0) {
+        if (n_ok) atomicAdd(&header[34], n_ok);
+        if (n_fail) atomicAdd(&header[35], n_fail);
+        if (dbg && n_batches) atomicAdd(&header[36], n_batches);
+    }
+}
+
 // ---- per-hypothesis correlation score (utils/loc_utils.py:592-637) ---------------------------------
 // score[h] = (1/Ns) sum_n sum_{k<K} cauchy(|R_h p_n + t_h - q_jk|, sigma) <vp_n, vq_jk>
 template <class IdxT, bool LAT>
@@ -2422,7 +2825,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          float sigma, int hyp_per_wave, int n_chunks,
                                                          float* __restrict__ partial, char* __restrict__ lat, unsigned int c_max,
                                                          const unsigned long long* __restrict__ served, int n_words,
-                                                         const int* __restrict__ inv)
+                                                         const int* __restrict__ inv, int after_cell_pass = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2488,7 +2891,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // unplaced list) are left to corr_score_fallback_kernel
             const int cell = todo_q ? lattice_cell(Lt, qx, qy, qz) : -1;
             const uint4 ce = cells[cell >= 0 ? cell : 0];
-            const bool use = cell >= 0 && ce.w == 0u && ce.y != 0u;
+            // (after the cell pass what is left in cells WITH a list are the queries of lists longer than that pass stages -- dense spots:
+            // 9 ns each here on a nuScenes-size pair, but 12 ns one wavefront per query (measured), so they stay)
+            const bool use = cell >= 0 && ce.w == 0u && ce.y != 0u && !(after_cell_pass & 2);
             const unsigned int first = ce.x;
             const int nquads = use ? (int)ce.y : 0;
             LaneSel S;
@@ -2747,16 +3152,23 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
 // Flattened, every wavefront takes queries of its own: leftover_flatten_kernel gives each record a contiguous range of
 // query slots (entry = record << 6 | lane, lanes ascending), corr_score_flat_kernel writes one value per slot, and
 // leftover_sum_kernel adds a record's values in lane order to its (hypothesis, chunk) partial sum -- the same additions
-// in the same order as the record kernel's, so the result is bit-identical.  More than kFlatMaxQ queries (header word 11
+// in the same order as the record kernel's, so the result is bit-identical.  More than flat_slots() queries (header word 11
 // set): the flat kernels return and the record kernel runs as before.
 constexpr unsigned int kFlatMaxQ = 1u << 21;
-constexpr int kFlatBlocks = 6144;   // workgroups of corr_score_flat_kernel (8 wavefronts each, queries dealt round-robin; 768 .. 16 384 measured: 1.17 .. 1.10 ms)
+constexpr int kFlatBlocks = 6144;   // workgroups of corr_score_flat_kernel (8 wavefronts each, visits of 4 queries dealt round-robin; 768 .. 16 384 measured: 1.17 .. 1.10 ms)
 struct FlatWs {
     unsigned int* rbase;   // [records] first query slot of the record
     unsigned int* qlist;   // [slots] record << 6 | lane
     float* qval;           // [slots]
+    unsigned int slots;
 };
-__host__ __device__ inline size_t flat_slots(long n_queries) { return (size_t)(n_queries < (long)kFlatMaxQ ? n_queries : (long)kFlatMaxQ); }
+// (capacity: 2^21 queries, or half of the job's if that is more -- a nuScenes-size job of 1.5e8 queries with outlier hypotheses
+// leaves tens of millions of far-off queries, and the record kernel costs 2.4x the flat one per query)
+__host__ __device__ inline size_t flat_slots(long n_queries)
+{
+    const long cap = n_queries / 2 > (long)kFlatMaxQ ? n_queries / 2 : (long)kFlatMaxQ;
+    return (size_t)(n_queries < cap ? n_queries : cap);
+}
 __host__ __device__ inline size_t flat_bytes(size_t n_records, long n_queries)
 {
     return align_up(n_records * 4, 256) + 2 * align_up(flat_slots(n_queries) * 4, 256);
@@ -2767,6 +3179,7 @@ __host__ __device__ inline FlatWs flat_ws(char* base, size_t n_records, long n_q
     f.rbase = reinterpret_cast<unsigned int*>(base);
     f.qlist = reinterpret_cast<unsigned int*>(base + align_up(n_records * 4, 256));
     f.qval = reinterpret_cast<float*>(base + align_up(n_records * 4, 256) + align_up(flat_slots(n_queries) * 4, 256));
+    f.slots = (unsigned int)flat_slots(n_queries);
     return f;
 }
 
@@ -2782,16 +3195,51 @@ __global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict_
         const unsigned int cnt = (unsigned int)__popcll(mask);
         const unsigned int base = atomicAdd(&header[10], cnt);
         f.rbase[r] = base;
-        if (base + cnt > kFlatMaxQ || base + cnt < base) { header[11] = 1u; continue; }
+        if (base + cnt > f.slots || base + cnt < base) { header[11] = 1u; continue; }
         for (unsigned int j = 0; mask != 0ull; mask &= mask - 1ull, ++j)
             f.qlist[base + j] = (r << 6) | (unsigned int)(__ffsll((long long)mask) - 1);
     }
 }
 
+// ---- bounding the queries OUTSIDE the lattice (UMEREG_CORR_BOUND_OUTSIDE) ----------------------------------------------------
+// An image q outside the lattice is at least a margin away from the target's bounding box (>= 20 % of its extent): every one of its
+// neighbours is at distance >= dB = dist(q, box), so its term is at most  eps = K w(dB) |vp_n| max_j |vq_j|  in magnitude -- no search
+// needed.  Such queries are the bulk of what outlier hypotheses leave (a nuScenes-size half-overlapping pair: 30 M of 150 M queries,
+// 87 ms through one wavefront per query), and an outlier hypothesis is exactly one that cannot win.  So, with the flag:
+//   pass 1 (corr_score_flat_kernel<1>): a listed query outside the lattice contributes 0 and adds eps (rounded up, fixed point: the
+//     sum is order-independent) to its hypothesis' slack E_h; everything else is computed as always;
+//   bound_survivors_kernel: S_h = the scores so far; a hypothesis with slack needs its bounded queries iff  S_h + E_h >= max_h'(S_h' - E_h')
+//     (allowances for the rounding of the sums on both sides);
+//   pass 2 (corr_score_flat_kernel<2>): the bounded queries of those hypotheses, exactly; sums and scores once more.
+// Result: the score of every hypothesis that can be the arg-max is exact (same neighbours, same terms); every other score lacks its
+// bounded terms (it is within E_h of the exact one, which is below the arg-max's) -- corr_select_best / FeatureCorrelator return what
+// they return without the flag.
+constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
+
+__global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict__ v4, int N, float* __restrict__ out, unsigned int* __restrict__ max_bits)
+{
+    // |v_n| of every 32-float row, rounded up; max_bits (optional) = the largest, as the bits of a non-negative float
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    if (n < N) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float4 a = v4[(size_t)n * 8 + k]; s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+    }
+    const float r = n < N ? sqrtf(s) * 1.00001f + 1e-30f : 0.f;
+    if (out && n < N) out[n] = r;
+    if (max_bits) {
+        const float m = wave_max_nonneg_f(r == r ? r : 3.0e38f);          // (a NaN row: no bound)
+        if (lane_id() == 0) atomicMax(max_bits, __float_as_uint(m));
+    }
+}
+
+template <int kMode>
 __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                        const float* __restrict__ src_pts, const float4* __restrict__ vp4,
                                                                        const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
-                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f)
+                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f,
+                                                                       const float* __restrict__ vpn, const unsigned int* __restrict__ vq_max_bits,
+                                                                       unsigned long long* __restrict__ slack, const unsigned int* __restrict__ surv)
 {
     __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
     __shared__ unsigned int chist[kCoopWaves][kWave];
@@ -2801,6 +3249,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
     const LatWs lw = lat_ws(c_max);
     const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
     if (header[11] != 0u) return;                      // too many queries: the record kernel serves them
+    if (kMode == 2 && header[40] == 0u) return;        // no hypothesis needs its bounded queries
     const unsigned int n_q = header[10];
     const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
@@ -2811,37 +3260,113 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
     const int grp = lane >> 3, sub = lane & 7;
     const float inv_sigma = 1.0f / sigma;
     const unsigned int n_waves = gridDim.x * kCoopWaves;
-    for (unsigned int q = blockIdx.x * kCoopWaves + wave; q < n_q; q += n_waves) {
-        const unsigned int ent = f.qlist[q];
-        const uint4 rec = queue[ent >> 6];
-        const int h = (int)rec.x, slot = (int)rec.y * kWave + (int)(ent & 63u);
-        if (slot >= Ns) {
-            if (lane == 0) f.qval[q] = 0.f;
-            continue;
-        }
-        const int qs = __float_as_int(S4s[slot].w);
-        const float sx = src_pts[(size_t)qs * 3], sy = src_pts[(size_t)qs * 3 + 1], sz = src_pts[(size_t)qs * 3 + 2];
-        const float* Th = T + (size_t)h * 16;
-        // (the same arithmetic as the record kernel and corr_score_kernel)
-        const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
-        const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
-        const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-        const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
-        const float4 a = vp4[(size_t)qs * 8 + sub];
-        float part = 0.f;
-        for (int e0 = 0; e0 < cnt; e0 += 8) {
-            const int e = e0 + grp;
-            const unsigned long long k = la[e < cnt ? e : 0];
-            const float wgt = cauchy_weight_hw(__uint_as_float((unsigned int)(k >> 32)), inv_sigma);   // :593, :588-589
-            const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
-            float d = a.x * o.x;
-            d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
-            part += e < cnt ? wgt * d : 0.f;
-        }
-        part = wave_sum_f(part);
-        if (lane == 0) f.qval[q] = part;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    Lattice Lt;
+    float bmn[3] = {0.f, 0.f, 0.f}, bmx[3] = {0.f, 0.f, 0.f}, vq_max = 0.f;
+    if (kMode != 0) {
+        const unsigned int* bbox = reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox);
+        Lt = load_lattice(bbox, c_max);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { bmn[k] = dec_ord(~bbox[k]); bmx[k] = dec_ord(bbox[3 + k]); }
+        vq_max = __uint_as_float(*vq_max_bits);
     }
+    // kFlatVisit consecutive entries per visit, one per lane for the bookkeeping (transform, bound); the searches one after the other, the
+    // whole wavefront on each.  (4, not 64: a KITTI-test pair leaves 2e5 queries, and 3 000 visits of 64 do not fill the chip -- 16 per visit
+    // measured 0.23 ms slower on that pair than one query per visit; the bookkeeping is ~1 % of a search either way.)
+    constexpr unsigned int kFlatVisit = 4;
+    for (unsigned int blk = blockIdx.x * kCoopWaves + wave; (unsigned long long)blk * kFlatVisit < n_q; blk += n_waves) {
+        const unsigned int q_l = blk * kFlatVisit + (unsigned int)lane;
+        const bool valid = lane < (int)kFlatVisit && q_l < n_q;
+        const unsigned int ent = f.qlist[valid ? q_l : 0u];
+        const uint4 rec = queue[ent >> 6];
+        const int h_l = (int)rec.x, slot_l = (int)rec.y * kWave + (int)(ent & 63u);
+        const bool in_cloud = valid && slot_l < Ns;
+        const int qs_l = __float_as_int(S4s[in_cloud ? slot_l : 0].w);
+        const float sx = src_pts[(size_t)qs_l * 3], sy = src_pts[(size_t)qs_l * 3 + 1], sz = src_pts[(size_t)qs_l * 3 + 2];
+        const float* Th = T + (size_t)h_l * 16;
+        // (the same arithmetic as the record kernel and corr_score_kernel)
+        const float qx_l = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float qy_l = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float qz_l = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        bool exact = in_cloud;
+        if (kMode != 0) {
+            // outside the lattice (NaN images are not: they go through the search as always)
+            const bool outside = in_cloud && qx_l == qx_l && qy_l == qy_l && qz_l == qz_l && lattice_cell(Lt, qx_l, qy_l, qz_l) < 0;
+            if (kMode == 1) {
+                exact = in_cloud && !outside;
+                if (outside) {
+                    const float dx = fmaxf(fmaxf(bmn[0] - qx_l, qx_l - bmx[0]), 0.f), dy = fmaxf(fmaxf(bmn[1] - qy_l, qy_l - bmx[1]), 0.f);
+                    const float dz = fmaxf(fmaxf(bmn[2] - qz_l, qz_l - bmx[2]), 0.f);
+                    const float dB = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) * 0.9999f - 1e-5f, 0.f);
+                    const float r = dB * inv_sigma * 0.9999f;
+                    const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[qs_l] * vq_max * 1.0001f;
+                    // (an infinite or NaN bound -- NaN features -- saturates: the hypothesis then needs its queries whatever the scores)
+                    const unsigned long long fx = eps < 1.0e12f ? (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull : (1ull << 62);
+                    atomicAdd(&slack[h_l], fx);
+                }
+            } else {
+                exact = outside && surv[h_l] != 0u;
+            }
+        }
+        if (valid && !exact) f.qval[q_l] = 0.f;
+        unsigned long long todo = __ballot(exact);
+        while (todo != 0ull) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const float qx = __shfl(qx_l, l, kWave), qy = __shfl(qy_l, l, kWave), qz = __shfl(qz_l, l, kWave);
+            const int qs = __shfl(qs_l, l, kWave);
+            const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
+            const float4 a = vp4[(size_t)qs * 8 + sub];
+            float part = 0.f;
+            for (int e0 = 0; e0 < cnt; e0 += 8) {
+                const int e = e0 + grp;
+                const unsigned long long k = la[e < cnt ? e : 0];
+                const float wgt = cauchy_weight_hw(__uint_as_float((unsigned int)(k >> 32)), inv_sigma);   // :593, :588-589
+                const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
+                float d = a.x * o.x;
+                d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                part += e < cnt ? wgt * d : 0.f;
+            }
+            part = wave_sum_f(part);
+            if (lane == 0) f.qval[blk * kFlatVisit + (unsigned int)l] = part;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+// which hypotheses need their bounded queries after all (see above): surv[h], header word 40 = how many, 41 = hypotheses with slack
+__global__ __launch_bounds__(1024) void bound_survivors_kernel(const float* __restrict__ scores, const unsigned long long* __restrict__ slack, int M, int Ns,
+                                                               unsigned int* __restrict__ surv, unsigned int* __restrict__ header)
+{
+    __shared__ float red[1024 / 64];
+    __shared__ unsigned int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0u;
+    auto margin = [&](int h, float s) {
+        const unsigned long long fx = slack[h];
+        const float e = fx >= (1ull << 62) ? 3.0e38f : (float)fx * kSlackUnit / (float)Ns;
+        return e * 1.0001f + 4e-6f * (fabsf(s) + 1.0f);                 // + what the two roundings of a sum of <= Ns + chunks terms can move it
+    };
+    float best = -3.0e38f;
+    for (int h = threadIdx.x; h < M; h += 1024) {
+        const float s = scores[h];
+        const float lo = s - margin(h, s);
+        if (lo == lo) best = fmaxf(best, lo);                            // (NaN scores never bound anything)
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) best = fmaxf(best, __shfl_xor(best, m, kWave));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    float thr = red[0];
+    for (int k = 1; k < 1024 / 64; ++k) thr = fmaxf(thr, red[k]);
+    for (int h = threadIdx.x; h < M; h += 1024) {
+        const float s = scores[h];
+        const bool has = slack[h] != 0ull;
+        const bool need = has && !(s + margin(h, s) < thr);              // (a NaN score with slack: recomputed, like everything unproven)
+        surv[h] = need ? 1u : 0u;
+        if (has) atomicAdd(&cnt[1], 1u);
+        if (need) atomicAdd(&cnt[0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { header[40] = cnt[0]; header[41] = cnt[1]; }
 }
 
 // ---- the same queries, first one wavefront per RECORD (round 3) --------------------------------------------------------
@@ -3029,10 +3554,11 @@ __global__ __launch_bounds__(128) void corr_score_record2_kernel(const char* __r
 }
 
 __global__ __launch_bounds__(256) void leftover_sum_kernel(const char* __restrict__ lat, unsigned int c_max, FlatWs f, int n_chunks,
-                                                           float* __restrict__ partial)
+                                                           float* __restrict__ partial, int second_pass = 0)
 {
     const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lat_ws(c_max).off_header);
     if (header[11] != 0u) return;
+    if (second_pass && header[40] == 0u) return;       // corr_score_flat_kernel<2> had nothing to do: the values are still the first pass's
     const uint4* queue = reinterpret_cast<const uint4*>(lat + lat_ws(c_max).total);
     const unsigned int n_rec = header[4];
     for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
@@ -3238,6 +3764,18 @@ static bool consensus_on(unsigned int c_max, int M, int flags, const void* T = n
     return c_max != 0 && !(flags & UMEREG_CORR_NO_CONSENSUS) && (M >= 256 || (flags & UMEREG_CORR_FORCE_CONSENSUS));
 }
 
+// the cell pass (corr_cell_kernel) rides on the consensus pass's result planes and on the lattice; big jobs only, unless forced
+static bool cell_pass_on(unsigned int c_max, int Ns, int M, int flags, const void* T = nullptr)
+{
+    if (!consensus_on(c_max, M, flags, T) || (flags & (UMEREG_CORR_NO_CELL_PASS | UMEREG_CORR_CONSENSUS_V1 | UMEREG_CORR_LEFT_COOP))) return false;
+    if ((unsigned long long)Ns * (unsigned long long)M >= (1ull << 32)) return false;          // 32-bit entries
+    return (long)M * Ns >= kCellMinQueries || (flags & UMEREG_CORR_CELL_PASS);
+}
+
+// bounding of the queries outside the lattice (corr_score_flat_kernel<1>): slack (u64 per hypothesis), survivor flags, |vp_n|, max |vq_j|
+static bool bound_on(unsigned int c_max, int flags) { return c_max != 0 && (flags & UMEREG_CORR_BOUND_OUTSIDE) && !(flags & UMEREG_CORR_NO_FLAT); }
+static size_t bound_bytes(int Ns, int M) { return align_up((size_t)M * 8, 256) + align_up((size_t)M * 4, 256) + align_up((size_t)Ns * 4, 256) + 256; }
+
 UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags)
 {
     if (Ns <= 0 || Nt <= 0 || M <= 0) return 0;
@@ -3249,7 +3787,9 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
                                                         2 * align_up(n_chunks * M * 4, 256) + align_up((size_t)Ns * 4, 256) + align_up(n_chunks * 16, 256) : 0;
     return grid_ws(Ns).total + 2 * grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)(Ns + 2 * (size_t)Nt) * 12, 256) + 256 +
-           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + flat_bytes((size_t)M * n_chunks, (long)M * Ns) : 0) + cons;
+           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + flat_bytes((size_t)M * n_chunks, (long)M * Ns) : 0) + cons +
+           (cell_pass_on(c_max, Ns, M, flags) ? cell_bytes(c_max, (long)M * Ns) : 0) +
+           (bound_on(c_max, flags) ? bound_bytes(Ns, M) : 0);
 }
 
 UMEREG_API int umereg_corr_weighted_features_f32(const float* src_feat, const float* tgt_feat, const float* src_w,
@@ -3349,6 +3889,11 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
     const long n_waves = (long)n_chunks * n_hg;
     const dim3 score_grid((unsigned)((n_waves + waves - 1) / waves)), score_block(waves * kWave);
+    const bool bound = bound_on(c_max, flags);
+    unsigned long long* b_slack = nullptr;
+    unsigned int* b_surv = nullptr;
+    float* b_vpn = nullptr;
+    unsigned int* b_vqmax = nullptr;
     float* val = nullptr;
     float* slices = nullptr;
     int* perm = nullptr;
@@ -3423,9 +3968,17 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // (with a consensus pass in front, every one of these kernels returns at once unless header word 8 says "lattice")
         const LatWs lw = lat_ws(c_max);
         if (hipMemsetAsync(lat + 256, 0, lw.off_wave_tot - 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice marks) failed"); return UMEREG_ELAUNCH; }
+        // (the flat list sits at the end of the workspace, the cell pass's counters, records and entries right before it)
+        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
+        const bool cell_pass = cell_pass_on(c_max, Ns, M, flags, T);
+        CellWs cw = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        if (cell_pass) {
+            cw = cell_ws(flat_base - cell_bytes(c_max, (long)M * Ns), c_max, (long)M * Ns);
+            if (hipMemsetAsync(cw.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) { set_error("hipMemsetAsync(cell counters) failed"); return UMEREG_ELAUNCH; }
+        }
         const int hpt = 16;
         hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
-                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of);
+                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw.cnt);
         UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
         int bcap, bwaves;
         size_t blds;
@@ -3450,17 +4003,40 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
         hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
+        if (cell_pass) {
+            // the unserved queries of cells with a list, sorted by cell (counted by lattice_mark_kernel), one wavefront per cell (see corr_cell_kernel)
+            const unsigned int nb = (c_max + 1023u) / 1024u;
+            hipLaunchKernelGGL(cell_apply_kernel<0>, dim3(nb), dim3(1024), 0, st, lat, c_max, cw);
+            hipLaunchKernelGGL(cell_blockscan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max, cw);
+            hipLaunchKernelGGL(cell_apply_kernel<1>, dim3(nb), dim3(1024), 0, st, lat, c_max, cw);
+            UMEREG_CHECK_LAUNCH("cell_apply_kernel");
+            const int hpc = 16;
+            const long items = (long)((Ns + 255) / 256) * ((M + hpc - 1) / hpc);
+            hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)(items < 16384 ? items : 16384)), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T, Ns, Nt, M,
+                               hpc, (const char*)lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw);
+            UMEREG_CHECK_LAUNCH("cell_scatter_kernel");
+            hipLaunchKernelGGL(corr_cell_kernel, dim3(2816), dim3(kWave), cell_lds_per_wave(K), st, (const char*)ws_tgt, src_pts,
+                               (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw, val, served,
+                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0);
+            UMEREG_CHECK_LAUNCH("corr_cell_kernel");
+        }
         corr_mark(3, st);
         const dim3 lat_grid(score_grid.x < 4096u ? score_grid.x : 4096u);
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), lat_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
-                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv);
+                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, cell_pass ? 1 : 0);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         corr_mark(4, st);
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
         // ... as a flat list of queries when they fit (header word 12 marks that the flat path ran), record by record otherwise
-        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
         const FlatWs fw = flat_ws(flat_base, (size_t)M * n_chunks_sz, (long)M * Ns);
+        if (bound) {
+            char* bb = flat_base - (cell_pass ? cell_bytes(c_max, (long)M * Ns) : 0) - bound_bytes(Ns, M);
+            b_slack = (unsigned long long*)bb;
+            b_surv = (unsigned int*)(bb + align_up((size_t)M * 8, 256));
+            b_vpn = (float*)((char*)b_surv + align_up((size_t)M * 4, 256));
+            b_vqmax = (unsigned int*)((char*)b_vpn + align_up((size_t)Ns * 4, 256));
+        }
         if ((flags & UMEREG_CORR_RECORD_STAGE) && !(flags & UMEREG_CORR_NO_FLAT)) {
             // first one wavefront per record (a staged set of the record's neighbours, one lane per query); the records keep the lanes it could not serve
             int rcap, rwaves;
@@ -3481,10 +4057,21 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         if (!(flags & UMEREG_CORR_NO_FLAT)) {
             hipLaunchKernelGGL(leftover_flatten_kernel, dim3(256), dim3(256), 0, st, lat, c_max, fw);
             UMEREG_CHECK_LAUNCH("leftover_flatten_kernel");
-            hipLaunchKernelGGL(corr_score_flat_kernel, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
-                               src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
+            if (bound) {
+                if (hipMemsetAsync(b_slack, 0, (size_t)M * 8, st) != hipSuccess || hipMemsetAsync(b_vqmax, 0, 4, st) != hipSuccess) { set_error("hipMemsetAsync(slack) failed"); return UMEREG_ELAUNCH; }
+                hipLaunchKernelGGL(row_norm_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, (const float4*)src_wfeat, Ns, b_vpn, (unsigned int*)nullptr);
+                hipLaunchKernelGGL(row_norm_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const float4*)tgt_wfeat, Nt, (float*)nullptr, b_vqmax);
+                UMEREG_CHECK_LAUNCH("row_norm_kernel");
+                hipLaunchKernelGGL(corr_score_flat_kernel<1>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
+                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
+                                   (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
+            } else {
+                hipLaunchKernelGGL(corr_score_flat_kernel<0>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
+                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
+                                   (const float*)nullptr, (const unsigned int*)nullptr, (unsigned long long*)nullptr, (const unsigned int*)nullptr);
+            }
             UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
-            hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial);
+            hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial, 0);
             UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
         }
         hipLaunchKernelGGL(corr_score_fallback_kernel, dim3((flags & UMEREG_CORR_NO_FLAT) ? 4096 : 512), dim3(kCoopWaves * kWave), 0, st, ws_coop,
@@ -3504,6 +4091,24 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
     }
     const int n_slices = val ? (Ns + kValSlice - 1) / kValSlice : 0;
+    if (bound) {
+        // the scores so far decide which hypotheses need their bounded queries; those queries, exactly; then the sums below once more
+        if (val) {
+            hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, (const char*)ws_src, slices);
+            UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
+        }
+        hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 3) / 4), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv, scores);
+        hipLaunchKernelGGL(bound_survivors_kernel, dim3(1), dim3(1024), 0, st, (const float*)scores, (const unsigned long long*)b_slack, M, Ns, b_surv, (unsigned int*)lat);
+        UMEREG_CHECK_LAUNCH("bound_survivors_kernel");
+        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
+        const FlatWs fw = flat_ws(flat_base, (size_t)M * n_chunks_sz, (long)M * Ns);
+        hipLaunchKernelGGL(corr_score_flat_kernel<2>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
+                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
+                           (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
+        UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
+        hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial, 1);
+        UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
+    }
     if (val) {
         hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, (const char*)ws_src, slices);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");

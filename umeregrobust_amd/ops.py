@@ -500,6 +500,8 @@ CORR_NO_LATTICE, CORR_FORCE_LATTICE, CORR_NO_CONSENSUS, CORR_FORCE_CONSENSUS, CO
 CORR_CONSENSUS_V1, CORR_DEBUG_STATS, CORR_FAR_MARGIN_SHIFT = 32, 64, 8      # include/umereg.h
 CORR_SRC_ROWS, CORR_RECORD_STAGE = 128, 1 << 18
 CORR_LEFT_COOP, CORR_LEFT_LATTICE = 1 << 16, 1 << 17
+CORR_CELL_PASS, CORR_NO_CELL_PASS, CORR_BOUND_OUTSIDE = 1 << 19, 1 << 20, 1 << 21
+CORR_BOUND_MIN_QUERIES = 1 << 25      # jobs from this size on: FeatureCorrelator bounds the queries outside the lattice (and the library runs its cell pass)
 
 
 def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None, flags=0):
@@ -531,8 +533,9 @@ CORR_STAGES = ("structures_and_orders", "consensus_pass", "lattice_build", "list
 
 def corr_scores_profile(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, flags=0):
     """corr_scores with its stages timed by HIP events on the launch stream (umereg_corr_scores_profile_f32; synchronises).
-    -> (scores [M], {stage name: ms}, header: the first 32 words of the call's workspace header as int64 -- served /
-    leftover counts and, with CORR_DEBUG_STATS in flags, the consensus pass's step statistics)."""
+    -> (scores [M], {stage name: ms}, header: the 64 words of the call's workspace header as int64 -- served / leftover counts,
+    the cell pass's (words 32-36) and the bound's (40, 41) counts and, with CORR_DEBUG_STATS in flags, the consensus pass's step
+    statistics)."""
     import ctypes
     lib = _lib.load()
     sp = _dev(src_pts, "src_pts"); tp = _dev(tgt_pts, "tgt_pts")
@@ -547,7 +550,7 @@ def corr_scores_profile(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0
                                                 int(flags), _ptr(scores), _ptr(ws), ws.numel(), _stream_ptr(dev), ms)
     _lib.check(rc, "umereg_corr_scores_profile_f32")
     off = lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, CORR_NO_LATTICE)      # = where the lattice header starts
-    header = (ws[off:off + 128].view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff) if ws.numel() >= off + 128 else None
+    header = (ws[off:off + 256].view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff) if ws.numel() >= off + 256 else None
     return scores, {k: float(v) for k, v in zip(CORR_STAGES, ms)}, header
 
 
