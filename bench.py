@@ -577,14 +577,16 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
         sf, tf = e.src_feat[0, si].contiguous(), e.tgt_feat[0, ti].contiguous()
         w = feature_spatial_var(torch.stack([sp, tp]), torch.stack([sf, tf]), knn=50)
         wsf, wtf = ops.corr_weighted_features(sf, tf, w[0], w[1])
-        kw = dict(K=20, sigma=float(args.corr_kernel_sigma))
+        # (the flags FeatureCorrelator passes: arg-max mode on jobs of >= 2^25 queries, see utils/loc_utils.py)
+        big = int(T.shape[0]) * int(sp.shape[0]) >= ops.CORR_BOUND_MIN_QUERIES
+        kw = dict(K=20, sigma=float(args.corr_kernel_sigma), flags=ops.CORR_BOUND_OUTSIDE if big else 0)
         ops.corr_scores_profile(sp, tp, wsf, wtf, T, **kw)
         acc = None
         for _ in range(reps):
             _, st, hdr = ops.corr_scores_profile(sp, tp, wsf, wtf, T, **kw)
             acc = st if acc is None else {k: acc[k] + v for k, v in st.items()}
         stages = {k: round(v / reps, 4) for k, v in acc.items()}
-        _, _, h = ops.corr_scores_profile(sp, tp, wsf, wtf, T, flags=ops.CORR_DEBUG_STATS, **kw)
+        _, _, h = ops.corr_scores_profile(sp, tp, wsf, wtf, T, **dict(kw, flags=kw["flags"] | ops.CORR_DEBUG_STATS))
     M, Ns = int(T.shape[0]), int(sp.shape[0])
     queries = M * Ns
     steps_a, zone_a, steps_b, zone_b, zoomed = int(h[19]), int(h[20]), int(h[21]), int(h[22]), int(h[23])
@@ -592,6 +594,8 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
     res = {"queries": queries, "hypotheses": M, "points_per_cloud": Ns, "stage_ms": stages,
            "served_by_the_consensus_pass": int(h[7]), "served_frac": round(int(h[7]) / queries, 5),
            "left_to": ("one_wavefront_per_query" if int(h[8]) else "candidate_lattice"), "left_queries": int(h[9]),
+           "cell_pass_served": int(h[34]), "outside_lattice_bounded": bool(big),
+           "hypotheses_with_bounded_queries": int(h[41]), "of_which_recomputed": int(h[40]),
            "consensus_pass": {"source_points_staged_near": int(h[16]), "source_points_staged_in_empty_regions": int(h[17]),
                               "avg_staged_target_points": round(float(h[18]) / max(int(h[16]) + int(h[17]), 1), 1),
                               "steps_rank_counting": steps_a, "avg_zone_rank_counting": round(zone_a / max(steps_a, 1), 2),

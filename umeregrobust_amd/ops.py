@@ -528,7 +528,7 @@ def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, tim
     return scores
 
 
-CORR_STAGES = ("structures_and_orders", "consensus_pass", "lattice_build", "list_kernel", "one_wavefront_per_query", "reduction", "total")
+CORR_STAGES = ("structures_and_orders", "consensus_pass", "lattice_build_and_cell_pass", "list_kernel", "one_wavefront_per_query", "reduction", "total")
 
 
 def corr_scores_profile(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, flags=0):
