@@ -104,14 +104,21 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
                                                             float radius, int order_only)
 {
     __shared__ int hist[kMaxCells];
+    __shared__ Grid g_sh;
     const GridWs w = grid_ws(N);
     char* wb = ws + blockIdx.y * ws_stride;
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     int* cell_of = reinterpret_cast<int*>(wb + w.off_cell);
     int* counts = reinterpret_cast<int*>(wb + w.off_counts) + (size_t)blockIdx.x * kMaxCells;
-    const Grid g = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
+    // (the geometry -- divisions and, in kNN mode, the cell-edge search loop -- by the first wavefront only: sixteen wavefronts doing
+    // it side by side share four SIMDs)
+    if (threadIdx.x < 64) {
+        const Grid g0 = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
+        if (threadIdx.x == 0) g_sh = g0;
+    }
     for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) hist[c] = 0;
     __syncthreads();
+    const Grid g = g_sh;
     const int j = blockIdx.x * kSortWG + threadIdx.x;
     if (j < N) {
         const float4 p = P4o[j];
@@ -127,31 +134,44 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
 }
 
 // ---- K2: exclusive scan over (cell, workgroup): bases[wg][c] = first slot of (wg, c) within cell c --
-// One workgroup; reads and writes go to different arrays so the per-cell loop over workgroups is a
-// stream of independent loads (a read-modify-write in place serialised ~50 dependent round trips).
-__global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius, int order_only)
+// kScanWGs workgroups of 256 lanes, one lane per cell: the lane walks its cell's column of the per-workgroup counts (independent
+// loads, sixteen in flight) and leaves the cell's total in tot[]; the scan of the 4 096 totals is done by every workgroup of the
+// scatter kernel for itself (16 KiB read, two barriers: cheaper than a launch, and than a last-workgroup-done hand-over -- an
+// agent-scope fence writes the XCD's L2 back on this part).  (One workgroup did all of it in round 2: 3 MB through one CU for a
+// 50 000-point cloud, 22 us.)
+constexpr int kScanWGs = kMaxCells / 256;
+__global__ __launch_bounds__(256) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius, int order_only)
 {
-    __shared__ int tot[kMaxCells];
-    __shared__ int part[1024 / 64];
     const GridWs w = grid_ws(N);
     char* wb = ws + blockIdx.y * ws_stride;
     const int* __restrict__ counts = reinterpret_cast<const int*>(wb + w.off_counts);
     int* __restrict__ bases = reinterpret_cast<int*>(wb + w.off_bases);
-    int* __restrict__ start = reinterpret_cast<int*>(wb + w.off_start);
-    const Grid gg = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
-    if (threadIdx.x == 0) store_grid(reinterpret_cast<unsigned int*>(wb + w.off_bbox), gg);     // for every later kernel
+    int* __restrict__ tot = reinterpret_cast<int*>(wb + w.off_tot);
+    unsigned int* bbox = reinterpret_cast<unsigned int*>(wb + w.off_bbox);
+    const Grid gg = load_grid_compute(bbox, radius, N);
+    if (blockIdx.x == 0 && threadIdx.x == 0) store_grid(bbox, gg);     // for every later kernel
     // cells beyond this are never populated (curve positions of an order-only structure: any of the 4096)
     const int n_cells = ((order_only >> blockIdx.y) & 1) ? kMaxCells : gg.nx * gg.ny * gg.nz;
-    for (int c = threadIdx.x; c < kMaxCells; c += 1024) {
-        int run = 0;
-        if (c >= n_cells) { tot[c] = 0; continue; }
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    int run = 0;
+    if (c < n_cells) {
         int g = 0;
-        for (; g + 8 <= w.n_wg; g += 8) {
-            int t[8];
+        for (; g + 16 <= w.n_wg; g += 16) {                  // (a round trip per batch: 16 in flight, 4 batches for a 50 000-point cloud)
+            int t[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = counts[(size_t)(g + u) * kMaxCells + c];
+            for (int u = 0; u < 16; ++u) t[u] = counts[(size_t)(g + u) * kMaxCells + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
+                bases[(size_t)(g + u) * kMaxCells + c] = run;
+                run += t[u];
+            }
+        }
+        for (; g + 4 <= w.n_wg; g += 4) {
+            int t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = counts[(size_t)(g + u) * kMaxCells + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 bases[(size_t)(g + u) * kMaxCells + c] = run;
                 run += t[u];
             }
@@ -161,43 +181,47 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(char* __restrict__ ws, 
             bases[(size_t)g * kMaxCells + c] = run;
             run += t;
         }
-        tot[c] = run;
     }
-    __syncthreads();
-    // exclusive scan of tot[0..4096): each thread owns 4 consecutive cells
-    const int c0 = threadIdx.x * 4;
-    const int t0 = tot[c0], t1 = tot[c0 + 1], t2 = tot[c0 + 2], t3 = tot[c0 + 3];
-    const int sum = t0 + t1 + t2 + t3;
-    int incl = sum;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int o = __shfl_up(incl, m, kWave);
-        if ((int)(threadIdx.x & 63) >= m) incl += o;
-    }
-    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) base += part[k];
-    const int excl = base + incl - sum;
-    start[c0] = excl;
-    start[c0 + 1] = excl + t0;
-    start[c0 + 2] = excl + t0 + t1;
-    start[c0 + 3] = excl + t0 + t1 + t2;
-    if (threadIdx.x == 1023) start[kMaxCells] = excl + sum;
+    tot[c] = run;
 }
 
 // ---- K3: stable scatter into cell-sorted order ------------------------------------------------
 __global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict__ ws, size_t ws_stride, int N)
 {
     __shared__ int slot[kMaxCells];
+    __shared__ int part[kSortWG / 64];
     const GridWs w = grid_ws(N);
     char* wb = ws + blockIdx.y * ws_stride;
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     float4* P4s = reinterpret_cast<float4*>(wb + w.off_p4s);
     const int* cell_of = reinterpret_cast<const int*>(wb + w.off_cell);
     const int* bases = reinterpret_cast<const int*>(wb + w.off_bases) + (size_t)blockIdx.x * kMaxCells;
-    const int* start = reinterpret_cast<const int*>(wb + w.off_start);
-    for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) slot[c] = start[c] + bases[c];
+    int* start = reinterpret_cast<int*>(wb + w.off_start);
+    {
+        // exclusive scan of the cells' totals (see grid_scan_kernel): kMaxCells / kSortWG = 4 consecutive cells per lane; workgroup 0
+        // leaves start[] for the kernels that search the structure
+        static_assert(kMaxCells == 4 * kSortWG, "4 cells per lane");
+        const int4 t = reinterpret_cast<const int4*>(wb + w.off_tot)[threadIdx.x];
+        const int4 bs = reinterpret_cast<const int4*>(bases)[threadIdx.x];
+        const int sum = t.x + t.y + t.z + t.w;
+        int incl = sum;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int o = __shfl_up(incl, m, kWave);
+            if ((int)(threadIdx.x & 63) >= m) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) base += part[k];
+        const int e0 = base + incl - sum, e1 = e0 + t.x, e2 = e1 + t.y, e3 = e2 + t.z;
+        const int c0 = threadIdx.x * 4;
+        slot[c0] = e0 + bs.x; slot[c0 + 1] = e1 + bs.y; slot[c0 + 2] = e2 + bs.z; slot[c0 + 3] = e3 + bs.w;
+        if (blockIdx.x == 0) {
+            reinterpret_cast<int4*>(start)[threadIdx.x] = make_int4(e0, e1, e2, e3);
+            if (threadIdx.x == kSortWG - 1) start[kMaxCells] = e3 + t.w;
+        }
+    }
     __syncthreads();
     const int j = blockIdx.x * kSortWG + threadIdx.x;
     const bool valid = j < N;
@@ -216,11 +240,12 @@ __global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict_
         }
     }
     // waves take turns in index order: slot[] is the running first-free slot of each cell
+    // (the point is read BEFORE the turns: a global round trip inside each of the 16 serial turns is 16 round trips per workgroup)
+    float4 p = P4o[valid ? j : 0];
+    p.w = __int_as_float(j);
     for (int wv = 0; wv < kSortWG / 64; ++wv) {
         if (wave == wv && valid) {
             const int pos = slot[c] + rank;
-            float4 p = P4o[j];
-            p.w = __int_as_float(j);
             P4s[pos] = p;
         }
         __syncthreads();
@@ -719,7 +744,7 @@ int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStrea
     UMEREG_CHECK_LAUNCH("pack_points_kernel");
     hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius, order_only);
     UMEREG_CHECK_LAUNCH("grid_hist_kernel");
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1, B), dim3(1024), 0, st, ws, w.total, N, radius, order_only);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(kScanWGs, B), dim3(256), 0, st, ws, w.total, N, radius, order_only);
     UMEREG_CHECK_LAUNCH("grid_scan_kernel");
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N);
     UMEREG_CHECK_LAUNCH("grid_scatter_kernel");

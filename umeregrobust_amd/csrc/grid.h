@@ -15,7 +15,7 @@ constexpr int kScanUnroll = 4;      // 64-point chunks in flight per wave in the
 
 // ---- workspace carve-up (per batch element) ---------------------------------------------------
 struct GridWs {
-    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_bbox, off_kperm, off_box, total;
+    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_tot, off_bbox, off_kperm, off_box, total;
     int Npad, n_wg;
 };
 
@@ -31,6 +31,7 @@ __host__ __device__ inline GridWs grid_ws(int N)
     w.off_counts = o; o += (size_t)w.n_wg * kMaxCells * 4;
     w.off_bases = o;  o += (size_t)w.n_wg * kMaxCells * 4;
     w.off_start = o;  o += (size_t)(kMaxCells + 64) * 4;
+    w.off_tot = o;    o += (size_t)kMaxCells * 4;      // points per cell (grid_scan_kernel), turned into start[] by every scatter workgroup
     w.off_bbox = o;   o += 64;
     w.off_kperm = o;  o += (size_t)w.Npad * 4;   // keypoint processing order (n_kp <= Npad)
     o = (o + 15) / 16 * 16;
