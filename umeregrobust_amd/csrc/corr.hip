@@ -1691,6 +1691,42 @@ __device__ __forceinline__ void cons2_scan(const unsigned int* hist, int lane, i
     inbin = any ? inb : 0;
 }
 
+// the same with 16-bit counters (two per word, 18 words per lane): stages of up to 65 535 points (the cell pass's long lists)
+constexpr int kHist16Words = 18;
+__device__ __forceinline__ void hist16_add(unsigned int* hist, int lane, int t)
+{
+    atomicAdd(&hist[(t >> 1) * kWave + lane], 1u << ((t & 1) * 16));
+}
+__device__ __forceinline__ void hist16_scan(const unsigned int* hist, int lane, int base, int K, int& bstar, int& before, int& inbin)
+{
+    unsigned int w[kHist16Words];
+    int cw[kHist16Words];
+    int run = base;
+#pragma unroll
+    for (int i = 0; i < kHist16Words; ++i) {
+        w[i] = hist[i * kWave + lane];
+        run += (int)(w[i] & 0xffffu) + (int)(w[i] >> 16);
+        cw[i] = run;
+    }
+    int ws = 0;
+#pragma unroll
+    for (int i = 0; i < kHist16Words; ++i) ws += cw[i] < K ? 1 : 0;
+    int cb = base;
+    unsigned int ww = 0u;
+#pragma unroll
+    for (int i = 0; i < kHist16Words; ++i) {
+        cb = (i + 1 == ws) ? cw[i] : cb;
+        ww = (i == ws) ? w[i] : ww;
+    }
+    const int h0 = (int)(ww & 0xffffu), h1 = (int)(ww >> 16);
+    const bool hit0 = cb + h0 >= K, hit1 = !hit0 && cb + h0 + h1 >= K;
+    const int b = hit0 ? ws * 2 : (hit1 ? ws * 2 + 1 : -1);
+    const bool any = ws < kHist16Words && b >= 0 && b <= 33;
+    bstar = any ? b : -1;
+    before = hit0 ? cb : cb + h0;
+    inbin = any ? (hit0 ? h0 : h1) : 0;
+}
+
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void corr_consensus2_kernel(
     const char* __restrict__ ws_tgt, const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
     const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed,
@@ -2479,7 +2515,11 @@ __host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
     w.cap = (unsigned int)cell_cap(queries);
     return w;
 }
-__device__ __forceinline__ bool cell_usable(const uint4& ce) { return ce.w == 0u && ce.y != 0u && ce.y * 4u <= (unsigned int)kCellCap; }
+#ifndef UMEREG_CELL_LONG
+#define UMEREG_CELL_LONG 1
+#endif
+constexpr int kCellCapLong = UMEREG_CELL_LONG ? 4 * kLatMaxQuads : kCellCap;      // the long-list instance of the kernel (16-bit counters, 512 stage slots)
+__device__ __forceinline__ bool cell_usable(const uint4& ce) { return ce.w == 0u && ce.y != 0u && ce.y * 4u <= (unsigned int)kCellCapLong; }
 
 // exclusive prefix sums of the marked cells' counts (cells without a usable list count as empty), in the order of the marked list:
 // phase 0: per-block sums; cell_blockscan_kernel: their offsets; phase 1: cnt[cell] = first entry, cur[cell] = 0, the cell's record
@@ -2571,14 +2611,22 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
     }
 }
 
-__host__ __device__ inline size_t cell_lds_per_wave(int K)
+__host__ __device__ inline size_t cell_d2_plane(int K, bool lng)
 {
-    // tie list (16-bit index plane) | stage (256 slots x 16 B) | the lane's K keys (d2 plane -- the byte histogram lives there until
+    const size_t hw = (size_t)(lng ? kHist16Words : kCons2HistWords) * kWave * 4;
+    return (size_t)K * kWave * 4 > hw ? (size_t)K * kWave * 4 : hw;
+}
+__host__ __device__ inline size_t cell_lds_per_wave(int K, bool lng)
+{
+    // tie list (16-bit index plane) | stage (256 or 512 slots x 16 B) | the lane's K keys (d2 plane -- the histogram lives there until
     // the second sweep starts --, 16-bit index plane)
-    const size_t d2_plane = (size_t)K * kWave * 4 > (size_t)kCons2HistWords * kWave * 4 ? (size_t)K * kWave * 4 : (size_t)kCons2HistWords * kWave * 4;
-    return (size_t)kCons2Tie * kWave * 6 + 256 * 16 + d2_plane + ((size_t)K * kWave * 2 + 255) / 256 * 256;
+    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : 256) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256;
 }
 
+// kLong = false: the cells whose list has <= kCellCap entries (byte counters, 256 stage slots: 14.5 KiB of LDS per wavefront);
+// kLong = true: the longer ones, up to kCellCapLong (16-bit counters, 512 slots: 18.5 KiB) -- dense spots, 3 % of the queries of a
+// nuScenes-size half-overlapping pair, which cost 9 ns each in the list kernel (21 of that pair's 85 ms)
+template <bool kLong>
 __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
                                                        const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T,
                                                        int Ns, int Nt, int M, int K, float sigma, char* __restrict__ lat, unsigned int c_max, CellWs cw,
@@ -2600,10 +2648,14 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     tie.ix = reinterpret_cast<IdxT*>(tie.d2 + kCons2Tie * kWave);
     float* stage = reinterpret_cast<float*>(lds + (size_t)kCons2Tie * kWave * 6);
     KeyList<IdxT> list;
-    list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + 256 * 16);
+    list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + (kLong ? 512 : 256) * 16);
     unsigned int* hist = list.d2;                    // (dead before the first key is written: see cell_lds_per_wave)
-    const size_t d2_plane = (size_t)K * kWave * 4 > (size_t)kCons2HistWords * kWave * 4 ? (size_t)K * kWave * 4 : (size_t)kCons2HistWords * kWave * 4;
-    list.ix = reinterpret_cast<IdxT*>(reinterpret_cast<char*>(list.d2) + d2_plane);
+    list.ix = reinterpret_cast<IdxT*>(reinterpret_cast<char*>(list.d2) + cell_d2_plane(K, kLong));
+    constexpr int kHW = kLong ? kHist16Words : kCons2HistWords;
+    auto h_add = [&](int t) __attribute__((always_inline)) { if (kLong) hist16_add(hist, lane, t); else cons2_hist_add(hist, lane, t); };
+    auto h_scan = [&](int base, int& bstar, int& before, int& inbin) __attribute__((always_inline)) {
+        if (kLong) hist16_scan(hist, lane, base, K, bstar, before, inbin); else cons2_scan(hist, lane, base, K, bstar, before, inbin);
+    };
     const int n_words = (M + 63) >> 6;
     const float inv_sigma = 1.0f / sigma;
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -2611,7 +2663,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     unsigned int n_ok = 0u, n_fail = 0u, n_batches = 0u;
     for (;;) {
         unsigned int i0 = 0u;
-        if (lane == 0) i0 = atomicAdd(&header[33], (unsigned int)kCellFetch);
+        if (lane == 0) i0 = atomicAdd(&header[kLong ? 37 : 33], (unsigned int)kCellFetch);
         i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
         if (i0 >= n_marked) break;
         // the records of the kCellFetch cells of this visit: lanes 0 .. 2 kCellFetch - 1 hold one 16-byte half each
@@ -2624,7 +2676,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
         const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
         const unsigned int lfirst = (unsigned int)__builtin_amdgcn_readlane((int)rl.x, 2 * ci + 1);
         const int quads = __builtin_amdgcn_readlane((int)rl.y, 2 * ci + 1);
-        if (n_e == 0u) continue;
+        if (n_e == 0u || (quads * 4 > kCellCap) != kLong) continue;
         // ---- the cell's list into the stage: quad q of the stage = the four positions of list word q (padding = a far point) ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int q = lane; q < quads; q += kWave) {
@@ -2674,17 +2726,17 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the previous step's epilogue read the plane the histogram shares)
 #pragma unroll
-            for (int w = 0; w < kCons2HistWords; ++w) hist[w * kWave + lane] = 0u;
+            for (int w = 0; w < kHW; ++w) hist[w * kWave + lane] = 0u;
             for (int u0 = 0; u0 < ((UMEREG_F1_ABLATE & 0x400000) ? 4 : m_use); u0 += 4) {
                 f2 t01, t23;
                 quad_d2(u0, t01, t23);
-                cons2_hist_add(hist, lane, cons2_bin(t01.x, lo, sc));
-                cons2_hist_add(hist, lane, cons2_bin(t01.y, lo, sc));
-                cons2_hist_add(hist, lane, cons2_bin(t23.x, lo, sc));
-                cons2_hist_add(hist, lane, cons2_bin(t23.y, lo, sc));
+                h_add(cons2_bin(t01.x, lo, sc));
+                h_add(cons2_bin(t01.y, lo, sc));
+                h_add(cons2_bin(t23.x, lo, sc));
+                h_add(cons2_bin(t23.y, lo, sc));
             }
             int b0, before, inbin;
-            cons2_scan(hist, lane, 0, K, b0, before, inbin);
+            h_scan(0, b0, before, inbin);
             if (!act || b0 < 1 || b0 > 32) b0 = -1;
             int b1 = -1;
             float lo1 = 0.f, sc1 = 0.f;
@@ -2694,7 +2746,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
                 sc1 = sc * (float)kBins;
                 if (zoom) {
 #pragma unroll
-                    for (int w = 0; w < kCons2HistWords; ++w) hist[w * kWave + lane] = 0u;
+                    for (int w = 0; w < kHW; ++w) hist[w * kWave + lane] = 0u;
                 }
                 for (int u0 = 0; u0 < m_use; u0 += 4) {
                     f2 t01, t23;
@@ -2702,11 +2754,11 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
                     const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (zoom && cons2_bin(d2v[k], lo, sc) == b0) cons2_hist_add(hist, lane, cons2_bin(d2v[k], lo1, sc1));
+                        if (zoom && cons2_bin(d2v[k], lo, sc) == b0) h_add(cons2_bin(d2v[k], lo1, sc1));
                 }
                 if (zoom) {
                     int bb, bef1, inb1;
-                    cons2_scan(hist, lane, before, K, bb, bef1, inb1);
+                    h_scan(before, bb, bef1, inb1);
                     b1 = bb;
                     before = bef1;
                     if (bb < 0 || K - bef1 > kCons2Tie) { b0 = -1; b1 = -1; }
@@ -2856,6 +2908,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // is enqueued only to find that it has nothing to do should not cost 98 k workgroup launches.)
     const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
     const long n_items = (long)n_chunks * n_hg;
+    constexpr int kRecReserve = 16;
+    unsigned int rec_next = 0u, rec_end = 0u, fbq_local = 0u;            // (wave-uniform)
     for (long wid = (long)blockIdx.x * (blockDim.x >> 6) + wave; wid < n_items; wid += (long)gridDim.x * (blockDim.x >> 6)) {
     const int chunk = (int)(wid / n_hg);
     const int hg = (int)(wid % n_hg);
@@ -2953,19 +3007,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // lanes the lattice could not serve: one record per (hypothesis, chunk) for corr_score_fallback_kernel, which adds
             // their terms to this partial sum afterwards (one writer per record: the result stays deterministic)
             const unsigned long long todo = __ballot(fb_lanes);
-            if (lane == 0) {
-                partial[(size_t)h * n_chunks + chunk] = acc;
-                if (todo != 0ull) {
-                    atomicAdd(&lat_header[6], (unsigned int)__popcll(todo));
-                    const unsigned int r = atomicAdd(&lat_header[4], 1u);
-                    queue[r] = make_uint4((unsigned int)h, (unsigned int)chunk, (unsigned int)todo, (unsigned int)(todo >> 32));
+            if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
+            if (todo != 0ull) {
+                // record slots are taken kRecReserve at a time (and the query count once per wavefront): half a million records of a
+                // nuScenes-size pair, two same-address atomics each, were 13 ms of serialised atomics.  Slots a wavefront reserves and does not
+                // use stay EMPTY records (mask 0), which every consumer skips.
+                if (rec_next == rec_end) {
+                    unsigned int b = 0u;
+                    if (lane == 0) b = atomicAdd(&lat_header[4], (unsigned int)kRecReserve);
+                    rec_next = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+                    rec_end = rec_next + (unsigned int)kRecReserve;
+                    if (lane < kRecReserve) queue[rec_next + (unsigned int)lane] = make_uint4(0u, 0u, 0u, 0u);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
+                if (lane == 0) queue[rec_next] = make_uint4((unsigned int)h, (unsigned int)chunk, (unsigned int)todo, (unsigned int)(todo >> 32));
+                ++rec_next;
+                fbq_local += (unsigned int)__popcll(todo);
             }
         } else {
             if (lane == 0) partial[(size_t)h * n_chunks + chunk] = acc;
         }
     }
     }   // (chunk, hypothesis group) items
+    if (LAT && lane == 0 && fbq_local != 0u) atomicAdd(&lat_header[6], fbq_local);
 #ifdef UMEREG_KNN_DEBUG
     if (lane == 0) {
         const unsigned long long dur = (unsigned long long)(clock64() - t_start);
@@ -3103,6 +3167,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
         const uint4 rec = queue[r];
         const int h = (int)rec.x, chunk = (int)rec.y;
         const unsigned long long mask = ((unsigned long long)rec.w << 32) | rec.z;
+        if (mask == 0ull) continue;                                      // (an empty record: reserved, not used)
         const int slot = chunk * kWave + lane;
         const int sidx = __float_as_int(S4s[slot < Ns ? slot : 0].w);
         const float sx = src_pts[(size_t)sidx * 3], sy = src_pts[(size_t)sidx * 3 + 1], sz = src_pts[(size_t)sidx * 3 + 2];
@@ -3564,6 +3629,7 @@ __global__ __launch_bounds__(256) void leftover_sum_kernel(const char* __restric
     for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
         const uint4 rec = queue[r];
         const unsigned int cnt = (unsigned int)(__popc(rec.z) + __popc(rec.w)), base = f.rbase[r];
+        if (cnt == 0u) continue;                                         // (an empty record: reserved, not used)
         float total = 0.f;                                               // the record's queries in lane order
         for (unsigned int j = 0; j < cnt; ++j) total += f.qval[base + j];
         partial[(size_t)rec.x * n_chunks + rec.y] += total;              // every record has one writer
@@ -3757,6 +3823,10 @@ UMEREG_API int umereg_corr_select_best_f32(const float* scores, const float* T, 
 
 UMEREG_API size_t umereg_corr_workspace_bytes(int Ns, int Nt, int M) { return umereg_corr_workspace_bytes_ex(Ns, Nt, M, 0); }
 
+// records the queue can hold: one per (hypothesis, chunk) + the slots the list kernel's wavefronts reserve 16 at a time and may not use
+// (<= 4 096 workgroups x 4 wavefronts x 15)
+static inline size_t queue_records(int M, size_t n_chunks) { return (size_t)M * n_chunks + (size_t)16 * 16384; }
+
 // the consensus pass rides on the lattice (it leaves the queries it cannot prove exact to it)
 static bool consensus_on(unsigned int c_max, int M, int flags, const void* T = nullptr)
 {
@@ -3787,7 +3857,7 @@ UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flag
                                                         2 * align_up(n_chunks * M * 4, 256) + align_up((size_t)Ns * 4, 256) + align_up(n_chunks * 16, 256) : 0;
     return grid_ws(Ns).total + 2 * grid_ws(Nt).total + align_up((size_t)M * n_chunks * 4, 256) +
            align_up((size_t)kColsumBlocks * 32 * 8, 256) + align_up((size_t)(Ns + 2 * (size_t)Nt) * 12, 256) + 256 +
-           (c_max ? lat_ws(c_max).total + align_up((size_t)M * n_chunks * 16, 256) + flat_bytes((size_t)M * n_chunks, (long)M * Ns) : 0) + cons +
+           (c_max ? lat_ws(c_max).total + align_up(queue_records(M, n_chunks) * 16, 256) + flat_bytes(queue_records(M, n_chunks), (long)M * Ns) : 0) + cons +
            (cell_pass_on(c_max, Ns, M, flags) ? cell_bytes(c_max, (long)M * Ns) : 0) +
            (bound_on(c_max, flags) ? bound_bytes(Ns, M) : 0);
 }
@@ -3903,7 +3973,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     if (c_max && hipMemsetAsync(lat, 0, 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice header) failed"); return UMEREG_ELAUNCH; }
     if (consensus_on(c_max, M, flags, T)) {
         // consensus pass: scores every (source point, hypothesis) whose image lies near the consensus image of the point
-        char* cons = lat + lat_ws(c_max).total + align_up((size_t)M * n_chunks_sz * 16, 256);
+        char* cons = lat + lat_ws(c_max).total + align_up(queue_records(M, n_chunks_sz) * 16, 256);
         val = (float*)cons;
         served = (unsigned long long*)(cons + align_up((size_t)Ns * M * 4, 256));
         float* Tmed = (float*)((char*)served + align_up((size_t)Ns * n_words * 8, 256));
@@ -3969,7 +4039,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         const LatWs lw = lat_ws(c_max);
         if (hipMemsetAsync(lat + 256, 0, lw.off_wave_tot - 256, st) != hipSuccess) { set_error("hipMemsetAsync(lattice marks) failed"); return UMEREG_ELAUNCH; }
         // (the flat list sits at the end of the workspace, the cell pass's counters, records and entries right before it)
-        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
+        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes(queue_records(M, n_chunks_sz), (long)M * Ns);
         const bool cell_pass = cell_pass_on(c_max, Ns, M, flags, T);
         CellWs cw = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
         if (cell_pass) {
@@ -4015,7 +4085,10 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)(items < 16384 ? items : 16384)), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T, Ns, Nt, M,
                                hpc, (const char*)lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw);
             UMEREG_CHECK_LAUNCH("cell_scatter_kernel");
-            hipLaunchKernelGGL(corr_cell_kernel, dim3(2816), dim3(kWave), cell_lds_per_wave(K), st, (const char*)ws_tgt, src_pts,
+            hipLaunchKernelGGL(corr_cell_kernel<false>, dim3(2816), dim3(kWave), cell_lds_per_wave(K, false), st, (const char*)ws_tgt, src_pts,
+                               (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw, val, served,
+                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0);
+            hipLaunchKernelGGL(corr_cell_kernel<true>, dim3(2048), dim3(kWave), cell_lds_per_wave(K, true), st, (const char*)ws_tgt, src_pts,
                                (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw, val, served,
                                (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0);
             UMEREG_CHECK_LAUNCH("corr_cell_kernel");
@@ -4029,7 +4102,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         corr_mark(4, st);
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
         // ... as a flat list of queries when they fit (header word 12 marks that the flat path ran), record by record otherwise
-        const FlatWs fw = flat_ws(flat_base, (size_t)M * n_chunks_sz, (long)M * Ns);
+        const FlatWs fw = flat_ws(flat_base, queue_records(M, n_chunks_sz), (long)M * Ns);
         if (bound) {
             char* bb = flat_base - (cell_pass ? cell_bytes(c_max, (long)M * Ns) : 0) - bound_bytes(Ns, M);
             b_slack = (unsigned long long*)bb;
@@ -4100,8 +4173,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 3) / 4), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv, scores);
         hipLaunchKernelGGL(bound_survivors_kernel, dim3(1), dim3(1024), 0, st, (const float*)scores, (const unsigned long long*)b_slack, M, Ns, b_surv, (unsigned int*)lat);
         UMEREG_CHECK_LAUNCH("bound_survivors_kernel");
-        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes((size_t)M * n_chunks_sz, (long)M * Ns);
-        const FlatWs fw = flat_ws(flat_base, (size_t)M * n_chunks_sz, (long)M * Ns);
+        char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes(queue_records(M, n_chunks_sz), (long)M * Ns);
+        const FlatWs fw = flat_ws(flat_base, queue_records(M, n_chunks_sz), (long)M * Ns);
         hipLaunchKernelGGL(corr_score_flat_kernel<2>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
                            (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
