@@ -3299,7 +3299,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict_
 }
 
 template <int kMode>
-__global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+__global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                        const float* __restrict__ src_pts, const float4* __restrict__ vp4,
                                                                        const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
                                                                        int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f,
@@ -3308,6 +3308,8 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
 {
     __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
     __shared__ unsigned int chist[kCoopWaves][kWave];
+    __shared__ float4 visit[kCoopWaves][4];            // the queries of a visit (image, source point): parked here, not in registers -- the
+                                                       // search needs 56 of the 64 a wavefront may hold at eight per SIMD
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
@@ -3373,12 +3375,16 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_flat_kernel(const 
             }
         }
         if (valid && !exact) f.qval[q_l] = 0.f;
-        unsigned long long todo = __ballot(exact);
-        while (todo != 0ull) {
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const float qx = __shfl(qx_l, l, kWave), qy = __shfl(qy_l, l, kWave), qz = __shfl(qz_l, l, kWave);
-            const int qs = __shfl(qs_l, l, kWave);
+        static_assert(kFlatVisit == 4, "visit[][4]");
+        if (lane < (int)kFlatVisit) visit[wave][lane] = make_float4(qx_l, qy_l, qz_l, __int_as_float(qs_l));
+        unsigned int todo = (unsigned int)__ballot(exact);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        while (todo != 0u) {
+            const int l = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            const float4 v = visit[wave][l];
+            const float qx = v.x, qy = v.y, qz = v.z;
+            const int qs = __float_as_int(v.w);
             const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
             const float4 a = vp4[(size_t)qs * 8 + sub];
             float part = 0.f;
