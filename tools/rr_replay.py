@@ -4,11 +4,14 @@ draw, correlation sub-samples x 2), so the two paths see the same random numbers
 
   (a) `--kt N`      N KITTI-size HARD pairs (N = 50 000 points, 10 000 keypoints, M = 2 500 hypotheses; partial overlap, 2 cm noise,
                     20 % corrupted features) -- the benchmark size, where f1 / f2 were otherwise only compared stage by stage;
-  (b) `--small N`   N reduced-size harder pairs (N = 4 096, M = 256; bench.py's RR_CHECK_HARD), enough of them for a recall figure.
+  (b) `--small N`   N reduced-size harder pairs (N = 4 096, M = 256; bench.py's RR_CHECK_HARD), enough of them for a recall figure;
+  (c) `--ns N`      N nuScenes-test-size HARD pairs (35 000 points, 5 000 keypoints = hypotheses, 30 000 correlation points, no match
+                    filtering): the sizes at which f1 runs its cell pass and bounds the queries outside the lattice (the oracle's
+                    brute force needs ~70 s per pair on 256 cores).
 
 Writes per-pair |dRRE|, |dRTE|, gate outcomes of both paths and the summary to the JSON given by --out (tracked copy:
 profiles/r03/rr_replay.json).  Runs on the GPU box (HIP path) and on its host cores (oracle, C/OpenMP + numpy).
-usage: python tools/rr_replay.py [--kt 8] [--small 128] [--out gpurun_out/rr_replay.json]"""
+usage: python tools/rr_replay.py [--kt 8] [--small 128] [--ns 0] [--out gpurun_out/rr_replay.json]"""
 import argparse
 import json
 import os
@@ -92,6 +95,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kt", type=int, default=8)
     ap.add_argument("--small", type=int, default=128)
+    ap.add_argument("--ns", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/rr_replay.json")
     c = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -103,9 +107,12 @@ def main():
         out["kitti_size"] = run("KT", c.kt, 50000, 10000, 2500, {}, 9000, args, dev)
     if c.small:
         out["reduced_size"] = run("small", c.small, 4096, 4096, 256, RR_CHECK_HARD, 20000, args, dev)
+    if c.ns:
+        args_ns = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("nuscenes_test"))
+        out["nuscenes_size"] = run("NS", c.ns, 35000, 5000, 5000, {}, 11000, args_ns, dev)
     os.makedirs(os.path.dirname(os.path.abspath(c.out)), exist_ok=True)
     json.dump(out, open(c.out, "w"), indent=1)
-    for k in ("kitti_size", "reduced_size"):
+    for k in ("kitti_size", "reduced_size", "nuscenes_size"):
         if k in out:
             r = out[k]
             print(k, r["pairs"], "pairs | cpu RR", r["cpu_rr_percent"], "hip RR", r["hip_rr_percent"], "| different gate outcome:",
