@@ -1581,6 +1581,38 @@ def test_corr_scores_bound_outside_keeps_the_arg_max(gpu):
     assert abs(float(got[am]) - float(want[0])) <= 2e-4 * abs(float(want[0])) + 1e-6
 
 
+def test_feature_correlator_on_a_big_job_picks_the_exact_arg_max(gpu):
+    """Jobs of >= 2^25 queries (the nuScenes-test / LoKITTI configs: 5 000 hypotheses x 30 000 points) run the cell pass by themselves and
+    FeatureCorrelator bounds the queries outside the lattice: the transform it returns is the one the exact scores pick (here 3 400
+    hypotheses x 10 000 points, a third of them garbage, so that the leftovers go to the lattice and thousands of queries are bounded)."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.utils.loc_utils import FeatureCorrelator
+    rng = np.random.RandomState(5)
+    Nt = Ns = 10000
+    M = 3400
+    assert M * Ns >= ops.CORR_BOUND_MIN_QUERIES
+    tgt = (rng.uniform(-40, 40, (Nt, 3)) * np.array([1, 1, 0.05])).astype(np.float32)
+    src = (tgt[rng.permutation(Nt)[:Ns]] + rng.standard_normal((Ns, 3)) * 0.05).astype(np.float32)
+    sf = rng.standard_normal((Ns, 32)).astype(np.float32); tf = rng.standard_normal((Nt, 32)).astype(np.float32)
+    Ts = np.tile(np.eye(4, dtype=np.float32), (M, 1, 1))
+    for m in range(M):
+        kind = rng.choice(3, p=[0.5, 0.2, 0.3])
+        th = np.deg2rad([0.3, 4.0, 90.0][kind]) * rng.randn()
+        Ts[m, :2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+        Ts[m, :3, 3] = rng.standard_normal(3) * [0.05, 1.5, 60.0][kind]
+    a_ = (T_(src, gpu)[None], T_(tgt, gpu)[None], T_(sf, gpu)[None], T_(tf, gpu)[None], T_(Ts, gpu))
+    fc = FeatureCorrelator(sigma=1.0, corr_num_nn=20)
+    best = fc.feature_corr_hypothesis_test(*a_)
+    idx, scores = int(fc.last_best_index), fc.last_scores.clone()
+    fx = FeatureCorrelator(sigma=1.0, corr_num_nn=20)
+    fx.exact_scores = True
+    best_x = fx.feature_corr_hypothesis_test(*a_)
+    assert idx == int(fx.last_best_index) and torch.equal(best, best_x)
+    assert abs(float(scores[idx] - fx.last_scores[idx])) <= 2e-6 * abs(float(fx.last_scores[idx])) + 1e-7
+    assert int((scores != fx.last_scores).sum()) > 0                      # some hypotheses were ruled out without their far queries
+    assert float(fx.last_scores.max()) == float(fx.last_scores[idx])
+
+
 def test_evaluate_pairs_overlapped_equals_one_pair_at_a_time(gpu):
     """evaluate.evaluate_pairs overlaps consecutive pairs on two HIP streams (pair i + 1 is prepared while the correlation
     scores of pair i are computed): same selections, same refined registrations, same host-RNG position afterwards as one
