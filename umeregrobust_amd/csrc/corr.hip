@@ -1945,7 +1945,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
         const float delta = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f;   // (1 ulp: inside the slack)
         // a lane can only pass the exactness test if d_K(q) + delta <= D, and d_K(q) >= d_K(q~) - delta
-        const bool act = pos_h < M && delta < D && dk <= D;                                 // (NaN transforms: false)
+        // Who takes part: a lane passes the exactness test iff d_K(q) + delta <= D, and d_K(q) is about d_K(q~) = dk -- a lane with
+        // delta > D - dk passes only if its own K-th neighbour is that much closer than the centre's.  Such lanes used to take part
+        // (delta < D was all that was asked): they rarely pass, and theirs are the largest deltas of the step, i.e. they set the width
+        // of everybody's zone.  Measured (UMEREG_CONS_ACT = percent of D - dk; 0 = the old rule): 100 serves 0.02 % fewer queries of a
+        // KITTI-test pair and 7 % fewer of a half-overlapping nuScenes-size one, and the call is 1 % / 15 % faster (2.01 -> 1.99 ms,
+        // 73.8 -> 63.0; LoKITTI-size 69.5 -> 62.6); 80 is better still on plain big jobs (42.6 -> 41.0) but pushes a half-overlapping
+        // KITTI-test pair's leftovers towards the 2 M where the lattice takes over (6.41 -> 6.52); 60 loses everywhere but there.
+#ifndef UMEREG_CONS_ACT
+#define UMEREG_CONS_ACT 100
+#endif
+        const bool act = pos_h < M && delta < D && dk <= D && (UMEREG_CONS_ACT == 0 || delta <= (D - dk) * (UMEREG_CONS_ACT * 0.01f));   // (NaN transforms: false)
         if (!__any(act)) {
             if (pos_h < M) val[(size_t)n * M + pos_h] = 0.f;
             if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = 0ull;
@@ -2191,7 +2201,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // thousand (hypothesis, chunk) wavefronts), 0 = the candidate lattice (many: hypotheses that do not agree, clouds that
 // barely overlap -- queries in empty parts of the target, where lists pay off).  Both sets of kernels are enqueued;
 // the ones not chosen return at once.
-constexpr unsigned int kLeftMax = 1u << 21;   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
+#ifndef UMEREG_LEFT_MAX
+#define UMEREG_LEFT_MAX 3000000u
+#endif
+constexpr unsigned int kLeftMax = UMEREG_LEFT_MAX;      // (2^21 until the end of round 3: over 32 half-overlapping KITTI-test pairs, whose leftovers straddle
+                                                        // 2 M, f1 averages 7.5 ms with 2^21 and 6.4 with 3 M or 4.5 M -- the flat list holds half the job's queries now)   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
 __global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force)
 {
     const long left = n_queries - (long)header[7];
