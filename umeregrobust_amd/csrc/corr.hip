@@ -2510,12 +2510,13 @@ struct CellWs {
     unsigned int* bsum;    // [1024 + 64] per-block sums / offsets of the scan
     uint4* rec;            // [2 c_max] per MARKED cell, in the order of the marked list: (cell, first entry, entries, d_K^2 bits), (list first, list quads, -, -)
     uint2* ent;            // [cap] (source point x M + position of the hypothesis in the chunk's order, hypothesis)
+    unsigned int* long_idx; // [c_max] positions (in the marked list) of the cells with queries and a list of more than kCellCap entries (header word 38: how many)
     unsigned int cap;
 };
 __host__ __device__ inline size_t cell_cap(long queries) { return (size_t)(queries < (long)kCellMaxEntries ? queries : (long)kCellMaxEntries); }
 __host__ inline size_t cell_bytes(unsigned int c_max, long queries)
 {
-    return 2 * align_up(((size_t)c_max + 64) * 4, 256) + align_up((1024 + 64) * 4, 256) + align_up((size_t)c_max * 32, 256) + align_up(cell_cap(queries) * 8, 256);
+    return 3 * align_up(((size_t)c_max + 64) * 4, 256) + align_up((1024 + 64) * 4, 256) + align_up((size_t)c_max * 32, 256) + align_up(cell_cap(queries) * 8, 256);
 }
 __host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
 {
@@ -2525,6 +2526,7 @@ __host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
     w.cur = reinterpret_cast<unsigned int*>(base + o);  o += align_up(((size_t)c_max + 64) * 4, 256);
     w.bsum = reinterpret_cast<unsigned int*>(base + o); o += align_up((1024 + 64) * 4, 256);
     w.rec = reinterpret_cast<uint4*>(base + o);         o += align_up((size_t)c_max * 32, 256);
+    w.long_idx = reinterpret_cast<unsigned int*>(base + o); o += align_up(((size_t)c_max + 64) * 4, 256);
     w.ent = reinterpret_cast<uint2*>(base + o);
     w.cap = (unsigned int)cell_cap(queries);
     return w;
@@ -2569,6 +2571,17 @@ __global__ __launch_bounds__(1024) void cell_apply_kernel(char* __restrict__ lat
         const unsigned int n_e = first >= cw.cap ? 0u : min(v, cw.cap - first);
         cw.rec[2 * (size_t)i] = make_uint4(id, first, n_e, reinterpret_cast<const unsigned int*>(lat + lw.off_dk2)[id]);
         cw.rec[2 * (size_t)i + 1] = make_uint4(ce.x, ce.y, 0u, 0u);
+    }
+    {
+        // the work list of the long-list instance (any order: every cell is computed on its own)
+        const bool lng = i < n && v != 0u && first < cw.cap && ce.y * 4u > (unsigned int)kCellCap;
+        const unsigned long long m = __ballot(lng);
+        if (m != 0ull) {
+            unsigned int b = 0u;
+            if (lane == 0) b = atomicAdd(const_cast<unsigned int*>(&header[38]), (unsigned int)__popcll(m));
+            b = (unsigned int)__shfl((int)b, 0, kWave);
+            if (lng) cw.long_idx[b + (unsigned int)mbcnt(m)] = i;
+        }
     }
 }
 __global__ __launch_bounds__(1024) void cell_blockscan_kernel(char* __restrict__ lat, unsigned int c_max, CellWs cw)
@@ -2677,13 +2690,18 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     unsigned int n_ok = 0u, n_fail = 0u, n_batches = 0u;
     for (;;) {
         unsigned int i0 = 0u;
-        if (lane == 0) i0 = atomicAdd(&header[kLong ? 37 : 33], (unsigned int)kCellFetch);
+        // (the long-list instance takes its cells one at a time from the list cell_apply_kernel<1> compacted for it -- a few per cent of
+        // the marked cells, clustered in dense spots: walking the whole marked list cost it a quarter of a million visits of the counter,
+        // ~12 ns apiece and serialised, and 32 cells per visit left stragglers with dozens of long cells: 6.8 -> 17.7 ms)
+        constexpr int kFetch = kLong ? 1 : kCellFetch;
+        if (lane == 0) i0 = atomicAdd(&header[kLong ? 37 : 33], (unsigned int)kFetch);
         i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
-        if (i0 >= n_marked) break;
+        if (i0 >= (kLong ? header[38] : n_marked)) break;
+        if (kLong) i0 = cw.long_idx[i0];
         // the records of the kCellFetch cells of this visit: lanes 0 .. 2 kCellFetch - 1 hold one 16-byte half each
         uint4 rl = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < 2 * kCellFetch && i0 + (unsigned int)(lane >> 1) < n_marked) rl = cw.rec[2 * (size_t)i0 + lane];
-        for (int ci = 0; ci < kCellFetch; ++ci) {
+        if (lane < 2 * kFetch && i0 + (unsigned int)(lane >> 1) < n_marked) rl = cw.rec[2 * (size_t)i0 + lane];
+        for (int ci = 0; ci < kFetch; ++ci) {
         const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
         const unsigned int first_e = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
         const unsigned int n_e = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
@@ -4061,7 +4079,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // (the flat list sits at the end of the workspace, the cell pass's counters, records and entries right before it)
         char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes(queue_records(M, n_chunks_sz), (long)M * Ns);
         const bool cell_pass = cell_pass_on(c_max, Ns, M, flags, T);
-        CellWs cw = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        CellWs cw = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
         if (cell_pass) {
             cw = cell_ws(flat_base - cell_bytes(c_max, (long)M * Ns), c_max, (long)M * Ns);
             if (hipMemsetAsync(cw.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) { set_error("hipMemsetAsync(cell counters) failed"); return UMEREG_ELAUNCH; }
