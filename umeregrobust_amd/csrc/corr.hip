@@ -2253,6 +2253,61 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
     }
 }
 
+// The unserved queries of a pair, walked in the consensus pass's order: lane = one slot of the source's processing order (a wavefront
+// = one chunk, so the hypothesis at position `pos` is the same for all its lanes: scalar loads of its transform), positions 64 at a
+// time = ONE served word per lane, and a word that is all ones costs nothing more.  (By source index and hypothesis number -- the first
+// form of lattice_mark_kernel / cell_scatter_kernel -- every (point, hypothesis) pair paid for its transform, an inverse-order look-up
+// and a scattered 8-byte read of its served word: 1.5e8 of each on a nuScenes-size pair.)  f(n, pos, h, qx, qy, qz) per unserved query.
+template <class F>
+__device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float* __restrict__ T,
+                                                  int Ns, int M, const unsigned long long* __restrict__ served, int n_words,
+                                                  const int* __restrict__ perm, F&& f)
+{
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s);
+    const int n_pb = (Ns + 255) / 256;
+    for (long item = blockIdx.x; item < (long)n_pb * n_words; item += gridDim.x) {
+        const int slot = (int)(item % n_pb) * 256 + threadIdx.x;
+        const int w = (int)(item / n_pb);
+        if (slot >= Ns) continue;
+        const int n = __float_as_int(S4s[slot].w);
+        unsigned long long todo = ~served[(size_t)n * n_words + w];
+        if (w == n_words - 1 && (M & 63)) todo &= (1ull << (M & 63)) - 1ull;
+        if (!__any(todo != 0ull)) continue;
+        const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
+        const int* perm_c = perm + (size_t)(slot >> 6) * M + (size_t)w * 64;
+        for (int b = 0; b < 64; ++b) {
+            const bool mine = (todo >> b) & 1ull;
+            if (!__any(mine)) continue;
+            const int h = perm_c[b];                                 // uniform
+            const float* Th = T + (size_t)h * 16;                    // uniform: scalar loads
+            // (the arithmetic of corr_score_kernel: the cell is the one every other kernel computes for this query)
+            const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+            const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+            const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+            if (mine) f(n, w * 64 + b, h, qx, qy, qz);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lattice_mark_order_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
+                                                                 const float* __restrict__ T, int Ns, int Nt, int M, char* __restrict__ lat, unsigned int c_max,
+                                                                 const unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm,
+                                                                 unsigned int* __restrict__ cell_cnt)
+{
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // the compacted path takes the leftovers
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    unsigned char* marks = reinterpret_cast<unsigned char*>(lat + lw.off_marks);
+    for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int, int, int, float qx, float qy, float qz) {
+        const int cell = lattice_cell(L, qx, qy, qz);
+        if (cell >= 0) {
+            marks[cell] = 1;
+            if (cell_cnt) atomicAdd(&cell_cnt[cell], 1u);       // (the cell pass's counting sort: see corr_cell_kernel)
+        }
+    });
+}
+
 // ascending list of the marked cells (one workgroup; deterministic order): cids[0 .. header[3])
 __global__ __launch_bounds__(1024) void lattice_compact_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt)
 {
@@ -2603,39 +2658,21 @@ __global__ __launch_bounds__(1024) void cell_blockscan_kernel(char* __restrict__
 }
 
 // the entries: every unserved query whose cell has a usable list, at cnt[cell] (= first) + cur[cell]++
-__global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
-                                                           const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
-                                                           const char* __restrict__ lat, unsigned int c_max,
-                                                           const unsigned long long* __restrict__ served, int n_words,
-                                                           const int* __restrict__ inv, const int* __restrict__ chunk_of, CellWs cw)
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
+                                                           const float* __restrict__ T, int Ns, int Nt, int M, const char* __restrict__ lat, unsigned int c_max,
+                                                           const unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm, CellWs cw)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // few leftovers: the queue takes them
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
     const uint4* cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
-    const int n_hg = (M + hyp_per_thread - 1) / hyp_per_thread;
-    const int n_pb = (Ns + 255) / 256;
-    for (long item = blockIdx.x; item < (long)n_pb * n_hg; item += gridDim.x) {
-        const int n = (int)(item % n_pb) * 256 + threadIdx.x;
-        const int h0 = (int)(item / n_pb) * hyp_per_thread, h1 = min(h0 + hyp_per_thread, M);
-        if (n >= Ns) continue;
-        const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
-        const int* inv_n = inv + (size_t)chunk_of[n] * M;
-        for (int h = h0; h < h1; ++h) {
-            const float* Th = T + (size_t)h * 16;     // uniform: scalar loads
-            const int ph = inv_n[h];
-            if ((served[(size_t)n * n_words + (ph >> 6)] >> (ph & 63)) & 1ull) continue;
-            // (the arithmetic of corr_score_kernel and lattice_mark_kernel: the cell is the one that was marked and counted)
-            const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
-            const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
-            const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-            const int cell = lattice_cell(L, qx, qy, qz);
-            if (cell < 0 || !cell_usable(cells[cell])) continue;
-            const unsigned int pos = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
-            if (pos < cw.cap) cw.ent[pos] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)ph, (unsigned int)h);
-        }
-    }
+    for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int n, int pos, int h, float qx, float qy, float qz) {
+        const int cell = lattice_cell(L, qx, qy, qz);
+        if (cell < 0 || !cell_usable(cells[cell])) return;
+        const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
+        if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+    });
 }
 
 __host__ __device__ inline size_t cell_d2_plane(int K, bool lng)
@@ -4085,8 +4122,14 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             if (hipMemsetAsync(cw.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) { set_error("hipMemsetAsync(cell counters) failed"); return UMEREG_ELAUNCH; }
         }
         const int hpt = 16;
-        hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
-                           Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw.cnt);
+        const long order_items = (long)((Ns + 255) / 256) * n_words;
+        const dim3 order_grid((unsigned)(order_items < 16384 ? order_items : 16384));
+        if (served)
+            hipLaunchKernelGGL(lattice_mark_order_kernel, order_grid, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M, lat, c_max,
+                               (const unsigned long long*)served, n_words, (const int*)perm, cw.cnt);
+        else
+            hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
+                               Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw.cnt);
         UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
         int bcap, bwaves;
         size_t blds;
@@ -4118,10 +4161,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(cell_blockscan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max, cw);
             hipLaunchKernelGGL(cell_apply_kernel<1>, dim3(nb), dim3(1024), 0, st, lat, c_max, cw);
             UMEREG_CHECK_LAUNCH("cell_apply_kernel");
-            const int hpc = 16;
-            const long items = (long)((Ns + 255) / 256) * ((M + hpc - 1) / hpc);
-            hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)(items < 16384 ? items : 16384)), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T, Ns, Nt, M,
-                               hpc, (const char*)lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw);
+            hipLaunchKernelGGL(cell_scatter_kernel, order_grid, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M,
+                               (const char*)lat, c_max, (const unsigned long long*)served, n_words, (const int*)perm, cw);
             UMEREG_CHECK_LAUNCH("cell_scatter_kernel");
             hipLaunchKernelGGL(corr_cell_kernel<false>, dim3(2816), dim3(kWave), cell_lds_per_wave(K, false), st, (const char*)ws_tgt, src_pts,
                                (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw, val, served,
