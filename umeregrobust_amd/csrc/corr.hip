@@ -2946,7 +2946,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          float sigma, int hyp_per_wave, int n_chunks,
                                                          float* __restrict__ partial, char* __restrict__ lat, unsigned int c_max,
                                                          const unsigned long long* __restrict__ served, int n_words,
-                                                         const int* __restrict__ inv, int after_cell_pass = 0)
+                                                         const int* __restrict__ inv, int after_cell_pass = 0, const int* __restrict__ perm_o = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2975,15 +2975,21 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // chip at any time then works in one neighbourhood of the target, and its table and feature rows are cache hits.
     // (Grid-stride over the (chunk, hypothesis group) items: the launch may be smaller than their number -- a kernel that
     // is enqueued only to find that it has nothing to do should not cost 98 k workgroup launches.)
-    const int n_hg = (M + hyp_per_wave - 1) / hyp_per_wave;
+    // With a consensus pass in front (served + its per-chunk orders): items are (chunk, served word) = 64 positions of the chunk's order,
+    // ONE served word per lane, and a word with nothing left costs nothing more (by hypothesis number every (point, hypothesis) pair paid
+    // an inverse-order look-up and a scattered read of its served word).
+    // (Only behind the cell pass, when next to nothing is left: with real work per position a word's 64 positions on one wavefront are
+    // too coarse an item -- a KITTI-test pair through the lattice alone took 16 ms instead of 8.)
+    const bool by_word = LAT && served != nullptr && perm_o != nullptr && after_cell_pass != 0;
+    const int n_hg = by_word ? n_words : (M + hyp_per_wave - 1) / hyp_per_wave;
     const long n_items = (long)n_chunks * n_hg;
     constexpr int kRecReserve = 16;
     unsigned int rec_next = 0u, rec_end = 0u, fbq_local = 0u;            // (wave-uniform)
     for (long wid = (long)blockIdx.x * (blockDim.x >> 6) + wave; wid < n_items; wid += (long)gridDim.x * (blockDim.x >> 6)) {
     const int chunk = (int)(wid / n_hg);
     const int hg = (int)(wid % n_hg);
-    const int h0 = hg * hyp_per_wave;
-    const int h1 = min(h0 + hyp_per_wave, M);
+    const int h0 = by_word ? 0 : hg * hyp_per_wave;
+    const int h1 = by_word ? 64 : min(h0 + hyp_per_wave, M);
     // source points in the cell-sorted order of their consensus-rotated copies (see mean_rotation_kernel): the
     // sorted table only supplies the order, coordinates are the caller's
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
@@ -2992,7 +2998,21 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int sidx = __float_as_int(S4s[valid ? slot : 0].w);
     float4 sp;
     sp.x = src_pts[(size_t)sidx * 3]; sp.y = src_pts[(size_t)sidx * 3 + 1]; sp.z = src_pts[(size_t)sidx * 3 + 2];
-    for (int h = h0; h < h1; ++h) {
+    unsigned long long word_l = 0ull;
+    if (by_word) {
+        word_l = valid ? ~served[(size_t)sidx * n_words + hg] : 0ull;
+        if (hg == n_words - 1 && (M & 63)) word_l &= (1ull << (M & 63)) - 1ull;
+        if (!__any(word_l != 0ull)) continue;
+    }
+    for (int it = h0; it < h1; ++it) {
+        int h = it;
+        bool todo_w = false;
+        if (by_word) {
+            if (hg * 64 + it >= M) break;
+            todo_w = (word_l >> it) & 1ull;
+            if (!__any(todo_w)) continue;
+            h = perm_o[(size_t)chunk * M + hg * 64 + it];             // uniform
+        }
         const float* Th = T + (size_t)h * 16;
         // source_transformed = p R^T + t  (utils/loc_utils.py:629)
         const float qx = fmaf(Th[2], sp.z, fmaf(Th[1], sp.y, Th[0] * sp.x)) + Th[3];
@@ -3000,8 +3020,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float qz = fmaf(Th[10], sp.z, fmaf(Th[9], sp.y, Th[8] * sp.x)) + Th[11];
         int cnt;
         // queries the consensus pass has already scored are not this kernel's business
-        const int ph = served ? inv[(size_t)chunk * M + h] : 0;       // position of the hypothesis in the order of this chunk (consensus pass)
-        const bool todo_q = valid && !(served && ((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull));
+        const int ph = (served && !by_word) ? inv[(size_t)chunk * M + h] : 0;       // position of the hypothesis in the order of this chunk (consensus pass)
+        const bool todo_q = by_word ? todo_w : (valid && !(served && ((served[(size_t)sidx * n_words + (ph >> 6)] >> (ph & 63)) & 1ull)));
         bool fb_lanes = false;
         const bool near_q = todo_q;
         if (!__any(todo_q)) {
@@ -4176,7 +4196,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         const dim3 lat_grid(score_grid.x < 4096u ? score_grid.x : 4096u);
         hipLaunchKernelGGL((corr_score_kernel<unsigned short, true>), lat_grid, score_block, lds, st, (const char*)ws_tgt, (const char*)ws_src,
                            src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, cap, sigma, hyp_per_wave, n_chunks, partial,
-                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, cell_pass ? 1 : 0);
+                           lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, cell_pass ? 1 : 0, (const int*)perm);
         UMEREG_CHECK_LAUNCH("corr_score_kernel");
         corr_mark(4, st);
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
