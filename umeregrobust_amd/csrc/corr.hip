@@ -4165,7 +4165,9 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         }
         // (grids of the kernels that usually find nothing to do -- the leftovers go to the queue up to 2 M -- are kept small: a
         // workgroup that returns at once still costs its launch, 50 us for 1 024 x 512 threads with 33 KiB of LDS each)
-        hipLaunchKernelGGL(lattice_dk_kernel, dim3(512), dim3(8 * kWave), 0, st, ws_coop, lat, c_max, Nt, K);
+        // (idle on jobs whose leftovers go to the queue -- every KITTI-test pair --, where its launch alone was 60 us of a pair's 3.7 ms
+        // beside other streams' kernels: the full grid only where the lattice is the likely path)
+        hipLaunchKernelGGL(lattice_dk_kernel, dim3((long)M * Ns >= kCellMinQueries ? 512 : 256), dim3(8 * kWave), 0, st, ws_coop, lat, c_max, Nt, K);
         UMEREG_CHECK_LAUNCH("lattice_dk_kernel");
         hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), (size_t)(kMaxCells + 64) * 4, st,
                            (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
@@ -4246,7 +4248,9 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial, 0);
             UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
         }
-        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3((flags & UMEREG_CORR_NO_FLAT) ? 4096 : 512), dim3(kCoopWaves * kWave), 0, st, ws_coop,
+        // (with the flat list in front this kernel only has work when that list overflowed -- more leftovers than half the job's queries --:
+        // 128 workgroups, its idle launch was 70 us per end-to-end pair at 512)
+        hipLaunchKernelGGL(corr_score_fallback_kernel, dim3((flags & UMEREG_CORR_NO_FLAT) ? 4096 : 128), dim3(kCoopWaves * kWave), 0, st, ws_coop,
                            (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma,
                            n_chunks, partial, (const char*)lat, c_max);
         UMEREG_CHECK_LAUNCH("corr_score_fallback_kernel");
