@@ -667,6 +667,72 @@ __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict_
     }
 }
 
+// K = 1 (evaluate.py:272,274: every raw point takes the feature of its nearest network point): eight lanes per query walk the rows
+// of the cells a box of half-width rho around the query touches (consecutive table entries per row), the nearest candidate is the minimum
+// of their (d2, original index) keys; found within rho -> done (the box holds the ball), found farther -> once more with rho = that
+// distance, not found -> rho doubles (until the box is the whole grid).  Same keys, same tie rule (lower index) as knn_wave -- the general
+// kernel pays its histogram / list machinery and one lane's serial row walks per query: 78 us + 30 us of query ordering for the 40 000
+// raw points of a KITTI pair against ~25 here.
+constexpr int kNn1Lanes = 8;
+__global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ p1, int n1, int n2,
+                                                         float* __restrict__ dists, int64_t* __restrict__ idx)
+{
+    const int b = blockIdx.y;
+    const GridWs w = grid_ws(n2);
+    const char* wb = ws + b * ws_stride;
+    const float4* __restrict__ P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
+    const int* __restrict__ start = reinterpret_cast<const int*>(wb + w.off_start);
+    const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), -1.0f, n2);
+    const int lane = lane_id();
+    const int sub = threadIdx.x & (kNn1Lanes - 1);
+    const int q = blockIdx.x * (256 / kNn1Lanes) + (int)(threadIdx.x / kNn1Lanes);
+    const bool live = q < n1;
+    const float* pq = p1 + ((size_t)b * n1 + (live ? q : 0)) * 3;
+    const float fx = pq[0], fy = pq[1], fz = pq[2];
+    float rho = 0.75f * fminf(1.0f / g.invx, fminf(1.0f / g.invy, 1.0f / g.invz));
+    unsigned long long m = ~0ull;
+    bool done = !live || !(fx == fx) || !(fy == fy) || !(fz == fz);          // (a NaN query finds nothing, as in knn_wave)
+    for (int pass = 0; pass < 64 && __any(!done); ++pass) {
+        const float r = rho * 1.0001f + 1e-6f;
+        const int x0 = cell_axis(fx - r, g.minx, g.invx, g.nx), x1 = cell_axis(fx + r, g.minx, g.invx, g.nx);
+        const int y0 = cell_axis(fy - r, g.miny, g.invy, g.ny), y1 = cell_axis(fy + r, g.miny, g.invy, g.ny);
+        const int z0 = cell_axis(fz - r, g.minz, g.invz, g.nz), z1 = cell_axis(fz + r, g.minz, g.invz, g.nz);
+        unsigned long long best = ~0ull;
+        if (!done)
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    const int cbase = (z * g.ny + y) * g.nx;
+                    const int beg = start[cbase + x0], end = start[cbase + x1 + 1];   // cells of one x-row are contiguous
+                    for (int k = beg + sub; k < end; k += kNn1Lanes) {
+                        const float4 t = P4s[k];
+                        const float dx = fx - t.x, dy = fy - t.y, dz = fz - t.z;
+                        float d2 = dx * dx;                                            // the operation sequence of every other structure
+                        d2 = d2 + dy * dy;
+                        d2 = d2 + dz * dz;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(t.w);
+                        if (d2 == d2 && key < best) best = key;
+                    }
+                }
+#pragma unroll
+        for (int d = 1; d < kNn1Lanes; d <<= 1) {
+            const unsigned long long o = __shfl_xor(best, d, kWave);
+            best = o < best ? o : best;
+        }
+        if (!done) {
+            const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.nx - 1 && y1 == g.ny - 1 && z1 == g.nz - 1;
+            const float bd = best != ~0ull ? sqrtf(__uint_as_float((unsigned int)(best >> 32))) : 3.0e38f;
+            if (best != ~0ull && (bd <= rho || whole)) { m = best; done = true; }
+            else if (whole) { done = true; }                                           // (nothing comparable in the whole table)
+            else rho = best != ~0ull ? bd * 1.0001f + 1e-6f : rho * 2.0f;
+        }
+    }
+    (void)lane;
+    if (live && sub == 0) {
+        dists[(size_t)b * n1 + q] = m != ~0ull ? __uint_as_float((unsigned int)(m >> 32)) : 0.f;
+        idx[(size_t)b * n1 + q] = m != ~0ull ? (int64_t)(unsigned int)(m & 0xffffffffull) : (int64_t)-1;
+    }
+}
+
 // ---- feature_spatial_var (utils/loc_utils.py:579-585) ---------------------------------------------
 // mean over the knn-1 nearest OTHER points (idx[:, :, 1:]) of |feat_i - feat_j|_2
 template <class IdxT>
@@ -3831,6 +3897,12 @@ UMEREG_API int umereg_knn_points_f32(const float* p1, const float* p2, int B, in
     }
     hipStream_t st = (hipStream_t)stream;
     if (int rc = launch_prep(p2, (char*)workspace, B, n2, -(float)K, st)) return rc;
+    if (K == 1) {
+        hipLaunchKernelGGL(nn1_points_kernel, dim3((n1 + 256 / kNn1Lanes - 1) / (256 / kNn1Lanes), B), dim3(256), 0, st, (const char*)workspace,
+                           grid_ws(n2).total, p1, n1, n2, dists, idx);
+        UMEREG_CHECK_LAUNCH("nn1_points_kernel");
+        return UMEREG_OK;
+    }
     const int ordered = n1 <= grid_ws(n2).Npad;
     if (ordered)
         if (int rc = launch_query_order((char*)workspace, p1, nullptr, B, n2, n1, -(float)K, st)) return rc;
