@@ -190,10 +190,14 @@ __global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict_
 {
     __shared__ int slot[kMaxCells];
     __shared__ int part[kSortWG / 64];
+    __shared__ uint4 wcnt[kMaxCells];                  // [cell][wavefront] point counts, a byte each (64 KiB)
+    static_assert(kSortWG / 64 == 16, "16 wavefronts: one 16-byte row per cell");
     const GridWs w = grid_ws(N);
     char* wb = ws + blockIdx.y * ws_stride;
     const float4* P4o = reinterpret_cast<const float4*>(wb + w.off_p4o);
     float4* P4s = reinterpret_cast<float4*>(wb + w.off_p4s);
+#pragma unroll
+    for (int k = 0; k < kMaxCells / kSortWG; ++k) wcnt[k * kSortWG + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     const int* cell_of = reinterpret_cast<const int*>(wb + w.off_cell);
     const int* bases = reinterpret_cast<const int*>(wb + w.off_bases) + (size_t)blockIdx.x * kMaxCells;
     int* start = reinterpret_cast<int*>(wb + w.off_start);
@@ -233,24 +237,31 @@ __global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict_
         unsigned long long todo = __ballot(valid);
         while (todo != 0ull) {
             const int leader = __ffsll((long long)todo) - 1;
-            const int lc = __shfl(c, leader, kWave);
+            const int lc = __builtin_amdgcn_readlane(c, leader);            // (the leader is wave-uniform: a register read, not a trip through LDS)
             const unsigned long long same = __ballot(valid && c == lc);
             if (c == lc) { rank = mbcnt(same); n_same = __popcll(same); }
             todo &= ~same;
         }
     }
-    // waves take turns in index order: slot[] is the running first-free slot of each cell
-    // (the point is read BEFORE the turns: a global round trip inside each of the 16 serial turns is 16 round trips per workgroup)
+    // A point's place = the cell's first slot for this workgroup + the points of the same cell in EARLIER wavefronts + its rank in its own:
+    // every wavefront publishes its per-cell counts as one byte of the cell's 16-byte row (a wavefront holds <= 64 points of a cell), one
+    // barrier, and a lane adds up the bytes before its wavefront's.  (Until round 3 the sixteen wavefronts took turns on slot[], two
+    // barriers a turn: 15 us for what is 7 now.)
     float4 p = P4o[valid ? j : 0];
     p.w = __int_as_float(j);
-    for (int wv = 0; wv < kSortWG / 64; ++wv) {
-        if (wave == wv && valid) {
-            const int pos = slot[c] + rank;
-            P4s[pos] = p;
+    if (valid && rank == 0) reinterpret_cast<unsigned char*>(wcnt)[c * 16 + wave] = (unsigned char)n_same;
+    __syncthreads();
+    if (valid) {
+        const uint4 w4 = wcnt[c];
+        const unsigned int words[4] = {w4.x, w4.y, w4.z, w4.w};
+        unsigned int base = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nb = min(max(wave - 4 * i, 0), 4);                       // bytes of this word that belong to earlier wavefronts
+            const unsigned int mask = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+            base = __builtin_amdgcn_sad_u8(words[i] & mask, 0u, base);
         }
-        __syncthreads();
-        if (wave == wv && valid && rank == 0) slot[c] += n_same;
-        __syncthreads();
+        P4s[slot[c] + (int)base + rank] = p;
     }
     // tail padding of the sorted table (read, never accepted, by the last chunk of the last run)
     if (blockIdx.x == 0 && threadIdx.x < 64)
