@@ -343,7 +343,10 @@ __device__ __forceinline__ float group32_max(float v)
 #ifndef UMEREG_COARSE_ABLATE
 #define UMEREG_COARSE_ABLATE 0   // timing experiments only (tools/exp_coarse_ablate.sh; results are wrong by construction): 1 no squares, 2 no filter, 4 no MFMAs, 8 no LDS reads
 #endif
-constexpr int kCoarseTA = 2;                         // A tiles (8 source keypoints each) per wave
+#ifndef UMEREG_COARSE_TA
+#define UMEREG_COARSE_TA 2     // (4 -- half the LDS reads per MFMA, 238 VGPRs -- measured 174 us against 142 in tools/exp_f16r_stats.py)
+#endif
+constexpr int kCoarseTA = UMEREG_COARSE_TA;          // A tiles (8 source keypoints each) per wave
 #ifndef UMEREG_COARSE_LATE_FILTER
 #define UMEREG_COARSE_LATE_FILTER 0   // 1: a tile's filter runs one tile late, behind the first MFMAs of the next tile (measured round 3: 168 us against 143 -- worse)
 #endif
