@@ -1139,6 +1139,36 @@ def test_knn_points_lattice_ties(gpu):
     assert np.array_equal(N_(out.idx), ref.idx) and np.array_equal(N_(out.dists), ref.dists)
 
 
+def test_knn_points_k1_edge_cases(gpu):
+    """K = 1 runs its own kernel (eight lanes per query over a growing box): exact ties on a lattice and duplicated points resolve
+    towards the lower index, a one-point target, a batch of two clouds, queries hundreds of metres away; a NaN query finds nothing
+    (index -1, distance 0), as in the general kernel."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(3)
+    g3 = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(2), indexing="ij"), -1).reshape(-1, 3)
+    p2 = (g3[rng.permutation(len(g3))] * 0.5).astype(np.float32)
+    p2 = np.concatenate([p2, p2[:20]])                                    # exact duplicates with higher indices
+    p1 = np.concatenate([p2[:60] + np.float32(0.25), (rng.standard_normal((40, 3)) * 3).astype(np.float32),
+                         np.array([[500.0, -300.0, 40.0], [-1e4, 0.0, 0.0]], np.float32)]).astype(np.float32)
+    ref = orc.knn_points(p1[None], p2[None], K=1)
+    out = ops.knn_points(T_(p1, gpu)[None], T_(p2, gpu)[None], K=1, return_nn=True)
+    assert np.array_equal(N_(out.idx), ref.idx) and np.array_equal(N_(out.dists), ref.dists)
+    assert np.array_equal(N_(out.knn[0]), p2[ref.idx[0]])
+    one = ops.knn_points(T_(p1, gpu)[None], T_(p2[:1], gpu)[None], K=1)
+    assert np.array_equal(N_(one.idx), np.zeros((1, len(p1), 1), np.int64))
+    assert np.array_equal(N_(one.dists), orc.knn_points(p1[None], p2[:1][None], K=1).dists)
+    b2 = np.stack([p2, (p2[::-1] + np.float32(7.0)).astype(np.float32)]); q2 = np.stack([p1, p1])
+    rb = [orc.knn_points(q2[i][None], b2[i][None], K=1) for i in range(2)]
+    ob = ops.knn_points(T_(q2, gpu), T_(b2, gpu), K=1)
+    for i in range(2):
+        assert np.array_equal(N_(ob.idx)[i], rb[i].idx[0]) and np.array_equal(N_(ob.dists)[i], rb[i].dists[0])
+    bad = p1.copy(); bad[5, 1] = np.nan
+    ok = np.ones(len(p1), bool); ok[5] = False
+    o = ops.knn_points(T_(bad, gpu)[None], T_(p2, gpu)[None], K=1)
+    assert int(N_(o.idx)[0, 5, 0]) == -1 and float(N_(o.dists)[0, 5, 0]) == 0.0
+    assert np.array_equal(N_(o.idx)[0, ok], ref.idx[0, ok]) and np.array_equal(N_(o.dists)[0, ok], ref.dists[0, ok])
+
+
 def test_feature_correlator_golden(gpu):
     """Golden G7: the reference's own feature_spatial_var / pc_corr scores / selected hypothesis."""
     from umeregrobust_amd.utils.loc_utils import FeatureCorrelator, feature_spatial_var
