@@ -20,7 +20,7 @@ for s,e,nm,_ in ev[1:]:
     else:
         if e>cur_e: cur_e=e; prev_name=nm
 busy+=cur_e-cur_s
-npairs=max(1,sum(1 for s,e,nm,_ in ev if nm=='dist_h'))
+npairs=max(1,sum(1 for s,e,nm,_ in ev if nm=='dist_h' or 'MatchScratch' in nm or 'coarse_h' in nm))
 print('span ms %.3f busy ms %.3f util %.3f pairs %d span/pair %.4f busy/pair %.4f'%(span/1e6,busy/1e6,busy/span,npairs,span/1e6/npairs,busy/1e6/npairs))
 for k,v in gaps.most_common(12): print(f"{v/1e3/npairs:8.1f} us/pair  n/pair={gapn[k]/npairs:.2f}  {k[0]} -> {k[1]}")
 dur=collections.Counter(); cnt=collections.Counter()
