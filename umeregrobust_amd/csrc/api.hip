@@ -211,15 +211,25 @@ inline double mt19937_double(uint32_t* key, int* pos)
 UMEREG_API int umereg_host_permutation_mt19937(uint32_t* mt_key, int* mt_pos, int64_t n, int64_t size, int64_t* perm, int64_t* out)
 {
     if (!mt_key || !mt_pos || !perm || !out || n <= 0 || size < 0 || size > n || n > 0xffffffffll || *mt_pos < 0 || *mt_pos > kMtN) return -1;
-    for (int64_t i = 0; i < n; ++i) perm[i] = i;
-    for (int64_t i = n - 1; i > 0; --i) {
-        uint32_t mask = (uint32_t)i;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        uint32_t v;
-        do { v = mt19937_next(mt_key, mt_pos) & mask; } while (v > (uint32_t)i);
-        const int64_t t = perm[i]; perm[i] = perm[v]; perm[v] = t;
+    // The same draws and swaps without the data-dependent branch of the rejection loop (a quarter of the words are rejected on
+    // average, up to half just above a power of two: a mispredicted branch per rejection was most of the 5.9 ns per element this
+    // loop took -- 1 ms of host time per end-to-end pair over its four draws): a rejected word swaps position i with itself and
+    // leaves i where it is.  32-bit entries in the caller's scratch (half the cache footprint).
+    uint32_t* p32 = reinterpret_cast<uint32_t*>(perm);
+    for (uint32_t i = 0; i < (uint32_t)n; ++i) p32[i] = i;
+    uint32_t i = (uint32_t)(n - 1);
+    uint32_t mask = i;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    while (i > 0u) {
+        while (i <= (mask >> 1)) mask >>= 1;                       // smallest 2^k - 1 >= i (changes 32 times at most)
+        const uint32_t v = mt19937_next(mt_key, mt_pos) & mask;
+        const uint32_t acc = v <= i ? 1u : 0u;
+        const uint32_t j = acc ? v : i;
+        const uint32_t a = p32[i], b = p32[j];
+        p32[i] = b; p32[j] = a;
+        i -= acc;
     }
-    memcpy(out, perm, (size_t)size * sizeof(int64_t));
+    for (int64_t k = 0; k < size; ++k) out[k] = (int64_t)p32[k];
     return 0;
 }
 
