@@ -22,4 +22,4 @@ evaluate.evaluate_pairs(pairs, args, rng=rng, refine=True)
 torch.cuda.synchronize()
 pr.disable()
 print("ms per pair", (time.perf_counter() - t0) / len(pairs) * 1e3)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
