@@ -384,13 +384,16 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
                                                score - bound get those queries computed exactly in a second pass.  scores[h] is then exact for every hypothesis that can be the
                                                arg-max; for the others it lacks the bounded terms (it is within the bound of the exact score, and the exact score is below the
                                                arg-max's): umereg_corr_select_best_f32 returns the same hypothesis */
+/* The workspace depends on the flags (the cell pass's entry buffer, the bound's slack): query it with the flags of the call.  On jobs
+ * of >= 2^25 queries (M x Ns) the cell pass is on by default: its entry buffer holds min(M x Ns, 2^26) entries of 8 bytes, the flat
+ * one-wavefront-per-query list half the job's queries at 8 bytes each. */
 size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
 int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
                               const float* tgt_wfeat, const float* T, int Ns, int Nt, int M, int K, float sigma,
                               int flags, float* scores, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same call with its stages timed by HIP events on the launch stream (measurement; it synchronises the stream):
- * stage_ms_host[0..5] = milliseconds of  structures + hypothesis orders | consensus pass (+ leftover queue) | lattice build |
+ * stage_ms_host[0..5] = milliseconds of  structures + hypothesis orders | consensus pass (+ leftover queue) | lattice build + cell pass |
  * list kernel | one-wavefront-per-query / per-record leftovers | reduction,   stage_ms_host[6] = the whole call.
  * A stage the configuration skips reads 0. */
 int umereg_corr_scores_profile_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,
