@@ -59,9 +59,9 @@ def parse():
                     help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
                          "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
     ap.add_argument("--match-pform", action="store_true",
-                    help="(experiments) run the P-form coarse kernel of the matcher (umereg_ume_match_set_variant(1))")
+                    help="(experiments) run the P-form coarse kernel of the matcher (umereg_match_opts.variant = 1, per call)")
     ap.add_argument("--match-tuning", default=None,
-                    help="(experiments) 'splits,share_mask' for umereg_ume_match_set_tuning, e.g. 0,0x80008009")
+                    help="(experiments) 'splits,share_mask' of umereg_match_opts, e.g. 0,0x80008009")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false",
                     help="enqueue phase A (a1-a5) as 12 launches per pair instead of replaying one captured hipGraph")
     ap.add_argument("--threaded-draw", action="store_true", help="host RNG draw on a worker thread (off: slower, see DESIGN 3.5)")
@@ -155,16 +155,13 @@ def main():
         e.mom_bytes = [sum(per_cloud)] if e.pair is not None else per_cloud
     dist_flops = 2.0 * (4 * n_kp) * (4 * n_kp) * 32                                  # Q-form GEMM, d_used = 512-equiv
 
-    if a.match_pform:
-        from umeregrobust_amd import _lib as _l0
-        _l0.load().umereg_ume_match_set_variant(1)
-    if a.match_tuning:
-        from umeregrobust_amd import _lib as _l
-        sp_, mk_ = a.match_tuning.split(",")
-        _l.load().umereg_ume_match_set_tuning(int(sp_), int(mk_, 0), 0)
+    match_opts = None
+    if a.match_pform or a.match_tuning:
+        sp_, mk_ = a.match_tuning.split(",") if a.match_tuning else ("0", "-1")
+        match_opts = ops.MatchOpts(variant=1 if a.match_pform else 0, splits=int(sp_), share_mask=int(mk_, 0))
     depth = max(1, a.depth)
     pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs,
-                                         stream_plan=a.stream_plan)
+                                         stream_plan=a.stream_plan, match_opts=match_opts)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
     # per-kernel HIP-event samples: `timing` from pairs that run ALONE (the kernel's own duration: what `roofline` prices),

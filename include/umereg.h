@@ -13,8 +13,8 @@
  *     layouts the reference's torch tensors have;
  *   - the library never allocates or frees device memory: outputs and workspaces are caller
  *     owned (size queries: *_workspace_bytes); the only mutable state is the thread-local
- *     last-error string and the four process-wide matcher knobs of umereg_ume_match_set_tuning /
- *     umereg_ume_match_set_variant (atomics; experiments and tests only, defaults otherwise);
+ *     last-error string -- options are per-call arguments (umereg_match_opts, the `flags` of the
+ *     *_ex entry points), never process-wide settings;
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous
  *     with respect to the host and re-entrant;
  *   - return value: UMEREG_OK (0) or a negative UMEREG_E* code; umereg_last_error() gives the
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UMEREG_ABI_VERSION 1
+#define UMEREG_ABI_VERSION 2 /* 2: per-call umereg_match_opts replace the process-wide matcher setters of version 1 */
 #define UMEREG_FEAT_DIM 32 /* evaluate.py:55 hard-codes 32 */
 
 enum {
@@ -177,28 +177,49 @@ size_t umereg_ume_match_q_scratch_bytes(int n1, int n2);
 int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
                             int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
                             void* stream);
-/* Tuning / test knobs of the filter + refine matcher, process-wide atomics (no environment variables are read by this
- * library; a matcher call reads each knob once, so a concurrent change is seen whole or not at all): splits = target splits of the coarse pass (0: automatic; it changes umereg_ume_match_q_scratch_bytes, so
- * set it before the size query), share_mask = limit-sharing schedule (-1: default), force_exhaustive != 0: refine every
- * block of rows exhaustively (a parity test uses it). */
-int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive);
-/* Which coarse kernel the filter + refine matcher runs, process-wide: 0 (default) = the Q-form kernel (16 basis-column
- * products per pair, squared and summed in the epilogue), 1 = the P-form kernel (one inner product of the packed
- * 32 x 32 projectors per pair, K = 528).  Same results bit for bit; it changes umereg_ume_match_q_scratch_bytes /
- * umereg_ume_match_workspace_bytes (the P-form keeps its packed operands there), so set it before the size query. */
-int umereg_ume_match_set_variant(int variant);
+/* Per-call options of the filter + refine matcher (tuning, experiments, parity tests).  A NULL pointer -- and every entry
+ * point without the _ex suffix -- means the defaults.  The scratch / workspace size depends on `variant` and `splits`: query it
+ * with the same options (the *_bytes_ex functions).  Nothing here is process-wide: two pipelines in one process may use
+ * different options concurrently.
+ *   variant          0 (default) = the Q-form coarse kernel (16 basis-column products per pair, squared and summed in the
+ *                    epilogue), 1 = the P-form kernel (one inner product of the packed 32 x 32 projectors per pair, K = 528; it
+ *                    keeps its packed operands in the scratch).  Same results bit for bit.
+ *   splits           target splits of the coarse pass (0 = automatic)
+ *   share_mask       limit-sharing schedule of the coarse pass, bit k = share after tile k of a split (< 0 = default)
+ *   force_exhaustive != 0: refine every block of rows exhaustively (a parity test uses it) */
+typedef struct umereg_match_opts {
+    int32_t variant;
+    int32_t splits;
+    int64_t share_mask;
+    int32_t force_exhaustive;
+    int32_t reserved; /* must be 0 */
+} umereg_match_opts;
+size_t umereg_ume_match_q_scratch_bytes_ex(int n1, int n2, const umereg_match_opts* opts);
+int umereg_ume_match_q_f16r_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                               int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
+                               const umereg_match_opts* opts, void* stream);
 
-/* the stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, in this order): reset zeroes the
- * per-row limits (a 4 n1 byte memset), coarse is the MFMA filter, refine the fp64 arg-min over the candidates */
+/* the stages of umereg_ume_match_q_f16r on their own (same scratch, same stream, same options, in this order): reset
+ * zeroes the per-row limits (a 4 n1 byte memset at the head of the scratch, whatever the options), coarse is the MFMA
+ * filter, refine the fp64 arg-min over the candidates */
 int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, int n1, int n2, void* stream);
 int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
                                 size_t scratch_bytes, void* stream);
 int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
                                 const void* scratch, size_t scratch_bytes, int64_t* match_idx,
                                 float* match_dist, void* stream);
+int umereg_ume_match_coarse_f16_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
+                                   size_t scratch_bytes, const umereg_match_opts* opts, void* stream);
+int umereg_ume_match_refine_f16_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                   const void* scratch, size_t scratch_bytes, int64_t* match_idx,
+                                   float* match_dist, const umereg_match_opts* opts, void* stream);
 int umereg_ume_match_f16r(const float* ume1, const float* ume2, int B, int n1, int n2,
                           int64_t* match_idx, float* match_dist, void* workspace,
                           size_t workspace_bytes, void* stream);
+size_t umereg_ume_match_workspace_bytes_ex(int B, int n1, int n2, const umereg_match_opts* opts);
+int umereg_ume_match_f16r_ex(const float* ume1, const float* ume2, int B, int n1, int n2,
+                             int64_t* match_idx, float* match_dist, void* workspace,
+                             size_t workspace_bytes, const umereg_match_opts* opts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1..a5 of one registration pair in one call                          evaluate.py:206-236
@@ -213,6 +234,12 @@ size_t umereg_pair_match_workspace_bytes(int N, int n_kp);
 int umereg_pair_match_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
                           float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
                           float* prob, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with explicit matcher options (workspace from umereg_pair_match_workspace_bytes_ex with the same options) */
+size_t umereg_pair_match_workspace_bytes_ex(int N, int n_kp, const umereg_match_opts* opts);
+int umereg_pair_match_ex_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
+                             float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
+                             float* prob, void* workspace, size_t workspace_bytes, const umereg_match_opts* opts,
+                             void* stream);
 
 /* The same chain as ONE executable hipGraph, for callers that process many pairs out of the same buffers (an evaluation
  * loop with resident or double-buffered inputs): captured once on `stream` (a non-default stream; nothing is executed by
@@ -223,6 +250,10 @@ int umereg_pair_match_f32(const float* pts, const float* feat, const int64_t* kp
 int umereg_pair_match_graph_create(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
                                    float radius, float tau, float* F, int64_t* match_idx, float* match_dist, float* prob,
                                    void* workspace, size_t workspace_bytes, void* stream, void** graph_out);
+int umereg_pair_match_graph_create_ex(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
+                                      float radius, float tau, float* F, int64_t* match_idx, float* match_dist, float* prob,
+                                      void* workspace, size_t workspace_bytes, const umereg_match_opts* opts, void* stream,
+                                      void** graph_out);
 int umereg_pair_match_graph_launch(void* graph, void* stream);
 /* Replay + the device -> host copy of the match probabilities (the operand of the host draw, evaluate.py:238; prob_host:
  * pinned host memory, n_kp floats, or NULL) in one call. */

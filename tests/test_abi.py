@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/umereg.h but not exported"
     # and the ctypes table mirrors the header one to one
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.load().umereg_abi_version() == 1
+    assert _lib.load().umereg_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_no_cpu_fallback_without_device():

@@ -298,7 +298,7 @@ def test_ume_dist_f16x2_vs_oracle(gpu, n1, n2):
 
 
 @pytest.mark.parametrize("n1,n2", [(1, 1), (63, 33), (64, 32), (65, 31), (250, 1000), (1000, 97), (3000, 2500), (6000, 5000)])
-def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
+def test_ume_match_f16r_vs_oracle(gpu, n1, n2, opts=None):
     """Filter + refine matching: single-product f16 coarse pass, candidates re-evaluated in fp64.  The result
     must be the arg-min of the fp64 truth wherever that arg-min is defined above the basis rounding (2^-22)."""
     from umeregrobust_amd import ops
@@ -309,7 +309,7 @@ def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
     u2[:, :, 1:] += 30.0 * u2[:, :, :1]
     k = min(n1, n2) // 2
     u2[:k] = u1[:k] @ (np.eye(4) + 0.1 * rng.standard_normal((4, 4))).astype(np.float32)
-    mr, dr = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+    mr, dr = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r", opts=opts)
     mr, dr = N_(mr[0]), N_(dr[0])
     D64 = orc.ume_cdist_f64(u1, u2)
     am = D64.argmin(axis=1)
@@ -327,7 +327,7 @@ def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
     mf, _ = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f32")
     assert (mr == N_(mf[0])).mean() >= 0.999 or n1 < 100
     for _ in range(3):
-        m2, d2 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+        m2, d2 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r", opts=opts)
         assert np.array_equal(N_(m2[0]), mr) and np.array_equal(N_(d2[0]), dr)
     # single-call ABI entry
     lib = __import__("umeregrobust_amd")._lib.load()
@@ -340,9 +340,10 @@ def test_ume_match_f16r_vs_oracle(gpu, n1, n2):
 
 
 def test_ume_match_f16r_pform_variant_equals_the_default(gpu):
-    """The P-form coarse filter (umereg_ume_match_set_variant(1): one inner product per pair over the packed 32 x 32
-    projectors, K = 528, no squares in the epilogue -- faster as a stage, slower in the pipelined path, hence not the
-    default): the matcher tests pass on it too, and it returns the same matches and distances as the default bit for bit."""
+    """The P-form coarse filter (umereg_match_opts.variant = 1, a PER-CALL option: one inner product per pair over the packed
+    32 x 32 projectors, K = 528, no squares in the epilogue -- faster as a stage, slower in the pipelined path, hence not the
+    default): the matcher tests pass on it too, and it returns the same matches and distances as the default bit for bit.
+    The options are arguments, not process state: default calls interleaved with P-form calls keep their own plan."""
     from umeregrobust_amd import ops
     lib = __import__("umeregrobust_amd")._lib.load()
     rng = np.random.RandomState(5)
@@ -350,21 +351,36 @@ def test_ume_match_f16r_pform_variant_equals_the_default(gpu):
     u2[:900] = u1[:900] @ (np.eye(4) + 0.05 * rng.standard_normal((4, 4))).astype(np.float32)
     u2[1000:1400] = u2[1000]                                       # a block of identical targets (candidate overflow)
     m0, d0 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
-    assert lib.umereg_ume_match_set_variant(2) != 0
-    assert lib.umereg_ume_match_set_variant(1) == 0
-    try:
-        for _ in range(3):
-            m1, d1 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
-            assert torch.equal(m0, m1) and torch.equal(d0, d1)
-        for n1, n2 in ((1, 1), (63, 33), (250, 1000), (3000, 2500)):
-            test_ume_match_f16r_vs_oracle(gpu, n1, n2)
-        test_ume_match_f16r_duplicates_and_degenerate(gpu)
-        test_ume_match_f16r_spatially_ordered_keypoints(gpu)
-    finally:
-        assert lib.umereg_ume_match_set_variant(0) == 0
+    pform = ops.MatchOpts(variant=1)
+    bad = ops.MatchOpts(variant=2)
+    assert lib.umereg_ume_match_q_scratch_bytes_ex(100, 100, __import__("umeregrobust_amd")._lib.opts_ptr(bad)) == 0
+    with pytest.raises(RuntimeError, match="unknown matcher variant"):
+        ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r", opts=bad)
+    assert lib.umereg_ume_match_q_scratch_bytes_ex(2500, 3100, __import__("umeregrobust_amd")._lib.opts_ptr(pform)) \
+        != lib.umereg_ume_match_q_scratch_bytes(2500, 3100)          # the P-form keeps its packed operands in the scratch
+    for _ in range(3):
+        m1, d1 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r", opts=pform)
+        assert torch.equal(m0, m1) and torch.equal(d0, d1)
+        m2, d2 = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")          # defaults, in between
+        assert torch.equal(m0, m2) and torch.equal(d0, d2)
+    for n1, n2 in ((1, 1), (63, 33), (250, 1000), (3000, 2500)):
+        test_ume_match_f16r_vs_oracle(gpu, n1, n2, opts=pform)
+    test_ume_match_f16r_duplicates_and_degenerate(gpu, opts=pform)
+    test_ume_match_f16r_spatially_ordered_keypoints(gpu, opts=pform)
+    # and through the one-call a1..a5 entry / its hipGraph form
+    p = __import__("umeregrobust_amd.synth", fromlist=["synth_pair"]).synth_pair(3, N=4096, n_kp=1024)
+    pts = torch.stack([T_(p.src_pts, gpu), T_(p.tgt_pts, gpu)]); feat = torch.stack([T_(p.src_feat, gpu), T_(p.tgt_feat, gpu)])
+    inds = torch.stack([T_(p.src_inds, gpu), T_(p.tgt_inds, gpu)])
+    ref = ops.pair_match(pts, feat, inds, 750, 5.0, 0.05)
+    alt = ops.pair_match(pts, feat, inds, 750, 5.0, 0.05, opts=pform)
+    g = ops.PairMatchGraph(pts, feat, inds, 750, 5.0, 0.05, opts=pform)
+    gl = g.launch()
+    torch.cuda.synchronize()
+    for x, y, z in zip(ref, alt, gl):
+        assert torch.equal(x, y) and torch.equal(x, z)
 
 
-def test_ume_match_f16r_duplicates_and_degenerate(gpu):
+def test_ume_match_f16r_duplicates_and_degenerate(gpu, opts=None):
     """Candidate-list overflow (hundreds of identical targets), all-zero UMEs and a one-target set: the
     exhaustive fallback of the refine kernel must give the lowest index among exact ties."""
     from umeregrobust_amd import ops
@@ -375,7 +391,7 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     u2[100:500] = u1[7]                     # 400 exact copies of source 7's UME -> > kCandCap candidates for row 7
     u2[600:650] = u1[9]
     u1[11] = 0.0                            # zero UME: Q = I[:, :4]
-    m, d = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r")
+    m, d = ops.ume_match(T_(u1, gpu)[None], T_(u2, gpu)[None], precision="f16r", opts=opts)
     m, d = N_(m[0]), N_(d[0])
     assert m[7] == 100 and d[7] < 2e-3
     assert m[9] == 600 and d[9] < 2e-3
@@ -385,14 +401,14 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     assert np.array_equal(m[clear], D64.argmin(axis=1)[clear])
     # all targets identical
     u3 = np.repeat(u2[:1], 333, axis=0)
-    m3, d3 = ops.ume_match(T_(u1, gpu)[None], T_(u3, gpu)[None], precision="f16r")
+    m3, d3 = ops.ume_match(T_(u1, gpu)[None], T_(u3, gpu)[None], precision="f16r", opts=opts)
     assert (N_(m3[0]) == 0).all()
     assert np.abs(N_(d3[0]) - orc.ume_cdist_f64(u1, u3)[:, 0]).max() < 2e-3
     # a whole block of identical sources against thousands of copies of the same UME: every (source, target)
     # pair ties, the candidate regions overflow and the refine kernel's exhaustive re-scan must take over
     u4 = u1[:40].copy(); u4[:16] = u1[0]
     u5 = np.repeat(u1[:1], 3000, axis=0); u5[2900:] = u2[:100]
-    m5, d5 = ops.ume_match(T_(u4, gpu)[None], T_(u5, gpu)[None], precision="f16r")
+    m5, d5 = ops.ume_match(T_(u4, gpu)[None], T_(u5, gpu)[None], precision="f16r", opts=opts)
     m5, d5 = N_(m5[0]), N_(d5[0])
     assert (m5[:16] == 0).all() and (d5[:16] < 2e-3).all()
     D5 = orc.ume_cdist_f64(u4, u5)
@@ -403,7 +419,7 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
     # overflow in a LATER target split only (regression: the overflow vote must count every split, not just the first):
     # the copies sit at the end of a long target list
     u6 = rng.standard_normal((6000, 32, 4)).astype(np.float32); u6[4000:] = u1[0]
-    m6, d6 = ops.ume_match(T_(u4, gpu)[None], T_(u6, gpu)[None], precision="f16r")
+    m6, d6 = ops.ume_match(T_(u4, gpu)[None], T_(u6, gpu)[None], precision="f16r", opts=opts)
     m6, d6 = N_(m6[0]), N_(d6[0])
     assert (m6[:16] == 4000).all() and (d6[:16] < 2e-3).all()
     mf6, _ = ops.ume_match(T_(u4, gpu)[None], T_(u6, gpu)[None], precision="f32")
@@ -411,25 +427,22 @@ def test_ume_match_f16r_duplicates_and_degenerate(gpu):
 
 
 def test_ume_match_f16r_forced_exhaustive_refine(gpu):
-    """The refine kernel's exhaustive fallback on every block of rows (umereg_ume_match_set_tuning(force_exhaustive)): it
+    """The refine kernel's exhaustive fallback on every block of rows (umereg_match_opts.force_exhaustive, per call): it
     must reproduce the exact-fp32 scan at sizes where several target splits and many row blocks exist."""
-    from umeregrobust_amd import _lib, ops
+    from umeregrobust_amd import ops
     rng = np.random.RandomState(3)
     u1 = T_(rng.standard_normal((1, 1500, 32, 4)).astype(np.float32), gpu)
     u2 = T_(rng.standard_normal((1, 7000, 32, 4)).astype(np.float32), gpu)
     mx, dx = ops.ume_match(u1, u2, precision="f32")
-    lib = _lib.load()
-    assert lib.umereg_ume_match_set_tuning(0, -1, 1) == 0
-    try:
-        mr, dr = ops.ume_match(u1, u2, precision="f16r")
-    finally:
-        assert lib.umereg_ume_match_set_tuning(0, -1, 0) == 0
+    mr, dr = ops.ume_match(u1, u2, precision="f16r", opts=ops.MatchOpts(force_exhaustive=1))
+    ms, ds = ops.ume_match(u1, u2, precision="f16r", opts=ops.MatchOpts(splits=5, share_mask=0))   # other plans, same result
     assert torch.equal(mr, mx) and float((dr - dx).abs().max()) < 1e-5
     mr2, dr2 = ops.ume_match(u1, u2, precision="f16r")          # and the normal path agrees with it bit for bit
     assert torch.equal(mr2, mr) and torch.equal(dr2, dr)
+    assert torch.equal(ms, mr) and torch.equal(ds, dr)
 
 
-def test_ume_match_f16r_spatially_ordered_keypoints(gpu):
+def test_ume_match_f16r_spatially_ordered_keypoints(gpu, opts=None):
     """Keypoints in spatial (scan) order make neighbouring rows AND columns similar -- crowds of candidates per
     tile, candidate regions filling up in a few target splits.  The matcher must return the same matches as for
     any other order (here: vs the exact-fp32 scan and vs its own result on the shuffled inputs)."""
@@ -442,14 +455,14 @@ def test_ume_match_f16r_spatially_ordered_keypoints(gpu):
     ks = p.src_inds[spatial(p.src_pts[p.src_inds])]; kt = p.tgt_inds[spatial(p.tgt_pts[p.tgt_inds])]
     F1 = ops.ume_moments(T_(p.src_pts, gpu)[None], None, T_(p.src_feat, gpu)[None], 750, 5.0, kp_index=T_(ks, gpu)[None])
     F2 = ops.ume_moments(T_(p.tgt_pts, gpu)[None], None, T_(p.tgt_feat, gpu)[None], 750, 5.0, kp_index=T_(kt, gpu)[None])
-    mr, dr = ops.ume_match(F1, F2, precision="f16r")
+    mr, dr = ops.ume_match(F1, F2, precision="f16r", opts=opts)
     mf, df = ops.ume_match(F1, F2, precision="f32")
     same = N_(mr[0]) == N_(mf[0])
     assert same.mean() >= 0.999
     assert np.abs(N_(dr[0]) - N_(df[0]))[same].max() < 2e-3 and np.abs(N_(dr[0]) - N_(df[0]))[~same].max(initial=0.0) < 2e-3
     rng = np.random.RandomState(0)
     s1, s2 = rng.permutation(6000), rng.permutation(6000)
-    ms, ds = ops.ume_match(F1[:, T_(s1, gpu)].contiguous(), F2[:, T_(s2, gpu)].contiguous(), precision="f16r")
+    ms, ds = ops.ume_match(F1[:, T_(s1, gpu)].contiguous(), F2[:, T_(s2, gpu)].contiguous(), precision="f16r", opts=opts)
     back = np.empty(6000, np.int64); back[s1] = s2[N_(ms[0])]
     dback = np.empty(6000, np.float32); dback[s1] = N_(ds[0])
     # identical distances; a different target only where two targets tie exactly (lowest index in the GIVEN order wins)

@@ -11,9 +11,7 @@ from umeregrobust_amd import ops, _lib
 n1, n2 = int(sys.argv[1]), int(sys.argv[2])
 splits = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 mask = int(sys.argv[4], 0) if len(sys.argv) > 4 else -1
-_lib.load().umereg_ume_match_set_tuning(splits, mask, 0)
-if os.environ.get('UMEREG_MATCH_PFORM') == '1':
-    _lib.load().umereg_ume_match_set_variant(1)
+OPTS = ops.MatchOpts(variant=1 if os.environ.get('UMEREG_MATCH_PFORM') == '1' else 0, splits=splits, share_mask=mask)
 dev = torch.device("cuda:0")
 rng = np.random.RandomState(n1 * 11 + n2)
 u1 = rng.standard_normal((n1, 32, 4)).astype(np.float32); u2 = rng.standard_normal((n2, 32, 4)).astype(np.float32)
@@ -24,7 +22,7 @@ a, b = torch.from_numpy(u1).to(dev)[None], torch.from_numpy(u2).to(dev)[None]
 mf, _ = ops.ume_match(a, b, precision="f32")
 bad = 0
 for it in range(40):
-    m, d = ops.ume_match(a, b, precision="f16r")
+    m, d = ops.ume_match(a, b, precision="f16r", opts=OPTS)
     nd = int((m != mf).sum())
     bad += nd > 0
     if nd and bad <= 5:

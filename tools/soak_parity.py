@@ -54,7 +54,7 @@ def umes(rng, n, kind, protos=None):
     return u
 
 
-def soak_match(rng):
+def soak_match(rng, opts=None):
     n1, n2 = rand_size(rng, 3000), rand_size(rng, 8000)
     kind = rng.choice(["plain", "corr", "clustered", "coherent"])
     protos = rng.standard_normal((max(1, n2 // 50), 32, 4)).astype(np.float32) if kind == "clustered" else None
@@ -67,7 +67,7 @@ def soak_match(rng):
         u2[dst] = u1[src] @ A
     if rng.rand() < 0.15 and n1 > 2:
         u1[rng.randint(0, n1)] = 0.0
-    m, d = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f16r")
+    m, d = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f16r", opts=opts)
     m, d = N_(m[0]), N_(d[0])
     D64 = orc.ume_cdist_f64(u1, u2)
     best = D64.min(axis=1) ** 2
@@ -79,7 +79,7 @@ def soak_match(rng):
         clear = srt[:, 1] - srt[:, 0] > 2e-5
         assert np.array_equal(m[clear], D64.argmin(axis=1)[clear]), f"clear arg-min differs ({kind}, {n1}x{n2})"
     assert np.abs(d - np.sqrt(got)).max() < 2e-3, f"distance off ({kind}, {n1}x{n2})"
-    m2, d2 = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f16r")
+    m2, d2 = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f16r", opts=opts)
     assert np.array_equal(N_(m2[0]), m) and np.array_equal(N_(d2[0]), d), "not deterministic"
     mf, _ = ops.ume_match(T_(u1)[None], T_(u2)[None], precision="f32")
     gf = D64[np.arange(n1), N_(mf[0])] ** 2
@@ -201,17 +201,11 @@ def soak_corr(rng):
 
 
 def soak_match_pform(rng):
-    """the same trial on the P-form coarse kernel (umereg_ume_match_set_variant(1)), plus: identical to the default's result"""
-    from umeregrobust_amd import _lib
-    lib = _lib.load()
+    """the same trial on the P-form coarse kernel (umereg_match_opts.variant = 1, per call), plus: identical to the default's result"""
     st = rng.get_state()
     ref = soak_match(rng)
     rng.set_state(st)
-    assert lib.umereg_ume_match_set_variant(1) == 0
-    try:
-        out = soak_match(rng)
-    finally:
-        lib.umereg_ume_match_set_variant(0)
+    out = soak_match(rng, opts=ops.MatchOpts(variant=1))
     assert out == ref
     return out + " (P-form)"
 

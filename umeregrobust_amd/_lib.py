@@ -74,8 +74,21 @@ SIGNATURES = {
     "umereg_pair_match_graph_destroy": (c_int, [c_void_p]),
     "umereg_pair_match_graph_launch_ex": (c_int, [c_void_p, c_void_p, c_void_p]),
     "umereg_pair_match_graph_solve": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "umereg_ume_match_set_tuning": (c_int, [c_int, ctypes.c_long, c_int]),
-    "umereg_ume_match_set_variant": (c_int, [c_int]),
+    # per-call matcher options (umereg_match_opts*; None = defaults)
+    "umereg_ume_match_q_scratch_bytes_ex": (c_size_t, [c_int, c_int, c_void_p]),
+    "umereg_ume_match_q_f16r_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p, c_void_p]),
+    "umereg_ume_match_coarse_f16_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "umereg_ume_match_refine_f16_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
+    "umereg_ume_match_workspace_bytes_ex": (c_size_t, [c_int, c_int, c_int, c_void_p]),
+    "umereg_ume_match_f16r_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_size_t, c_void_p, c_void_p]),
+    "umereg_pair_match_workspace_bytes_ex": (c_size_t, [c_int, c_int, c_void_p]),
+    "umereg_pair_match_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "umereg_pair_match_graph_create_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "umereg_voxel_first_index_workspace_bytes": (c_size_t, [c_int]),
     "umereg_voxel_first_index_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_host_permutation_mt19937": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p]),
@@ -100,6 +113,26 @@ SIGNATURES = {
                                                c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "umereg_corr_select_best_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
 }
+
+ABI_VERSION = 2
+
+
+class MatchOpts(ctypes.Structure):
+    """umereg_match_opts (include/umereg.h): per-call options of the filter + refine matcher."""
+    _fields_ = [("variant", ctypes.c_int32), ("splits", ctypes.c_int32), ("share_mask", ctypes.c_int64),
+                ("force_exhaustive", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+    def __init__(self, variant=0, splits=0, share_mask=-1, force_exhaustive=0):
+        super().__init__(int(variant), int(splits), int(share_mask), int(force_exhaustive), 0)
+
+    def key(self):
+        return (self.variant, self.splits, self.share_mask, self.force_exhaustive)
+
+
+def opts_ptr(opts):
+    """ctypes argument for a `const umereg_match_opts*` parameter (None -> NULL = the defaults)."""
+    return None if opts is None else ctypes.addressof(opts)
+
 
 _lib = None
 
@@ -126,8 +159,8 @@ def load():
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.umereg_abi_version() != 1:
-        raise NativeLibraryError(f"ABI version mismatch: {lib.umereg_abi_version()} != 1")
+    if lib.umereg_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: {lib.umereg_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

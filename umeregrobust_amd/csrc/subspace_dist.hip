@@ -1036,27 +1036,37 @@ static size_t qb_bytes(int n2) { return align_up((size_t)n2, 32) * 128 * sizeof(
 struct CoarsePlan {
     int n_ablk, n_blocks, n_btiles, splits, tiles_per_split;
 };
-// explicit tuning knobs of the filter + refine matcher (umereg_ume_match_set_tuning; process-wide, set them before the
-// scratch-size query of the calls they should affect).  0 / -1 = automatic.  Atomics: a setter may race with matcher calls
-// on other host threads without tearing (each call reads every knob once, in coarse_plan / carve_scratch); a call that
-// overlaps a change sees the old or the new value -- change them only between calls if the scratch size depends on them.
-static std::atomic<int> g_tune_splits{0};
-static std::atomic<long> g_tune_share_mask{-1};
-static std::atomic<int> g_tune_exhaustive{0};
-
-// umereg_ume_match_set_variant(1) selects the P-form coarse kernel (one inner product per pair, no squares) instead of
-// the Q-form one.  Bit-identical results; 11 % faster as a stage on MI355X but 4 % slower in the pipelined path, where it
-// leaves no room on the CUs for the kernels of the other pairs in flight: kept as a variant.
-static std::atomic<int> g_match_variant{0};
-static bool use_pform() { return g_match_variant.load(std::memory_order_relaxed) == 1; }
+// Per-call options of the filter + refine matcher (umereg_match_opts in umereg.h; NULL = the defaults).  There is no
+// process-wide matcher state: a call's plan (splits, region capacity, scratch layout) is a function of its arguments only.
+struct MatchOpts {
+    int variant = 0;            // 0 = Q-form coarse kernel, 1 = P-form (one inner product per pair, no squares; DESIGN.md 3.3:
+                                // 11 % faster as a stage on MI355X, 4 % slower in the pipelined path -- kept as a variant)
+    int splits = 0;             // target splits of the coarse pass (0 = automatic)
+    long long share_mask = -1;  // limit-sharing schedule (< 0 = kShareMask)
+    int exhaustive = 0;         // refine every block of rows exhaustively (parity test)
+};
+static int resolve_opts(const umereg_match_opts* o, MatchOpts& m, const char* who)
+{
+    m = MatchOpts();
+    if (!o) return UMEREG_OK;
+    UMEREG_REQUIRE(o->variant == 0 || o->variant == 1, "%s: unknown matcher variant %d (0 = Q-form, 1 = P-form)", who, (int)o->variant);
+    UMEREG_REQUIRE(o->splits >= 0 && o->force_exhaustive >= 0, "%s: negative matcher option", who);
+    UMEREG_REQUIRE(o->share_mask <= 0xffffffffll, "%s: share_mask does not fit 32 bits", who);
+    m.variant = o->variant;
+    m.splits = o->splits;
+    m.share_mask = o->share_mask;
+    m.exhaustive = o->force_exhaustive ? 1 : 0;
+    return UMEREG_OK;
+}
+static bool use_pform(const MatchOpts& o) { return o.variant == 1; }
 constexpr int kNumCU = 256;   // MI355X
 
-static CoarsePlan coarse_plan(int n1, int n2)
+static CoarsePlan coarse_plan(int n1, int n2, const MatchOpts& o)
 {
     CoarsePlan p;
     p.n_btiles = (n2 + 31) / 32;
     int splits;
-    if (use_pform()) {
+    if (use_pform(o)) {
         p.n_ablk = (n1 + kPWG - 1) / kPWG;
         p.n_blocks = p.n_ablk * kPWaves;
         splits = kNumCU / p.n_ablk;   // one workgroup per CU, one round
@@ -1065,7 +1075,7 @@ static CoarsePlan coarse_plan(int n1, int n2)
         p.n_blocks = p.n_ablk * kDistWaves;
         splits = (2560 + p.n_ablk - 1) / p.n_ablk;   // ~10 workgroups per CU
     }
-    if (const int ts = g_tune_splits.load(std::memory_order_relaxed); ts > 0) splits = ts;   // umereg_ume_match_set_tuning
+    if (o.splits > 0) splits = o.splits;   // umereg_match_opts.splits
     if (splits > kMaxSplits) splits = kMaxSplits;
     if (splits > p.n_btiles) splits = p.n_btiles;
     if (splits < 1) splits = 1;
@@ -1073,20 +1083,20 @@ static CoarsePlan coarse_plan(int n1, int n2)
     p.splits = (p.n_btiles + p.tiles_per_split - 1) / p.tiles_per_split;
     return p;
 }
-static size_t region_cap() { return use_pform() ? (size_t)kPRegionCap : (size_t)kRegionCap; }
-static size_t cand_bytes(int n1, const CoarsePlan& p)
+static size_t region_cap(const MatchOpts& o) { return use_pform(o) ? (size_t)kPRegionCap : (size_t)kRegionCap; }
+static size_t cand_bytes(int n1, const CoarsePlan& p, const MatchOpts& o)
 {
-    return align_up(((size_t)n1 + (size_t)p.n_blocks * p.splits * (1 + region_cap())) * sizeof(unsigned int), 256);
+    return align_up(((size_t)n1 + (size_t)p.n_blocks * p.splits * (1 + region_cap(o))) * sizeof(unsigned int), 256);
 }
 // packed projector fragments of both sets (P-form only): [n_blocks][34][64] + [n_btiles][34][64] half8
-static size_t pfrag_bytes(const CoarsePlan& p)
+static size_t pfrag_bytes(const CoarsePlan& p, const MatchOpts& o)
 {
-    return use_pform() ? ((size_t)p.n_blocks + (size_t)p.n_btiles) * kPK * 64 * sizeof(half8) : 0;
+    return use_pform(o) ? ((size_t)p.n_blocks + (size_t)p.n_btiles) * kPK * 64 * sizeof(half8) : 0;
 }
-static size_t match_scratch_bytes(int n1, int n2)
+static size_t match_scratch_bytes(int n1, int n2, const MatchOpts& o = MatchOpts())
 {
-    const CoarsePlan p = coarse_plan(n1, n2);
-    return cand_bytes(n1, p) + pfrag_bytes(p);
+    const CoarsePlan p = coarse_plan(n1, n2, o);
+    return cand_bytes(n1, p, o) + pfrag_bytes(p, o);
 }
 
 }  // namespace umereg
@@ -1099,50 +1109,59 @@ UMEREG_API size_t umereg_ume_cdist_workspace_bytes(int B, int n1, int n2)
     return qa_bytes(n1) + qb_bytes(n2);
 }
 
-UMEREG_API size_t umereg_ume_match_workspace_bytes(int B, int n1, int n2)
+UMEREG_API size_t umereg_ume_match_workspace_bytes_ex(int B, int n1, int n2, const umereg_match_opts* opts)
 {
     if (B <= 0 || n1 <= 0 || n2 <= 0) return 0;
-    return qa_bytes(n1) + qb_bytes(n2) + match_scratch_bytes(n1, n2) + 8 * (size_t)n1;   // covers the n1 x 8 B keys of the scan variants
+    MatchOpts o;
+    if (resolve_opts(opts, o, "ume_match_workspace_bytes_ex")) return 0;
+    return qa_bytes(n1) + qb_bytes(n2) + match_scratch_bytes(n1, n2, o) + 8 * (size_t)n1;   // covers the n1 x 8 B keys of the scan variants
 }
+UMEREG_API size_t umereg_ume_match_workspace_bytes(int B, int n1, int n2) { return umereg_ume_match_workspace_bytes_ex(B, n1, n2, nullptr); }
 
-UMEREG_API size_t umereg_ume_match_q_scratch_bytes(int n1, int n2) { return n1 > 0 && n2 > 0 ? match_scratch_bytes(n1, n2) : 0; }
+UMEREG_API size_t umereg_ume_match_q_scratch_bytes_ex(int n1, int n2, const umereg_match_opts* opts)
+{
+    MatchOpts o;
+    if (n1 <= 0 || n2 <= 0 || resolve_opts(opts, o, "ume_match_q_scratch_bytes_ex")) return 0;
+    return match_scratch_bytes(n1, n2, o);
+}
+UMEREG_API size_t umereg_ume_match_q_scratch_bytes(int n1, int n2) { return umereg_ume_match_q_scratch_bytes_ex(n1, n2, nullptr); }
 
 static int match_args(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch, size_t scratch_bytes,
-                      const char* who)
+                      const MatchOpts& o, const char* who)
 {
     UMEREG_REQUIRE(Q1_rows_h && Q2_cols_h, "%s: null basis pointer", who);
     UMEREG_REQUIRE(n1 > 0 && n2 > 0, "%s: n1, n2 must be positive (got %d, %d)", who, n1, n2);
     UMEREG_REQUIRE(n2 < (1 << 27), "%s: n2 must be below 2^27 (got %d)", who, n2);
     UMEREG_REQUIRE(((uintptr_t)Q1_rows_h & 15) == 0 && ((uintptr_t)Q2_cols_h & 15) == 0, "%s: misaligned basis pointer", who);
     if (int rc = check_device()) return rc;
-    if (!scratch || scratch_bytes < match_scratch_bytes(n1, n2) || ((uintptr_t)scratch & 15)) {
-        set_error("%s: scratch too small or misaligned (%zu < %zu)", who, scratch_bytes, match_scratch_bytes(n1, n2));
+    if (!scratch || scratch_bytes < match_scratch_bytes(n1, n2, o) || ((uintptr_t)scratch & 15)) {
+        set_error("%s: scratch too small or misaligned (%zu < %zu)", who, scratch_bytes, match_scratch_bytes(n1, n2, o));
         return UMEREG_EWORKSPACE;
     }
     return UMEREG_OK;
 }
 
-static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p)
+static MatchScratch carve_scratch(void* scratch, int n1, const CoarsePlan& p, const MatchOpts& o)
 {
     MatchScratch ms;
     ms.rowlim = (unsigned int*)scratch;
     ms.cnt = ms.rowlim + n1;
     ms.cand = ms.cnt + (size_t)p.n_blocks * p.splits;
     ms.splits = p.splits;
-    ms.share_mask = kShareMask;
-    ms.force_exhaustive = g_tune_exhaustive.load(std::memory_order_relaxed) ? 1 : 0;
-    if (const long sm = g_tune_share_mask.load(std::memory_order_relaxed); sm >= 0) ms.share_mask = (unsigned int)sm;
+    ms.share_mask = o.share_mask >= 0 ? (unsigned int)o.share_mask : kShareMask;
+    ms.force_exhaustive = o.exhaustive;
     return ms;
 }
-static half8* pfrag_rows(void* scratch, int n1, const CoarsePlan& p) { return (half8*)((char*)scratch + cand_bytes(n1, p)); }
-static half8* pfrag_cols(void* scratch, int n1, const CoarsePlan& p) { return pfrag_rows(scratch, n1, p) + (size_t)p.n_blocks * kPK * 64; }
+static half8* pfrag_rows(void* scratch, int n1, const CoarsePlan& p, const MatchOpts& o) { return (half8*)((char*)scratch + cand_bytes(n1, p, o)); }
+static half8* pfrag_cols(void* scratch, int n1, const CoarsePlan& p, const MatchOpts& o) { return pfrag_rows(scratch, n1, p, o) + (size_t)p.n_blocks * kPK * 64; }
 
+// (the reset touches the first 4 n1 bytes only -- the per-row limits lead the scratch whatever the options)
 UMEREG_API int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, int n1, int n2, void* stream)
 {
     UMEREG_REQUIRE(n1 > 0 && n2 > 0, "ume_match_reset_f16: n1, n2 must be positive (got %d, %d)", n1, n2);
     if (int rc = check_device()) return rc;
-    if (!scratch || scratch_bytes < match_scratch_bytes(n1, n2) || ((uintptr_t)scratch & 15)) {
-        set_error("ume_match_reset_f16: scratch too small or misaligned (%zu < %zu)", scratch_bytes, match_scratch_bytes(n1, n2));
+    if (!scratch || scratch_bytes < (size_t)n1 * sizeof(unsigned int) || ((uintptr_t)scratch & 15)) {
+        set_error("ume_match_reset_f16: scratch too small or misaligned (%zu < %zu)", scratch_bytes, (size_t)n1 * sizeof(unsigned int));
         return UMEREG_EWORKSPACE;
     }
     // the per-row limits start at 0; everything else in the scratch is written before it is read
@@ -1153,16 +1172,18 @@ UMEREG_API int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, i
     return UMEREG_OK;
 }
 
-UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
-                                           size_t scratch_bytes, void* stream)
+UMEREG_API int umereg_ume_match_coarse_f16_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
+                                              size_t scratch_bytes, const umereg_match_opts* opts, void* stream)
 {
-    if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, "ume_match_coarse_f16")) return rc;
+    MatchOpts o;
+    if (int rc = resolve_opts(opts, o, "ume_match_coarse_f16")) return rc;
+    if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, o, "ume_match_coarse_f16")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const CoarsePlan p = coarse_plan(n1, n2);
-    const MatchScratch ms = carve_scratch(scratch, n1, p);
-    if (use_pform()) {
-        half8* const PA = pfrag_rows(scratch, n1, p);
-        half8* const PB = pfrag_cols(scratch, n1, p);
+    const CoarsePlan p = coarse_plan(n1, n2, o);
+    const MatchScratch ms = carve_scratch(scratch, n1, p, o);
+    if (use_pform(o)) {
+        half8* const PA = pfrag_rows(scratch, n1, p, o);
+        half8* const PB = pfrag_cols(scratch, n1, p, o);
         const int tiles = p.n_blocks > p.n_btiles ? p.n_blocks : p.n_btiles;
         hipLaunchKernelGGL(pform_pack_kernel, dim3(tiles, 2), dim3(256), 0, st, (const _Float16*)Q1_rows_h, (const _Float16*)Q2_cols_h,
                            n1, n2, p.n_blocks, p.n_btiles, PA, PB);
@@ -1177,16 +1198,23 @@ UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2
     UMEREG_CHECK_LAUNCH("ume_coarse_h_kernel");
     return UMEREG_OK;
 }
+UMEREG_API int umereg_ume_match_coarse_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
+                                           size_t scratch_bytes, void* stream)
+{
+    return umereg_ume_match_coarse_f16_ex(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, nullptr, stream);
+}
 
-UMEREG_API int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
-                                           const void* scratch, size_t scratch_bytes, int64_t* match_idx,
-                                           float* match_dist, void* stream)
+UMEREG_API int umereg_ume_match_refine_f16_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                              const void* scratch, size_t scratch_bytes, int64_t* match_idx,
+                                              float* match_dist, const umereg_match_opts* opts, void* stream)
 {
     UMEREG_REQUIRE(match_idx, "ume_match_refine_f16: null match_idx");
-    if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, (void*)scratch, scratch_bytes, "ume_match_refine_f16")) return rc;
-    const CoarsePlan p = coarse_plan(n1, n2);
-    const MatchScratch ms = carve_scratch((void*)scratch, n1, p);
-    if (use_pform())
+    MatchOpts o;
+    if (int rc = resolve_opts(opts, o, "ume_match_refine_f16")) return rc;
+    if (int rc = match_args(Q1_rows_h, Q2_cols_h, n1, n2, (void*)scratch, scratch_bytes, o, "ume_match_refine_f16")) return rc;
+    const CoarsePlan p = coarse_plan(n1, n2, o);
+    const MatchScratch ms = carve_scratch((void*)scratch, n1, p, o);
+    if (use_pform(o))
         hipLaunchKernelGGL((match_refine_kernel<kPRows, kPRegionCap>), dim3(p.n_blocks), dim3(256), 0, (hipStream_t)stream,
                            (const _Float16*)Q1_rows_h, (const _Float16*)Q2_cols_h, n1, n2, ms, match_idx, match_dist);
     else
@@ -1195,15 +1223,27 @@ UMEREG_API int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2
     UMEREG_CHECK_LAUNCH("match_refine_kernel");
     return UMEREG_OK;
 }
+UMEREG_API int umereg_ume_match_refine_f16(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                           const void* scratch, size_t scratch_bytes, int64_t* match_idx,
+                                           float* match_dist, void* stream)
+{
+    return umereg_ume_match_refine_f16_ex(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, match_idx, match_dist, nullptr, stream);
+}
 
+UMEREG_API int umereg_ume_match_q_f16r_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
+                                          int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
+                                          const umereg_match_opts* opts, void* stream)
+{
+    UMEREG_REQUIRE(match_idx, "ume_match_q_f16r: null match_idx");
+    if (int rc = umereg_ume_match_reset_f16(scratch, scratch_bytes, n1, n2, stream)) return rc;
+    if (int rc = umereg_ume_match_coarse_f16_ex(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, opts, stream)) return rc;
+    return umereg_ume_match_refine_f16_ex(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, match_idx, match_dist, opts, stream);
+}
 UMEREG_API int umereg_ume_match_q_f16r(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2,
                                        int64_t* match_idx, float* match_dist, void* scratch, size_t scratch_bytes,
                                        void* stream)
 {
-    UMEREG_REQUIRE(match_idx, "ume_match_q_f16r: null match_idx");
-    if (int rc = umereg_ume_match_reset_f16(scratch, scratch_bytes, n1, n2, stream)) return rc;
-    if (int rc = umereg_ume_match_coarse_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, stream)) return rc;
-    return umereg_ume_match_refine_f16(Q1_rows_h, Q2_cols_h, n1, n2, scratch, scratch_bytes, match_idx, match_dist, stream);
+    return umereg_ume_match_q_f16r_ex(Q1_rows_h, Q2_cols_h, n1, n2, match_idx, match_dist, scratch, scratch_bytes, nullptr, stream);
 }
 
 UMEREG_API int umereg_ume_dist_q_f32(const float* Q1_rows, const float* Q2_cols, int n1, int n2, float* D,
@@ -1296,8 +1336,11 @@ UMEREG_API int umereg_ume_dist_q_f16x2(const void* Q1_rows_h, const void* Q2_col
 
 static int dist_common(const float* ume1, const float* ume2, int B, int n1, int n2, float* D,
                        int64_t* match_idx, float* match_dist, void* workspace, size_t workspace_bytes,
-                       size_t need, void* stream, const char* who, bool f16x2 = false, bool refine = false)
+                       size_t need, void* stream, const char* who, bool f16x2 = false, bool refine = false,
+                       const umereg_match_opts* opts = nullptr)
 {
+    MatchOpts mo;
+    if (int rc = resolve_opts(opts, mo, who)) return rc;
     UMEREG_REQUIRE(ume1 && ume2, "%s: null UME pointer", who);
     UMEREG_REQUIRE(B > 0 && n1 > 0 && n2 > 0, "%s: B, n1, n2 must be positive (got %d, %d, %d)", who, B, n1, n2);
     UMEREG_REQUIRE(((uintptr_t)ume1 & 15) == 0 && ((uintptr_t)ume2 & 15) == 0, "%s: UME pointers must be 16-byte aligned", who);
@@ -1317,7 +1360,7 @@ static int dist_common(const float* ume1, const float* ume2, int B, int n1, int 
         float* Db = D ? D + (size_t)b * n1 * n2 : nullptr;
         int64_t* mi = match_idx ? match_idx + (size_t)b * n1 : nullptr;
         float* md = match_dist ? match_dist + (size_t)b * n1 : nullptr;
-        const int rc = refine  ? umereg_ume_match_q_f16r(QA, QB, n1, n2, mi, md, keys, match_scratch_bytes(n1, n2), stream)
+        const int rc = refine  ? umereg_ume_match_q_f16r_ex(QA, QB, n1, n2, mi, md, keys, match_scratch_bytes(n1, n2, mo), opts, stream)
                        : f16x2 ? umereg_ume_dist_q_f16x2(QA, QB, n1, n2, Db, mi, md, match_idx ? keys : nullptr, stream)
                                : umereg_ume_dist_q_f32(QA, QB, n1, n2, Db, mi, md, match_idx ? keys : nullptr, stream);
         if (rc) return rc;
@@ -1361,34 +1404,55 @@ UMEREG_API int umereg_ume_match_f16x2(const float* ume1, const float* ume2, int 
                        umereg_ume_match_workspace_bytes(B, n1, n2), stream, "ume_match_f16x2", true);
 }
 
+UMEREG_API int umereg_ume_match_f16r_ex(const float* ume1, const float* ume2, int B, int n1, int n2,
+                                        int64_t* match_idx, float* match_dist, void* workspace,
+                                        size_t workspace_bytes, const umereg_match_opts* opts, void* stream)
+{
+    UMEREG_REQUIRE(match_idx, "ume_match_f16r: null match_idx");
+    MatchOpts mo;
+    if (int rc = resolve_opts(opts, mo, "ume_match_f16r")) return rc;
+    return dist_common(ume1, ume2, B, n1, n2, nullptr, match_idx, match_dist, workspace, workspace_bytes,
+                       umereg_ume_match_workspace_bytes_ex(B, n1, n2, opts), stream, "ume_match_f16r", true, true, opts);
+}
 UMEREG_API int umereg_ume_match_f16r(const float* ume1, const float* ume2, int B, int n1, int n2,
                                      int64_t* match_idx, float* match_dist, void* workspace,
                                      size_t workspace_bytes, void* stream)
 {
-    UMEREG_REQUIRE(match_idx, "ume_match_f16r: null match_idx");
-    return dist_common(ume1, ume2, B, n1, n2, nullptr, match_idx, match_dist, workspace, workspace_bytes,
-                       umereg_ume_match_workspace_bytes(B, n1, n2), stream, "ume_match_f16r", true, true);
+    return umereg_ume_match_f16r_ex(ume1, ume2, B, n1, n2, match_idx, match_dist, workspace, workspace_bytes, nullptr, stream);
 }
 
 // ---- a1..a5 of one registration pair in ONE call -----------------------------------------------------------------
 // reference evaluate.py:206-236: UME matrices of both clouds, matching, match probabilities -- everything up to the
 // host RNG draw.  Pure composition of the entry points above (same kernels, same results); exists because a pair
 // is ~12 launches and a Python caller pays ~10 us per ctypes call.
-UMEREG_API size_t umereg_pair_match_workspace_bytes(int N, int n_kp)
+UMEREG_API size_t umereg_pair_match_workspace_bytes_ex(int N, int n_kp, const umereg_match_opts* opts)
 {
     if (N <= 0 || n_kp <= 0) return 0;
-    return align_up(umereg_ume_moments_workspace_bytes(2, N), 256) + umereg_ume_match_workspace_bytes(1, n_kp, n_kp);
+    const size_t m = umereg_ume_match_workspace_bytes_ex(1, n_kp, n_kp, opts);
+    return m ? align_up(umereg_ume_moments_workspace_bytes(2, N), 256) + m : 0;
 }
+UMEREG_API size_t umereg_pair_match_workspace_bytes(int N, int n_kp) { return umereg_pair_match_workspace_bytes_ex(N, n_kp, nullptr); }
 
 UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
                                      float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
                                      float* prob, void* workspace, size_t workspace_bytes, void* stream)
 {
+    return umereg_pair_match_ex_f32(pts, feat, kp_index, N, n_kp, K, radius, tau, F, match_idx, match_dist, prob, workspace,
+                                    workspace_bytes, nullptr, stream);
+}
+
+UMEREG_API int umereg_pair_match_ex_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
+                                        float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
+                                        float* prob, void* workspace, size_t workspace_bytes, const umereg_match_opts* opts,
+                                        void* stream)
+{
+    MatchOpts mo;
+    if (int rc = resolve_opts(opts, mo, "pair_match")) return rc;
     UMEREG_REQUIRE(pts && feat && kp_index && F && match_idx && match_dist, "pair_match: null pointer");
     UMEREG_REQUIRE(N > 0 && n_kp > 0, "pair_match: N, n_kp must be positive (got %d, %d)", N, n_kp);
     UMEREG_REQUIRE(!prob || tau > 0.f, "pair_match: tau must be positive when prob is requested");
     if (int rc = check_device()) return rc;
-    const size_t need = umereg_pair_match_workspace_bytes(N, n_kp);
+    const size_t need = umereg_pair_match_workspace_bytes_ex(N, n_kp, opts);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
         set_error("pair_match: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
         return UMEREG_EWORKSPACE;
@@ -1403,8 +1467,8 @@ UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const 
     if (int rc = umereg_ume_moments_packed_f32(ws_mom, nullptr, kp_index, feat, 2, N, n_kp, UMEREG_FEAT_DIM, K, radius,
                                                ordered ? UMEREG_MOMENTS_ORDERED : 0, F, nullptr, nullptr, stream))
         return rc;
-    if (int rc = umereg_ume_match_f16r(F, F + (size_t)n_kp * 128, 1, n_kp, n_kp, match_idx, match_dist, ws_match,
-                                       workspace_bytes - mom_bytes, stream))
+    if (int rc = umereg_ume_match_f16r_ex(F, F + (size_t)n_kp * 128, 1, n_kp, n_kp, match_idx, match_dist, ws_match,
+                                          workspace_bytes - mom_bytes, opts, stream))
         return rc;
     if (prob)
         if (int rc = umereg_match_prob_f32(match_dist, n_kp, tau, prob, stream)) return rc;
@@ -1431,6 +1495,15 @@ UMEREG_API int umereg_pair_match_graph_create(const float* pts, const float* fea
                                               float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
                                               float* prob, void* workspace, size_t workspace_bytes, void* stream, void** graph_out)
 {
+    return umereg_pair_match_graph_create_ex(pts, feat, kp_index, N, n_kp, K, radius, tau, F, match_idx, match_dist, prob, workspace,
+                                             workspace_bytes, nullptr, stream, graph_out);
+}
+
+UMEREG_API int umereg_pair_match_graph_create_ex(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
+                                                 float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
+                                                 float* prob, void* workspace, size_t workspace_bytes,
+                                                 const umereg_match_opts* opts, void* stream, void** graph_out)
+{
     UMEREG_REQUIRE(graph_out, "pair_match_graph_create: null graph_out");
     UMEREG_REQUIRE(stream, "pair_match_graph_create: capture needs a non-default stream");
     *graph_out = nullptr;
@@ -1441,8 +1514,8 @@ UMEREG_API int umereg_pair_match_graph_create(const float* pts, const float* fea
         set_error("pair_match_graph_create: hipStreamBeginCapture failed");
         return UMEREG_ELAUNCH;
     }
-    const int rc = umereg_pair_match_f32(pts, feat, kp_index, N, n_kp, K, radius, tau, F, match_idx, match_dist, prob, workspace,
-                                         workspace_bytes, stream);
+    const int rc = umereg_pair_match_ex_f32(pts, feat, kp_index, N, n_kp, K, radius, tau, F, match_idx, match_dist, prob, workspace,
+                                            workspace_bytes, opts, stream);
     hipGraph_t g = nullptr;
     const hipError_t e_end = hipStreamEndCapture(st, &g);
     if (rc != UMEREG_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -1521,21 +1594,5 @@ UMEREG_API int umereg_pair_match_graph_destroy(void* graph)
     (void)hipGraphExecDestroy(h->exec);
     (void)hipGraphDestroy(h->graph);
     delete h;
-    return UMEREG_OK;
-}
-
-UMEREG_API int umereg_ume_match_set_variant(int variant)
-{
-    if (variant != 0 && variant != 1) { set_error("ume_match_set_variant: unknown variant %d (0 = Q-form, 1 = P-form)", variant); return UMEREG_EINVAL; }
-    g_match_variant.store(variant, std::memory_order_relaxed);
-    return UMEREG_OK;
-}
-
-UMEREG_API int umereg_ume_match_set_tuning(int splits, long share_mask, int force_exhaustive)
-{
-    if (splits < 0 || force_exhaustive < 0) { set_error("ume_match_set_tuning: negative argument"); return UMEREG_EINVAL; }
-    g_tune_splits.store(splits, std::memory_order_relaxed);
-    g_tune_share_mask.store(share_mask, std::memory_order_relaxed);
-    g_tune_exhaustive.store(force_exhaustive, std::memory_order_relaxed);
     return UMEREG_OK;
 }

@@ -142,7 +142,7 @@ def my_ume_generation(pts, kpts, feat, args):
 
 
 def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D=False, timing=None,
-             pair=None, graph=None):
+             pair=None, graph=None, match_opts=None):
     """evaluate.py:195-236 up to the match probabilities: everything before the host RNG draw.
     graph: an ops.PairMatchGraph built over `pair`'s buffers -- the same kernels replayed as one hipGraph launch."""
     dev = src_pts.device
@@ -158,7 +158,7 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
             and not getattr(args, "hungarian_matching_flag", False):
         # the whole of a1..a5 in one native call (same kernels as the layered path below)
         F, m_tgt, ume_d, prob = ops.pair_match(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn,
-                                               args.tau if args.filter_by_ume_dist_cond else None)
+                                               args.tau if args.filter_by_ume_dist_cond else None, opts=match_opts)
         return SimpleNamespace(ume_src=F[0:1], ume_tgt=F[1:2], match=m_tgt, match_d=ume_d, prob=prob, D=None,
                                src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=F.shape[1], dev=dev,
                                src_pts=src_pts, tgt_pts=tgt_pts)
@@ -193,7 +193,7 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
         m_tgt = D.min(dim=-1)[1]
         ume_d = torch.gather(D, 2, m_tgt.unsqueeze(-1)).squeeze(-1)
     else:
-        m_tgt, ume_d = ops.ume_match(ume_src, ume_tgt, timing=t_dist)
+        m_tgt, ume_d = ops.ume_match(ume_src, ume_tgt, timing=t_dist, opts=match_opts)
     prob = ops.match_prob(ume_d[0], args.tau) if args.filter_by_ume_dist_cond else None   # (:235-236)
     return SimpleNamespace(ume_src=ume_src, ume_tgt=ume_tgt, match=m_tgt, match_d=ume_d, prob=prob, D=D,
                            src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=num_kpts, dev=dev,
@@ -323,12 +323,14 @@ class RegistrationPipeline:
     be called in order.
     """
 
-    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False, use_graphs=False, stream_plan=None):
+    def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False, use_graphs=False, stream_plan=None,
+                 match_opts=None):
         """threaded_draw: run the host draw (event wait + choice) on one worker thread, in submission
         order, so it also overlaps the main thread's kernel enqueues (the native draw releases the GIL).
         Use depth >= 3 with it.  The worker is then the only consumer of `rng` between submit and finish,
         so inject the keypoint indices (or draw them from a different generator)."""
         self.args, self.rng, self.depth = args, rng, depth
+        self.match_opts = match_opts       # ops.MatchOpts of THIS pipeline's matcher calls (per call, not process state)
         # use_graphs: replay phase A (12 launches) as one hipGraph per (slot, PairBatch): for loops that keep submitting
         # the same PairBatch objects (resident or double-buffered inputs).  The graph writes into buffers it owns, so the
         # tensors of a pair are valid until the same (slot, PairBatch) is submitted again, its rtume_tform / g_index (slot
@@ -392,7 +394,7 @@ class RegistrationPipeline:
         entry = self.graphs.get(key)
         if entry is not None:
             graph, owner = entry
-            if owner is pair and graph.matches(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau):
+            if owner is pair and graph.matches(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau, self.match_opts):
                 self.graphs[key] = self.graphs.pop(key)                 # most recently used last
                 return graph
             self._retire(key)
@@ -407,7 +409,7 @@ class RegistrationPipeline:
         with torch.cuda.stream(self.streams[k]):
             # buffers owned by the graph are allocated under the slot's stream: that is the stream its kernels run on, so
             # the caching allocator cannot hand them to somebody else while a replay is in flight
-            graph = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau)
+            graph = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau, opts=self.match_opts)
         self.graphs[key] = (graph, pair)          # the strong reference keeps id(pair) from being reused while the entry lives
         return graph
 
@@ -447,7 +449,8 @@ class RegistrationPipeline:
                                 tgt_pts=tgt_pts, ready=ev, slot=k, rng=rng, draw=None, graph=graph)
             return a
         with torch.cuda.stream(st):
-            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, graph)
+            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, graph,
+                         match_opts=self.match_opts)
             if a.prob is not None:
                 if self.host_prob[k] is None or self.host_prob[k].numel() != a.prob.numel():
                     self.host_prob[k] = torch.empty(a.prob.numel(), dtype=torch.float32, pin_memory=True)

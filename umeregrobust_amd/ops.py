@@ -18,6 +18,7 @@ ORDER_KEYPOINTS = True   # process keypoints in cell-sorted, XCD-sliced order (c
 # arg-min engines: "f32" exact-fp32 MFMA scan; "f16x2" split-f16 MFMA scan (fp32-class, ~4x faster);
 # "f16r" single-product f16 filter + fp64 refine of the candidates (exact arg-min of the fp64 distance)
 DEFAULT_MATCH_PRECISION = "f16r"
+MatchOpts = _lib.MatchOpts   # per-call matcher options (umereg_match_opts): MatchOpts(variant=1) = the P-form coarse kernel
 
 _workspaces = {}
 
@@ -196,7 +197,7 @@ def _check_umes(ume1, ume2, who):
         raise ValueError(f"{who}: expected ume1 [B,n1,32,4], ume2 [B,n2,32,4]; got {tuple(ume1.shape)}, {tuple(ume2.shape)}")
 
 
-def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
+def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32", opts=None):
     lib = _lib.load()
     ume1 = _dev(ume1, "ume1"); ume2 = _dev(ume2, "ume2")
     _check_umes(ume1, ume2, "ume_cdist/ume_match")
@@ -219,7 +220,8 @@ def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
     dist_fn = lib.umereg_ume_dist_q_f16x2 if half else lib.umereg_ume_dist_q_f32
     qa = lib.umereg_qbasis_bytes(n1, lay_a)
     qb = lib.umereg_qbasis_bytes(n2, lay_b)
-    scratch = lib.umereg_ume_match_q_scratch_bytes(n1, n2) if refine else 8 * n1 + 256
+    op = _lib.opts_ptr(opts)
+    scratch = lib.umereg_ume_match_q_scratch_bytes_ex(n1, n2, op) if refine else 8 * n1 + 256
     ws = _workspace(dev, qa + qb + scratch, "dist")
     base = ws.data_ptr()
     st = _stream_ptr(dev)
@@ -232,12 +234,12 @@ def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32"):
             ev = _timed(timing, dev)
             if refine:
                 # the two stages of umereg_ume_match_q_f16r; `timing` brackets the coarse (dominant) stage
-                rc = lib.umereg_ume_match_coarse_f16(base, base + qa, n1, n2, base + qa + qb, scratch, st)
+                rc = lib.umereg_ume_match_coarse_f16_ex(base, base + qa, n1, n2, base + qa + qb, scratch, op, st)
                 _lib.check(rc, "umereg_ume_match_coarse_f16")
                 _timed_end(timing, ev, dev)
                 timing = getattr(timing, "refine", None)
                 ev = _timed(timing, dev)
-                rc = lib.umereg_ume_match_refine_f16(base, base + qa, n1, n2, base + qa + qb, scratch, _ptr(m[b]), _ptr(d[b]), st)
+                rc = lib.umereg_ume_match_refine_f16_ex(base, base + qa, n1, n2, base + qa + qb, scratch, _ptr(m[b]), _ptr(d[b]), op, st)
             else:
                 rc = dist_fn(base, base + qa, n1, n2, _ptr(D[b]) if want_D else None,
                              _ptr(m[b]) if want_match else None, _ptr(d[b]) if want_match else None,
@@ -253,9 +255,10 @@ def ume_cdist(ume1, ume2, timing=None, precision="f32"):
     return _dist_q(ume1, ume2, True, False, timing, precision)[0]
 
 
-def ume_match(ume1, ume2, timing=None, precision=None):
-    """Fused ume_cdist + row arg-min (reference evaluate.py:215,224,234): (m [B,n1] i64, d [B,n1] f32)."""
-    _, m, d = _dist_q(ume1, ume2, False, True, timing, precision or DEFAULT_MATCH_PRECISION)
+def ume_match(ume1, ume2, timing=None, precision=None, opts=None):
+    """Fused ume_cdist + row arg-min (reference evaluate.py:215,224,234): (m [B,n1] i64, d [B,n1] f32).
+    opts: MatchOpts for the filter + refine engine ("f16r"), per call (None = defaults)."""
+    _, m, d = _dist_q(ume1, ume2, False, True, timing, precision or DEFAULT_MATCH_PRECISION, opts)
     return m, d
 
 
@@ -616,7 +619,7 @@ def ume_svdvals(ume):
     return sv
 
 
-def pair_match(pts, feat, kp_index, K, radius, tau=None):
+def pair_match(pts, feat, kp_index, K, radius, tau=None, opts=None):
     """a1..a5 of one registration pair in one native call (reference evaluate.py:206-236).
     pts [2,N,3], feat [2,N,32], kp_index int64 [2,n_kp] (row 0 = source, row 1 = target) ->
     (F [2,n_kp,32,4], match [1,n_kp] i64, match_d [1,n_kp] f32, prob [n_kp] f32 | None).  Same kernels and results
@@ -634,12 +637,13 @@ def pair_match(pts, feat, kp_index, K, radius, tau=None):
     m = torch.empty((1, n), dtype=torch.int64, device=dev)
     d = torch.empty((1, n), dtype=torch.float32, device=dev)
     prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
-    ws = _workspace(dev, lib.umereg_pair_match_workspace_bytes(N, n), "pair")
+    op = _lib.opts_ptr(opts)
+    ws = _workspace(dev, lib.umereg_pair_match_workspace_bytes_ex(N, n, op), "pair")
     with torch.cuda.device(dev):
-        rc = lib.umereg_pair_match_f32(_ptr(pts), _ptr(feat), _ptr(kp_index), N, n, int(K), float(radius),
-                                       float(tau) if tau is not None else 0.0, _ptr(F), _ptr(m), _ptr(d), _ptr(prob),
-                                       _ptr(ws), ws.numel(), _stream_ptr(dev))
-    _lib.check(rc, "umereg_pair_match_f32")
+        rc = lib.umereg_pair_match_ex_f32(_ptr(pts), _ptr(feat), _ptr(kp_index), N, n, int(K), float(radius),
+                                          float(tau) if tau is not None else 0.0, _ptr(F), _ptr(m), _ptr(d), _ptr(prob),
+                                          _ptr(ws), ws.numel(), op, _stream_ptr(dev))
+    _lib.check(rc, "umereg_pair_match_ex_f32")
     return F, m, d, prob
 
 
@@ -648,10 +652,16 @@ class PairMatchGraph:
     and outputs / workspace owned by this object.  launch() replays it on the current stream and returns the same
     (F, match, match_d, prob) tensors every time -- valid until the next launch() of this object."""
 
-    def __init__(self, pts, feat, kp_index, K, radius, tau=None):
+    def __init__(self, pts, feat, kp_index, K, radius, tau=None, opts=None):
         import ctypes
         lib = _lib.load()
         self.pts = _dev(pts, "pts"); self.feat = _dev(feat, "feat"); self.kp_index = _dev(kp_index, "kp_index", torch.int64)
+        for given, used, name in ((pts, self.pts, "pts"), (feat, self.feat, "feat"), (kp_index, self.kp_index, "kp_index")):
+            if used.data_ptr() != given.data_ptr():
+                # the graph is captured over fixed addresses: a converted COPY would be what it reads on every replay, not the
+                # caller's buffer -- and its signature would never match the caller's tensors (a re-capture per submit)
+                raise ValueError(f"PairMatchGraph: {name} must be contiguous {used.dtype} on the device (got {given.dtype}, "
+                                 f"contiguous={given.is_contiguous()}): a graph replays from the caller's own buffers")
         if self.pts.dim() != 3 or self.pts.shape[0] != 2 or self.feat.shape[:2] != self.pts.shape[:2] or self.feat.shape[2] != 32 \
                 or self.kp_index.dim() != 2 or self.kp_index.shape[0] != 2 or self.kp_index.shape[1] == 0:
             raise ValueError("PairMatchGraph: expected pts [2,N,3], feat [2,N,32], kp_index [2,n_kp]")
@@ -660,33 +670,35 @@ class PairMatchGraph:
         self.dev = dev
         # what the captured kernels were recorded against: replaying the graph for anything else would silently compute
         # from the old buffers / parameters (see `matches`)
-        self.signature = self.signature_of(self.pts, self.feat, self.kp_index, K, radius, tau)
+        self.opts = opts
+        self.signature = self.signature_of(self.pts, self.feat, self.kp_index, K, radius, tau, opts)
         self.F = torch.empty((2, n, 32, 4), dtype=torch.float32, device=dev)
         self.m = torch.empty((1, n), dtype=torch.int64, device=dev)
         self.d = torch.empty((1, n), dtype=torch.float32, device=dev)
         self.prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
-        self.ws = torch.empty(lib.umereg_pair_match_workspace_bytes(N, n), dtype=torch.uint8, device=dev)
+        op = _lib.opts_ptr(opts)
+        self.ws = torch.empty(lib.umereg_pair_match_workspace_bytes_ex(N, n, op), dtype=torch.uint8, device=dev)
         self._lib = lib
         handle = ctypes.c_void_p()
         cap = torch.cuda.Stream(dev)                     # capture needs a non-default stream; nothing runs on it
         cap.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.device(dev):
-            rc = lib.umereg_pair_match_graph_create(_ptr(self.pts), _ptr(self.feat), _ptr(self.kp_index), N, n, int(K), float(radius),
-                                                    float(tau) if tau is not None else 0.0, _ptr(self.F), _ptr(self.m), _ptr(self.d),
-                                                    _ptr(self.prob), _ptr(self.ws), self.ws.numel(), cap.cuda_stream,
-                                                    ctypes.byref(handle))
-        _lib.check(rc, "umereg_pair_match_graph_create")
+            rc = lib.umereg_pair_match_graph_create_ex(_ptr(self.pts), _ptr(self.feat), _ptr(self.kp_index), N, n, int(K), float(radius),
+                                                       float(tau) if tau is not None else 0.0, _ptr(self.F), _ptr(self.m), _ptr(self.d),
+                                                       _ptr(self.prob), _ptr(self.ws), self.ws.numel(), op, cap.cuda_stream,
+                                                       ctypes.byref(handle))
+        _lib.check(rc, "umereg_pair_match_graph_create_ex")
         self.handle = handle
 
     @staticmethod
-    def signature_of(pts, feat, kp_index, K, radius, tau):
+    def signature_of(pts, feat, kp_index, K, radius, tau, opts=None):
         """(address, shape, dtype) of every captured input buffer + the scalar parameters baked into the graph."""
         return tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in (pts, feat, kp_index)) + \
-            (int(K), float(radius), None if tau is None else float(tau))
+            (int(K), float(radius), None if tau is None else float(tau), None if opts is None else opts.key())
 
-    def matches(self, pts, feat, kp_index, K, radius, tau):
+    def matches(self, pts, feat, kp_index, K, radius, tau, opts=None):
         """True if replaying this graph computes a1..a5 of exactly these buffers with these parameters."""
-        return self.handle is not None and self.signature == self.signature_of(pts, feat, kp_index, K, radius, tau)
+        return self.handle is not None and self.signature == self.signature_of(pts, feat, kp_index, K, radius, tau, opts)
 
     def launch(self):
         with torch.cuda.device(self.dev):
