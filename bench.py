@@ -27,16 +27,27 @@ import sys
 import time
 from types import SimpleNamespace
 
-import numpy as np
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+
+# one process per GPU: N ranks share the host's cores.  Every rank runs numpy draws, the ICP's stop-test polling and torch's
+# intra-op pool; left alone each would start one thread per core (8 x 256 threads on an 8-GPU node) that wander across sockets.
+# So, BEFORE numpy / torch exist in this process: the rank is pinned to its share (<= 8 cores) of the NUMA node its GPU hangs
+# off, and the BLAS / OpenMP pools are sized to it (umeregrobust_amd/hostpin.py; a world of 1 keeps every core -- the CPU-baseline
+# leg runs there).
+from umeregrobust_amd.hostpin import pin_rank_from_env  # noqa: E402
+
+_fd = [sys.argv[i + 1] for i, v in enumerate(sys.argv[:-1]) if v == "--force-device"]
+HOST_PIN = pin_rank_from_env(force_device=_fd[0] if _fd else None)
+
+import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 L2_PEAK_GBS = 34500.0        # aggregate L2 -> CU rate, same guide ("L2 (per XCD)": ~34.5 TB/s)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same guide)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (same guide; 2:1-sparsity figures excluded)
+VALU_F64_PEAK_TFLOPS = 78.6    # fp64 vector FMA: half the fp32 vector rate of the same guide (157.3 TFLOP/s)
 # the reduced-size recall check uses a harsher variant than the KT-size hard leg (calibrated so that recall sits near 75 %)
 RR_CHECK_HARD = dict(sector_deg=180.0, sector_shift_deg=120.0, noise_sigma=0.03, feat_corrupt=0.5)
 GATES = ((1.5, 0.6), (1.5, 0.3), (1.0, 0.1))   # (deg, m): evaluate.py:304 (code), README "Normal", evaluate.py:305 "Strict"
@@ -50,7 +61,16 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=64, help="registration pairs per step and GPU")
     ap.add_argument("--config", default="KT", choices=["K1", "KT", "NS", "SY"])
     ap.add_argument("--kind", default="test", choices=["test", "rot"])
-    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic pairs (cycled; pair g uses pool[g %% pool])")
+    ap.add_argument("--pool", type=int, default=64,
+                    help="distinct synthetic pairs resident in HBM (cycled; pair g uses pool[g %% pool]).  The reference's loop runs over "
+                         "distinct pairs (evaluate.py:175): with the default graph mode every submitted pair is NEW to the pipeline")
+    ap.add_argument("--graph-mode", default="slot", choices=["slot", "pair", "none"],
+                    help="phase A (a1-a5) as a hipGraph: 'slot' = one graph per pipeline slot over staging buffers it owns, every pair "
+                         "copied in device to device (any stream of distinct pairs; what `value` is measured on); 'pair' = one graph per "
+                         "(slot, resident PairBatch), replayed in place (callers that cycle through resident buffers; the headline of "
+                         "rounds 2-3, reported as config.resident_replay); 'none' = 12 plain launches per pair")
+    ap.add_argument("--resident-steps", type=int, default=5,
+                    help="steps of the additional 'pair'-mode leg over 4 resident pairs (config.resident_replay; 0 = skip)")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=4,
@@ -62,8 +82,7 @@ def parse():
                     help="(experiments) run the P-form coarse kernel of the matcher (umereg_match_opts.variant = 1, per call)")
     ap.add_argument("--match-tuning", default=None,
                     help="(experiments) 'splits,share_mask' of umereg_match_opts, e.g. 0,0x80008009")
-    ap.add_argument("--no-graphs", dest="graphs", action="store_false",
-                    help="enqueue phase A (a1-a5) as 12 launches per pair instead of replaying one captured hipGraph")
+    ap.add_argument("--no-graphs", dest="graphs", action="store_false", help="the same as --graph-mode none")
     ap.add_argument("--threaded-draw", action="store_true", help="host RNG draw on a worker thread (off: slower, see DESIGN 3.5)")
     ap.add_argument("--no-batch-clouds", dest="batch_clouds", action="store_false",
                     help="run source and target clouds as two launches instead of one batch of 2")
@@ -80,8 +99,33 @@ def parse():
                     help="additionally time the end-to-end legs with this many pairs in flight (reported as `side_by_side`; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="max pairs timed by the CPU baseline leg (stops after ~10 s)")
-    ap.add_argument("--cpu-rr-pairs", type=int, default=64, help="max hard pairs of the CPU-vs-HIP recall check (stops after ~25 s)")
+    ap.add_argument("--cpu-rr-pairs", type=int, default=128,
+                    help="hard pairs of the CPU-vs-HIP recall check (the oracle costs ~1 s per reduced-size pair on a 256-core host; "
+                         "stops after --cpu-rr-budget seconds of CPU time)")
+    ap.add_argument("--cpu-rr-budget", type=float, default=400.0)
     return ap.parse_args()
+
+
+def _synth_one(job):
+    from umeregrobust_amd.synth import synth_pair
+    seed, kw = job
+    return synth_pair(seed=seed, **kw)
+
+
+def synth_many(seeds, kw, workers):
+    """The pool's synthetic pairs (0.4 s of numpy each at KITTI size), generated on a few worker processes: `spawn`, so that the
+    children never see this process's HIP context; they import numpy only (umeregrobust_amd.synth).  Serial on any failure."""
+    seeds = list(seeds)
+    workers = max(1, min(8, int(workers), len(seeds)))
+    if workers > 1 and len(seeds) >= 8:
+        try:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+                return list(ex.map(_synth_one, [(s_, kw) for s_ in seeds], chunksize=max(1, len(seeds) // (4 * workers))))
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] parallel pool generation failed ({e!r}); generating serially", file=sys.stderr)
+    return [_synth_one((s_, kw)) for s_ in seeds]
 
 
 def gate_counts(rre, rte):
@@ -91,13 +135,10 @@ def gate_counts(rre, rte):
 
 def main():
     a = parse()
-    # one process per GPU: N ranks share the host's cores.  Every rank runs numpy draws, the ICP's stop-test polling and torch's
-    # intra-op pool; left alone each would start one thread per core (8 x 256 threads on an 8-GPU node).  Pin the pools before
-    # torch / numpy create them (the CPU-baseline leg, world 1 only, keeps all cores).
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     host_threads = os.cpu_count() or 1
     if world_env > 1:
-        host_threads = max(1, min(8, host_threads // world_env))
+        host_threads = HOST_PIN["threads"] if HOST_PIN else max(1, min(8, host_threads // world_env))
         for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
             os.environ.setdefault(var, str(host_threads))
     import torch
@@ -107,20 +148,26 @@ def main():
 
     import umeregrobust_amd
     from umeregrobust_amd import evaluate, ops
-    from umeregrobust_amd.dist import init_distributed
+    from umeregrobust_amd.dist import LaunchError, check_launch, device_for_rank, init_distributed
     from umeregrobust_amd.synth import CONFIGS, synth_pair, synth_pair_hard
     from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
 
     ops.DEFAULT_MATCH_PRECISION = a.precision
-    if a.force_device is not None:
-        os.environ["LOCAL_RANK"] = str(a.force_device)
-    rank, local_rank, world = init_distributed(backend=a.dist_backend, force=a.force_dist)
-    collective = world > 1 or a.force_dist
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    # everything that can be wrong about the launch is checked BEFORE the rendezvous, by every rank alike: a mis-launched job
+    # ends with one line per rank instead of hanging in init_process_group
+    try:
+        rank, local_rank, world = check_launch(expected_world=a.gpus)
+        if not torch.cuda.is_available():
+            raise LaunchError("bench.py needs a HIP device (no CPU fallback)")
+        dev_index = device_for_rank(local_rank, torch.cuda.device_count(), a.force_device)
+    except LaunchError as e:
+        sys.exit(f"bench.py: {e}")
     umeregrobust_amd.require_native()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    rank, local_rank, world = init_distributed(backend=a.dist_backend, device_index=dev_index, force=a.force_dist)
+    collective = world > 1 or a.force_dist
+    local_rank = dev_index                      # (everything below addresses the bound device)
+    dev = torch.device("cuda", dev_index)
 
     cfg = CONFIGS[a.config]
     args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path(
@@ -139,9 +186,10 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------
     # the pool and every pair's RNG seed depend on the pair's GLOBAL index g = rank + world * i only, so the integer
     # results of an N-GPU run equal those of a 1-GPU run over the same number of pairs
+    graph_mode = a.graph_mode if a.graphs else "none"
     pool = []
-    for i in range(max(1, a.pool)):
-        e = resident(synth_pair(seed=i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))
+    for p_host in synth_many(range(max(1, a.pool)), dict(N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]), host_threads):
+        e = resident(p_host)
         e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
             if a.batch_clouds else None
         pool.append(e)
@@ -160,10 +208,15 @@ def main():
         sp_, mk_ = a.match_tuning.split(",") if a.match_tuning else ("0", "-1")
         match_opts = ops.MatchOpts(variant=1 if a.match_pform else 0, splits=int(sp_), share_mask=int(mk_, 0))
     depth = max(1, a.depth)
-    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=a.graphs,
+    pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw,
+                                         use_graphs=False if graph_mode == "none" else graph_mode,
                                          stream_plan=a.stream_plan, match_opts=match_opts)
     # hypotheses, ok(1.5deg,0.6m), ok(1.5deg,0.3m), ok(1deg,0.1m): integer atomics, one tensor per stream slot
     counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]
+    scratch_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]   # (the resident-replay leg's; not reported)
+
+    def leg_counts(slot):
+        return counts[slot] if leg.pipe is pipe else scratch_counts[slot]
     # per-kernel HIP-event samples: `timing` from pairs that run ALONE (the kernel's own duration: what `roofline` prices),
     # `timing_situ` from pairs inside the pipeline (what a profiler of this command sees: kernels of 4 pairs share the chip)
     timing = {"moments": [], "dist": ops.TimingList()}
@@ -172,19 +225,22 @@ def main():
     n_local = (a.warmup + a.steps) * P
     rngs = [np.random.RandomState(1234 + rank + world * i) for i in range(n_local)]   # pair g draws from RandomState(1234 + g)
 
+    leg = SimpleNamespace(pipe=pipe, pool=pool)      # (the resident-replay leg below swaps in its own pipeline and pool)
+
     def submit(i, tm=None):
+        pipe, pool = leg.pipe, leg.pool
         e = pool[(rank + world * i) % len(pool)]
         h = pipe.submit(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, src_inds=e.src_inds, tgt_inds=e.tgt_inds,
-                        timing=tm, pair=e.pair, rng=rngs[i])
+                        timing=tm, pair=e.pair, rng=rngs[i % len(rngs)])
         h.entry = e
         if tm is timing:
             mom_bytes_log.extend(e.mom_bytes)
         return h
 
     def finish(h):
-        out = pipe.finish(h, order_caller=False)                # host RNG draw + SE(3) hypotheses (consumed on the pair's own stream below)
-        with torch.cuda.stream(pipe.stream_of(h)):              # a7 + recall gates, on the device
-            ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, counts[h.slot])
+        out = leg.pipe.finish(h, order_caller=False)            # host RNG draw + SE(3) hypotheses (consumed on the pair's own stream below)
+        with torch.cuda.stream(leg.pipe.stream_of(h)):          # a7 + recall gates, on the device
+            ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, leg_counts(h.slot))
 
     def run(first, n, record):
         pending = []
@@ -230,6 +286,29 @@ def main():
         elapsed = float(tmax.item())
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # the path's one collective (32 B)
 
+    # ---- the same leg the way rounds 2-3 measured it: 'pair'-mode graphs replayed in place over 4 RESIDENT pairs (a caller that
+    # cycles through double-buffered inputs).  Untimed by the driver's clock contract (`value` above is the distinct-pairs leg);
+    # reported as config.resident_replay so that both modes are on record from the same box and run. ----
+    resident_replay = None
+    if a.resident_steps > 0 and graph_mode == "slot" and all(e.pair is not None for e in pool):
+        leg.pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs="pair",
+                                                 stream_plan=a.stream_plan, match_opts=match_opts)
+        leg.pool = pool[:4]
+        run(0, 2 * P, False)
+        fence()
+        t1 = time.perf_counter()
+        run(2 * P, a.resident_steps * P, False)
+        fence()
+        el_r = time.perf_counter() - t1
+        if collective:
+            tmax = torch.tensor([el_r], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el_r = float(tmax.item())
+        resident_replay = {"pairs_per_s": round(a.resident_steps * P * world / el_r, 1), "steps": a.resident_steps, "resident_pairs": len(leg.pool),
+                           "note": "phase A as one hipGraph per (slot, resident PairBatch), replayed in place: no input copies, the same four "
+                                   "pairs' tables stay in L2 / MALL (how rounds 2-3 measured `value`)"}
+        leg.pipe, leg.pool = pipe, pool
+
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     def situ(lst):
         v = [s.elapsed_time(e_) for s, e_ in lst]
@@ -240,19 +319,25 @@ def main():
     mom_total_ms, dist_total_ms = float(np.sum(mom_ms)), float(np.sum(dist_ms))
     mom_gbs = float(np.sum(mom_bytes_log)) / (mom_total_ms * 1e-3) / 1e9
     dist_tfs = dist_flops * len(dist_ms) / (dist_total_ms * 1e-3) / 1e12
-    roof_mom = {"kernel": "ume_moments_kernel", "bound": "hbm", "achieved": round(mom_gbs, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+    # The moment kernel's bound is VALU issue, not HBM: its gathers come out of L2 (hit rate 0.97, fabric traffic 5 % of the
+    # algorithmic bytes), its SIMDs issue VALU instructions 80 % of the time -- 16 fp64 FMA/ADD per lane and neighbour slot.  So the
+    # fraction quoted is fp64 flops against the fp64 vector peak; SURVEY 8(d)'s bytes figure stays as a labelled extra (against the
+    # HBM peak it exceeds 1 -- the bytes never reach HBM -- and is therefore NOT reported as `frac`).
+    mom_flops_log = [b_ / 140.0 * 224.0 for b_ in mom_bytes_log]          # ~ neighbours x 32 channels x (1 add + 3 FMA); 524 B/keypoint ignored
+    mom_tfs = float(np.sum(mom_flops_log)) / (mom_total_ms * 1e-3) / 1e12
+    roof_mom = {"kernel": "ume_moments_kernel", "bound": "valu", "achieved": round(mom_tfs, 2), "peak": VALU_F64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(mom_tfs / VALU_F64_PEAK_TFLOPS, 4), "traffic": None,
                 "l2_frac": round(mom_gbs / L2_PEAK_GBS, 4),
+                "survey_8d_algorithmic_gb_per_s": round(mom_gbs, 1), "survey_8d_over_hbm_peak": round(mom_gbs / HBM_PEAK_GBS, 4),
                 "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
                 "in_situ_avg_launch_ms": situ(timing_situ["moments"]),
                 "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0),
-                "note": "algorithmic bytes = SURVEY 8(d) per-keypoint figure (140 n_i + 524) summed over both clouds of a pair. "
-                        "They are neighbour gathers from 8 MB tables that L2 / Infinity Cache serve (`traffic` = fabric bytes is "
-                        "~5 % of them), so `frac` against the HBM peak can exceed 1 and is NOT a utilisation; the rate that "
-                        "actually bounds the gathers is the aggregate L2 -> CU bandwidth: `l2_frac` = achieved / 34.5 TB/s.  What the "
-                        "kernel is closest to is neither: `valu_busy_frac` (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles) ~0.8 -- the fp64 "
-                        "accumulation (16 DFMA/DADD + 7 conversions per lane and neighbour slot) that buys the order-independent, "
-                        "3e-7-of-fp64 result"}
+                "algorithmic_fp64_flops_per_launch": round(float(np.mean(mom_flops_log)), 0),
+                "note": "achieved = fp64 flops of the moment sums (neighbours x 32 channels x 7: one add for sum f, three FMAs for "
+                        "sum f p^T) / kernel time; peak = fp64 vector rate (64 lanes x 2 flop / 4 cycles x 1 024 SIMDs x 2.4 GHz). "
+                        "`survey_8d_*`: SURVEY 8(d)'s algorithmic bytes (140 n_i + 524 per keypoint) / time -- gathers from 8 MB tables "
+                        "that L2 serves, so the ratio to the HBM peak can exceed 1 and is not a utilisation; `l2_frac` = the same rate "
+                        "over the 34.5 TB/s aggregate L2 -> CU bandwidth"}
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
@@ -311,7 +396,8 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "world": {"ranks": world, "backend": (dist.get_backend() if collective else None), "device": torch.cuda.get_device_name(dev),
-                  "devices_visible": torch.cuda.device_count(), "host_threads_per_rank": host_threads,
+                  "devices_visible": torch.cuda.device_count(), "device_index_rank0": dev_index, "host_threads_per_rank": host_threads,
+                  "host_cpus_rank0": (HOST_PIN or {}).get("cpus"), "gpu_numa_node_rank0": (HOST_PIN or {}).get("numa_node"),
                   "note": "one process per GPU; the named path has no data-path collective, the counters below are summed with one "
                           "all-reduce (RCCL over xGMI when backend = nccl)"},
         "config": {"workload": f"{a.config}: named hot path a1-a7 on synthetic KITTI-shaped pairs "
@@ -320,7 +406,12 @@ def main():
                    "pairs_per_step_per_gpu": P, "ms_per_pair": round(1e3 * elapsed / (a.steps * P), 4),
                    "sharding": f"pairs[rank::{world}] (no data-path collective)",
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
-                   "pairs_in_flight": depth, "phase_a_as_hipgraph": bool(a.graphs),
+                   "pairs_in_flight": depth, "phase_a_as_hipgraph": graph_mode,
+                   "distinct_pairs_in_the_pool": len(pool),
+                   "value_is": ("named path a1-a7, pairs/s, over a stream of DISTINCT resident pairs (each copied device to device into its "
+                                "pipeline slot's staging buffers, 14 MB, then one graph replay): what a loop like evaluate.py:175 gets"
+                                if graph_mode == "slot" else f"named path a1-a7, pairs/s, graph mode '{graph_mode}'"),
+                   "resident_replay": resident_replay,
                    "roofline_sampling": "one pair per step runs alone (pipeline drained before and after, inside the timed region): "
                                         "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per step "
                                         "timed inside the pipeline, beside the kernels of the other pairs in flight", "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
@@ -547,6 +638,23 @@ def main():
         # KT pair, scaled to the M hypotheses of a pair -- the CPU figure next to end_to_end.stage_ms
         result["cpu_baseline"]["f1_selection"] = cpu_f1_leg(orc, pool[0], args, cfg)
         result["cpu_baseline"]["rr_check"] = rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard)
+    # the numbers a user of evaluate.py feels, where the driver's parser keeps them (it drops unknown top-level keys)
+    e2e, e2h = result.get("end_to_end"), result.get("end_to_end_hard")
+    f1s = result.get("f1_selection") or {}
+    result["config"]["end_to_end_pairs_per_s"] = {
+        "plain_pair_by_pair": e2e and e2e["pairs_per_s"], "plain_evaluate_pairs": e2e and e2e.get("evaluate_pairs_loop", {}).get("pairs_per_s"),
+        "plain_side_by_side": e2e and e2e.get("side_by_side", {}).get("pairs_per_s"),
+        "hard_pair_by_pair": e2h and e2h["pairs_per_s"], "hard_side_by_side": e2h and e2h.get("side_by_side", {}).get("pairs_per_s"),
+        "f1_ms_plain": f1s.get("plain", {}).get("stage_ms", {}).get("total"), "f1_ms_hard": f1s.get("hard", {}).get("stage_ms", {}).get("total"),
+        "what": "a1-a7 + raw-cloud prep + f1 hypothesis selection + f2 ICP per pair (evaluate.py:195-309), whole job"}
+    # the dominant kernel of a REGISTRATION (not of the named path): the consensus pass of f1
+    cons = (f1s.get("plain") or {}).get("rooflines", {})
+    for k_, v_ in cons.items():
+        result["rooflines"][k_] = v_
+    rr = (result.get("cpu_baseline") or {}).get("rr_check")
+    if rr:
+        result["cpu_baseline"]["rr_pairs"] = rr["pairs"]
+        result["cpu_baseline"]["rr_pairs_with_a_different_gate_outcome"] = len(rr["pairs_with_a_different_gate_outcome_same_draws"])
     if rank == 0:
         print(json.dumps(result), flush=True)
     if collective:
@@ -615,6 +723,19 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
             res["kernels"][k] = dict(v, bound="valu_issue", peak_valu_ginst_per_s=round(VALU_ISSUE_PEAK_GINST, 1),
                                      counters_source="profiles/f1_sq_summary.json (rocprofv3 --pmc SQ passes of tools/exp_f1_prod.py, "
                                                      "an earlier run of the same kernels; tools/f1_pmc.sh)")
+        # the dominant kernel of a registration, priced against its bound -- VALU issue: wave64 VALU instructions (tracked counter pass
+        # of the same kernel on the same pair) / (live duration of the consensus stage x 1 024 SIMDs x 2.4 GHz / 4 cycles)
+        c2 = tracked.get("corr_consensus2_kernel")
+        if c2 and stages.get("consensus_pass"):
+            ginst = float(c2["sq_insts_valu"]) / (stages["consensus_pass"] * 1e-3) / 1e9
+            res["rooflines"] = {"corr_consensus2_kernel": {
+                "kernel": "corr_consensus2_kernel", "bound": "valu_issue", "achieved": round(ginst, 1), "peak": round(VALU_ISSUE_PEAK_GINST, 1),
+                "unit": "Ginst/s (wave64 VALU)", "frac": round(ginst / VALU_ISSUE_PEAK_GINST, 4), "traffic": None,
+                "avg_launch_ms": stages["consensus_pass"], "valu_instructions_per_launch": float(c2["sq_insts_valu"]),
+                "valu_busy_frac": c2.get("valu_busy_frac"), "avg_waves_per_simd": c2.get("avg_waves_per_simd"),
+                "note": f"{which} KT pair ({M} hypotheses x {Ns} points); duration live (HIP events inside the native call), instruction "
+                        "count from profiles/f1_sq_summary.json (rocprofv3 --pmc pass of the same kernel on the same pair); the kernel "
+                        "touches HBM for 2 M vector-memory instructions against 6e8 VALU: there is no memory roofline to quote"}}
     return res
 
 
@@ -656,11 +777,11 @@ def cpu_f1_leg(orc, e, args, cfg, n_hyp=8):
                                                f"(oracle pc_corr_cost, C/OpenMP), scaled to M={cfg['M']}"}
 
 
-def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M=256, budget_s=20.0):
+def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M=256):
     """Registration recall of the WHOLE pipeline (a1-a7 + raw prep + f1 + f2) on hard pairs at reduced size: the CPU oracle
     (a restatement of the reference's loop iteration, evaluate.py:195-309) vs this library with the oracle's five host draws per
-    pair REPLAYED, so the comparison is pair by pair.  Bounded by `budget_s` of CPU time; the long form (128 pairs at this size and
-    8 at KITTI size) is tools/rr_replay.py -> profiles/r03/rr_replay.json."""
+    pair REPLAYED, so the comparison is pair by pair.  --cpu-rr-pairs pairs (default 128: recall known to +-7 %), bounded by
+    --cpu-rr-budget seconds of CPU time; KITTI-size and nuScenes-size pairs: tools/rr_replay.py -> profiles/r0N/rr_replay.json."""
     small = SimpleNamespace(**vars(args))
     small.ume_n_samples = M
     small.pc_corr_max_size = N
@@ -668,7 +789,7 @@ def rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard, N=4096, M
     rows = []
     t_cpu = 0.0
     for i in range(a.cpu_rr_pairs):
-        if t_cpu > budget_s:
+        if t_cpu > a.cpu_rr_budget:
             break
         p = synth_pair_hard(seed=20000 + i, N=N, n_kp=N, kind=a.kind, voxel=0.3, **RR_CHECK_HARD)
         rec = Recorder(np.random.RandomState(31 + i))

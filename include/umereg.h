@@ -258,6 +258,12 @@ int umereg_pair_match_graph_launch(void* graph, void* stream);
 /* Replay + the device -> host copy of the match probabilities (the operand of the host draw, evaluate.py:238; prob_host:
  * pinned host memory, n_kp floats, or NULL) in one call. */
 int umereg_pair_match_graph_launch_ex(void* graph, float* prob_host, void* stream);
+/* Replay for ANOTHER pair of the same shape -- the loop of evaluate.py:175 runs over distinct pairs: pts [2,N,3], feat [2,N,32],
+ * kp_index [2,n_kp] of the new pair (device pointers) are first copied device to device into the buffers the graph was captured
+ * over (which must therefore be the caller's to overwrite: a pipeline slot's persistent staging buffers), then the graph is
+ * replayed and the probabilities downloaded as in _launch_ex.  NULL, or the captured pointer itself, skips that copy. */
+int umereg_pair_match_graph_launch_from(void* graph, const float* pts, const float* feat, const int64_t* kp_index,
+                                        float* prob_host, void* stream);
 /* The continuation after the host draw (evaluate.py:238-254): upload the kept match indices (cond_host int64 [n_cond], pinned
  * host memory; NULL = every match) and solve one SE(3) per kept match from the graph's own outputs:
  * T_out[k] from (F_src[cond[k]], F_tgt[match[cond[k]]]).  cond_dev int64 [n_cond], T_out f32 [n_cond,4,4]: device buffers. */
@@ -410,8 +416,8 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
 #define UMEREG_CORR_LEFT_LATTICE (1 << 17) /* ... to the candidate lattice whatever its size (by default the count decides) */
 #define UMEREG_CORR_CELL_PASS (1 << 19)    /* the cell pass (leftovers sorted by lattice cell, one wavefront per cell) also on jobs below 2^25 queries (tests, tuning) */
 #define UMEREG_CORR_NO_CELL_PASS (1 << 20) /* never (the round-3-start path: list kernel + one wavefront per query) */
-#define UMEREG_CORR_BOUND_OUTSIDE (1 << 21) /* arg-max mode: a listed query whose image lies outside the candidate lattice (>= 20 % of the target's extent away from its
-                                               bounding box) is BOUNDED (K w(dist to the box) |vp| max|vq|) instead of searched; hypotheses whose score + bound reaches the best
+#define UMEREG_CORR_BOUND_OUTSIDE (1 << 21) /* arg-max mode: a listed query whose image lies outside the candidate lattice (beyond its margin around the target's bounding
+                                               box: max(20 % of the x/y extent, 3 m) in x / y, max(6 %, 3 m) in z) is BOUNDED by its distance dB to that box (K w(dist to the box) |vp| max|vq|) instead of searched; hypotheses whose score + bound reaches the best
                                                score - bound get those queries computed exactly in a second pass.  scores[h] is then exact for every hypothesis that can be the
                                                arg-max; for the others it lacks the bounded terms (it is within the bound of the exact score, and the exact score is below the
                                                arg-max's): umereg_corr_select_best_f32 returns the same hypothesis */
@@ -433,7 +439,8 @@ int umereg_corr_scores_profile_f32(const float* src_pts, const float* tgt_pts, c
                                    float* stage_ms_host);
 
 /* FeatureCorrelator's pick (utils/loc_utils.py:676-680: argsort by score, the n_hypotheses best, the best of those =
- * the arg-max): T_best f32 [4,4] = T[argmax scores] (lowest index among equal scores; a NaN score never wins),
+ * the arg-max): T_best f32 [4,4] = T[argmax scores] (lowest index among equal scores; a NaN score wins, the lowest-indexed one --
+ * torch.argsort(descending=True) and torch.argmax order NaN above every number, so the reference picks a NaN-scored hypothesis too),
  * best_index int64 [1] (optional).  Everything stays on the device: no host read of the index. */
 int umereg_corr_select_best_f32(const float* scores, const float* T, int M, float* T_best, int64_t* best_index, void* stream);
 

@@ -196,6 +196,28 @@ def gen_g9(loc_utils, evaluate):
     print("G9 hungarian: twins matched", twins, "| kept", out["cond"].shape, "| T", out["T_filt"].shape, out["T_all"].shape)
 
 
+def gen_g11(loc_utils):
+    """G11: the reference's own `ume_kp_layer.forward` (utils/loc_utils.py:380-431; dead code in the reference's pipeline, a
+    kept type of the API surface) on the clouds of G6: diag_only=True on 64 keypoints, diag_only=False on 8, and the n_rand
+    triplet form (host numpy RNG, seeded) -- T, D and the squeezed UME matrices it returns."""
+    g = np.load(os.path.join(OUT, "g6_pair_k1.npz"))
+    src, tgt, sf, tf = (_t(g[k])[None] for k in ("src_pts", "tgt_pts", "src_feat", "tgt_feat"))
+    kp_s = _t(g["src_pts"][g["src_inds"][:64]])[None]
+    kp_t = _t(g["tgt_pts"][g["tgt_inds"][:64]])[None]
+    out = dict(n_diag=np.int64(64), n_full=np.int64(8), n_rand=np.int64(16), rand_seed=np.int64(11))
+    with torch.no_grad():
+        T, D, G, H = loc_utils.ume_kp_layer(750, 5, diag_only=True)(src, sf, kp_s, tgt, tf, kp_t)
+        out.update(T_diag=T.numpy(), D_diag=D.numpy(), G_diag=G.numpy(), H_diag=H.numpy())
+        T, D, G, H = loc_utils.ume_kp_layer(750, 5, diag_only=False)(src, sf, kp_s[:, :8], tgt, tf, kp_t[:, :8])
+        out.update(T_full=T.numpy(), D_full=D.numpy(), G_full=G.numpy(), H_full=H.numpy())
+        np.random.seed(11)
+        T, D, _, _ = loc_utils.ume_kp_layer(750, 5, diag_only=True, n_rand=16)(src, sf, kp_s, tgt, tf, kp_t)
+        out.update(T_rand=T.numpy(), D_rand=D.numpy())
+    np.savez_compressed(os.path.join(OUT, "g11_ume_kp_layer.npz"), **out)
+    err = np.abs(out["T_diag"][0] - g["gt_tform"]).max(axis=(1, 2))
+    print("G11 ume_kp_layer:", {k: v.shape for k, v in out.items() if getattr(v, "ndim", 0) > 0}, "max |T_diag - gt|", float(err.max()))
+
+
 def gen_g10():
     """G10: the reference's own `batch_collate_fn_dset` (datasets/kitti/kitti_dataset.py:546-616) on three seeded items
     of different sizes, batch of 3 with dilution (max_pc_size below every cloud) and a batch of 1 without."""
@@ -229,6 +251,10 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g10":
         import_reference()
         gen_g10()
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g11":
+        loc_utils, eval_utils, evaluate = import_reference()
+        gen_g11(loc_utils)
         return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
         loc_utils, eval_utils, evaluate = import_reference()
@@ -390,7 +416,8 @@ def main():
 
     gen_g8(loc_utils, eval_utils)
     gen_g9(loc_utils, evaluate)
-    gen_g10()                       # (the default run rebuilds EVERY fixture; `--only g9|g10`, `g8` rebuild one)
+    gen_g10()                       # (the default run rebuilds EVERY fixture; `--only g9|g10|g11`, `g8` rebuild one)
+    gen_g11(loc_utils)              # (reads the G6 fixture written above)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

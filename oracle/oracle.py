@@ -272,6 +272,36 @@ def batch_estimate_transform_ume_old(G, H, with_dist=True):
 
 
 # ---------------------------------------------------------------------------------------------
+# a8  utils/loc_utils.py:357-431  ume_kp_layer.forward (dead in the reference's pipeline; a kept type)
+# ---------------------------------------------------------------------------------------------
+def ume_kp_layer_forward(source_points, source_features, source_kp, target_points, target_features, target_kp,
+                         ume_knn, ume_desc_rad, diag_only=False, triplets=None):
+    """[bs,N,3], [bs,N,d], [bs,n_kp,3] x 2 -> (T, D, G_kp.squeeze(), H_kp.squeeze()) as the reference returns them.
+    triplets int [n_rand,3]: the indices `np.random.choice(np.arange(G.shape[0]), (n_rand, 3))` drew (:411), injected."""
+    bs, n_kp = source_kp.shape[0], source_kp.shape[1]
+    # :383-393 -- ball_query + ball_query_gather (index -1 -> zero row) + ume_mat: the moment matrix of my_ume_generation
+    G_kp = my_ume_generation(source_points, source_kp, source_features, ume_knn, ume_desc_rad)[:, :, None]    # unsqueeze(2)
+    H_kp = my_ume_generation(target_points, target_kp, target_features, ume_knn, ume_desc_rad)[:, None]       # unsqueeze(1)
+    if not diag_only:
+        G, H = np.broadcast_arrays(G_kp, H_kp)                                   # :397
+    else:
+        G, H = G_kp, H_kp                                                        # :401
+    G = G.reshape(-1, *G.shape[3:])
+    H = H.reshape(-1, *H.shape[3:])
+    if triplets is not None:
+        G = G[triplets[:, 0]] + G[triplets[:, 1]] + G[triplets[:, 2]]            # :412
+        H = H[triplets[:, 0]] + H[triplets[:, 1]] + H[triplets[:, 2]]            # :413
+    T, D = batch_estimate_transform_ume_old(G, H)                                # :414
+    if not diag_only:
+        T = T.reshape(bs, n_kp, n_kp, 4, 4)                                      # :426-427
+        D = D.reshape(bs, n_kp, n_kp)
+    else:
+        T = T.reshape(bs, -1, 4, 4)                                              # :429-432
+        D = D.reshape(bs, -1)
+    return T, D, np.squeeze(G_kp), np.squeeze(H_kp)
+
+
+# ---------------------------------------------------------------------------------------------
 # a7  utils/eval_utils.py:60-76  relative_rotation_error
 # ---------------------------------------------------------------------------------------------
 def relative_rotation_error(R, R_hat):

@@ -769,7 +769,10 @@ def test_hungarian_matching_golden(gpu):
 
 def test_pipeline_with_hipgraph_equals_plain(gpu):
     """RegistrationPipeline(use_graphs=True) replays phase A (a1..a5, 12 launches) as one captured hipGraph per
-    (slot, PairBatch): same results, bit for bit, as the launches it was captured from, pair after pair."""
+    (slot, PairBatch); use_graphs="slot" as ONE graph per slot over staging buffers the slot owns, refilled device to device
+    with every submitted pair (a loop over DISTINCT pairs, reference evaluate.py:175 -- the pairs here are handed over as fresh
+    PairBatch objects every time and dropped by the caller right after the submit): same results, bit for bit, as the launches they
+    were captured from, pair after pair."""
     from types import SimpleNamespace
     from umeregrobust_amd import evaluate
     from umeregrobust_amd.synth import synth_pair
@@ -781,12 +784,15 @@ def test_pipeline_with_hipgraph_equals_plain(gpu):
         c = (t(p.src_pts), t(p.tgt_pts), t(p.src_feat), t(p.tgt_feat))
         entries.append((c, evaluate.PairBatch.from_clouds(*c, T_(p.src_inds, gpu), T_(p.tgt_inds, gpu))))
     outs = {}
-    for graphs in (False, True):
+    for graphs in (False, True, "slot"):
         pipe = evaluate.RegistrationPipeline(args, gpu, depth=2, rng=None, use_graphs=graphs)
         res, pending = [], []
         for i in range(9):                                   # every (slot, entry) combination is replayed at least once
             c, pb = entries[i % 3]
+            if graphs == "slot":                             # a fresh copy per submit, released at once: nothing may depend on it
+                pb = evaluate.PairBatch(pb.pts.clone(), pb.feat.clone(), pb.inds.clone())
             pending.append(pipe.submit(*c, pair=pb, rng=np.random.RandomState(100 + i)))
+            del pb
             if len(pending) == 2:
                 o = pipe.finish(pending.pop(0))
                 res.append((o.rtume_tform.clone(), o.match.clone(), o.match_d.clone(), np.asarray(o.cond).copy()))
@@ -795,9 +801,21 @@ def test_pipeline_with_hipgraph_equals_plain(gpu):
             res.append((o.rtume_tform.clone(), o.match.clone(), o.match_d.clone(), np.asarray(o.cond).copy()))
         torch.cuda.synchronize()
         outs[graphs] = res
-    assert len(outs[True]) == 9
-    for a_, b_ in zip(outs[False], outs[True]):
-        assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1]) and torch.equal(a_[2], b_[2]) and np.array_equal(a_[3], b_[3])
+    assert len(outs[True]) == 9 and len(outs["slot"]) == 9
+    for mode in (True, "slot"):
+        for a_, b_ in zip(outs[False], outs[mode]):
+            assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1]) and torch.equal(a_[2], b_[2]) and np.array_equal(a_[3], b_[3])
+    assert len(pipe.slot_graphs) == 2 and not pipe.graphs            # two slots, two graphs, whatever the number of pairs
+    # a pair of another shape on the same pipeline: the slot's graph is rebuilt, not replayed over stale sizes
+    p = synth_pair(31, N=4096, n_kp=1024)
+    t = lambda a: T_(a, gpu)[None]
+    c = (t(p.src_pts), t(p.tgt_pts), t(p.src_feat), t(p.tgt_feat))
+    pb = evaluate.PairBatch.from_clouds(*c, T_(p.src_inds, gpu), T_(p.tgt_inds, gpu))
+    o = pipe.finish(pipe.submit(*c, pair=pb, rng=np.random.RandomState(7)))
+    r = evaluate.register_pair(*c, args, rng=np.random.RandomState(7), src_inds=p.src_inds, tgt_inds=p.tgt_inds)
+    assert torch.equal(o.rtume_tform, r.rtume_tform) and torch.equal(o.match, r.match)
+    with pytest.raises(ValueError, match="use_graphs"):
+        evaluate.RegistrationPipeline(args, gpu, use_graphs="always")
 
 
 def test_pipeline_slot_guard_and_per_pair_rng(gpu):
@@ -884,6 +902,44 @@ def test_bench_two_ranks_equal_one_rank_over_the_same_pairs(gpu):
     for key in ("rr_1.5deg_0.6m", "rr_1.5deg_0.3m", "rr_1deg_0.1m"):
         assert e1[key] == e2[key] and e1["selected_before_icp"][key] == e2["selected_before_icp"][key]
     assert abs(e1["mRRE_deg"] - e2["mRRE_deg"]) < 1e-4 and abs(e1["mRTE_m"] - e2["mRTE_m"]) < 1e-4
+
+
+def test_bench_eight_ranks_equal_one_rank_over_the_same_pairs(gpu):
+    """First contact with an 8-GPU node, rehearsed on one GPU: `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`, every
+    rank on device 0 (--force-device 0), collectives on gloo.  K1 shape, one step of one pair per rank: the eight ranks cover the
+    global pairs 0..7 of the named path and 0..7 of the end-to-end leg, and the summed integer counts must EQUAL a 1-rank run over
+    the same eight pairs.  Every rank is pinned to its own share of the host (hostpin) before numpy / torch exist.
+    Also: `--gpus 8` started without torch.distributed.run ends at once with a message (no rendezvous, no hang)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    common = ["--config", "K1", "--warmup", "1", "--steps", "1", "--no-cpu-baseline", "--e2e-hard-pairs", "0", "--e2e-side-by-side", "0",
+              "--pool", "8"]
+    bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8"] + common, capture_output=True, text=True,
+                         timeout=300, env=env, cwd=repo)
+    assert bad.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in bad.stderr and "torch.distributed.run" in bad.stderr
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                         "127.0.0.1", "--master-port", "29651", os.path.join(repo, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
+                         "--force-device", "0", "--pairs-per-step", "1", "--e2e-pairs", "1"] + common,
+                        capture_output=True, text=True, timeout=1500, env=env, cwd=repo)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    j8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+    assert j8["n_gpus"] == 8 and j8["world"]["ranks"] == 8 and j8["world"]["backend"] == "gloo" and j8["scaling"] == "weak"
+    assert 1 <= j8["world"]["host_threads_per_rank"] <= 8 and j8["world"]["host_cpus_rank0"]
+    assert j8["config"]["sharding"].startswith("pairs[rank::8]")
+    r1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--pairs-per-step", "8", "--e2e-pairs", "8"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["hypothesis_quality"]["counts"] == j8["hypothesis_quality"]["counts"]      # 8 ranks x 1 pair == 1 rank x 8 pairs
+    e1, e8 = j1["end_to_end"], j8["end_to_end"]
+    assert e1["pairs"] == e8["pairs"] == 8
+    for key in ("rr_1.5deg_0.6m", "rr_1.5deg_0.3m", "rr_1deg_0.1m"):
+        assert e1[key] == e8[key] and e1["selected_before_icp"][key] == e8["selected_before_icp"][key]
+    assert abs(e1["mRRE_deg"] - e8["mRRE_deg"]) < 1e-4 and abs(e1["mRTE_m"] - e8["mRTE_m"]) < 1e-4
 
 
 @pytest.mark.parametrize("case", ["kitti", "lattice_ties", "sparse_far", "tiny"])
@@ -1012,21 +1068,49 @@ def test_errors_are_loud(gpu):
         ops.ume_svdvals(torch.zeros((4, 32, 3), device=gpu))
 
 
-def test_ume_kp_layer_runs(gpu):
-    """reference utils/loc_utils.py:357-431 -- dead in the reference, kept constructible and runnable."""
+def test_ume_kp_layer_vs_the_reference_forward(gpu):
+    """a8, reference utils/loc_utils.py:357-431 (dead in the reference's pipeline, a kept type of the API surface): `forward`
+    against golden G11 = the reference's OWN `ume_kp_layer.forward` on the G6 clouds (oracle/gen_golden.py gen_g11), with the
+    bars of a2 (UME matrices) and a6 (T: R <= 1e-4 on well-posed pairs, t at the reference's fp32 noise floor, never worse than
+    the reference against an fp64 evaluation; D <= 3e-3 where the bases are well conditioned)."""
     from umeregrobust_amd.utils.loc_utils import ume_kp_layer
-    g = load_golden("g6_pair_k1.npz")
+    g6, g = load_golden("g6_pair_k1.npz"), load_golden("g11_ume_kp_layer.npz")
     layer = ume_kp_layer(750, 5, diag_only=True)
     t = lambda a: T_(a, gpu)[None]
-    kp_s = t(g["src_pts"][g["src_inds"][:64]])
-    kp_t = t(g["tgt_pts"][g["tgt_inds"][:64]])
-    T, D, G, H = layer(t(g["src_pts"]), t(g["src_feat"]), kp_s, t(g["tgt_pts"]), t(g["tgt_feat"]), kp_t)
-    assert T.shape == (1, 64, 4, 4) and D.shape == (1, 64)
-    assert np.abs(N_(T[0]) - g["gt_tform"]).max(axis=(1, 2)).max() < 5e-3      # keypoints 0..255 are twins
+    kp_s = t(g6["src_pts"][g6["src_inds"][:64]])
+    kp_t = t(g6["tgt_pts"][g6["tgt_inds"][:64]])
+    args = (t(g6["src_pts"]), t(g6["src_feat"]), kp_s, t(g6["tgt_pts"]), t(g6["tgt_feat"]), kp_t)
+    T, D, G, H = layer(*args)
+    assert T.shape == (1, 64, 4, 4) and D.shape == (1, 64) and G.shape == (64, 32, 4) and H.shape == (64, 32, 4)
+    T, D, G, H = N_(T), N_(D), N_(G), N_(H)
+    scale = np.abs(g["G_diag"]).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(G - g["G_diag"]) / scale).max() < 2e-4 and (np.abs(H - g["H_diag"]) / scale).max() < 2e-4   # the a2 bar
+    dR = np.abs(T[0, :, :3, :3] - g["T_diag"][0, :, :3, :3]).max(axis=(1, 2))
+    dt = np.abs(T[0, :, :3, 3] - g["T_diag"][0, :, :3, 3]).max(axis=1)
+    assert dR.max() < 1e-4 and np.median(dt) < 1e-4 and dt.max() < 2e-3                                         # the a6 bars
+    T64 = rtume_f64(g["G_diag"], g["H_diag"])
+    e_build, e_ref = np.abs(T[0] - T64).max(axis=(1, 2)), np.abs(g["T_diag"][0] - T64).max(axis=(1, 2))
+    assert np.median(e_build) <= np.median(e_ref) + 1e-7              # closer to the fp64 evaluation than the reference itself
+    wc = well_conditioned(g["G_diag"]) & well_conditioned(g["H_diag"])
+    assert wc.mean() > 0.5 and np.abs(D - g["D_diag"])[0][wc].max() < 3e-3
+    assert np.abs(T[0] - g6["gt_tform"]).max(axis=(1, 2)).max() < 5e-3      # these keypoints are twins
+    # the full n_kp x n_kp form (:395-399)
     full = ume_kp_layer(750, 5, diag_only=False)
-    T2, D2, _, _ = full(t(g["src_pts"]), t(g["src_feat"]), kp_s[:, :8], t(g["tgt_pts"]), t(g["tgt_feat"]), kp_t[:, :8])
-    assert T2.shape == (1, 8, 8, 4, 4) and D2.shape == (1, 8, 8)
-    assert torch.allclose(T2[0, torch.arange(8), torch.arange(8)], T[0, :8], atol=1e-6)
+    T2, D2, G2, H2 = full(args[0], args[1], kp_s[:, :8], args[3], args[4], kp_t[:, :8])
+    assert T2.shape == (1, 8, 8, 4, 4) and D2.shape == (1, 8, 8) and G2.shape == (8, 32, 4)
+    T2n = N_(T2)
+    diag = np.arange(8)
+    assert np.abs(T2n[0, diag, diag] - g["T_full"][0, diag, diag]).max() < 1e-4       # matched pairs: well posed
+    assert np.median(np.abs(T2n - g["T_full"])) < 1e-4                               # mismatched ones: at the reference's noise
+    wc8 = wc[:8, None] & wc[None, :8]
+    assert np.abs(N_(D2)[0] - g["D_full"][0])[wc8].max() < 3e-3
+    assert torch.allclose(T2[0, torch.arange(8), torch.arange(8)], torch.from_numpy(T[0, :8]).to(gpu), atol=1e-6)
+    # the n_rand triplet form (:409-413): the draw comes from the host numpy RNG, like the reference's
+    np.random.seed(int(g["rand_seed"]))
+    T3, D3, _, _ = ume_kp_layer(750, 5, diag_only=True, n_rand=int(g["n_rand"]))(*args)
+    assert T3.shape == (1, 16, 4, 4) and D3.shape == (1, 16)
+    assert np.abs(N_(T3)[0, :, :3, :3] - g["T_rand"][0, :, :3, :3]).max() < 1e-4
+    assert np.median(np.abs(N_(T3) - g["T_rand"])) < 1e-4
 
 
 def test_hypothesis_gates(gpu):
@@ -1622,6 +1706,40 @@ def test_corr_scores_bound_outside_keeps_the_arg_max(gpu):
     assert int(got.argmax()) == am and abs(float(got[am] - ref[am])) <= 2e-6 * abs(float(ref[am])) + 1e-7
     want = orc.pc_corr_cost(Ts[am:am + 1, :3, :3], Ts[am:am + 1, :3, 3], src2, tgt, 20, sf, tf, 1.5)
     assert abs(float(got[am]) - float(want[0])) <= 2e-4 * abs(float(want[0])) + 1e-6
+
+
+def test_corr_bound_saturates_and_nan_scores_win_like_torch(gpu):
+    """Two degenerate-input behaviours of the arg-max mode (advisor, round 3):
+    (1) a NaN target feature row makes every outside query's bound infinite.  The saturation is a STICKY bit: any number of such
+        queries (here thousands per hypothesis -- an added constant wrapped to zero at the fourth) leaves the hypothesis marked
+        "needs its queries", so nothing is ever scored from a partial sum that claims to be exact: header word 40 (recomputed
+        hypotheses) equals word 41 (hypotheses with bounded queries), and the scores equal the exact run's;
+    (2) `umereg_corr_select_best_f32` orders a NaN score ABOVE every number, lowest index first -- what torch.argsort(descending) +
+        torch.argmax (utils/loc_utils.py:676-680) do, checked against torch on the same scores."""
+    from umeregrobust_amd import ops
+    src, tgt, sf, tf, Ts = _garbage_hypotheses_case(seed=23)
+    Ts[::3, 0, 3] += 150.0
+    tf = tf.copy(); tf[7] = np.nan                                # one NaN feature row in the target: vq_max is poisoned
+    a_ = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    base = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS
+    ref = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base)
+    got, _, hdr = ops.corr_scores_profile(*a_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE)
+    assert int(hdr[41]) >= len(Ts) // 3 and int(hdr[40]) == int(hdr[41]), (int(hdr[40]), int(hdr[41]))
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert float((got[fin] - ref[fin]).abs().max()) <= 2e-6 * float(ref[fin].abs().max()) + 1e-7
+    # (2) NaN ordering
+    rng = np.random.RandomState(3)
+    sc = rng.standard_normal(5000).astype(np.float32)
+    T = T_(rng.standard_normal((5000, 4, 4)).astype(np.float32), gpu)
+    for nan_at in ((), (4000, 77, 1300), (0,), (4999,)):
+        s_ = sc.copy(); s_[list(nan_at)] = np.nan
+        st = torch.from_numpy(s_)
+        order = torch.argsort(st, descending=True)                                    # the reference's statements, on the CPU
+        want = int(order[:10][torch.argmax(st[order[:10]])])
+        Tb, ib = ops.corr_select_best(T_(s_, gpu), T)
+        assert int(ib) == want == (min(nan_at) if nan_at else int(np.argmax(sc))), (nan_at, int(ib), want)
+        assert torch.equal(Tb, T[want])
 
 
 def test_feature_correlator_on_a_big_job_picks_the_exact_arg_max(gpu):

@@ -3,6 +3,7 @@ synthetic generator contract, metric accumulation and the 2-rank (gloo) shard + 
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -150,7 +151,7 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_shard_and_allreduce_gloo(world, tmp_path):
     """N > 1 path on CPU: pairs[rank::world] + the one all-reduce reproduce the single-process metrics exactly."""
     script = tmp_path / "worker.py"
@@ -189,3 +190,62 @@ def test_host_draws_from_concurrent_threads():
     for s in range(4):
         for u, w in got[s]:
             assert np.array_equal(u, want[s][0]) and np.array_equal(w, want[s][1])
+
+
+# ---------------------------------------------------------------------------------------- first contact with N GPUs
+def test_launch_checks_fail_before_the_rendezvous(monkeypatch):
+    """A mis-launched job must end with a message, not hang in init_process_group: WORLD_SIZE != --gpus, a rank without a
+    device, an inconsistent environment -- all raised before anything blocks, by every rank alike."""
+    from umeregrobust_amd.dist import LaunchError, check_launch, device_for_rank
+    monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    assert check_launch(expected_world=1) == (0, 0, 1)
+    with pytest.raises(LaunchError, match=r"--gpus 8 but WORLD_SIZE=1.*torch\.distributed\.run"):
+        check_launch(expected_world=8)
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "9")
+    with pytest.raises(LaunchError, match="inconsistent launch environment"):
+        check_launch(expected_world=8)
+    # device binding: LOCAL_RANK is the device index, every rank sees every device (no HIP_VISIBLE_DEVICES per rank)
+    assert [device_for_rank(r, 8) for r in range(8)] == list(range(8))
+    assert [device_for_rank(r, 1, force_device=0) for r in range(8)] == [0] * 8       # the 1-GPU test configuration
+    with pytest.raises(LaunchError, match="needs device 5 but only 4"):
+        device_for_rank(5, 4)
+    with pytest.raises(LaunchError, match="no HIP device"):
+        device_for_rank(0, 0)
+
+
+def test_rendezvous_times_out_with_a_clear_error(tmp_path):
+    """A rank that never arrives: the others fail after the configured timeout (UMEREG_DIST_TIMEOUT_S) with the address, the
+    backend and the rank in the message -- not after torch's default half hour."""
+    script = tmp_path / "lonely.py"
+    script.write_text("import os, sys\nsys.path.insert(0, os.environ['UMEREG_REPO'])\n"
+                      "from umeregrobust_amd.dist import init_distributed, LaunchError\n"
+                      "try:\n    init_distributed(backend='gloo')\nexcept LaunchError as e:\n    print('LAUNCH_ERROR', e)\n")
+    env = dict(os.environ, UMEREG_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0",
+               UMEREG_DIST_TIMEOUT_S="3")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert "LAUNCH_ERROR rank 0/2" in out.stdout and "127.0.0.1:29677" in out.stdout and "gloo" in out.stdout, out.stdout + out.stderr[-1500:]
+    assert time.time() - t0 < 60
+
+
+def test_host_cores_follow_the_gpus_numa_node():
+    """Every rank gets a disjoint share (<= 8 cores) of the NUMA node its GPU hangs off; unknown topology falls back to an
+    even split; importing the helper pulls in neither torch nor numpy (it runs before their thread pools exist)."""
+    from umeregrobust_amd.hostpin import cpus_for_rank, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    node_cpus = {0: parse_cpulist("0-63,128-191"), 1: parse_cpulist("64-127,192-255")}       # a two-socket MI355X host
+    gpus = [0, 0, 0, 0, 1, 1, 1, 1]
+    shares = [cpus_for_rank(r, 8, gpus, node_cpus) for r in range(8)]
+    assert all(len(s_) == 8 for s_ in shares) and len({c for s_ in shares for c in s_}) == 64          # disjoint
+    for r, s_ in enumerate(shares):
+        assert set(s_) <= set(node_cpus[gpus[r]])                                                     # on the GPU's own node
+    flat = [cpus_for_rank(r, 8, None, {0: list(range(16))}) for r in range(8)]                         # topology unknown
+    assert flat == [[2 * r, 2 * r + 1] for r in range(8)]
+    few = [cpus_for_rank(r, 8, [None] * 8, {0: [0, 1, 2]}, allowed=[0, 1, 2]) for r in range(8)]       # more ranks than cores
+    assert all(len(s_) == 1 for s_ in few)
+    code = ("import os, sys; os.environ.update(WORLD_SIZE='4', LOCAL_RANK='1'); sys.path.insert(0, %r); "
+            "from umeregrobust_amd.hostpin import pin_rank_from_env; r = pin_rank_from_env(); "
+            "print('PIN', r['threads'], len(os.sched_getaffinity(0)), 'torch' in sys.modules, 'numpy' in sys.modules, os.environ['OMP_NUM_THREADS'])" % REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    n = min(8, max(1, len(os.sched_getaffinity(0)) // 4))
+    assert f"PIN {n} {n} False False {n}" in out.stdout, out.stdout + out.stderr

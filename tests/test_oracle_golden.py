@@ -97,6 +97,31 @@ def test_rtume_vs_reference():
     assert np.allclose(np.linalg.det(T[62:, :3, :3].astype(np.float64)), 1.0, atol=1e-5)
 
 
+def test_ume_kp_layer_vs_reference():
+    """a8: the oracle's restatement of `ume_kp_layer.forward` against the reference's own outputs (golden G11: diag_only on 64
+    keypoints, the full n_kp x n_kp form on 8, the n_rand triplet form with the seeded host draw)."""
+    g6, g = load_golden("g6_pair_k1.npz"), load_golden("g11_ume_kp_layer.npz")
+    b = lambda a: a[None]    # noqa: E731
+    kp_s, kp_t = g6["src_pts"][g6["src_inds"][:64]], g6["tgt_pts"][g6["tgt_inds"][:64]]
+    args = (b(g6["src_pts"]), b(g6["src_feat"]), b(kp_s), b(g6["tgt_pts"]), b(g6["tgt_feat"]), b(kp_t))
+    T, D, G, H = orc.ume_kp_layer_forward(*args, 750, 5.0, diag_only=True)
+    assert T.shape == g["T_diag"].shape and D.shape == g["D_diag"].shape and G.shape == g["G_diag"].shape
+    scale = np.abs(g["G_diag"]).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(G - g["G_diag"]) / scale).max() < 2e-4 and (np.abs(H - g["H_diag"]) / scale).max() < 2e-4
+    assert np.abs(T[..., :3, :3] - g["T_diag"][..., :3, :3]).max() < 1e-4
+    assert np.median(np.abs(T[..., :3, 3] - g["T_diag"][..., :3, 3])) < 1e-4
+    wc = well_conditioned(g["G_diag"]) & well_conditioned(g["H_diag"])
+    assert np.abs(D - g["D_diag"])[0][wc].max() < 3e-3
+    sub = tuple(a[:, :8] if i in (2, 5) else a for i, a in enumerate(args))
+    T2, D2, _, _ = orc.ume_kp_layer_forward(*sub, 750, 5.0, diag_only=False)
+    assert T2.shape == g["T_full"].shape == (1, 8, 8, 4, 4) and D2.shape == (1, 8, 8)
+    assert np.median(np.abs(T2 - g["T_full"])) < 1e-4
+    np.random.seed(int(g["rand_seed"]))
+    trip = np.random.choice(np.arange(64), (int(g["n_rand"]), 3))                 # utils/loc_utils.py:411
+    T3, D3, _, _ = orc.ume_kp_layer_forward(*args, 750, 5.0, diag_only=True, triplets=trip)
+    assert T3.shape == g["T_rand"].shape and np.median(np.abs(T3 - g["T_rand"])) < 1e-4
+
+
 def test_rre_vs_reference():
     g = load_golden("g5_rre.npz")
     rre = orc.relative_rotation_error(g["R"], g["R_hat"])

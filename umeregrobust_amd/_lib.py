@@ -73,6 +73,7 @@ SIGNATURES = {
     "umereg_pair_match_graph_launch": (c_int, [c_void_p, c_void_p]),
     "umereg_pair_match_graph_destroy": (c_int, [c_void_p]),
     "umereg_pair_match_graph_launch_ex": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "umereg_pair_match_graph_launch_from": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "umereg_pair_match_graph_solve": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     # per-call matcher options (umereg_match_opts*; None = defaults)
     "umereg_ume_match_q_scratch_bytes_ex": (c_size_t, [c_int, c_int, c_void_p]),

@@ -3422,7 +3422,8 @@ __global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict_
 }
 
 // ---- bounding the queries OUTSIDE the lattice (UMEREG_CORR_BOUND_OUTSIDE) ----------------------------------------------------
-// An image q outside the lattice is at least a margin away from the target's bounding box (>= 20 % of its extent): every one of its
+// An image q outside the lattice is at least a margin away from the target's bounding box (max(20 % of the x/y extent, 3 m) in x / y,
+// max(6 %, 3 m) in z; what makes the bound VALID is dB, the distance to the box, not the size of that margin): every one of its
 // neighbours is at distance >= dB = dist(q, box), so its term is at most  eps = K w(dB) |vp_n| max_j |vq_j|  in magnitude -- no search
 // needed.  Such queries are the bulk of what outlier hypotheses leave (a nuScenes-size half-overlapping pair: 30 M of 150 M queries,
 // 87 ms through one wavefront per query), and an outlier hypothesis is exactly one that cannot win.  So, with the flag:
@@ -3521,9 +3522,11 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
                     const float dB = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) * 0.9999f - 1e-5f, 0.f);
                     const float r = dB * inv_sigma * 0.9999f;
                     const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[qs_l] * vq_max * 1.0001f;
-                    // (an infinite or NaN bound -- NaN features -- saturates: the hypothesis then needs its queries whatever the scores)
-                    const unsigned long long fx = eps < 1.0e12f ? (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull : (1ull << 62);
-                    atomicAdd(&slack[h_l], fx);
+                    // (an infinite, NaN or absurdly large bound -- NaN features -- sets the sticky top bit: the hypothesis then needs its
+                    // queries whatever the scores.  Finite terms are < 2^34 each, so even 2^20 of them cannot carry into that bit, and any
+                    // number of saturated queries leaves it set -- an added 2^62 per query wrapped to 0 at the fourth.)
+                    if (eps < 1.0e3f) atomicAdd(&slack[h_l], (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull);
+                    else atomicOr(&slack[h_l], 1ull << 63);
                 }
             } else {
                 exact = outside && surv[h_l] != 0u;
@@ -3568,7 +3571,7 @@ __global__ __launch_bounds__(1024) void bound_survivors_kernel(const float* __re
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0u;
     auto margin = [&](int h, float s) {
         const unsigned long long fx = slack[h];
-        const float e = fx >= (1ull << 62) ? 3.0e38f : (float)fx * kSlackUnit / (float)Ns;
+        const float e = (fx >> 63) ? 3.0e38f : (float)fx * kSlackUnit / (float)Ns;
         return e * 1.0001f + 4e-6f * (fabsf(s) + 1.0f);                 // + what the two roundings of a sum of <= Ns + chunks terms can move it
     };
     float best = -3.0e38f;
@@ -3830,7 +3833,9 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const float* __restric
 
 // ---- FeatureCorrelator's pick (utils/loc_utils.py:676-680): the hypothesis with the highest score -------------------------
 // The reference sorts all scores, keeps the n_hypotheses best and returns the best of those: the arg-max.  One workgroup:
-// arg-max over the M scores (lowest index among equal scores; NaN scores never win unless every score is NaN, then index 0),
+// arg-max over the M scores (lowest index among equal scores; a NaN score WINS, the lowest-indexed one: torch.argsort(descending)
+// and torch.argmax both order NaN above every number, so the reference returns a NaN-scored hypothesis too -- loudly wrong input
+// stays loud),
 // and the winning 4 x 4 transform copied out -- instead of a top-k, an arg-max and an index_select launch with their sorts.
 __global__ __launch_bounds__(1024) void corr_select_best_kernel(const float* __restrict__ scores, const float* __restrict__ T, int M,
                                                                 float* __restrict__ T_best, int64_t* __restrict__ best_index)
@@ -3840,7 +3845,7 @@ __global__ __launch_bounds__(1024) void corr_select_best_kernel(const float* __r
     unsigned long long best = 0ull;
     for (int h = threadIdx.x; h < M; h += blockDim.x) {
         const float v = scores[h];
-        const unsigned int e = v == v ? enc_ord(v) : 0u;                  // NaN: below every number
+        const unsigned int e = v == v ? enc_ord(v) : 0xffffffffu;         // NaN: above every number, as torch orders it
         const unsigned long long k = ((unsigned long long)e << 32) | (unsigned int)(~(unsigned int)h);
         best = k > best ? k : best;
     }

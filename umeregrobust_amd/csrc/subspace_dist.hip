@@ -1489,6 +1489,11 @@ struct PairMatchGraph {
     const int64_t* match_idx;
     const float* prob;
     int n_kp;
+    // the input buffers the chain was captured over (umereg_pair_match_graph_launch_from refills them)
+    float* pts;                // [2, N, 3]
+    float* feat;               // [2, N, 32]
+    int64_t* kp_index;         // [2, n_kp]
+    int N;
 };
 
 UMEREG_API int umereg_pair_match_graph_create(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
@@ -1532,7 +1537,7 @@ UMEREG_API int umereg_pair_match_graph_create_ex(const float* pts, const float* 
         set_error("pair_match_graph_create: hipGraphInstantiate failed (%s)", hipGetErrorString(e_inst));
         return UMEREG_ELAUNCH;
     }
-    PairMatchGraph* h = new PairMatchGraph{g, ex, F, match_idx, prob, n_kp};
+    PairMatchGraph* h = new PairMatchGraph{g, ex, F, match_idx, prob, n_kp, (float*)pts, (float*)feat, (int64_t*)kp_index, N};
     *graph_out = h;
     return UMEREG_OK;
 }
@@ -1563,6 +1568,32 @@ UMEREG_API int umereg_pair_match_graph_launch_ex(void* graph, float* prob_host, 
         return UMEREG_ELAUNCH;
     }
     return UMEREG_OK;
+}
+
+// Replay for ANOTHER pair of the same shape (an evaluation loop over distinct pairs, reference evaluate.py:175): the new pair's
+// inputs are copied device to device into the buffers the chain was captured over (14 MB at KITTI size: ~5 us of HBM time), then
+// the graph is replayed and the probabilities are downloaded -- one call, no re-capture.  The capture buffers must be the
+// caller's to overwrite (a pipeline slot's persistent staging buffers), and as with every replay launches of one handle must not
+// overlap.  A source pointer equal to the captured one is skipped (NULL = that input is already in place).
+UMEREG_API int umereg_pair_match_graph_launch_from(void* graph, const float* pts, const float* feat, const int64_t* kp_index,
+                                                   float* prob_host, void* stream)
+{
+    UMEREG_REQUIRE(graph, "pair_match_graph_launch_from: null graph");
+    PairMatchGraph* h = (PairMatchGraph*)graph;
+    hipStream_t st = (hipStream_t)stream;
+    const struct { const void* src; void* dst; size_t bytes; } cp[3] = {
+        {pts, h->pts, (size_t)2 * h->N * 3 * sizeof(float)},
+        {feat, h->feat, (size_t)2 * h->N * UMEREG_FEAT_DIM * sizeof(float)},
+        {kp_index, h->kp_index, (size_t)2 * h->n_kp * sizeof(int64_t)}};
+    for (const auto& c : cp) {
+        if (!c.src || c.src == c.dst) continue;
+        if (hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("pair_match_graph_launch_from: hipMemcpyAsync (device to device) failed");
+            return UMEREG_ELAUNCH;
+        }
+    }
+    return umereg_pair_match_graph_launch_ex(graph, prob_host, stream);
 }
 
 // The continuation after the host draw (evaluate.py:238-254): upload the kept match indices and solve one SE(3) per kept

@@ -335,8 +335,15 @@ class RegistrationPipeline:
         # the same PairBatch objects (resident or double-buffered inputs).  The graph writes into buffers it owns, so the
         # tensors of a pair are valid until the same (slot, PairBatch) is submitted again, its rtume_tform / g_index (slot
         # buffers) until the slot's next finish(): consume or clone them before submitting `depth` more pairs.
-        self.use_graphs = use_graphs
+        # use_graphs = "slot": ONE graph per pipeline slot, captured over staging buffers the slot owns; every submitted pair of that
+        # shape is copied into them device to device (14 MB at KITTI size) and the graph replayed -- what a loop over DISTINCT pairs
+        # (reference evaluate.py:175: 1 475 of them) needs: no re-capture, no dependence on the caller keeping its tensors in place.
+        # use_graphs = True / "pair": the per-(slot, PairBatch) form above, for callers that cycle through resident PairBatch objects.
+        if use_graphs not in (False, True, "pair", "slot"):
+            raise ValueError(f"use_graphs must be False, True / 'pair' or 'slot' (got {use_graphs!r})")
+        self.use_graphs = "pair" if use_graphs is True else use_graphs
         self.graphs = {}                 # (slot, id(pair)) -> (PairMatchGraph, pair), least recently used first
+        self.slot_graphs = {}            # slot -> PairMatchGraph over the slot's own staging buffers ("slot" mode)
         self.max_graphs = 64
         self.pool = None
         if threaded_draw:
@@ -413,6 +420,24 @@ class RegistrationPipeline:
         self.graphs[key] = (graph, pair)          # the strong reference keeps id(pair) from being reused while the entry lives
         return graph
 
+    def _slot_graph(self, k, pair):
+        """"slot" mode: the slot's graph over its own staging buffers, (re)built when the shape or a baked-in parameter changes."""
+        args = self.args
+        tau = args.tau if args.filter_by_ume_dist_cond else None
+        g = self.slot_graphs.get(k)
+        if g is not None and g.pts.shape == pair.pts.shape and g.kp_index.shape == pair.inds.shape \
+                and g.matches(g.pts, g.feat, g.kp_index, args.ume_max_nn, args.ume_r_nn, tau, self.match_opts):
+            return g
+        if g is not None:
+            self.streams[k].synchronize()         # the old exec may still be running on the slot's stream
+        with torch.cuda.stream(self.streams[k]):
+            stage = (torch.empty_like(pair.pts), torch.empty_like(pair.feat), torch.empty_like(pair.inds))
+            for dst, src in zip(stage, (pair.pts, pair.feat, pair.inds)):
+                dst.copy_(src)                    # (valid inputs for the capture-time size checks; nothing runs during a capture)
+            g = ops.PairMatchGraph(*stage, args.ume_max_nn, args.ume_r_nn, tau, opts=self.match_opts)
+        self.slot_graphs[k] = g
+        return g
+
     def _retire(self, key):
         entry = self.graphs.pop(key, None)
         if entry is not None:
@@ -430,9 +455,11 @@ class RegistrationPipeline:
         # keypoint order, grid scan, softmax, RTUME -- then run beside the machine-filling kernels of the other:
         # 0.416 -> 0.36 ms per pair)
         graph = None
+        refill = False
         if self.use_graphs and pair is not None and timing is None and ops.DEFAULT_MATCH_PRECISION == "f16r" \
                 and not getattr(self.args, "hungarian_matching_flag", False):
-            graph = self._graph_for(k, pair)
+            refill = self.use_graphs == "slot" and self.pool is None and torch.cuda.current_device() == self.dev.index
+            graph = self._slot_graph(k, pair) if refill else self._graph_for(k, pair)
         if graph is not None and self.pool is None and torch.cuda.current_device() == self.dev.index:
             # graph fast path: replay + probability download in one native call on the slot's stream, no torch stream /
             # device contexts, a per-slot event (the host side of a pair is as long as its GPU side: every 10 us count)
@@ -441,7 +468,10 @@ class RegistrationPipeline:
                 hp = self.host_prob[k]
                 if hp is None or hp.numel() != graph.prob.numel():
                     hp = self.host_prob[k] = torch.empty(graph.prob.numel(), dtype=torch.float32, pin_memory=True)
-            graph.launch_ex(hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
+            if refill:
+                graph.launch_from(pair.pts, pair.feat, pair.inds, hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
+            else:
+                graph.launch_ex(hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
             ev = self.ready_ev[k]
             ev.record(st)
             a = SimpleNamespace(ume_src=graph.F[0:1], ume_tgt=graph.F[1:2], match=graph.m, match_d=graph.d, prob=graph.prob, D=None,

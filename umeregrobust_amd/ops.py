@@ -713,6 +713,19 @@ class PairMatchGraph:
         if rc:
             _lib.check(rc, "umereg_pair_match_graph_launch_ex")
 
+    def launch_from(self, pts, feat, kp_index, prob_host_ptr, stream_ptr):
+        """Replay for another pair of the same shape: its inputs (contiguous f32 / int64 device tensors) are copied device to
+        device into this graph's capture buffers, then launch_ex.  Only for graphs built over buffers of their own (a pipeline
+        slot's staging buffers): the capture buffers are overwritten."""
+        for t, mine, name in ((pts, self.pts, "pts"), (feat, self.feat, "feat"), (kp_index, self.kp_index, "kp_index")):
+            if t.shape != mine.shape or t.dtype != mine.dtype or not t.is_contiguous() or t.device != mine.device:
+                raise ValueError(f"PairMatchGraph.launch_from: {name} must be a contiguous {mine.dtype} tensor of shape {tuple(mine.shape)} "
+                                 f"on {mine.device} (got {t.dtype}, {tuple(t.shape)}, {t.device})")
+        rc = self._lib.umereg_pair_match_graph_launch_from(self.handle, pts.data_ptr(), feat.data_ptr(), kp_index.data_ptr(),
+                                                           prob_host_ptr or None, stream_ptr)
+        if rc:
+            _lib.check(rc, "umereg_pair_match_graph_launch_from")
+
     def solve(self, cond_host_ptr, n_cond, cond_dev, T_out, stream_ptr):
         """evaluate.py:238-254 after the host draw, from this graph's outputs (see umereg_pair_match_graph_solve)."""
         rc = self._lib.umereg_pair_match_graph_solve(self.handle, cond_host_ptr or None, int(n_cond), cond_dev.data_ptr() if cond_dev is not None else None,

@@ -201,7 +201,11 @@ class FeatureCorrelator:
         self.P = P
         self.corr_num_nn = corr_num_nn
         self.last_scores = None
-        self.exact_scores = False
+        self.last_best_index = None     # device int64 [1]: index of the hypothesis the last call returned
+        # True after a call whose `last_scores` are the reference's mmf_score for EVERY hypothesis; False when the last call ran in
+        # arg-max mode (big jobs, see below): the winner's score is exact, scores of ruled-out hypotheses lack their bounded terms
+        self.last_scores_exact = None
+        self.exact_scores = False       # True: never use the arg-max mode (every score exact, whatever the job size)
 
     def feature_corr_hypothesis_test(self, source_pc, target_pc, source_feat, target_feat, T_kp, src_norm=None,
                                      tgt_norm=None, timing=None):
@@ -225,6 +229,7 @@ class FeatureCorrelator:
         mmf_score = ops.corr_scores(source_pc[0], target_pc[0], wsf, wtf, T_kp, K=self.corr_num_nn, sigma=self.sigma,
                                     timing=timing, flags=flags)                             # :666-673
         self.last_scores = mmf_score
+        self.last_scores_exact = flags == 0
         # :676-680 -- argsort by score, the n_hypotheses best, the best of those: whatever n_hypotheses >= 1 is, that is the
         # arg-max.  One native launch, everything stays on the device (`T_kp[argmax]` would read the index back to the host
         # and stall it until the scores are done -- the caller can use that time, see evaluate.evaluate_pairs)
