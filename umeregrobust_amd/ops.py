@@ -222,6 +222,8 @@ def _dist_q(ume1, ume2, want_D, want_match, timing, precision="f32", opts=None):
     qb = lib.umereg_qbasis_bytes(n2, lay_b)
     op = _lib.opts_ptr(opts)
     scratch = lib.umereg_ume_match_q_scratch_bytes_ex(n1, n2, op) if refine else 8 * n1 + 256
+    if scratch == 0:
+        _lib.check(-1, "umereg_ume_match_q_scratch_bytes_ex")          # invalid options: the size query left the reason in last_error
     ws = _workspace(dev, qa + qb + scratch, "dist")
     base = ws.data_ptr()
     st = _stream_ptr(dev)
@@ -638,6 +640,8 @@ def pair_match(pts, feat, kp_index, K, radius, tau=None, opts=None):
     d = torch.empty((1, n), dtype=torch.float32, device=dev)
     prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
     op = _lib.opts_ptr(opts)
+    if lib.umereg_pair_match_workspace_bytes_ex(N, n, op) == 0:
+        _lib.check(-1, "umereg_pair_match_workspace_bytes_ex")
     ws = _workspace(dev, lib.umereg_pair_match_workspace_bytes_ex(N, n, op), "pair")
     with torch.cuda.device(dev):
         rc = lib.umereg_pair_match_ex_f32(_ptr(pts), _ptr(feat), _ptr(kp_index), N, n, int(K), float(radius),
