@@ -873,6 +873,14 @@ __device__ __forceinline__ float cauchy_weight_hw(float d2, float inv_sigma)
     const float r = __builtin_amdgcn_sqrtf(d2) * inv_sigma;
     return __builtin_amdgcn_rcpf(1.0f + r * r);
 }
+// The same weight without the square root: (|d| / sigma)^2 = d2 / sigma^2, so 1 / (1 + d2 * (1 / sigma^2)) -- one FMA and the hardware
+// reciprocal (quarter rate: 16 cycles; the square root was another 16).  Against the reference's sqrt -> divide -> square -> add ->
+// divide chain it differs by <= 3 ulp per term (2e-7 relative, like cauchy_weight_hw); used where the weight is evaluated per
+// CANDIDATE rather than per kept neighbour -- the sweeps of the consensus pass and of the cell pass (round 4).
+__device__ __forceinline__ float cauchy_weight_fast(float d2, float inv_sigma2)
+{
+    return __builtin_amdgcn_rcpf(fmaf(d2, inv_sigma2, 1.0f));
+}
 
 // ---- score epilogue ---------------------------------------------------------------------------------------------
 // sum over this wave's valid queries of  sum_{k < cnt} cauchy(d_k) <vp_n, vq_jk>  from the K kept keys of every lane.
@@ -1715,6 +1723,27 @@ __device__ __forceinline__ int cons2_bin(float d2, float lo, float sc)
     const int t = (int)fmaf(d2 - lo, sc, 1.0f);
     return min(max(t, 0), 33);
 }
+// The smallest non-negative float x with cons2_bin(x, lo, sc) >= b (b in 1..33).  cons2_bin is monotone non-decreasing in x, so
+// {bin < b} = {x < edge}: the second sweep of a histogram step classifies a candidate with ONE comparison per class instead of
+// re-evaluating the bin function (subtract, FMA, conversion, clamp) -- with the exact edge, so that the classes are the very sets
+// the first sweep counted.  The edge lies within ~4e-6 bins of lo + (b - 1) * width (the two roundings of the bin function):
+// bisection over float bit patterns inside that bracket, widened to the whole axis in the (never observed) case that it is wrong.
+__device__ __forceinline__ float cons2_edge(int b, float lo, float sc, float width)
+{
+    if (cons2_bin(0.f, lo, sc) >= b) return 0.f;
+    const float xs = fmaf((float)(b - 1), width, lo);
+    const float U = 4e-5f * width + 4.0f * 1.1920929e-7f * xs;      // (1.5e-5 bins by the analysis above, with margin; verified below)
+    unsigned int lb = __float_as_uint(fmaxf(xs - U, 0.f)), hb = __float_as_uint(xs + U);
+    if (cons2_bin(__uint_as_float(lb), lo, sc) >= b) lb = 0u;                  // (bin(0) < b was checked above)
+    if (cons2_bin(__uint_as_float(hb), lo, sc) < b) hb = 0x7f7fffffu;          // (a huge d2 is in bin 33 >= b)
+    while (hb - lb > 1u) {                                                      // invariant: bin(lb) < b <= bin(hb)
+        const unsigned int mid = lb + ((hb - lb) >> 1);
+        const bool up = cons2_bin(__uint_as_float(mid), lo, sc) >= b;
+        hb = up ? mid : hb;
+        lb = up ? lb : mid;
+    }
+    return __uint_as_float(hb);
+}
 __device__ __forceinline__ void cons2_hist_add(unsigned int* hist, int lane, int t)
 {
     atomicAdd(&hist[(t >> 2) * kWave + lane], 1u << ((t & 3) * 8));       // lane-private byte counter (ds_add_u32)
@@ -1996,10 +2025,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float inv_sigma = 1.0f / sigma;
     // weight 1 / (1 + (|d| / sigma)^2) (cauchy_kernel :588-589 on torch.linalg.norm :593): hardware square root and reciprocal,
     // each within 1 ulp of the IEEE forms the other structures use (see corr_consensus_kernel)
-    auto wgt = [&](float d2) __attribute__((always_inline)) {
-        const float r = __builtin_amdgcn_sqrtf(d2) * inv_sigma;
-        return __builtin_amdgcn_rcpf(1.0f + r * r);
-    };
+    const float inv_sigma2 = inv_sigma * inv_sigma;
+    auto wgt = [&](float d2) __attribute__((always_inline)) { return cauchy_weight_fast(d2, inv_sigma2); };
     for (int h0 = 0; h0 < M; h0 += kWave) {
         const int pos_h = h0 + lane;
         const int h = perm[pos_h < M ? pos_h : 0];
@@ -2178,59 +2205,57 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 m2 = min(m_use, (cnt2 + 3) & ~3);
             }
             int ntie = 0;
-            auto sweep2 = [&](auto zoomed_tag) __attribute__((always_inline)) {
-                constexpr bool kZoomed = decltype(zoomed_tag)::value;
-                for (int u0 = s_min; u0 < m2; u0 += 4) {
-                    f2 t01, t23;
-                    quad_d2(u0, t01, t23);
-                    const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
-                    int cls[4];                                       // 1 = below the K-th neighbour's bin, 2 = in it, 0 = beyond
+            // classes of the second sweep by comparison with the exact bin edges (cons2_edge): below the K-th neighbour's bin
+            // <=> d2 < thA, in it <=> thA <= d2 < thB.  Zoomed lanes: the second level decides inside bin b0, i.e.
+            // thA = clamp(edge1(b1), edge(b0), edge(b0 + 1)), thB = max(thA, min(edge(b0 + 1), edge1(b1 + 1))).  Lanes without a
+            // selection (b0 < 0): both 0, no candidate is in any class.
+            float thA = 0.f, thB = 0.f;
+            if (b0 >= 0) {
+                const float e0 = cons2_edge(b0, lo, sc, width), e1 = cons2_edge(b0 + 1, lo, sc, width);
+                thA = e0; thB = e1;
+                if (b1 >= 0) {
+                    const float w1 = width * (1.0f / (float)kBins);
+                    const float f0 = cons2_edge(b1, lo1, sc1, w1), f1 = cons2_edge(b1 + 1, lo1, sc1, w1);
+                    thA = fminf(fmaxf(f0, e0), e1);
+                    thB = fmaxf(thA, fminf(e1, f1));
+                }
+            }
+            for (int u0 = s_min; u0 < m2; u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
+                bool c1[4], c2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { c1[k] = d2v[k] < thA; c2[k] = !c1[k] && d2v[k] < thB; }
+                if (__any(c1[0] || c1[1] || c1[2] || c1[3])) {
+                    const f4 dt = *reinterpret_cast<const f4*>(dots + u0);
+                    const float dv[4] = {dt.x, dt.y, dt.z, dt.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = fmaf(c1[k] ? wgt(d2v[k]) : 0.f, dv[k], acc);
+                }
+                if (__any(c2[0] || c2[1] || c2[2] || c2[3])) {
+                    const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
+                    const float wv[4] = {W.x, W.y, W.z, W.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int t0 = cons2_bin(d2v[k], lo, sc);
-                        int c = t0 < b0 ? 1 : (t0 == b0 ? 2 : 0);
-                        if (kZoomed) {                                // (zoomed lanes: the second level decides inside bin b0)
-                            const int t1 = cons2_bin(d2v[k], lo1, sc1);
-                            const int c1 = t1 < b1 ? 1 : (t1 == b1 ? 2 : 0);
-                            c = (b1 >= 0 && c == 2) ? c1 : c;
-                        }
-                        cls[k] = c;
-                    }
-                    const int any_cls = cls[0] | cls[1] | cls[2] | cls[3];
-                    if (__any((any_cls & 1) != 0)) {
-                        const f4 dt = *reinterpret_cast<const f4*>(dots + u0);
-                        const float dv[4] = {dt.x, dt.y, dt.z, dt.w};
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
+                        const bool is_tie = c2[k];
+                        const bool put = is_tie && ntie < kCons2Tie;
+                        if (put) tie.set(ntie, lane, key);
+                        ntie += put ? 1 : 0;
+                        if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
+                            unsigned long long mk = 0ull;
+                            int mp = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float term = wgt(d2v[k]) * dv[k];
-                            acc += cls[k] == 1 ? term : 0.f;
-                        }
-                    }
-                    if (__any((any_cls & 2) != 0)) {
-                        const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
-                        const float wv[4] = {W.x, W.y, W.z, W.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
-                            const bool is_tie = cls[k] == 2;
-                            const bool put = is_tie && ntie < kCons2Tie;
-                            if (put) tie.set(ntie, lane, key);
-                            ntie += put ? 1 : 0;
-                            if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
-                                unsigned long long mk = 0ull;
-                                int mp = 0;
-#pragma unroll
-                                for (int e = 0; e < kCons2Tie; ++e) {
-                                    const unsigned long long ke = tie.get(e, lane);
-                                    if (ke >= mk) { mk = ke; mp = e; }
-                                }
-                                if (is_tie && !put && key < mk) tie.set(mp, lane, key);
+                            for (int e = 0; e < kCons2Tie; ++e) {
+                                const unsigned long long ke = tie.get(e, lane);
+                                if (ke >= mk) { mk = ke; mp = e; }
                             }
+                            if (is_tie && !put && key < mk) tie.set(mp, lane, key);
                         }
                     }
                 }
-            };
-            if (__any(b1 >= 0)) sweep2(std::true_type()); else sweep2(std::false_type());
+            }
             {
                 // (the bin function is monotone in d2, so every key of the K-th neighbour's bin is at or above everything the second
                 // sweep summed on the fly: the K-th distance found is the largest key kept here or one of the sure-in prefix, whose
@@ -2902,51 +2927,50 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the histogram is dead: its plane takes the keys now)
             const int need_t = K - before;
             int ntie = 0, cnt_l = 0;
-            auto sweep2 = [&](auto zoomed_tag) __attribute__((always_inline)) {
-                constexpr bool kZoomed = decltype(zoomed_tag)::value;
-                for (int u0 = 0; u0 < ((UMEREG_F1_ABLATE & 0x400000) ? 4 : m_use); u0 += 4) {
-                    f2 t01, t23;
-                    quad_d2(u0, t01, t23);
-                    const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
-                    int cls[4];                                       // 1 = below the K-th neighbour's bin, 2 = in it, 0 = beyond
+            // classes by comparison with the exact bin edges, as in the consensus pass (cons2_edge): below the K-th neighbour's bin
+            // <=> d2 < thA, in it <=> thA <= d2 < thB; zoomed lanes take the second level's edges inside bin b0
+            float thA = 0.f, thB = 0.f;
+            if (b0 >= 0) {
+                const float e0 = cons2_edge(b0, lo, sc, width), e1 = cons2_edge(b0 + 1, lo, sc, width);
+                thA = e0; thB = e1;
+                if (b1 >= 0) {
+                    const float w1 = width * (1.0f / (float)kBins);
+                    const float f0 = cons2_edge(b1, lo1, sc1, w1), f1 = cons2_edge(b1 + 1, lo1, sc1, w1);
+                    thA = fminf(fmaxf(f0, e0), e1);
+                    thB = fmaxf(thA, fminf(e1, f1));
+                }
+            }
+            for (int u0 = 0; u0 < ((UMEREG_F1_ABLATE & 0x400000) ? 4 : m_use); u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
+                bool c1[4], c2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { c1[k] = d2v[k] < thA; c2[k] = !c1[k] && d2v[k] < thB; }
+                if (__any(c1[0] || c1[1] || c1[2] || c1[3] || c2[0] || c2[1] || c2[2] || c2[3])) {
+                    const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
+                    const float wv[4] = {W.x, W.y, W.z, W.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int t0 = cons2_bin(d2v[k], lo, sc);
-                        int c = t0 < b0 ? 1 : (t0 == b0 ? 2 : 0);
-                        if (kZoomed) {
-                            const int t1 = cons2_bin(d2v[k], lo1, sc1);
-                            const int c1 = t1 < b1 ? 1 : (t1 == b1 ? 2 : 0);
-                            c = (b1 >= 0 && c == 2) ? c1 : c;
-                        }
-                        cls[k] = c;
-                    }
-                    const int any_cls = cls[0] | cls[1] | cls[2] | cls[3];
-                    if (__any(any_cls != 0)) {
-                        const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
-                        const float wv[4] = {W.x, W.y, W.z, W.w};
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
+                        if (c1[k] && cnt_l < K) { list.set(cnt_l, lane, key); ++cnt_l; }       // (at most `before` < K of them)
+                        const bool is_tie = c2[k];
+                        const bool put = is_tie && ntie < kCons2Tie;
+                        if (put) tie.set(ntie, lane, key);
+                        ntie += put ? 1 : 0;
+                        if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
+                            unsigned long long mk = 0ull;
+                            int mp = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
-                            if (cls[k] == 1 && cnt_l < K) { list.set(cnt_l, lane, key); ++cnt_l; }       // (at most `before` < K of them)
-                            const bool is_tie = cls[k] == 2;
-                            const bool put = is_tie && ntie < kCons2Tie;
-                            if (put) tie.set(ntie, lane, key);
-                            ntie += put ? 1 : 0;
-                            if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
-                                unsigned long long mk = 0ull;
-                                int mp = 0;
-#pragma unroll
-                                for (int t = 0; t < kCons2Tie; ++t) {
-                                    const unsigned long long ke = tie.get(t, lane);
-                                    if (ke >= mk) { mk = ke; mp = t; }
-                                }
-                                if (is_tie && !put && key < mk) tie.set(mp, lane, key);
+                            for (int t = 0; t < kCons2Tie; ++t) {
+                                const unsigned long long ke = tie.get(t, lane);
+                                if (ke >= mk) { mk = ke; mp = t; }
                             }
+                            if (is_tie && !put && key < mk) tie.set(mp, lane, key);
                         }
                     }
                 }
-            };
-            if (__any(b1 >= 0)) sweep2(std::true_type()); else sweep2(std::false_type());
+            }
             {
                 const int bound = wave_max_nonneg(ntie);
                 while (__any(ntie > need_t)) drop_max(tie, ntie, ntie > need_t, bound, lane);
@@ -2958,7 +2982,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             // ---- epilogue: the K keys of every lane -> weights in place (lanes without a selection: weight 0 on point 0, so that the
             // loop below has no branch and its row reads can be in flight ten at a time); 8 lanes share a feature row ----
             for (int t = 0; t < K; ++t) {
-                const float w = cauchy_weight_hw(__uint_as_float(list.d2[t * kWave + lane]), inv_sigma);
+                const float w = cauchy_weight_fast(__uint_as_float(list.d2[t * kWave + lane]), inv_sigma * inv_sigma);   // (the consensus pass's form)
                 list.d2[t * kWave + lane] = ok ? __float_as_uint(w) : 0u;
                 if (!ok) list.ix[KeyList<IdxT>::ix_at(t, lane)] = (IdxT)0;
             }
