@@ -1088,9 +1088,13 @@ def test_ume_kp_layer_vs_the_reference_forward(gpu):
     dR = np.abs(T[0, :, :3, :3] - g["T_diag"][0, :, :3, :3]).max(axis=(1, 2))
     dt = np.abs(T[0, :, :3, 3] - g["T_diag"][0, :, :3, 3]).max(axis=1)
     assert dR.max() < 1e-4 and np.median(dt) < 1e-4 and dt.max() < 2e-3                                         # the a6 bars
-    T64 = rtume_f64(g["G_diag"], g["H_diag"])
+    # against the fp64 evaluation of the whole layer (moments accumulated in fp64 by the oracle's C loop, RTUME in fp64): the build is
+    # closer to it than the reference's own fp32 forward
+    G64 = orc.ume_moments(g6["src_pts"], g6["src_pts"][g6["src_inds"][:64]], g6["src_feat"], 750, 5.0, "f64")
+    H64 = orc.ume_moments(g6["tgt_pts"], g6["tgt_pts"][g6["tgt_inds"][:64]], g6["tgt_feat"], 750, 5.0, "f64")
+    T64 = rtume_f64(G64, H64)
     e_build, e_ref = np.abs(T[0] - T64).max(axis=(1, 2)), np.abs(g["T_diag"][0] - T64).max(axis=(1, 2))
-    assert np.median(e_build) <= np.median(e_ref) + 1e-7              # closer to the fp64 evaluation than the reference itself
+    assert np.median(e_build) <= np.median(e_ref) + 1e-7
     wc = well_conditioned(g["G_diag"]) & well_conditioned(g["H_diag"])
     assert wc.mean() > 0.5 and np.abs(D - g["D_diag"])[0][wc].max() < 3e-3
     assert np.abs(T[0] - g6["gt_tform"]).max(axis=(1, 2)).max() < 5e-3      # these keypoints are twins
@@ -1714,8 +1718,8 @@ def test_corr_bound_saturates_and_nan_scores_win_like_torch(gpu):
         queries (here thousands per hypothesis -- an added constant wrapped to zero at the fourth) leaves the hypothesis marked
         "needs its queries", so nothing is ever scored from a partial sum that claims to be exact: header word 40 (recomputed
         hypotheses) equals word 41 (hypotheses with bounded queries), and the scores equal the exact run's;
-    (2) `umereg_corr_select_best_f32` orders a NaN score ABOVE every number, lowest index first -- what torch.argsort(descending) +
-        torch.argmax (utils/loc_utils.py:676-680) do, checked against torch on the same scores."""
+    (2) `umereg_corr_select_best_f32` orders a NaN score ABOVE every number, lowest index first -- torch.argsort(descending) +
+        torch.argmax (utils/loc_utils.py:676-680) return a NaN-scored hypothesis too (which one of several is unspecified there)."""
     from umeregrobust_amd import ops
     src, tgt, sf, tf, Ts = _garbage_hypotheses_case(seed=23)
     Ts[::3, 0, 3] += 150.0
@@ -1738,8 +1742,14 @@ def test_corr_bound_saturates_and_nan_scores_win_like_torch(gpu):
         order = torch.argsort(st, descending=True)                                    # the reference's statements, on the CPU
         want = int(order[:10][torch.argmax(st[order[:10]])])
         Tb, ib = ops.corr_select_best(T_(s_, gpu), T)
-        assert int(ib) == want == (min(nan_at) if nan_at else int(np.argmax(sc))), (nan_at, int(ib), want)
-        assert torch.equal(Tb, T[want])
+        # torch puts the NaNs first but in no particular order among themselves (its sort is not stable: the pick was index 13 on one
+        # host and 4000 on another); this library's rule is the LOWEST NaN index.  Without NaNs the picks are identical.
+        assert bool(np.isnan(s_[want])) == bool(nan_at) == bool(np.isnan(s_[int(ib)]))
+        if nan_at:
+            assert int(ib) == min(nan_at), (nan_at, int(ib), want)
+        else:
+            assert int(ib) == want == int(np.argmax(sc))
+        assert torch.equal(Tb, T[int(ib)])
 
 
 def test_feature_correlator_on_a_big_job_picks_the_exact_arg_max(gpu):
