@@ -434,6 +434,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         n_fl = max(1, n_fl)
         sel_timing, ev, errs, icp_it = [[] for _ in range(n_fl)], [[] for _ in range(n_fl)], [[] for _ in range(n_fl)], [[] for _ in range(n_fl)]
+        done = [[] for _ in range(n_fl)]
         sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
         ref_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
         streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
@@ -454,26 +455,36 @@ def main():
             rng, (kp_s, kp_t) = pre if pre is not None else draws(i)
             stamps = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             stamps[0].record()
-            out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=rng, src_inds=kp_s,
-                                         tgt_inds=kp_t)                                                               # :195-254
+            # (the voxel thinning of :261-264 is enqueued behind a1-a5 and runs while the host makes the weighted draw)
+            out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=rng, src_inds=kp_s, tgt_inds=kp_t,
+                                         after_phase_a=lambda: evaluate.prepare_selection(e.src_pts[0], e.tgt_pts[0], args))   # :195-254
+            prep = getattr(out, "side", None)
             stamps[1].record()
-            _, _, R_hat, t_hat = evaluate.select_hypothesis(e.src_pts[0], e.tgt_pts[0], e.src_pts, e.tgt_pts, e.src_feat,
-                                                            e.tgt_feat, out.rtume_tform, e.gt, args, rng=rng,
-                                                            timing=sel_timing[w] if timed else None)                # :258-296
+            _, _, R_hat, t_hat, T_sel = evaluate.select_hypothesis(e.src_pts[0], e.tgt_pts[0], e.src_pts, e.tgt_pts, e.src_feat,
+                                                                   e.tgt_feat, out.rtume_tform, e.gt, args, rng=rng,
+                                                                   timing=sel_timing[w] if timed else None, prepared=prep,
+                                                                   return_tform=True)                               # :258-296
             stamps[2].record()
             nxt = draws(i_next) if i_next is not None else None      # host work in the shadow of the score kernels
-            T_sel = eye.clone()[None]
-            T_sel[0, :3, :3] = R_hat[0]
-            T_sel[0, :3, 3] = t_hat[0]
-            reg = ops.icp_point_to_point(e.src_pts[0], e.tgt_pts[0], T_sel[0].double().cpu().numpy(), 0.2, 200)     # :63-109
+            # the ICP starts from the selected transform on the device: enqueued behind the scores, no host read in between
+            reg = ops.icp_point_to_point(e.src_pts[0], e.tgt_pts[0], T_sel[0], 0.2, 200)                            # :63-109
             stamps[3].record()
             if timed:
-                ops.hypothesis_gates(T_sel.contiguous(), e.gt, sel_counts[w])
-                T_ref = torch.from_numpy(reg.transformation).float().to(dev)[None].contiguous()
-                errs[w].append(ops.hypothesis_gates(T_ref, e.gt, ref_counts[w], return_errors=True))
+                # (the metrics of :301-309 are computed after the loop, as in the reference: nothing of them sits between two pairs)
+                done[w].append((T_sel, reg.transformation, e.gt))
                 ev[w].append(stamps)
                 icp_it[w].append(reg.iterations)
             return nxt
+
+        def metrics(w):
+            """RRE / RTE and the recall gates of this worker's timed pairs (evaluate.py:301-309), after its loop -- inside the timed
+            region: one upload of the refined transforms, two gate launches per pair"""
+            if not done[w]:
+                return
+            T_ref_all = torch.from_numpy(np.stack([d_[1] for d_ in done[w]]).astype(np.float32)).to(dev)
+            for k_, (T_sel, _, gt_) in enumerate(done[w]):
+                ops.hypothesis_gates(T_sel.contiguous(), gt_, sel_counts[w])
+                errs[w].append(ops.hypothesis_gates(T_ref_all[k_:k_ + 1], gt_, ref_counts[w], return_errors=True))
 
         def worker(w, first, n, timed):
             torch.cuda.set_device(dev)
@@ -482,6 +493,8 @@ def main():
                 pre = None
                 for k, i in enumerate(mine):
                     pre = one(i, timed, w, pre, mine[k + 1] if k + 1 < len(mine) else None)
+                if timed:
+                    metrics(w)
                 streams[w].synchronize()
 
         def run_all(first, n, timed):

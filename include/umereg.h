@@ -468,6 +468,14 @@ int umereg_icp_point_to_point_f32(const float* src, const float* tgt, int n_src,
                                   int max_iteration, double relative_fitness, double relative_rmse,
                                   double* T_out_host, double* fitness_host, double* inlier_rmse_host,
                                   int* iterations_host, void* workspace, size_t workspace_bytes, void* stream);
+/* The same from an initial transform that lives on the DEVICE (T_init_dev f32 [4,4], row major) -- the hypothesis
+ * umereg_corr_select_best_f32 wrote: it is read by the first kernel when that runs, so the ICP chain is enqueued behind the
+ * selection with no host read of the hypothesis in between (evaluate.py:63-96 reads R_hat / t_hat back first). */
+int umereg_icp_point_to_point_dev_f32(const float* src, const float* tgt, int n_src, int n_tgt,
+                                      const float* T_init_dev, float max_correspondence_distance,
+                                      int max_iteration, double relative_fitness, double relative_rmse,
+                                      double* T_out_host, double* fitness_host, double* inlier_rmse_host,
+                                      int* iterations_host, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

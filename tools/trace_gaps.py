@@ -30,4 +30,5 @@ for k,v in dur.most_common(16): print(f"{v/1e3/npairs:8.1f} us/pair  n/pair={cnt
 # print one pair's sequence
 i0=[i for i,x in enumerate(ev) if x[2]=='pack_points'][3]
 t0=ev[i0][0]
-for s,e,nm,st in ev[i0:i0+34]: print(f"  +{(s-t0)/1e3:8.1f} us  dur {(e-s)/1e3:7.1f}  stream {st:>3s}  {nm}")
+import os
+for s,e,nm,st in ev[i0:i0+int(os.environ.get('GAP_SEQ','34'))]: print(f"  +{(s-t0)/1e3:8.1f} us  dur {(e-s)/1e3:7.1f}  stream {st:>3s}  {nm}")

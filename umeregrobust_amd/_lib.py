@@ -64,6 +64,8 @@ SIGNATURES = {
     "umereg_icp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "umereg_icp_point_to_point_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_double, c_double,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_icp_point_to_point_dev_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_double, c_double,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_host_choice_round": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "umereg_host_choice_check": (c_int, [c_void_p, c_int, c_void_p]),
     "umereg_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

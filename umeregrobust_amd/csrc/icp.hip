@@ -216,6 +216,17 @@ __global__ void icp_init_kernel(IcpState* __restrict__ state, IcpInit init)
     }
 }
 
+// the same from a transform that is still being computed on the device (the hypothesis f1 selects, f32 [4,4] row major): read by the
+// kernel when it runs, so the whole ICP chain can be enqueued behind the selection without a host round trip in between
+__global__ void icp_init_dev_kernel(IcpState* __restrict__ state, const float* __restrict__ T_dev)
+{
+    if (threadIdx.x < 16) state->T[threadIdx.x] = (double)T_dev[threadIdx.x];
+    if (threadIdx.x == 0) {
+        state->fitness = 0.0; state->rmse = 0.0; state->prev_fitness = 0.0; state->prev_rmse = 0.0;
+        state->iters = 0; state->done = 0; state->have_prev = 0; state->pad = 0;
+    }
+}
+
 static size_t icp_extra_bytes(int n_src)
 {
     const size_t n_blocks = ((size_t)n_src + kIcpBlock - 1) / kIcpBlock;
@@ -235,13 +246,39 @@ UMEREG_API size_t umereg_icp_workspace_bytes(int n_src, int n_tgt)
 // src f32 [n_src,3], tgt f32 [n_tgt,3] (device); T_init / T_out: HOST double [16] row major; fitness,
 // inlier_rmse, iterations: HOST outputs (may be NULL).  Synchronous with respect to `stream`: the loop's stop
 // test lives on the device, the host polls it once per batch of iterations (4, then 8 at a time).
+static int icp_run(const float* src, const float* tgt, int n_src, int n_tgt, const double* T_init_host, const float* T_init_dev,
+                   float max_correspondence_distance, int max_iteration, double relative_fitness, double relative_rmse,
+                   double* T_out_host, double* fitness_host, double* inlier_rmse_host, int* iterations_host, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 UMEREG_API int umereg_icp_point_to_point_f32(const float* src, const float* tgt, int n_src, int n_tgt,
                                              const double* T_init_host, float max_correspondence_distance,
                                              int max_iteration, double relative_fitness, double relative_rmse,
                                              double* T_out_host, double* fitness_host, double* inlier_rmse_host,
                                              int* iterations_host, void* workspace, size_t workspace_bytes, void* stream)
 {
-    UMEREG_REQUIRE(src && tgt && T_init_host && T_out_host, "icp_point_to_point: null pointer");
+    UMEREG_REQUIRE(T_init_host, "icp_point_to_point: null T_init");
+    return icp_run(src, tgt, n_src, n_tgt, T_init_host, nullptr, max_correspondence_distance, max_iteration, relative_fitness, relative_rmse,
+                   T_out_host, fitness_host, inlier_rmse_host, iterations_host, workspace, workspace_bytes, stream);
+}
+
+UMEREG_API int umereg_icp_point_to_point_dev_f32(const float* src, const float* tgt, int n_src, int n_tgt,
+                                                 const float* T_init_dev, float max_correspondence_distance,
+                                                 int max_iteration, double relative_fitness, double relative_rmse,
+                                                 double* T_out_host, double* fitness_host, double* inlier_rmse_host,
+                                                 int* iterations_host, void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(T_init_dev, "icp_point_to_point_dev: null T_init");
+    return icp_run(src, tgt, n_src, n_tgt, nullptr, T_init_dev, max_correspondence_distance, max_iteration, relative_fitness, relative_rmse,
+                   T_out_host, fitness_host, inlier_rmse_host, iterations_host, workspace, workspace_bytes, stream);
+}
+
+static int icp_run(const float* src, const float* tgt, int n_src, int n_tgt, const double* T_init_host, const float* T_init_dev,
+                   float max_correspondence_distance, int max_iteration, double relative_fitness, double relative_rmse,
+                   double* T_out_host, double* fitness_host, double* inlier_rmse_host, int* iterations_host, void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(src && tgt && T_out_host, "icp_point_to_point: null pointer");
     UMEREG_REQUIRE(n_src > 0 && n_tgt > 0, "icp_point_to_point: empty cloud (n_src %d, n_tgt %d)", n_src, n_tgt);
     UMEREG_REQUIRE(max_correspondence_distance > 0.f && max_iteration >= 0, "icp_point_to_point: bad distance / iteration limit");
     if (int rc = check_device()) return rc;
@@ -258,7 +295,10 @@ UMEREG_API int umereg_icp_point_to_point_f32(const float* src, const float* tgt,
     if (int rc = launch_prep(tgt, ws, 1, n_tgt, -1.0f, st)) return rc;   // kNN-mode grid for K = 1
     IcpState h;
     memset(&h, 0, sizeof(h));
-    {
+    if (T_init_dev) {
+        hipLaunchKernelGGL(icp_init_dev_kernel, dim3(1), dim3(64), 0, st, state, T_init_dev);
+        UMEREG_CHECK_LAUNCH("icp_init_dev_kernel");
+    } else {
         IcpInit init;
         for (int k = 0; k < 16; ++k) init.T[k] = T_init_host[k];
         hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, st, state, init);

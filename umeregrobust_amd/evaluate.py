@@ -24,9 +24,11 @@ def _index_tensor(idx, dev):
     return torch.as_tensor(np.asarray(idx), dtype=torch.int64, device=dev)
 
 
-def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, corr_sigma, args, timing=None):
+def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, corr_sigma, args, timing=None, return_tform=False):
     """reference evaluate.py:20-47: pick the hypothesis with the highest feature correlation and report
-    its error.  Returns (R_err [bs], t_err [bs], R_hat [bs,3,3], t_hat [bs,3]); errors stay on the device."""
+    its error.  Returns (R_err [bs], t_err [bs], R_hat [bs,3,3], t_hat [bs,3]); errors stay on the device.
+    return_tform: additionally the selected 4 x 4 transforms [bs,4,4] (contiguous, on the device: the ICP can start from them
+    without a host read, see ops.icp_point_to_point)."""
     hypotisis_matcher = FeatureCorrelator(sigma=corr_sigma, batch=args.corr_batch_size, n_hypotheses=10)
     tform_hat = []
     for b_idx in range(args.batch_size):
@@ -41,7 +43,20 @@ def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, cor
     t_gt = gt_tform[:, :3, 3]
     R_err = relative_rotation_error(R_hat.contiguous(), R_gt.contiguous())
     t_err = (t_hat - t_gt).norm(dim=-1)
+    if return_tform:
+        return R_err, t_err, R_hat, t_hat, tform_hat
     return R_err, t_err, R_hat, t_hat
+
+
+def prepare_selection(src_pts_raw, tgt_pts_raw, args):
+    """The device-only first step of select_hypothesis (voxel thinning of the raw clouds, evaluate.py:261-264), launched ahead of time:
+    it depends on the raw clouds alone, so a loop can enqueue it BEFORE the named path of the same pair and find the voxel counts
+    waiting when the hypothesis selection starts (one host synchronisation less per pair).  Consumes no random numbers.
+    -> handle for select_hypothesis(prepared=...), or None when the inputs do not qualify (host tensors, other dtypes)."""
+    if src_pts_raw.is_cuda and tgt_pts_raw.is_cuda and src_pts_raw.dtype == torch.float32 and tgt_pts_raw.dtype == torch.float32 \
+            and src_pts_raw.dim() == 2 and tgt_pts_raw.dim() == 2:
+        return ops.VoxelThinning(src_pts_raw.contiguous(), args.corr_ds, tgt_pts_raw.contiguous(), 0.3)
+    return None
 
 
 def sparse_quantize(coordinates, return_index=True, quantization_size=1.0):
@@ -70,7 +85,7 @@ def sparse_quantize(coordinates, return_index=True, quantization_size=1.0):
 
 
 def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_feat, rtume_tform, gt_tform, args,
-                      rng=np.random, timing=None):
+                      rng=np.random, timing=None, prepared=None, return_tform=False):
     """reference evaluate.py:258-296 (one loop iteration): voxel-thin the RAW clouds (corr_ds / 0.3 m), give every
     kept point the feature of its nearest network point (K=1), random-subsample to pc_corr_max_size with the host
     RNG and let the FeatureCorrelator pick one RTUME hypothesis.
@@ -78,7 +93,9 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     rtume_tform [1,M,4,4]; gt_tform [4,4].  -> (R_err, t_err, R_hat_corr [1,3,3], t_hat_corr [1,3])."""
     dev = src_pts.device
     src_pts_raw, tgt_pts_raw = src_pts_raw.to(dev), tgt_pts_raw.to(dev)
-    if src_pts_raw.is_cuda and src_pts_raw.dtype == torch.float32 and tgt_pts_raw.dtype == torch.float32:
+    if prepared is not None:
+        src_inds, tgt_inds = prepared.result()               # (launched by prepare_selection, ahead of the named path)
+    elif src_pts_raw.is_cuda and src_pts_raw.dtype == torch.float32 and tgt_pts_raw.dtype == torch.float32:
         # both clouds behind one host read of the two voxel counts (the voxel coordinates themselves are not used, :261-264)
         src_inds, tgt_inds = ops.voxel_first_index(src_pts_raw.contiguous(), args.corr_ds, tgt_pts_raw.contiguous(), 0.3)
     else:
@@ -106,23 +123,28 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
         tgt_feat_corr = tgt_feat[0][ind[1][0, :, 0]][None]
     return pc_fcht(pc1_pts=src_pts_raw.contiguous(), pc2_pts=tgt_pts_raw.contiguous(), pc1_feat=src_feat_corr.contiguous(),
                    pc2_feat=tgt_feat_corr.contiguous(), rtume_hypotises=rtume_tform, gt_tform=gt_tform,
-                   corr_sigma=args.corr_kernel_sigma, args=args, timing=timing)
+                   corr_sigma=args.corr_kernel_sigma, args=args, timing=timing, return_tform=return_tform)
 
 
-def refine_registration(R_hat, t_hat, args, pairs):
+def refine_registration(R_hat, t_hat, args, pairs, tform_dev=None):
     """reference evaluate.py:63-109 (`refine_registration`): point-to-point ICP from every selected (R_hat, t_hat),
     max correspondence distance 0.2 m, max_iteration=200, then RRE / RTE against the ground truth.
     The reference re-opens its dataset here; this takes the raw clouds instead:
     pairs = iterable of (src_pts_raw [n,3], tgt_pts_raw [m,3], gt_tform [4,4]).
+    tform_dev: optional [P,4,4] float32 DEVICE tensor holding the same (R_hat, t_hat) as 4 x 4 transforms: the ICP then starts from
+    it on the device (no host read of the hypothesis before its first kernels are enqueued).
     -> (T_est [P,4,4] f32, rre [P] deg, rte [P] m), like the reference."""
     T_est_arr, rre_arr, rte_arr = [], [], []
     max_corr = float(getattr(args, "icp_max_correspondence_distance", 0.2))
     max_it = int(getattr(args, "icp_max_iteration", 200))
     for itr, (src_pts_raw, tgt_pts_raw, gt_tform) in enumerate(pairs):
-        tform_hat = np.zeros((4, 4))
-        tform_hat[:3, :3] = np.asarray(R_hat[itr].detach().cpu() if isinstance(R_hat[itr], torch.Tensor) else R_hat[itr])
-        tform_hat[:3, 3] = np.asarray(t_hat[itr].detach().cpu() if isinstance(t_hat[itr], torch.Tensor) else t_hat[itr])
-        tform_hat[3, 3] = 1
+        if tform_dev is not None:
+            tform_hat = tform_dev[itr].contiguous()
+        else:
+            tform_hat = np.zeros((4, 4))
+            tform_hat[:3, :3] = np.asarray(R_hat[itr].detach().cpu() if isinstance(R_hat[itr], torch.Tensor) else R_hat[itr])
+            tform_hat[:3, 3] = np.asarray(t_hat[itr].detach().cpu() if isinstance(t_hat[itr], torch.Tensor) else t_hat[itr])
+            tform_hat[3, 3] = 1
         reg = ops.icp_point_to_point(src_pts_raw, tgt_pts_raw, tform_hat, max_corr, max_it)
         new_tform = torch.from_numpy(reg.transformation).float()
         T_est_arr.append(new_tform)
@@ -286,13 +308,16 @@ def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):
 
 
 def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src_inds=None, tgt_inds=None,
-                  cond=None, materialize_D=False, timing=None):
+                  cond=None, materialize_D=False, timing=None, after_phase_a=None):
     """The named hot path for one pair (reference evaluate.py:195-254).
 
     src_pts/tgt_pts [1,N,3], src_feat/tgt_feat [1,N,32] on the GPU.  Host-RNG draws mirror the
     reference's np.random.choice calls (:199-200, :238) and can be injected (src_inds, tgt_inds,
     cond) for replay.  Returns a namespace with rtume_tform [1,M,4,4] and the intermediates the
     downstream stages (hypothesis selection) need.
+    after_phase_a: optional callable, invoked once a1-a5 are enqueued and before the host waits for the match probabilities: device
+    work that does not depend on this function's results (the voxel thinning of the raw clouds, evaluate.prepare_selection) then
+    runs while the host draws.  It must not consume `rng`.
     """
     assert src_pts.shape[0] == 1, "the reference evaluates with batch_size: 1"
     src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds)
@@ -304,6 +329,8 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src
         # grid-build and keypoint-order launches)
         pair = PairBatch.from_clouds(src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds)
     a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D, timing, pair=pair)
+    if after_phase_a is not None:
+        a.side = after_phase_a()
     if args.filter_by_ume_dist_cond and cond is None:
         # tau-weighted sub-sampling of matches (:233-245): the draw consumes the HOST numpy RNG
         num_matches = min(a.num_kpts, args.ume_n_samples)
@@ -603,15 +630,16 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
     refined = []      # per pair (T_est [1,4,4], rre [1], rte [1]) when the ICP runs inside the loop
 
     def read_back(p):
-        R_hat, t_hat, st, _keep = p     # _keep: the pair's input tensors stay alive until its last kernel is done
+        R_hat, t_hat, st, _keep, T_dev = p     # _keep: the pair's input tensors stay alive until its last kernel is done
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-            R_sel.append(R_hat.cpu())
-            t_sel.append(t_hat.cpu())
             if refine and st is not None:
                 # The reference refines all pairs after the loop (:301).  The ICP consumes no random numbers and touches
                 # nothing but its own pair, so running it here -- on the pair's stream, while the NEXT pair's correlation
                 # scores keep the GPU busy on the other one -- gives the same registrations with its host round trips hidden.
-                refined.append(refine_registration(R_sel[-1], t_sel[-1], args, [raw[len(R_sel) - 1]]))
+                # It starts from the selected transform ON THE DEVICE: its kernels are enqueued right behind the selection.
+                refined.append(refine_registration(R_hat, t_hat, args, [raw[len(R_sel)]], tform_dev=T_dev))
+            R_sel.append(R_hat.cpu())
+            t_sel.append(t_hat.cpu())
 
     for pair in pairs:
         dev = pair["src_pts"].device
@@ -625,15 +653,19 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
             st = streams[k % 2]
             st.wait_stream(torch.cuda.current_stream(dev))      # the pair's tensors were made on the caller's stream
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-            out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng)   # :195-254
             src_raw = pair.get("src_pts_raw", pair["src_pts"][0])
             tgt_raw = pair.get("tgt_pts_raw", pair["tgt_pts"][0])
-            _, _, R_hat, t_hat = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
-                                                   pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng)  # :258-296
+            # the voxel thinning of :261-264 (no random numbers) is enqueued behind a1-a5, so that it runs while the host makes the
+            # weighted draw of :238 and its counts are waiting when the selection starts
+            out = register_pair(pair["src_pts"], pair["tgt_pts"], pair["src_feat"], pair["tgt_feat"], args, rng=rng,
+                                after_phase_a=lambda: prepare_selection(src_raw, tgt_raw, args))                        # :195-254
+            _, _, R_hat, t_hat, T_dev = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
+                                                          pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng,
+                                                          prepared=getattr(out, "side", None), return_tform=True)       # :258-296
         raw.append((src_raw, tgt_raw, pair["gt_tform"]))
         if pending is not None:
             read_back(pending)        # the previous pair's result: its scores ran beside everything above
-        pending = (R_hat, t_hat, st, pair)
+        pending = (R_hat, t_hat, st, pair, T_dev)
         if st is None:
             read_back(pending)
             pending = None

@@ -432,6 +432,29 @@ def voxel_first_index(pts, voxel, pts2=None, voxel2=None):
     return idx[:m] if idx2 is None else (idx[:m], idx2[:m2])
 
 
+class VoxelThinning:
+    """voxel_first_index of two clouds LAUNCHED now and read later: the kernels and the asynchronous copy of the voxel counts into
+    pinned memory are enqueued by the constructor; result() waits for that copy only (an event), so everything enqueued on the
+    stream in between -- the named path of the same pair -- runs without a host synchronisation for the counts."""
+
+    def __init__(self, pts, voxel, pts2, voxel2):
+        dev = pts.device
+        self.cnt = torch.empty(4, dtype=torch.int32, device=dev)
+        self.idx = _voxel_first_index_launch(pts, voxel, self.cnt[0:2])
+        self.idx2 = _voxel_first_index_launch(pts2, voxel2, self.cnt[2:4])
+        self.host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        self.host.copy_(self.cnt, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(dev))
+
+    def result(self):
+        self.ev.synchronize()
+        m, bad, m2, bad2 = self.host.tolist()
+        if bad or bad2:
+            raise ValueError("voxel_first_index: a coordinate is NaN, infinite or beyond 2^20 voxels from the origin")
+        return self.idx[:m], self.idx2[:m2]
+
+
 def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **_ignored):
     """pytorch3d.ops.knn_points drop-in (reference utils/loc_utils.py:580,623; evaluate.py:272,274).
     p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] squared, ascending; idx [B,n1,K] i64; knn [B,n1,K,3] | None).
@@ -579,16 +602,23 @@ def icp_point_to_point(src_pts, tgt_pts, T_init, max_correspondence_distance=0.2
                        relative_fitness=1e-6, relative_rmse=1e-6):
     """Point-to-point ICP with open3d's registration_icp semantics (reference evaluate.py:93-96).
     src_pts [n,3], tgt_pts [m,3] (device f32), T_init [4,4] (any float tensor / array) ->
-    SimpleNamespace(transformation float64 [4,4] numpy, fitness, inlier_rmse, iterations)."""
+    SimpleNamespace(transformation float64 [4,4] numpy, fitness, inlier_rmse, iterations).
+    A T_init that is a contiguous float32 DEVICE tensor is not read back: the first kernel reads it when it runs, so the chain is
+    enqueued behind whatever is still computing it (the hypothesis selection)."""
     import numpy as np
     from types import SimpleNamespace
     lib = _lib.load()
     sp = _dev(src_pts, "src_pts"); tp = _dev(tgt_pts, "tgt_pts")
     if sp.dim() != 2 or tp.dim() != 2 or sp.shape[1] != 3 or tp.shape[1] != 3:
         raise ValueError(f"icp_point_to_point: expected [n,3] clouds, got {tuple(sp.shape)}, {tuple(tp.shape)}")
-    T0 = np.ascontiguousarray(np.asarray(T_init.detach().cpu() if isinstance(T_init, torch.Tensor) else T_init, dtype=np.float64))
-    if T0.shape != (4, 4):
+    if not isinstance(T_init, torch.Tensor):
+        T_init = np.asarray(T_init)
+    on_dev = isinstance(T_init, torch.Tensor) and T_init.is_cuda and T_init.dtype == torch.float32 and T_init.is_contiguous() \
+        and T_init.device == sp.device
+    if tuple(T_init.shape) != (4, 4):
         raise ValueError("icp_point_to_point: T_init must be 4x4")
+    T0 = None if on_dev else np.ascontiguousarray(np.asarray(T_init.detach().cpu() if isinstance(T_init, torch.Tensor) else T_init,
+                                                             dtype=np.float64))
     n, m = sp.shape[0], tp.shape[0]
     if n == 0 or m == 0:
         raise ValueError("icp_point_to_point: empty cloud")
@@ -598,10 +628,11 @@ def icp_point_to_point(src_pts, tgt_pts, T_init, max_correspondence_distance=0.2
     iters = np.zeros(1, dtype=np.int32)
     ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp")
     with torch.cuda.device(dev):
-        rc = lib.umereg_icp_point_to_point_f32(_ptr(sp), _ptr(tp), n, m, T0.ctypes.data, float(max_correspondence_distance),
-                                               int(max_iteration), float(relative_fitness), float(relative_rmse),
-                                               T.ctypes.data, out.ctypes.data, out.ctypes.data + 8, iters.ctypes.data,
-                                               _ptr(ws), ws.numel(), _stream_ptr(dev))
+        fn = lib.umereg_icp_point_to_point_dev_f32 if on_dev else lib.umereg_icp_point_to_point_f32
+        rc = fn(_ptr(sp), _ptr(tp), n, m, T_init.data_ptr() if on_dev else T0.ctypes.data, float(max_correspondence_distance),
+                int(max_iteration), float(relative_fitness), float(relative_rmse),
+                T.ctypes.data, out.ctypes.data, out.ctypes.data + 8, iters.ctypes.data,
+                _ptr(ws), ws.numel(), _stream_ptr(dev))
     _lib.check(rc, "umereg_icp_point_to_point_f32")
     return SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
 
