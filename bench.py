@@ -350,6 +350,9 @@ def main():
                      "in_situ_avg_launch_ms": situ(timing_situ["dist"]),
                      "algorithmic_flops_per_launch": dist_flops,
                      "refine_avg_launch_ms": round(float(np.mean(ref_ms)), 4) if ref_ms else None,
+                     "frac_of_sustained_mfma_stream": round(0.082 / max(float(np.mean(dist_ms)), 1e-9), 4),
+                     "sustained_note": "this kernel's bare MFMA stream (no squares, no filter) takes 0.082 ms on random operands: the rate the "
+                                       "part sustains on non-zero f16 data (DESIGN 3.3, tools/probe); frac_of_sustained = 0.082 / avg_launch_ms",
                      "d_used": ("528 (P-form: one inner product of the packed 32 x 32 projectors per pair) + fp64 refine of the candidates"
                                 if a.match_pform else
                                 "512-equivalent (Q-form), single f16 MFMA product (hi planes) + fp64 refine of the candidates")}
@@ -613,6 +616,10 @@ def main():
         f1 = {"plain": f1_profile(evaluate, ops, torch, pool[0], args, dev)}
         if hard_pool_first is not None:
             f1["hard"] = f1_profile(evaluate, ops, torch, hard_pool_first, args, dev)
+        if a.config != "KT":      # (configs whose corr_ds thins the source: also the job the end-to-end leg really runs)
+            f1["plain_as_fed"] = f1_profile(evaluate, ops, torch, pool[0], args, dev, thinned=True)
+            if hard_pool_first is not None:
+                f1["hard_as_fed"] = f1_profile(evaluate, ops, torch, hard_pool_first, args, dev, thinned=True)
         result["f1_selection"] = f1
 
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, rank 0, N = 1 ----
@@ -678,22 +685,32 @@ def main():
 VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0     # wave64 VALU instructions per ns the chip can issue: 1024 SIMDs x 2.4 GHz / 4 cycles each
 
 
-def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
-    """reference utils/loc_utils.py:656-681 on one resident pair, the way evaluate.select_hypothesis feeds it (network points
-    as raw clouds, pc_corr_max_size sub-sample, weighted features): per-stage HIP-event times of the native call, the
-    consensus pass's statistics (one extra, untimed call with UMEREG_CORR_DEBUG_STATS) and the tracked SQ counters."""
+def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
+    """reference utils/loc_utils.py:656-681 on one resident pair (network points as raw clouds, weighted features): per-stage
+    HIP-event times of the native call, the consensus pass's statistics (one extra, untimed call with UMEREG_CORR_DEBUG_STATS) and the
+    tracked SQ counters.  thinned=False: both clouds sub-sampled to pc_corr_max_size points (the job size the configs allow: 2 500 x
+    10 000 x 10 000 at KITTI-test, 5 000 x 30 000 x 30 000 at nuScenes-test / LoKITTI sizes); thinned=True: exactly what
+    evaluate.select_hypothesis hands over for this pair -- voxel thinning at corr_ds / 0.3 m first (evaluate.py:261-264), which at
+    nuScenes-test's corr_ds = 1 m leaves a third of the source."""
     from umeregrobust_amd.utils.loc_utils import feature_spatial_var
     with torch.no_grad():
         out = evaluate.register_pair(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, args, rng=np.random.RandomState(0),
                                      src_inds=e.src_inds, tgt_inds=e.tgt_inds)
         T = out.rtume_tform[0].contiguous()
         rs = np.random.RandomState(1)
-        n = min(args.pc_corr_max_size, e.src_pts.shape[1])
-        si = torch.from_numpy(rs.choice(e.src_pts.shape[1], n, replace=False)).to(dev)
-        ti = torch.from_numpy(rs.choice(e.tgt_pts.shape[1], n, replace=False)).to(dev)
+        if thinned:
+            s_keep, t_keep = ops.voxel_first_index(e.src_pts[0].contiguous(), args.corr_ds, e.tgt_pts[0].contiguous(), 0.3)
+        else:
+            s_keep = torch.arange(e.src_pts.shape[1], device=dev)
+            t_keep = torch.arange(e.tgt_pts.shape[1], device=dev)
+        si = s_keep[torch.from_numpy(rs.choice(s_keep.numel(), min(args.pc_corr_max_size, s_keep.numel()), replace=False)).to(dev)]
+        ti = t_keep[torch.from_numpy(rs.choice(t_keep.numel(), min(args.pc_corr_max_size, t_keep.numel()), replace=False)).to(dev)]
         sp, tp = e.src_pts[0, si].contiguous(), e.tgt_pts[0, ti].contiguous()
         sf, tf = e.src_feat[0, si].contiguous(), e.tgt_feat[0, ti].contiguous()
-        w = feature_spatial_var(torch.stack([sp, tp]), torch.stack([sf, tf]), knn=50)
+        if sp.shape == tp.shape:
+            w = feature_spatial_var(torch.stack([sp, tp]), torch.stack([sf, tf]), knn=50)
+        else:
+            w = (feature_spatial_var(sp[None], sf[None], knn=50)[0], feature_spatial_var(tp[None], tf[None], knn=50)[0])
         wsf, wtf = ops.corr_weighted_features(sf, tf, w[0], w[1])
         # (the flags FeatureCorrelator passes: arg-max mode on jobs of >= 2^25 queries, see utils/loc_utils.py)
         big = int(T.shape[0]) * int(sp.shape[0]) >= ops.CORR_BOUND_MIN_QUERIES
@@ -709,7 +726,9 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5):
     queries = M * Ns
     steps_a, zone_a, steps_b, zone_b, zoomed = int(h[19]), int(h[20]), int(h[21]), int(h[22]), int(h[23])
     visits = 64.0 * (float(h[28]) + float(h[29]))
-    res = {"queries": queries, "hypotheses": M, "points_per_cloud": Ns, "stage_ms": stages,
+    res = {"queries": queries, "hypotheses": M, "points_per_cloud": Ns, "source_points": Ns, "target_points": int(tp.shape[0]),
+           "clouds": ("as evaluate.select_hypothesis hands them over (voxel thinning at corr_ds / 0.3 m, then the sub-sample)" if thinned
+                      else "both clouds sub-sampled to pc_corr_max_size points"), "stage_ms": stages,
            "served_by_the_consensus_pass": int(h[7]), "served_frac": round(int(h[7]) / queries, 5),
            "left_to": ("one_wavefront_per_query" if int(h[8]) else "candidate_lattice"), "left_queries": int(h[9]),
            "cell_pass_served": int(h[34]), "outside_lattice_bounded": bool(big),
