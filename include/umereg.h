@@ -114,6 +114,10 @@ int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const i
  *   centre, slot fold, normaliser and division in fp64.  9 % faster on MI355X, but 2.6e-5 (row-relative maximum) from the fp64
  *   evaluation instead of correctly rounded (see ume_moments_kernel); the default accumulates every term in fp64. */
 #define UMEREG_MOMENTS_ACC_F32 4
+/*   flags & UMEREG_MOMENTS_ACC_MFMA (opt-in, measurement): the same fp64 sums as the default on the matrix pipe
+ *   (v_mfma_f64_4x4x4_4b_f64): exact fp32 x fp32 products, fp64 accumulation in another order -- the default's arithmetic class
+ *   (within 1e-15 of it before the rounding to fp32). */
+#define UMEREG_MOMENTS_ACC_MFMA 8
 int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
                               int n_kp, float radius, void* stream);
 /*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers

@@ -564,7 +564,17 @@ constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 me
 // conversions are saved -- for a result 2.6e-5 (row-relative maximum; median 1e-7) from the fp64 evaluation instead of 0, 4.6e-4 on
 // saturated balls of random features, where the normaliser sum_c sum f cancels (the reference's own fp32 sums: 1.6e-4 / 8.7e-4).
 // Three per cent of a pair for two orders of magnitude of accuracy: it stays an option, not the default.
-template <bool kF64>
+// kAcc = 2 (UMEREG_MOMENTS_ACC_MFMA, round 4): the same fp64 sums on the matrix pipe -- v_mfma_f64_4x4x4_4b_f64, four blocks of
+// D(4x4) += A(4x4) B(4x4) per instruction.  Operand lanes (measured, tools/probe/mfma_f64_layout.hip): A lane = 16 k + 4 b + i,
+// B lane = 16 k + 4 b + j, D lane = 16 i + 4 b + j.  A group of 8 neighbours: lane l = 16 k + r loads the 16-byte slice (channel quad
+// cq = r & 7) of neighbour slot ns = 4 (r >> 3) + k -- the loads of today, permuted -- and ONE coordinate word j = l & 3 of the same
+// neighbour ({1, x, y, z}[j]); MFMA m = 0..3 takes the slice's m-th channel as A and that word as B, so that row (b, i) of D_m
+// accumulates channel 4 cq + m against {1, x, y, z} over the neighbour slots of its half (r >> 3).  fp32 x fp32 products are exact in
+// fp64 and the sums are fp64: the arithmetic class of kAcc = 1 in another order.  Per 8 neighbours: 5 conversions + 4 MFMAs (256 FMAs
+// each) instead of 16 FMA + 7 conversions + 6 broadcast moves per lane; 4 accumulator registers pairs instead of 16; the fold of the
+// two halves is one exchange across lane bit 3.  The matrix pipe's f64 rate equals the vector pipe's on this part (64.6 TFLOP/s
+// measured), so what is saved is the conversions and moves, not the FMAs: see DESIGN 3.1 for the measurement.
+template <int kAcc>
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
@@ -625,6 +635,56 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
         for (int e = lane; e < K; e += kWave) o[e] = e < count ? (int64_t)lst[e] : (int64_t)-1;
     }
 
+    constexpr bool kF64 = kAcc != 0;
+    if (kAcc == 2) {
+        // ---- fp64 sums on the matrix pipe (see above) ----
+        const int mk = lane >> 4, mr = lane & 15, mcq = mr & 7, mns = 4 * (mr >> 3) + mk, mj = lane & 3;
+        const float* Pf = reinterpret_cast<const float*>(Pb);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        auto mtrip = [&](int e0, bool ragged, auto U_) __attribute__((always_inline)) {
+            constexpr int kU = decltype(U_)::value;
+            float4 ff[kU];
+            float pc[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const unsigned int jn = (unsigned int)lst[min(e0 + u * 8 + mns, count - 1)];
+                ff[u] = fb[(size_t)jn * 8 + mcq];
+                pc[u] = Pf[(size_t)jn * 4 + (mj > 0 ? mj - 1 : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (ragged) {
+                    const bool v = e0 + u * 8 + mns < count;
+                    ff[u].x = v ? ff[u].x : 0.f; ff[u].y = v ? ff[u].y : 0.f;
+                    ff[u].z = v ? ff[u].z : 0.f; ff[u].w = v ? ff[u].w : 0.f;
+                }
+                const double bq = mj == 0 ? 1.0 : (double)pc[u];
+                acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].x, bq, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].y, bq, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].z, bq, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].w, bq, acc[3], 0, 0, 0);
+            }
+        };
+        const int mfull = count & ~(8 * kMomUnroll - 1);
+        for (int e0 = 0; e0 < mfull; e0 += 8 * kMomUnroll) mtrip(e0, false, std::integral_constant<int, kMomUnroll>{});
+        for (int e0 = mfull; e0 < count; e0 += 8) mtrip(e0, e0 + 8 > count, std::integral_constant<int, 1>{});
+        // D lane = 16 i + 4 b + j: channel 4 ((4 b + i) & 7) + m, column j, the neighbour half b >> 1 -- the halves differ in lane bit 3
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] += shfl_xor_f64(acc[m], 8);
+        // normaliser: sum over the 32 channels of column 0 (evaluate.py:59): the j = 0 lanes of the lower half, all four m
+        const bool lower = (lane & 8) == 0;
+        double s = (lower && mj == 0) ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) s += shfl_xor_f64(s, m);
+        const double inv_den = (flags & UMEREG_MOMENTS_RAW) ? 1.0 : 1.0 / (s + 1e-6);
+        if (lower) {
+            const int di = lane >> 4, db = (lane >> 2) & 1, dcq = 4 * db + di;      // (b < 2 here: (4 b + i) & 7 = 4 b + i)
+            float* o = F + (((size_t)b * n_kp + kp) * 32 + 4 * dcq) * 4 + mj;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[m * 4] = (float)(acc[m] * inv_den);
+        }
+        return;
+    }
     const int slot = lane >> 3;  // neighbour slot 0..7
     const int qd = lane & 7;     // channel quad: channels 4*qd .. 4*qd+3
     double a0[4] = {0, 0, 0, 0}, ax[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0}, az[4] = {0, 0, 0, 0};
@@ -865,12 +925,17 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     int cap, waves;
     lds_plan(K, &cap, &waves);
     dim3 grid((n_kp + waves - 1) / waves, B);
-    if (!(flags & UMEREG_MOMENTS_ACC_F32))
-        hipLaunchKernelGGL(ume_moments_kernel<true>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+    UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_MFMA)), "ume_moments: ACC_F32 and ACC_MFMA exclude each other");
+    if (flags & UMEREG_MOMENTS_ACC_MFMA)
+        hipLaunchKernelGGL(ume_moments_kernel<2>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
+    else if (!(flags & UMEREG_MOMENTS_ACC_F32))
+        hipLaunchKernelGGL(ume_moments_kernel<1>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
                            (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
                            n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
     else
-        hipLaunchKernelGGL(ume_moments_kernel<false>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+        hipLaunchKernelGGL(ume_moments_kernel<0>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
                            (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
                            n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
