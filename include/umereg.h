@@ -85,7 +85,7 @@ int umereg_ball_query_f32(const float* p1, const float* p2, const int64_t* lengt
  * Fused ball query (K = args.ume_max_nn, radius = args.ume_r_nn) + feature gather + UME moment
  * matrix:  F = [sum f, sum f p^T] / (sum_c sum f_c + 1e-6)   ->  F f32 [B,n_kp,32,4].
  * The 960 MB gathered intermediate of the reference (evaluate.py:54-55) is never formed.
- * Moments are accumulated in fp64 and rounded once to fp32.
+ * Moments are accumulated in fp64 (on the matrix pipe: v_mfma_f64_4x4x4_4b_f64) and rounded once to fp32.
  *   pts [B,N,3]  kpts [B,n_kp,3]  feat [B,N,32]
  *   nn_count int32 [B,n_kp]   neighbours used per keypoint (0 => F row is exactly 0)  (may be NULL)
  *   nn_idx   int64 [B,n_kp,K] the neighbourhood actually used, -1 padded              (may be NULL)
@@ -114,10 +114,10 @@ int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const i
  *   centre, slot fold, normaliser and division in fp64.  9 % faster on MI355X, but 2.6e-5 (row-relative maximum) from the fp64
  *   evaluation instead of correctly rounded (see ume_moments_kernel); the default accumulates every term in fp64. */
 #define UMEREG_MOMENTS_ACC_F32 4
-/*   flags & UMEREG_MOMENTS_ACC_MFMA (opt-in, measurement): the same fp64 sums as the default on the matrix pipe
- *   (v_mfma_f64_4x4x4_4b_f64): exact fp32 x fp32 products, fp64 accumulation in another order -- the default's arithmetic class
- *   (within 1e-15 of it before the rounding to fp32). */
-#define UMEREG_MOMENTS_ACC_MFMA 8
+/*   flags & UMEREG_MOMENTS_ACC_VALU (measurement / A-B): the fp64 sums on the vector pipe (16 v_fma_f64 per lane and neighbour
+ *   slot: the kernel of rounds 1-3) instead of the matrix pipe (v_mfma_f64_4x4x4_4b_f64, the default: exact fp32 x fp32 products,
+ *   fp64 accumulation -- the same arithmetic in another order, bit-identical results on every input tried, 13 % faster). */
+#define UMEREG_MOMENTS_ACC_VALU 8
 int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
                               int n_kp, float radius, void* stream);
 /*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers

@@ -146,6 +146,47 @@ def test_moments_kitti_shape_vs_oracle(gpu):
     assert torch.equal(F, F2)
 
 
+def test_moments_matrix_pipe_equals_vector_pipe(gpu):
+    """The default accumulates the moment sums in fp64 on the MATRIX pipe (v_mfma_f64_4x4x4_4b_f64, round 4); acc="f64valu"
+    (UMEREG_MOMENTS_ACC_VALU) is the vector-pipe loop of rounds 1-3.  Both form exact fp32 x fp32 products and add them in fp64, in
+    different orders: the fp32 results must agree to the last bit wherever fp64's 1e-16 reordering noise cannot cross an fp32
+    rounding boundary -- i.e. (nearly) everywhere; at most a handful of 1-ulp differences are tolerated, and both sit within 3e-7
+    of the fp64 oracle.  Cases: the G12 golden cloud, ragged counts (K = 1, 7, 8, 9, 33, 750), a saturated ball, an empty ball,
+    the un-normalised matrix, keypoints given as indices, a batch of two clouds."""
+    from umeregrobust_amd import ops
+    from umeregrobust_amd.synth import synth_pair
+    g = load_golden("g12_ballquery_moments.npz")
+    pts, kpts, feat = T_(g["pts"], gpu)[None], T_(g["kpts"], gpu)[None], T_(g["feat"], gpu)[None]
+
+    def same(a, b, what):
+        a, b = N_(a), N_(b)
+        diff = a != b
+        assert diff.mean() < 1e-4, f"{what}: {int(diff.sum())} of {a.size} entries differ"
+        if diff.any():
+            assert (np.abs(a - b)[diff] <= 2.4e-7 * np.abs(a[diff]) + 1e-38).all(), what      # one ulp of fp32
+
+    for K, r in ((1, 5.0), (7, 5.0), (8, 5.0), (9, 5.0), (33, 5.0), (750, 5.0), (64, 50.0), (4, 0.6)):
+        Fm, cm = ops.ume_moments(pts, kpts, feat, K, r, return_count=True)
+        Fv, cv = ops.ume_moments(pts, kpts, feat, K, r, return_count=True, acc="f64valu")
+        assert torch.equal(cm, cv)
+        same(Fm, Fv, f"K={K} r={r}")
+        F64 = orc.ume_moments(g["pts"], g["kpts"], g["feat"], K, r, accum="f64")
+        scale = np.abs(F64).max(axis=(1, 2), keepdims=True) + 1e-30
+        assert (np.abs(N_(Fm)[0] - F64) / scale).max() < 3e-7
+    same(ops.ume_moments(pts, kpts, feat, 750, 5.0, normalize=False), ops.ume_moments(pts, kpts, feat, 750, 5.0, normalize=False, acc="f64valu"),
+         "raw")
+    p = synth_pair(4, N=20000, n_kp=3000)
+    pts2 = torch.stack([T_(p.src_pts, gpu), T_(p.tgt_pts, gpu)]); feat2 = torch.stack([T_(p.src_feat, gpu), T_(p.tgt_feat, gpu)])
+    inds = torch.stack([T_(p.src_inds, gpu), T_(p.tgt_inds, gpu)])
+    same(ops.ume_moments(pts2, None, feat2, 750, 5.0, kp_index=inds), ops.ume_moments(pts2, None, feat2, 750, 5.0, kp_index=inds, acc="f64valu"),
+         "batch of two, indexed keypoints")
+    rs = np.random.RandomState(0)
+    dense = rs.uniform(-6, 6, (30000, 3)).astype(np.float32)                            # every ball saturates at K = 750
+    f = rs.standard_normal((30000, 32)).astype(np.float32)
+    d_ = (T_(dense, gpu)[None], T_(dense[:300], gpu)[None], T_(f, gpu)[None])
+    same(ops.ume_moments(*d_, 750, 5.0), ops.ume_moments(*d_, 750, 5.0, acc="f64valu"), "saturated")
+
+
 def test_moments_packed_f32_option(gpu):
     """acc="f32" (UMEREG_MOMENTS_ACC_F32, opt-in): packed fp32 sums of keypoint-centred terms.  Same neighbourhoods; the matrix
     is no longer correctly rounded but stays inside the reference's own fp32 summation noise (measured: 2.6e-5 row-relative

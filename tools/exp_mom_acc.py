@@ -34,19 +34,19 @@ for name, (P, kp, feat) in cases.items():
     F64 = orc.ume_moments(P, kp, feat, 750, 5.0, accum="f64")
     F32ref = orc.ume_moments(P, kp, feat, 750, 5.0, accum="f32")
     Fd = None
-    for acc in ("f32", "f64", "mfma"):
+    for acc in ("f32", "f64valu", "f64"):
         F = ops.ume_moments(t(P)[None], t(kp)[None], t(feat)[None], 750, 5.0, acc=acc)[0].cpu().numpy()
-        if acc == "f64":
+        if acc == "f64valu":
             Fd = F
-        if acc == "mfma":
-            print(f"{name:18s} mfma vs f64 (both fp64 sums, another order): entries that differ {int((F != Fd).sum())} of {F.size}, "
+        if acc == "f64":
+            print(f"{name:18s} matrix pipe vs vector pipe (both fp64 sums, another order): entries that differ {int((F != Fd).sum())} of {F.size}, "
                   f"max |diff| / row max {float((np.abs(F - Fd) / (np.abs(Fd).max(axis=(1, 2), keepdims=True) + 1e-30)).max()):.2e}", flush=True)
         mx, med = err(F, F64)
         print(f"{name:18s} acc={acc}: max rel err {mx:.2e}  median row max {med:.2e}   (reference-order fp32 sums: {err(F32ref, F64)[0]:.2e})", flush=True)
 # time: both clouds of the KT pair as one batch of 2, the way the pipeline runs it
 pts2 = torch.stack([t(p.src_pts), t(p.tgt_pts)]); feat2 = torch.stack([t(p.src_feat), t(p.tgt_feat)])
 inds = torch.stack([t(p.src_inds), t(p.tgt_inds)])
-for acc in ("f32", "f64", "mfma", "f32", "f64", "mfma", "f64", "mfma"):
+for acc in ("f32", "f64valu", "f64", "f32", "f64valu", "f64", "f64valu", "f64"):
     tm = []
     for _ in range(12):
         ops.ume_moments(pts2, None, feat2, 750, 5.0, kp_index=inds, timing=tm, acc=acc)

@@ -555,8 +555,9 @@ __device__ __forceinline__ float bcast8(float v)
 
 constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 measured no faster, and costs 2 waves/SIMD)
 
-// kF64 = true (default): every neighbour term accumulated in fp64 (order-independent to 1e-16, the correctly rounded fp32 matrix).
-// kF64 = false (UMEREG_MOMENTS_ACC_F32, opt-in): the neighbour sums in packed fp32 on KEYPOINT-CENTRED coordinates -- sum f (p - c)^T
+// kAcc = 1 (UMEREG_MOMENTS_ACC_VALU): every neighbour term accumulated in fp64 on the vector pipe (order-independent to 1e-16, the
+// correctly rounded fp32 matrix) -- the default of rounds 1-3, bit-identical to today's kAcc = 2 on every input tried.
+// kAcc = 0 (UMEREG_MOMENTS_ACC_F32, opt-in): the neighbour sums in packed fp32 on KEYPOINT-CENTRED coordinates -- sum f (p - c)^T
 // with |p - c| <= radius instead of |p| <= 50 m, the term  c (sum f)^T  added back once, in fp64, together with the fold of the 8
 // neighbour slots, the normaliser and the division: 8 v_pk_add / v_pk_fma + 3 subtractions per lane and neighbour instead of 16 fp64
 // operations + 7 conversions.  Measured on MI355X (tools/exp_mom_acc.py, KT pair): 101 us against 111 us -- 9 %, not the 40 % the
@@ -564,7 +565,7 @@ constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 me
 // conversions are saved -- for a result 2.6e-5 (row-relative maximum; median 1e-7) from the fp64 evaluation instead of 0, 4.6e-4 on
 // saturated balls of random features, where the normaliser sum_c sum f cancels (the reference's own fp32 sums: 1.6e-4 / 8.7e-4).
 // Three per cent of a pair for two orders of magnitude of accuracy: it stays an option, not the default.
-// kAcc = 2 (UMEREG_MOMENTS_ACC_MFMA, round 4): the same fp64 sums on the matrix pipe -- v_mfma_f64_4x4x4_4b_f64, four blocks of
+// kAcc = 2 (the default since round 4; kAcc = 1, the loop of rounds 1-3, stays behind UMEREG_MOMENTS_ACC_VALU): the same fp64 sums on the matrix pipe -- v_mfma_f64_4x4x4_4b_f64, four blocks of
 // D(4x4) += A(4x4) B(4x4) per instruction.  Operand lanes (measured, tools/probe/mfma_f64_layout.hip): A lane = 16 k + 4 b + i,
 // B lane = 16 k + 4 b + j, D lane = 16 i + 4 b + j.  A group of 8 neighbours: lane l = 16 k + r loads the 16-byte slice (channel quad
 // cq = r & 7) of neighbour slot ns = 4 (r >> 3) + k -- the loads of today, permuted -- and ONE coordinate word j = l & 3 of the same
@@ -636,8 +637,15 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     }
 
     constexpr bool kF64 = kAcc != 0;
+#ifndef UMEREG_MOM_ABLATE
+#define UMEREG_MOM_ABLATE 0   // timing experiments only: 1 = no gather / accumulation (search cost alone)
+#endif
+#ifndef UMEREG_MOM_MFMA_UNROLL
+#define UMEREG_MOM_MFMA_UNROLL 4      // groups of 8 neighbours whose loads are in flight together (tools/exp_mom_acc.py measures alternatives)
+#endif
     if (kAcc == 2) {
         // ---- fp64 sums on the matrix pipe (see above) ----
+        constexpr int kMU = UMEREG_MOM_MFMA_UNROLL;
         const int mk = lane >> 4, mr = lane & 15, mcq = mr & 7, mns = 4 * (mr >> 3) + mk, mj = lane & 3;
         const float* Pf = reinterpret_cast<const float*>(Pb);
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -665,8 +673,9 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
                 acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].w, bq, acc[3], 0, 0, 0);
             }
         };
-        const int mfull = count & ~(8 * kMomUnroll - 1);
-        for (int e0 = 0; e0 < mfull; e0 += 8 * kMomUnroll) mtrip(e0, false, std::integral_constant<int, kMomUnroll>{});
+        const int mfull = (UMEREG_MOM_ABLATE & 1) ? 0 : (count / (8 * kMU)) * (8 * kMU);
+        for (int e0 = 0; e0 < mfull; e0 += 8 * kMU) mtrip(e0, false, std::integral_constant<int, kMU>{});
+        if (!(UMEREG_MOM_ABLATE & 1))
         for (int e0 = mfull; e0 < count; e0 += 8) mtrip(e0, e0 + 8 > count, std::integral_constant<int, 1>{});
         // D lane = 16 i + 4 b + j: channel 4 ((4 b + i) & 7) + m, column j, the neighbour half b >> 1 -- the halves differ in lane bit 3
 #pragma unroll
@@ -746,9 +755,6 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
             }
         }
     };
-#ifndef UMEREG_MOM_ABLATE
-#define UMEREG_MOM_ABLATE 0   // timing experiments only: 1 = no gather / accumulation (search cost alone)
-#endif
     // full trips of 8 x kMomUnroll neighbours, then the tail in trips of 8 (a single ragged 32-neighbour trip wasted half a
     // trip per keypoint on average)
     const int full = (UMEREG_MOM_ABLATE & 1) ? 0 : count & ~(8 * kMomUnroll - 1);
@@ -925,8 +931,8 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     int cap, waves;
     lds_plan(K, &cap, &waves);
     dim3 grid((n_kp + waves - 1) / waves, B);
-    UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_MFMA)), "ume_moments: ACC_F32 and ACC_MFMA exclude each other");
-    if (flags & UMEREG_MOMENTS_ACC_MFMA)
+    UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_VALU)), "ume_moments: ACC_F32 and ACC_VALU exclude each other");
+    if (!(flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)))
         hipLaunchKernelGGL(ume_moments_kernel<2>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
                            (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
                            n_kp, K, cap, radius, flags, F, nn_count, nn_idx);

@@ -112,7 +112,7 @@ def _timed_end(timing, ev, dev):
         timing.append(ev)
 
 
-MOMENTS_ORDERED, MOMENTS_RAW, MOMENTS_ACC_F32, MOMENTS_ACC_MFMA = 1, 2, 4, 8      # include/umereg.h
+MOMENTS_ORDERED, MOMENTS_RAW, MOMENTS_ACC_F32, MOMENTS_ACC_VALU = 1, 2, 4, 8      # include/umereg.h
 
 
 def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None, kp_index=None,
@@ -123,10 +123,12 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
     kp_index: optional int64 [B,n] -- keypoints as indices into pts (kpts may then be None): the gather
     `pts[0, inds]` of reference evaluate.py:201-202 fused into the kernel.
     normalize=False: the un-normalised matrix of generate_ume_from_keypoints2 (utils/loc_utils.py:160-162).
-    acc: "f64" (default) -- every term accumulated in fp64; "f32" -- neighbour sums in packed fp32 on keypoint-centred
+    acc: "f64" (default) -- every term accumulated in fp64, on the matrix pipe (v_mfma_f64_4x4x4_4b_f64); "f64valu" -- the same sums on the
+    vector pipe (the kernel of rounds 1-3: bit-identical results, 13 % slower; kept for A/B); "f32" -- neighbour sums in packed fp32 on keypoint-centred
     coordinates, everything after them in fp64 (UMEREG_MOMENTS_ACC_F32: 9 % faster, 2.6e-5 instead of correctly rounded)."""
-    if acc not in ("f32", "f64", "mfma"):
-        raise ValueError(f"ume_moments: acc must be 'f32', 'f64' or 'mfma' (got {acc!r})")
+    if acc not in ("f32", "f64", "f64valu"):
+        raise ValueError(f"ume_moments: acc must be 'f64' (default: fp64 sums on the matrix pipe), 'f64valu' (the same on the vector "
+                         f"pipe) or 'f32' (got {acc!r})")
     lib = _lib.load()
     pts = _dev(pts, "pts"); feat = _dev(feat, "feat")
     if kp_index is not None:
@@ -163,7 +165,7 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
             ev = _timed(timing, dev)
             rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(kp_index), _ptr(feat), B, N, n, d, int(K),
                                                    float(radius), ordered | (0 if normalize else MOMENTS_RAW) |
-                                                   (MOMENTS_ACC_F32 if acc == "f32" else MOMENTS_ACC_MFMA if acc == "mfma" else 0), _ptr(F), _ptr(cnt), _ptr(nidx),
+                                                   (MOMENTS_ACC_F32 if acc == "f32" else MOMENTS_ACC_VALU if acc == "f64valu" else 0), _ptr(F), _ptr(cnt), _ptr(nidx),
                                                    _stream_ptr(dev))
             _lib.check(rc, "umereg_ume_moments_packed_f32")
             _timed_end(timing, ev, dev)
