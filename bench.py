@@ -47,7 +47,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~
 L2_PEAK_GBS = 34500.0        # aggregate L2 -> CU rate, same guide ("L2 (per XCD)": ~34.5 TB/s)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same guide)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (same guide; 2:1-sparsity figures excluded)
-VALU_F64_PEAK_TFLOPS = 78.6    # fp64 vector FMA: half the fp32 vector rate of the same guide (157.3 TFLOP/s)
+MFMA_F64_PEAK_TFLOPS = 78.6    # fp64 matrix (v_mfma_f64_*) = fp64 vector FMA rate on MI355X: half the fp32 vector rate of the same guide (157.3);
+                               # measured with four independent v_mfma_f64_4x4x4_4b chains per wave: 64.6 TFLOP/s (profiles/r04/mfma_f64_layout.txt)
 # the reduced-size recall check uses a harsher variant than the KT-size hard leg (calibrated so that recall sits near 75 %)
 RR_CHECK_HARD = dict(sector_deg=180.0, sector_shift_deg=120.0, noise_sigma=0.03, feat_corrupt=0.5)
 GATES = ((1.5, 0.6), (1.5, 0.3), (1.0, 0.1))   # (deg, m): evaluate.py:304 (code), README "Normal", evaluate.py:305 "Strict"
@@ -319,14 +320,14 @@ def main():
     mom_total_ms, dist_total_ms = float(np.sum(mom_ms)), float(np.sum(dist_ms))
     mom_gbs = float(np.sum(mom_bytes_log)) / (mom_total_ms * 1e-3) / 1e9
     dist_tfs = dist_flops * len(dist_ms) / (dist_total_ms * 1e-3) / 1e12
-    # The moment kernel's bound is VALU issue, not HBM: its gathers come out of L2 (hit rate 0.97, fabric traffic 5 % of the
-    # algorithmic bytes), its SIMDs issue VALU instructions 80 % of the time -- 16 fp64 FMA/ADD per lane and neighbour slot.  So the
-    # fraction quoted is fp64 flops against the fp64 vector peak; SURVEY 8(d)'s bytes figure stays as a labelled extra (against the
-    # HBM peak it exceeds 1 -- the bytes never reach HBM -- and is therefore NOT reported as `frac`).
+    # The moment kernel's bound is the fp64 matrix pipe, not HBM: its gathers come out of L2 (hit rate 0.97, fabric traffic 5 % of the
+    # algorithmic bytes); since round 4 its sums run as v_mfma_f64_4x4x4_4b_f64 (exact fp32 x fp32 products, fp64 accumulation).  So the
+    # fraction quoted is fp64 flops against the f64 MFMA peak; SURVEY 8(d)'s bytes figure stays as a labelled extra (against the HBM
+    # peak it exceeds 1 -- the bytes never reach HBM -- and is therefore NOT reported as `frac`).
     mom_flops_log = [b_ / 140.0 * 224.0 for b_ in mom_bytes_log]          # ~ neighbours x 32 channels x (1 add + 3 FMA); 524 B/keypoint ignored
     mom_tfs = float(np.sum(mom_flops_log)) / (mom_total_ms * 1e-3) / 1e12
-    roof_mom = {"kernel": "ume_moments_kernel", "bound": "valu", "achieved": round(mom_tfs, 2), "peak": VALU_F64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(mom_tfs / VALU_F64_PEAK_TFLOPS, 4), "traffic": None,
+    roof_mom = {"kernel": "ume_moments_kernel", "bound": "mfma", "achieved": round(mom_tfs, 2), "peak": MFMA_F64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(mom_tfs / MFMA_F64_PEAK_TFLOPS, 4), "traffic": None,
                 "l2_frac": round(mom_gbs / L2_PEAK_GBS, 4),
                 "survey_8d_algorithmic_gb_per_s": round(mom_gbs, 1), "survey_8d_over_hbm_peak": round(mom_gbs / HBM_PEAK_GBS, 4),
                 "avg_launch_ms": round(float(np.mean(mom_ms)), 4), "launches": len(mom_ms),
@@ -334,10 +335,11 @@ def main():
                 "algorithmic_bytes_per_launch": round(float(np.mean(mom_bytes_log)), 0),
                 "algorithmic_fp64_flops_per_launch": round(float(np.mean(mom_flops_log)), 0),
                 "note": "achieved = fp64 flops of the moment sums (neighbours x 32 channels x 7: one add for sum f, three FMAs for "
-                        "sum f p^T) / kernel time; peak = fp64 vector rate (64 lanes x 2 flop / 4 cycles x 1 024 SIMDs x 2.4 GHz). "
-                        "`survey_8d_*`: SURVEY 8(d)'s algorithmic bytes (140 n_i + 524 per keypoint) / time -- gathers from 8 MB tables "
-                        "that L2 serves, so the ratio to the HBM peak can exceed 1 and is not a utilisation; `l2_frac` = the same rate "
-                        "over the 34.5 TB/s aggregate L2 -> CU bandwidth"}
+                        "sum f p^T; the matrix pipe executes x 8 / 7 of them -- the column of ones) / kernel time, search and epilogue "
+                        "(a third of the kernel) included; peak = f64 MFMA rate = f64 vector rate on this part (78.6 TFLOP/s nominal, "
+                        "64.6 measured for this instruction).  `survey_8d_*`: SURVEY 8(d)'s algorithmic bytes (140 n_i + 524 per "
+                        "keypoint) / time -- gathers from 8 MB tables that L2 serves, so the ratio to the HBM peak can exceed 1 and is "
+                        "not a utilisation; `l2_frac` = the same rate over the 34.5 TB/s aggregate L2 -> CU bandwidth"}
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is
