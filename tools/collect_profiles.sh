@@ -12,11 +12,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 900 python $ROOT/bench.py > $OUT/bench_default.log 2>&1; grep "^{" $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
+timeout -s KILL 1500 python $ROOT/bench.py > $OUT/bench_default.log 2>&1; grep "^{" $OUT/bench_default.log | tail -1 > $OUT/bench_default.json
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 f=$(ls $OUT/stats/*/run_kernel_stats.csv $OUT/stats/run_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
 rm -rf $OUT/stats
-SMALL="--steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e"
+SMALL="--steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e --pool 4 --resident-steps 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py $SMALL > $OUT/pmc_$c.log 2>&1
   f=$(ls $OUT/pmc_$c/*/pmc_counter_collection.csv $OUT/pmc_$c/pmc_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/pmc_$c.csv
@@ -26,6 +26,7 @@ mkdir -p $OUT/sq
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" \
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_TRANS SQ_INSTS_SMEM SQ_INSTS_FLAT" \
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE GRBM_COUNT" \
            "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
