@@ -18,10 +18,74 @@ from .utils.loc_utils import (FeatureCorrelator, batch_estimate_transform_ume_ol
                                ume_kp_layer)
 
 
+class _PinnedRing:
+    """Host -> device uploads of the loop's index arrays (keypoint draws, the weighted draw, the correlation sub-samples: 20-80 KB
+    each, five per pair) and the download of the match probabilities, through a small ring of PINNED buffers: a copy out of pageable
+    numpy memory blocks the host for 50-100 us (staging + synchronisation), a pinned one is an asynchronous enqueue.  A buffer is
+    reused only after the event recorded behind its last copy has completed (a no-op wait in practice: a pair passes several host
+    synchronisations before the ring comes round).  One ring per host thread (threading.local): the end-to-end legs run pairs on
+    several threads."""
+    SLOTS = 8
+
+    def __init__(self):
+        self.buf = [None] * self.SLOTS
+        self.ev = [None] * self.SLOTS
+        self.k = 0
+
+    def slot(self, nbytes):
+        k = self.k = (self.k + 1) % self.SLOTS
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        if self.buf[k] is None or self.buf[k].numel() < nbytes:
+            self.buf[k] = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, pin_memory=True)
+        return k, self.buf[k]
+
+    def mark(self, k, dev):
+        if self.ev[k] is None:
+            self.ev[k] = torch.cuda.Event()
+        self.ev[k].record(torch.cuda.current_stream(dev))
+
+
+_ring_tls = __import__("threading").local()
+
+
+def _ring():
+    r = getattr(_ring_tls, "ring", None)
+    if r is None:
+        r = _ring_tls.ring = _PinnedRing()
+    return r
+
+
 def _index_tensor(idx, dev):
+    """int64 index tensor on `dev`; numpy / list input goes up asynchronously through the pinned ring."""
     if isinstance(idx, torch.Tensor):
         return idx.to(device=dev, dtype=torch.int64)
-    return torch.as_tensor(np.asarray(idx), dtype=torch.int64, device=dev)
+    a = np.ascontiguousarray(np.asarray(idx), dtype=np.int64)
+    dev = torch.device(dev)
+    if dev.type != "cuda" or a.size < 256:
+        return torch.as_tensor(a, dtype=torch.int64, device=dev)
+    ring = _ring()
+    k, buf = ring.slot(a.nbytes)
+    host = buf[:a.nbytes].view(torch.int64).view(a.shape)
+    host.numpy()[...] = a
+    out = torch.empty(a.shape, dtype=torch.int64, device=dev)
+    out.copy_(host, non_blocking=True)
+    ring.mark(k, dev)
+    return out
+
+
+def _to_host(t):
+    """numpy copy of a device tensor through the pinned ring: asynchronous copy + a wait on its own event (a plain .cpu() takes
+    the pageable path: tens of microseconds more per call)."""
+    if not t.is_cuda:
+        return t.detach().numpy()
+    ring = _ring()
+    k, buf = ring.slot(t.numel() * t.element_size())
+    host = buf[:t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+    host.copy_(t, non_blocking=True)
+    ring.mark(k, t.device)
+    ring.ev[k].synchronize()
+    return host.numpy().copy()
 
 
 def pc_fcht(pc1_pts, pc2_pts, pc1_feat, pc2_feat, rtume_hypotises, gt_tform, corr_sigma, args, timing=None, return_tform=False):
@@ -236,8 +300,13 @@ class PairBatch:
         """Stacks two [1,N,*] clouds (one device copy); returns None if their shapes differ."""
         if src_pts.shape != tgt_pts.shape or src_inds.shape != tgt_inds.shape:
             return None
-        return cls(torch.cat([src_pts, tgt_pts], 0), torch.cat([src_feat, tgt_feat], 0),
-                   torch.stack([src_inds.view(-1), tgt_inds.view(-1)], 0))
+        base = getattr(src_inds, "_base", None)
+        if base is not None and base is getattr(tgt_inds, "_base", None) and base.dim() == 2 and base.shape[0] == 2 \
+                and base.is_contiguous() and src_inds.data_ptr() == base.data_ptr() and tgt_inds.data_ptr() == base[1].data_ptr():
+            inds = base                   # the two index sets are the rows of one [2, n_kp] upload already (_draw_keypoints)
+        else:
+            inds = torch.stack([src_inds.view(-1), tgt_inds.view(-1)], 0)
+        return cls(torch.cat([src_pts, tgt_pts], 0), torch.cat([src_feat, tgt_feat], 0), inds)
 
 
 class PairResult(SimpleNamespace):
@@ -304,6 +373,9 @@ def _draw_keypoints_host(n_src, n_tgt, args, rng, src_inds=None, tgt_inds=None):
 def _draw_keypoints(src_pts, tgt_pts, args, rng, src_inds, tgt_inds):
     """Keypoint draws (:195-204): host numpy RNG unless injected; -> device index tensors."""
     src_inds, tgt_inds = _draw_keypoints_host(src_pts.shape[1], tgt_pts.shape[1], args, rng, src_inds, tgt_inds)
+    if not isinstance(src_inds, torch.Tensor) and not isinstance(tgt_inds, torch.Tensor) and len(src_inds) == len(tgt_inds):
+        both = _index_tensor(np.stack([np.asarray(src_inds), np.asarray(tgt_inds)]), src_pts.device)      # one upload: [2, n_kp]
+        return both[0], both[1]
     return _index_tensor(src_inds, src_pts.device), _index_tensor(tgt_inds, src_pts.device)
 
 
@@ -334,7 +406,7 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src
     if args.filter_by_ume_dist_cond and cond is None:
         # tau-weighted sub-sampling of matches (:233-245): the draw consumes the HOST numpy RNG
         num_matches = min(a.num_kpts, args.ume_n_samples)
-        cond = choice_noreplace(rng, a.num_kpts, num_matches, a.prob.cpu().numpy())
+        cond = choice_noreplace(rng, a.num_kpts, num_matches, _to_host(a.prob))
     return _phase_b(a, args, cond)
 
 
