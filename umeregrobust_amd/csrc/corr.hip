@@ -1710,12 +1710,27 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 // d_K(q~) + margin of the image, found through the chunk boxes of the sorted table (coop_knn for d_K, then one pruned sweep)
 // -- the fine range of (2) is what makes the thin shell their neighbours live in selectable in one histogram.
 constexpr float kConsFarMarginCells = 2.5f;   // default margin of the far-point stage (see corr_consensus2_kernel), in grid cells
-constexpr int kCons2Cap = 252;           // staged target points per source point (byte counters: see above)
-constexpr int kCons2Tie = 8;             // list entries per lane for the candidates of the K-th neighbour's bin
+#ifndef UMEREG_CONS2_CAP
+#define UMEREG_CONS2_CAP 252
+#endif
+#ifndef UMEREG_CONS2_TIE
+#define UMEREG_CONS2_TIE 8
+#endif
+#ifndef UMEREG_CONS2_WAVES
+#define UMEREG_CONS2_WAVES 3
+#endif
+constexpr int kCons2Cap = UMEREG_CONS2_CAP;   // staged target points per source point (<= 252: byte counters, see above)
+constexpr int kCons2Tie = 8;             // list entries per lane for the candidates of the K-th neighbour's bin (cell pass)
+constexpr int kC2Tie = UMEREG_CONS2_TIE; // the same in the consensus pass (its LDS budget decides the wavefronts per SIMD)
+constexpr int kC2Slots = (kCons2Cap + 4 + 3) & ~3;   // stage slots: the points + one quad of far-point padding
+static_assert(kCons2Cap <= 252 && kCons2Cap % 4 == 0, "byte counters; quad-aligned cap");
 constexpr int kCons2Zone = 12;           // zone size up to which the rank-counting path is taken
 constexpr int kCons2HistWords = 9;       // 36 byte counters per lane: bin t = 0 below the range, 1..32, 33 at or beyond it
-constexpr size_t kCons2WorkBytes = (size_t)kCons2HistWords * kWave * 4 + (size_t)kCons2Tie * kWave * 8;   // 6 400: >= 252 raw points, >= coop_knn's lists
-__host__ __device__ constexpr size_t cons2_lds_per_wave() { return kCons2WorkBytes + 256 * 16 + 256 * 4 * 2; }
+constexpr size_t kC2MinWork = (size_t)kCoopCap * 8 * 2 + 256 > (size_t)kCons2Cap * 16 ? (size_t)kCoopCap * 8 * 2 + 256 : (size_t)kCons2Cap * 16;
+constexpr size_t kC2ListWork = (size_t)kCons2HistWords * kWave * 4 + (size_t)kC2Tie * kWave * 8;
+// histogram + tie list; during set-up the same bytes hold the collected raw points and coop_knn's two key lists + histogram
+constexpr size_t kCons2WorkBytes = kC2ListWork > kC2MinWork ? kC2ListWork : kC2MinWork;
+__host__ __device__ constexpr size_t cons2_lds_per_wave() { return kCons2WorkBytes + (size_t)kC2Slots * 16 + (size_t)kC2Slots * 4 * 2; }
 
 __device__ __forceinline__ int cons2_bin(float d2, float lo, float sc)
 {
@@ -1822,7 +1837,7 @@ __device__ __forceinline__ void hist16_scan(const unsigned int* hist, int lane, 
     inbin = any ? (hit0 ? h0 : h1) : 0;
 }
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void corr_consensus2_kernel(
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS2_WAVES, UMEREG_CONS2_WAVES))) void corr_consensus2_kernel(
     const char* __restrict__ ws_tgt, const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
     const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed,
     const int* __restrict__ perm, int Ns, int Nt, int M, int K, float sigma, float far_margin_cells, float* __restrict__ val,
@@ -1841,13 +1856,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     unsigned int* hist = reinterpret_cast<unsigned int*>(my);
     KeyList<IdxT> tie;
     tie.d2 = reinterpret_cast<unsigned int*>(my + (size_t)kCons2HistWords * kWave * 4);
-    tie.ix = tie.d2 + kCons2Tie * kWave;
+    tie.ix = tie.d2 + kC2Tie * kWave;
     float4* raw = reinterpret_cast<float4*>(my);                                   // setup only: collected, unsorted
     // the stage: sorted by (distance from the centre, index), quad-padded, one 64-byte record per quad of points:
     // x[4] y[4] z[4] w[4] (w = original index << kConsIdxBits | stage position)
     float* stage = reinterpret_cast<float*>(my + kCons2WorkBytes);
-    float* dots = stage + 256 * 4;
-    float* dc2 = dots + 256;                                                       // squared distance from the centre (ascending)
+    float* dots = stage + kC2Slots * 4;
+    float* dc2 = dots + kC2Slots;                                                       // squared distance from the centre (ascending)
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     const Grid& g = c.g;
     const int n_words = (M + 63) >> 6;
@@ -2167,7 +2182,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             // zoom into the bin once (x32); a lane that still needs more than the list holds is left to the other structures.
             int b1 = -1;
             float lo1 = 0.f, sc1 = 0.f;
-            const bool zoom = b0 >= 0 && K - before > kCons2Tie;
+            const bool zoom = b0 >= 0 && K - before > kC2Tie;
             if (__any(zoom)) {
                 lo1 = lo + (float)(b0 - 1) * width;
                 sc1 = sc * (float)kBins;
@@ -2188,7 +2203,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     cons2_scan(hist, lane, before, K, bb, bef1, inb1);
                     b1 = bb;
                     before = bef1;
-                    if (bb < 0 || K - bef1 > kCons2Tie) { b0 = -1; b1 = -1; }     // exact ties by the dozen: not this pass's business
+                    if (bb < 0 || K - bef1 > kC2Tie) { b0 = -1; b1 = -1; }     // exact ties by the dozen: not this pass's business
                 }
                 if (dbg && lane == 0) atomicAdd(stats + 16, 1u);
             }
@@ -2240,14 +2255,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     for (int k = 0; k < 4; ++k) {
                         const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
                         const bool is_tie = c2[k];
-                        const bool put = is_tie && ntie < kCons2Tie;
+                        const bool put = is_tie && ntie < kC2Tie;
                         if (put) tie.set(ntie, lane, key);
                         ntie += put ? 1 : 0;
                         if (__any(is_tie && !put)) {              // a full list: the new key replaces the largest one if it is smaller
                             unsigned long long mk = 0ull;
                             int mp = 0;
 #pragma unroll
-                            for (int e = 0; e < kCons2Tie; ++e) {
+                            for (int e = 0; e < kC2Tie; ++e) {
                                 const unsigned long long ke = tie.get(e, lane);
                                 if (ke >= mk) { mk = ke; mp = e; }
                             }
@@ -2263,7 +2278,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int bound = wave_max_nonneg(ntie);
                 while (__any(ntie > need_t)) drop_max(tie, ntie, ntie > need_t, bound, lane);
 #pragma unroll
-                for (int e = 0; e < kCons2Tie; ++e) {
+                for (int e = 0; e < kC2Tie; ++e) {
                     if (e < bound) {
                         const bool on = e < ntie;
                         const float d2 = __uint_as_float(tie.d2[e * kWave + lane]);
