@@ -25,6 +25,8 @@ variants = (sys.argv[3] if len(sys.argv) > 3 else "v1,off,4,8,16").split(",")
 dev = torch.device("cuda:0")
 lib = _lib.load()
 cfg = sys.argv[4] if len(sys.argv) > 4 else "KT"
+as_fed = cfg.endswith("F")            # e.g. NSF: the clouds as evaluate.select_hypothesis hands them over (voxel thinning at corr_ds / 0.3 m first)
+cfg = cfg[:-1] if as_fed else cfg
 bench_of = {"KT": "kitti_test", "NS": "nuscenes_test", "LK": "lokitti", "K1": "kitti_test", "SY": "kitti_test"}[cfg]
 args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path(bench_of))
 shape = CONFIGS["KT" if cfg == "LK" else cfg]
@@ -72,7 +74,12 @@ for which in kinds:
     rs = np.random.RandomState(1)
     n_raw = sp.shape[1]
     n_sel = min(int(args.pc_corr_max_size), n_raw)
-    si, ti = t(rs.choice(n_raw, n_sel, replace=False)), t(rs.choice(n_raw, n_sel, replace=False))
+    if as_fed:
+        s_keep, t_keep = ops.voxel_first_index(sp[0].contiguous(), args.corr_ds, tp[0].contiguous(), 0.3)
+        si = s_keep[t(rs.choice(s_keep.numel(), min(int(args.pc_corr_max_size), s_keep.numel()), replace=False))]
+        ti = t_keep[t(rs.choice(t_keep.numel(), min(int(args.pc_corr_max_size), t_keep.numel()), replace=False))]
+    else:
+        si, ti = t(rs.choice(n_raw, n_sel, replace=False)), t(rs.choice(n_raw, n_sel, replace=False))
     a, b, fa, fb = sp[0, si].contiguous(), tp[0, ti].contiguous(), sf[0, si].contiguous(), tf[0, ti].contiguous()
     M, Ns, Nt = T.shape[0], a.shape[0], b.shape[0]
     off = lib.umereg_corr_workspace_bytes_ex(Ns, Nt, M, ops.CORR_NO_LATTICE)

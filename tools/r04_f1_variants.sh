@@ -7,8 +7,8 @@ mkdir -p $(dirname $O); : > $O
 cd $R
 for round in 1 2; do
   for lib in "$@"; do
-    for cfg in KT NS; do
-      v=def; [ $cfg = NS ] && v=defB
+    for cfg in ${CFGS:-KT NS}; do
+      v=def; [ $cfg != KT ] && v=defB
       echo "---- round $round lib ${lib:-shipped} $cfg" >> $O
       ALTLIB=$lib timeout 600 python tools/exp_f1_v2.py 5 plain,hard $v $cfg 2>&1 | grep "^plain\|^hard" | cut -c1-110 >> $O
     done
