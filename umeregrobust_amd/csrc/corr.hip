@@ -541,10 +541,10 @@ __device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int 
 // do not fit the pool, and queries outside the lattice take the grid walk -- same result, by construction.
 constexpr int kLatMaxQuads = 128;                 // longest list (in quads of 4 entries)
 #ifndef UMEREG_LAT_MAXCELLS
-#define UMEREG_LAT_MAXCELLS (1u << 20)
+#define UMEREG_LAT_MAXCELLS (1u << 19)   // (2^20 until round 4: see lattice_budget)
 #endif
 #ifndef UMEREG_LAT_POOLQ
-#define UMEREG_LAT_POOLQ 32
+#define UMEREG_LAT_POOLQ 64
 #endif
 constexpr unsigned int kLatMinCells = 4096, kLatMaxCells = UMEREG_LAT_MAXCELLS;
 constexpr size_t kLatPoolQuadsPerCell = UMEREG_LAT_POOLQ;       // pool size = cells x this (quads): mean list <= 128 entries (16 ran out on a half-overlapping
@@ -625,6 +625,18 @@ __device__ __forceinline__ Lattice load_lattice(const unsigned int* __restrict__
 }
 
 // cell id of a query (brick-major), or -1 outside the lattice (also for NaN coordinates)
+// The lattice's cell budget for THIS call (header word 42, written by leftover_decide_kernel once the consensus pass has counted what
+// it leaves): a cell costs its build -- d_K of the centre, count, fill: ~7 ns of the whole chip -- whether 4 or 60 queries land in it,
+// and a 64-lane step of the cell pass costs the same half empty, so fewer, larger cells win when the leftovers are few.  Measured on
+// nuScenes-test shaped jobs (tools/r04_f1_variants.sh; cells 2^20 / 2^19 / 2^18): 13 000 x 30 000 plain (11 M leftovers) 21.4 / 18.5
+// / 17.3 ms, half-overlapping (32 M) 30.4 / 26.8 / 33.0; 30 000 x 30 000 plain (25 M) 34.1 / 31.0 / 30.1, half-overlapping (95 M)
+// 53.3 / 53.5 / 85 (lists outgrow the pool).  Rule: leftovers / 40 cells, between 2^18 and the workspace's c_max (2^19).
+// Every kernel that maps a point to a lattice cell reads the same word, so the geometry is one per call; 0 = the workspace's c_max.
+__device__ __forceinline__ unsigned int lattice_budget(const char* __restrict__ lat, unsigned int c_max)
+{
+    const unsigned int e = reinterpret_cast<const unsigned int*>(lat)[42];      // (the header is the first 256 bytes of the lattice workspace)
+    return e != 0u && e < c_max ? e : c_max;
+}
 __device__ __forceinline__ int lattice_cell(const Lattice& L, float qx, float qy, float qz)
 {
     const float tx = (qx - L.lox) * L.inv_h, ty = (qy - L.loy) * L.inv_h, tz = (qz - L.loz) * L.inv_hz;
@@ -2312,10 +2324,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
 #endif
 constexpr unsigned int kLeftMax = UMEREG_LEFT_MAX;      // (2^21 until the end of round 3: over 32 half-overlapping KITTI-test pairs, whose leftovers straddle
                                                         // 2 M, f1 averages 7.5 ms with 2^21 and 6.4 with 3 M or 4.5 M -- the flat list holds half the job's queries now)   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
-__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force)
+__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force, unsigned int c_max)
 {
     const long left = n_queries - (long)header[7];
     header[9] = (unsigned int)(left < 0xffffffffl ? left : 0xffffffffl);
+    {
+        // the lattice's cell budget for this call (lattice_budget): leftovers / 40, at least 2^18, at most the workspace's c_max
+        const long want = left / 40;
+        const long lo = (long)c_max < (1l << 18) ? (long)c_max : (1l << 18);
+        header[42] = (unsigned int)(want < lo ? lo : (want > (long)c_max ? (long)c_max : want));
+    }
     header[8] = force == 1 ? 1u : (force == 2 ? 0u : (left <= (long)kLeftMax ? 1u : 0u));   // force: UMEREG_CORR_LEFT_COOP / _LATTICE (tuning)
 }
 
@@ -2338,7 +2356,7 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // the compacted path takes the leftovers
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     unsigned char* marks = reinterpret_cast<unsigned char*>(lat + lw.off_marks);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int h0 = blockIdx.y * hyp_per_thread, h1 = min(h0 + hyp_per_thread, M);
@@ -2403,7 +2421,7 @@ __global__ __launch_bounds__(256) void lattice_mark_order_kernel(const char* __r
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // the compacted path takes the leftovers
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     unsigned char* marks = reinterpret_cast<unsigned char*>(lat + lw.off_marks);
     for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int, int, int, float qx, float qy, float qz) {
         const int cell = lattice_cell(L, qx, qy, qz);
@@ -2420,7 +2438,7 @@ __global__ __launch_bounds__(1024) void lattice_compact_kernel(const char* __res
     __shared__ unsigned int part[1024];
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const uint4* marks16 = reinterpret_cast<const uint4*>(lat + lw.off_marks);
     unsigned int* cids = reinterpret_cast<unsigned int*>(lat + lw.off_cids);
     unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
@@ -2486,7 +2504,7 @@ __global__ __launch_bounds__(8 * 64) void lattice_dk_kernel(const char* __restri
     if (header[8] != 0u) return;
     const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
     uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
     const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
     const unsigned int n_marked = header[3];
@@ -2520,7 +2538,7 @@ __global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restri
     const unsigned int n_marked = header[3];
     const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
     if (blockIdx.x * (blockDim.x >> 6) * kLatLanes >= n_marked) return;          // the whole workgroup is beyond the list
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const bool valid = lane < kLatLanes && wid * kLatLanes + lane < n_marked;
     const int id = (int)cids[valid ? wid * kLatLanes + lane : 0];
     KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
@@ -2606,7 +2624,7 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(const char* __restric
     const uint4 ce = valid ? cells[id] : make_uint4(0u, 0u, 0u, 1u);
     const int quads = ce.w == 0u ? (int)ce.y : 0;
     if (!__any(quads > 0)) return;
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
     int incl = quads;
 #pragma unroll
@@ -2771,7 +2789,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // few leftovers: the queue takes them
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const uint4* cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
     for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int n, int pos, int h, float qx, float qy, float qz) {
         const int cell = lattice_cell(L, qx, qy, qz);
@@ -2811,7 +2829,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     if (header[8] != 0u) return;
     const unsigned int n_marked = header[3];
     const unsigned long long* pool = reinterpret_cast<const unsigned long long*>(lat + lw.off_pool);
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
     KeyList<IdxT> tie;
     tie.d2 = reinterpret_cast<unsigned int*>(lds);
@@ -3066,7 +3084,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint4* queue = nullptr;
     if (LAT) {
         const LatWs lw = lat_ws(c_max);
-        Lt = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), c_max);
+        Lt = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
         cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
         pool = reinterpret_cast<const uint2*>(lat + lw.off_pool);
         lat_header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
@@ -3526,7 +3544,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
     float bmn[3] = {0.f, 0.f, 0.f}, bmx[3] = {0.f, 0.f, 0.f}, vq_max = 0.f;
     if (kMode != 0) {
         const unsigned int* bbox = reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox);
-        Lt = load_lattice(bbox, c_max);
+        Lt = load_lattice(bbox, lattice_budget(lat, c_max));
 #pragma unroll
         for (int k = 0; k < 3; ++k) { bmn[k] = dec_ord(~bbox[k]); bmx[k] = dec_ord(bbox[3 + k]); }
         vq_max = __uint_as_float(*vq_max_bits);
@@ -4236,7 +4254,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         }
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
         hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns,
-                           (flags & UMEREG_CORR_LEFT_COOP) ? 1 : ((flags & UMEREG_CORR_LEFT_LATTICE) ? 2 : 0));
+                           (flags & UMEREG_CORR_LEFT_COOP) ? 1 : ((flags & UMEREG_CORR_LEFT_LATTICE) ? 2 : 0), c_max);
         UMEREG_CHECK_LAUNCH("leftover_decide_kernel");
         if (hipMemsetAsync(partial, 0, (size_t)M * n_chunks_sz * 4, st) != hipSuccess) { set_error("hipMemsetAsync(partial) failed"); return UMEREG_ELAUNCH; }
         hipLaunchKernelGGL(leftover_queue_kernel, dim3((unsigned)(((long)n_chunks * n_words + 3) / 4)), dim3(256), 0, st, (const char*)ws_src, Ns, M,
