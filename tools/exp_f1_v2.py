@@ -27,9 +27,9 @@ lib = _lib.load()
 cfg = sys.argv[4] if len(sys.argv) > 4 else "KT"
 as_fed = cfg.endswith("F")            # e.g. NSF: the clouds as evaluate.select_hypothesis hands them over (voxel thinning at corr_ds / 0.3 m first)
 cfg = cfg[:-1] if as_fed else cfg
-bench_of = {"KT": "kitti_test", "NS": "nuscenes_test", "LK": "lokitti", "K1": "kitti_test", "SY": "kitti_test"}[cfg]
+bench_of = {"KT": "kitti_test", "NS": "nuscenes_test", "LK": "lokitti", "LN": "lonuscenes", "K1": "kitti_test", "SY": "kitti_test"}[cfg]
 args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path(bench_of))
-shape = CONFIGS["KT" if cfg == "LK" else cfg]
+shape = CONFIGS["KT" if cfg == "LK" else ("NS" if cfg == "LN" else cfg)]
 if not shape["filter_by_ume_dist_cond"]:
     args.filter_by_ume_dist_cond = False
     args.ume_n_samples = shape["M"]

@@ -540,6 +540,12 @@ __device__ __forceinline__ KnnCtx make_ctx(const char* wb, const GridWs& w, int 
 // position of a padding point (d2 ~ 3e36: never admitted).  Cells whose list would exceed kLatMaxQuads, cells that
 // do not fit the pool, and queries outside the lattice take the grid walk -- same result, by construction.
 constexpr int kLatMaxQuads = 128;                 // longest list (in quads of 4 entries)
+#ifndef UMEREG_LAT_DIV
+#define UMEREG_LAT_DIV 40        // leftover queries per lattice cell the budget aims at (lattice_budget)
+#endif
+#ifndef UMEREG_LAT_MINBUDGET
+#define UMEREG_LAT_MINBUDGET (1l << 18)     // the budget's floor
+#endif
 #ifndef UMEREG_LAT_MAXCELLS
 #define UMEREG_LAT_MAXCELLS (1u << 19)   // (2^20 until round 4: see lattice_budget)
 #endif
@@ -566,7 +572,8 @@ struct LatWs {
 
 // header words: [0] pool quads handed out, [1] cells, [2] marked cells without a list, [3] marked cells,
 //               [4] fallback records, [6] fallback queries; cell pass: [32] queries listed, [33] next marked cell to take,
-//               [34] queries served, [35] queries it listed and could not select for, [36] batches
+//               [34] queries served, [35] queries it listed and could not select for, [36] batches, [37] / [38] next / number of work items
+//               of the long-list instance, [43] / [39] the same for the short-list instance's big cells (kCellChunk), [42] the call's cell budget
 __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
 {
     LatWs w;
@@ -2329,9 +2336,9 @@ __global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n
     const long left = n_queries - (long)header[7];
     header[9] = (unsigned int)(left < 0xffffffffl ? left : 0xffffffffl);
     {
-        // the lattice's cell budget for this call (lattice_budget): leftovers / 40, at least 2^18, at most the workspace's c_max
-        const long want = left / 40;
-        const long lo = (long)c_max < (1l << 18) ? (long)c_max : (1l << 18);
+        // the lattice's cell budget for this call (lattice_budget): leftovers / UMEREG_LAT_DIV, at least 2^18, at most the workspace's c_max
+        const long want = left / UMEREG_LAT_DIV;
+        const long lo = (long)c_max < UMEREG_LAT_MINBUDGET ? (long)c_max : UMEREG_LAT_MINBUDGET;
         header[42] = (unsigned int)(want < lo ? lo : (want > (long)c_max ? (long)c_max : want));
     }
     header[8] = force == 1 ? 1u : (force == 2 ? 0u : (left <= (long)kLeftMax ? 1u : 0u));   // force: UMEREG_CORR_LEFT_COOP / _LATTICE (tuning)
@@ -2682,20 +2689,30 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(const char* __restric
 constexpr int kCellCap = 252;                       // list entries (byte counters: see corr_consensus2_kernel)
 constexpr size_t kCellMaxEntries = (size_t)1 << 26; // queries the pass can list (512 MiB of entries)
 constexpr long kCellMinQueries = 1l << 25;          // jobs below this never enqueue the pass (a KITTI-test pair: 2.5e7 queries, leftovers <= 2 M go to the queue)
-constexpr int kCellFetch = 4;                       // marked cells a wavefront takes per visit of the work counter
+constexpr int kCellFetch = 4;                       // work items a wavefront takes per visit of the work counter
+#ifndef UMEREG_CELL_CHUNK
+#define UMEREG_CELL_CHUNK 512
+#endif
+constexpr unsigned int kCellChunk = UMEREG_CELL_CHUNK;            // queries per work item: a cell with more is cut into several (any wavefront takes any of them).  Cells in EMPTY
+                                                    // parts of the target collect the images of every hypothesis for the source points around them -- 10^5 queries in one
+                                                    // cell of a half-overlapping KITTI-test pair, 1 600 steps of ONE wavefront while the chip idles (25 ms for 1.4 M queries)
 struct CellWs {
     unsigned int* cnt;     // [c_max] unserved queries per cell (lattice_mark_kernel), then (cell_apply_kernel) the cell's first entry
     unsigned int* cur;     // [c_max] scatter cursor
     unsigned int* bsum;    // [1024 + 64] per-block sums / offsets of the scan
     uint4* rec;            // [2 c_max] per MARKED cell, in the order of the marked list: (cell, first entry, entries, d_K^2 bits), (list first, list quads, -, -)
     uint2* ent;            // [cap] (source point x M + position of the hypothesis in the chunk's order, hypothesis)
-    unsigned int* long_idx; // [c_max] positions (in the marked list) of the cells with queries and a list of more than kCellCap entries (header word 38: how many)
+    uint2* items_s;        // [cell_items] work items (position of the cell in the marked list, chunk of kCellChunk entries) of the cells with a list of <= kCellCap
+                           // entries (header word 39: how many), in the order the atomics gave (roughly the marked list's)
+    uint2* items_l;        // [cell_items] the same for the cells with a longer list (header word 38: how many)
     unsigned int cap;
 };
 __host__ __device__ inline size_t cell_cap(long queries) { return (size_t)(queries < (long)kCellMaxEntries ? queries : (long)kCellMaxEntries); }
+__host__ __device__ inline size_t cell_items(unsigned int c_max, long queries) { return (size_t)c_max + cell_cap(queries) / kCellChunk + 64; }
 __host__ inline size_t cell_bytes(unsigned int c_max, long queries)
 {
-    return 3 * align_up(((size_t)c_max + 64) * 4, 256) + align_up((1024 + 64) * 4, 256) + align_up((size_t)c_max * 32, 256) + align_up(cell_cap(queries) * 8, 256);
+    return 2 * align_up(((size_t)c_max + 64) * 4, 256) + 2 * align_up(cell_items(c_max, queries) * 8, 256) + align_up((1024 + 64) * 4, 256) +
+           align_up((size_t)c_max * 32, 256) + align_up(cell_cap(queries) * 8, 256);
 }
 __host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
 {
@@ -2705,7 +2722,8 @@ __host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
     w.cur = reinterpret_cast<unsigned int*>(base + o);  o += align_up(((size_t)c_max + 64) * 4, 256);
     w.bsum = reinterpret_cast<unsigned int*>(base + o); o += align_up((1024 + 64) * 4, 256);
     w.rec = reinterpret_cast<uint4*>(base + o);         o += align_up((size_t)c_max * 32, 256);
-    w.long_idx = reinterpret_cast<unsigned int*>(base + o); o += align_up(((size_t)c_max + 64) * 4, 256);
+    w.items_s = reinterpret_cast<uint2*>(base + o);     o += align_up(cell_items(c_max, queries) * 8, 256);
+    w.items_l = reinterpret_cast<uint2*>(base + o);     o += align_up(cell_items(c_max, queries) * 8, 256);
     w.ent = reinterpret_cast<uint2*>(base + o);
     w.cap = (unsigned int)cell_cap(queries);
     return w;
@@ -2744,23 +2762,30 @@ __global__ __launch_bounds__(1024) void cell_apply_kernel(char* __restrict__ lat
         return;
     }
     const unsigned int first = cw.bsum[blockIdx.x] + base + (unsigned int)incl - v;
+    const unsigned int n_e = (i >= n || first >= cw.cap) ? 0u : min(v, cw.cap - first);
     if (i < n) {
         cw.cnt[id] = first;
         cw.cur[id] = 0u;
-        const unsigned int n_e = first >= cw.cap ? 0u : min(v, cw.cap - first);
         cw.rec[2 * (size_t)i] = make_uint4(id, first, n_e, reinterpret_cast<const unsigned int*>(lat + lw.off_dk2)[id]);
         cw.rec[2 * (size_t)i + 1] = make_uint4(ce.x, ce.y, 0u, 0u);
     }
-    {
-        // the work list of the long-list instance (any order: every cell is computed on its own)
-        const bool lng = i < n && v != 0u && first < cw.cap && ce.y * 4u > (unsigned int)kCellCap;
-        const unsigned long long m = __ballot(lng);
-        if (m != 0ull) {
-            unsigned int b = 0u;
-            if (lane == 0) b = atomicAdd(const_cast<unsigned int*>(&header[38]), (unsigned int)__popcll(m));
-            b = (unsigned int)__shfl((int)b, 0, kWave);
-            if (lng) cw.long_idx[b + (unsigned int)mbcnt(m)] = i;
-        }
+    // the work lists of the two instances of corr_cell_kernel (any order: every query is computed on its own): one item per kCellChunk entries
+    // of a cell, a run of consecutive slots per wavefront and list
+    const bool lng = ce.y * 4u > (unsigned int)kCellCap;
+    // (the short-list instance walks the marked list itself, in brick order, for every cell of up to kCellChunk queries: only the bigger cells go
+    // through its item list -- an item per cell cost the ordinary pair 5 %: one more dependent load per visit, and the atomics' order is not the bricks')
+    const unsigned int n_it = (!lng && n_e <= kCellChunk) ? 0u : (n_e + kCellChunk - 1u) / kCellChunk;
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+        const unsigned int mine = lng == (kind == 1) ? n_it : 0u;
+        const int isc = wave_incl_scan((int)mine);
+        const unsigned int tot = (unsigned int)__shfl(isc, 63, kWave);
+        if (tot == 0u) continue;
+        unsigned int b = 0u;
+        if (lane == 0) b = atomicAdd(const_cast<unsigned int*>(&header[kind ? 38 : 39]), tot);
+        b = (unsigned int)__shfl((int)b, 0, kWave);
+        uint2* dst = (kind ? cw.items_l : cw.items_s) + b + ((unsigned int)isc - mine);
+        for (unsigned int k = 0; k < mine; ++k) dst[k] = make_uint2(i, k);
     }
 }
 __global__ __launch_bounds__(1024) void cell_blockscan_kernel(char* __restrict__ lat, unsigned int c_max, CellWs cw)
@@ -2849,23 +2874,42 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     unsigned int n_ok = 0u, n_fail = 0u, n_batches = 0u;
+    bool big_phase = !kLong;
     for (;;) {
         unsigned int i0 = 0u;
         // (the long-list instance takes its cells one at a time from the list cell_apply_kernel<1> compacted for it -- a few per cent of
         // the marked cells, clustered in dense spots: walking the whole marked list cost it a quarter of a million visits of the counter,
         // ~12 ns apiece and serialised, and 32 cells per visit left stragglers with dozens of long cells: 6.8 -> 17.7 ms)
+        // The short-list instance first takes the chunks of the cells with more than kCellChunk queries (item list, one per visit: the big work
+        // goes first and spreads), then walks the marked list, kCellFetch cells per visit, skipping those cells; the long-list instance has its
+        // item list only.
         constexpr int kFetch = kLong ? 1 : kCellFetch;
-        if (lane == 0) i0 = atomicAdd(&header[kLong ? 37 : 33], (unsigned int)kFetch);
+        const bool from_list = kLong || big_phase;
+        const int fetch = from_list ? 1 : kFetch;
+        if (lane == 0) i0 = atomicAdd(&header[kLong ? 37 : (big_phase ? 43 : 33)], (unsigned int)fetch);
         i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
-        if (i0 >= (kLong ? header[38] : n_marked)) break;
-        if (kLong) i0 = cw.long_idx[i0];
-        // the records of the kCellFetch cells of this visit: lanes 0 .. 2 kCellFetch - 1 hold one 16-byte half each
+        const unsigned int n_items = from_list ? header[kLong ? 38 : 39] : n_marked;
+        if (i0 >= n_items) {
+            if (!kLong && big_phase) { big_phase = false; continue; }
+            break;
+        }
+        // the cells of this visit: lanes 0 .. 2 fetch - 1 hold one 16-byte half of a record each (and the chunk to take)
         uint4 rl = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < 2 * kFetch && i0 + (unsigned int)(lane >> 1) < n_marked) rl = cw.rec[2 * (size_t)i0 + lane];
+        uint2 it = make_uint2(0u, 0u);
+        if (lane < 2 * fetch && i0 + (unsigned int)(lane >> 1) < n_items) {
+            it = make_uint2(i0 + (unsigned int)(lane >> 1), 0u);
+            if (from_list) it = (kLong ? cw.items_l : cw.items_s)[i0 + (unsigned int)(lane >> 1)];
+            if (it.x < n_marked) rl = cw.rec[2 * (size_t)it.x + (lane & 1)];
+        }
         for (int ci = 0; ci < kFetch; ++ci) {
         const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
-        const unsigned int first_e = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
-        const unsigned int n_e = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
+        const unsigned int cell_first = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
+        const unsigned int cell_ne = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
+        const unsigned int chunk0 = (unsigned int)__builtin_amdgcn_readlane((int)it.y, 2 * ci) * kCellChunk;
+        if (chunk0 >= cell_ne) continue;                      // (also the slots past the end of the list: cell_ne = 0)
+        if (!from_list && cell_ne > kCellChunk) continue;     // (its chunks were in the item list)
+        const unsigned int first_e = cell_first + chunk0;
+        const unsigned int n_e = min(cell_ne - chunk0, kCellChunk);
         const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
         const unsigned int lfirst = (unsigned int)__builtin_amdgcn_readlane((int)rl.x, 2 * ci + 1);
         const int quads = __builtin_amdgcn_readlane((int)rl.y, 2 * ci + 1);
