@@ -2833,7 +2833,8 @@ __host__ __device__ inline size_t cell_lds_per_wave(int K, bool lng)
 {
     // tie list (16-bit index plane) | stage (256 or 512 slots x 16 B) | the lane's K keys (d2 plane -- the histogram lives there until
     // the second sweep starts --, 16-bit index plane)
-    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : 256) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256;
+    // | the cells of the current group (kCellFetch x 8 words)
+    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : 256) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256 + (size_t)kCellFetch * 32;
 }
 
 // kLong = false: the cells whose list has <= kCellCap entries (byte counters, 256 stage slots: 14.5 KiB of LDS per wavefront);
@@ -2864,6 +2865,8 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + (kLong ? 512 : 256) * 16);
     unsigned int* hist = list.d2;                    // (dead before the first key is written: see cell_lds_per_wave)
     list.ix = reinterpret_cast<IdxT*>(reinterpret_cast<char*>(list.d2) + cell_d2_plane(K, kLong));
+    unsigned int* tab = reinterpret_cast<unsigned int*>(lds + cell_lds_per_wave(K, kLong) - (size_t)kCellFetch * 32);
+    constexpr unsigned int kStageQuads = kLong ? 128u : 64u;
     constexpr int kHW = kLong ? kHist16Words : kCons2HistWords;
     auto h_add = [&](int t) __attribute__((always_inline)) { if (kLong) hist16_add(hist, lane, t); else cons2_hist_add(hist, lane, t); };
     auto h_scan = [&](int base, int& bstar, int& before, int& inbin) __attribute__((always_inline)) {
@@ -2901,23 +2904,42 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             if (from_list) it = (kLong ? cw.items_l : cw.items_s)[i0 + (unsigned int)(lane >> 1)];
             if (it.x < n_marked) rl = cw.rec[2 * (size_t)it.x + (lane & 1)];
         }
-        for (int ci = 0; ci < kFetch; ++ci) {
-        const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
-        const unsigned int cell_first = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
-        const unsigned int cell_ne = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
-        const unsigned int chunk0 = (unsigned int)__builtin_amdgcn_readlane((int)it.y, 2 * ci) * kCellChunk;
-        if (chunk0 >= cell_ne) continue;                      // (also the slots past the end of the list: cell_ne = 0)
-        if (!from_list && cell_ne > kCellChunk) continue;     // (its chunks were in the item list)
-        const unsigned int first_e = cell_first + chunk0;
-        const unsigned int n_e = min(cell_ne - chunk0, kCellChunk);
-        const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
-        const unsigned int lfirst = (unsigned int)__builtin_amdgcn_readlane((int)rl.x, 2 * ci + 1);
-        const int quads = __builtin_amdgcn_readlane((int)rl.y, 2 * ci + 1);
-        if (n_e == 0u || (quads * 4 > kCellCap) != kLong) continue;
-        // ---- the cell's list into the stage: quad q of the stage = the four positions of list word q (padding = a far point) ----
+        // The cells of a visit are taken in GROUPS: as many consecutive ones as fit the stage together (their lists back to back, <= kStageQuads quads),
+        // and the queries of a group's cells -- consecutive in the entry buffer but for the cells this instance skips -- fill the 64-lane steps
+        // together: a lane carries its cell's part of the stage, centre and d_K.  (One cell per step left the steps half empty: 31 queries per
+        // step on a nuScenes-size job, 12 on a KITTI-size one, and a step costs the same whatever its fill.)
+        int ci = 0;
+        while (ci < fetch) {
+        int g = 0;
+        unsigned int Q = 0u, N = 0u;
+        while (ci < fetch) {
+            const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
+            const unsigned int cell_first = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
+            const unsigned int cell_ne = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
+            const unsigned int chunk0 = (unsigned int)__builtin_amdgcn_readlane((int)it.y, 2 * ci) * kCellChunk;
+            const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
+            const unsigned int lfirst = (unsigned int)__builtin_amdgcn_readlane((int)rl.x, 2 * ci + 1);
+            const unsigned int quads = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci + 1);
+            // skipped: the slots past the end of the list (cell_ne = 0), cells without queries, (marked-list walk) cells whose chunks were in the
+            // item list, cells of the other instance
+            const bool take = chunk0 < cell_ne && (from_list || cell_ne <= kCellChunk) && quads != 0u && ((int)quads * 4 > kCellCap) == kLong &&
+                              quads <= kStageQuads;
+            if (!take) { ++ci; continue; }
+            if (g > 0 && Q + quads > kStageQuads) break;
+            const unsigned int n_e = min(cell_ne - chunk0, kCellChunk);
+            if (lane == 0) {
+                unsigned int* t = tab + g * 8;
+                t[0] = (unsigned int)id; t[1] = cell_first + chunk0; t[2] = dk2b; t[3] = lfirst; t[4] = Q; t[5] = quads; t[6] = N; t[7] = n_e;
+            }
+            Q += quads; N += n_e; ++g; ++ci;
+        }
+        if (g == 0) break;
+        // ---- the group's lists into the stage: quad q of the stage = the four positions of a list word (padding = a far point) ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int q = lane; q < quads; q += kWave) {
-            const unsigned long long w = pool[(size_t)lfirst + q];
+        for (unsigned int q = (unsigned int)lane; q < Q; q += kWave) {
+            int c = 0;
+            for (int k = 1; k < g; ++k) c += q >= tab[k * 8 + 4] ? 1 : 0;
+            const unsigned long long w = pool[(size_t)tab[c * 8 + 3] + (q - tab[c * 8 + 4])];
             float* q4 = stage + q * 16;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2926,13 +2948,19 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int m_use = quads * 4;
-        float ccx, ccy, ccz;
-        lattice_cell_centre(L, id, ccx, ccy, ccz);
-        const float dk = sqrtf(__uint_as_float(dk2b));
-        for (unsigned int b0e = 0u; b0e < n_e; b0e += kWave) {
-            const bool valid = b0e + (unsigned int)lane < n_e;
-            const uint2 eh = cw.ent[first_e + (valid ? b0e + (unsigned int)lane : 0u)];
+        for (unsigned int b0e = 0u; b0e < N; b0e += kWave) {
+            const unsigned int qi = b0e + (unsigned int)lane;
+            const bool valid = qi < N;
+            int c = 0;
+            for (int k = 1; k < g; ++k) c += qi >= tab[k * 8 + 6] ? 1 : 0;
+            const uint4 t0 = *reinterpret_cast<const uint4*>(tab + c * 8), t1 = *reinterpret_cast<const uint4*>(tab + c * 8 + 4);
+            const float* stage_l = stage + t1.x * 16u;          // this lane's cell: its part of the stage,
+            const int m_l = valid ? (int)t1.y * 4 : 0;          // its list (entries, padded to quads),
+            const int m_use = wave_max_nonneg(m_l);             // the longest list of the step
+            float ccx, ccy, ccz;
+            lattice_cell_centre(L, (int)t0.x, ccx, ccy, ccz);
+            const float dk = sqrtf(__uint_as_float(t0.z));
+            const uint2 eh = cw.ent[t0.y + (valid ? qi - t1.z : 0u)];
             const unsigned int e = eh.x;
             const int n = (int)(e / (unsigned int)M), ph = (int)(e % (unsigned int)M);
             const float px = src_pts[(size_t)n * 3], py = src_pts[(size_t)n * 3 + 1], pz = src_pts[(size_t)n * 3 + 2];
@@ -2952,7 +2980,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             const float sc = __builtin_amdgcn_rcpf(width);
             const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
             auto quad_d2 = [&](int u0, f2& t01, f2& t23) __attribute__((always_inline)) {
-                const f4* q4 = reinterpret_cast<const f4*>(stage + u0 * 4);
+                const f4* q4 = reinterpret_cast<const f4*>(stage_l + u0 * 4);
                 const f4 X = q4[0], Y = q4[1], Z = q4[2];
                 const f2 dx01 = qx2 - X.xy, dx23 = qx2 - X.zw;
                 const f2 dy01 = qy2 - Y.xy, dy23 = qy2 - Y.zw;
@@ -2960,6 +2988,10 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
                 t01 = dx01 * dx01; t23 = dx23 * dx23;
                 t01 = t01 + dy01 * dy01; t23 = t23 + dy23 * dy23;
                 t01 = t01 + dz01 * dz01; t23 = t23 + dz23 * dz23;
+                // past the end of this lane's list lies the next cell's: those quads count as padding (a far point: last bin, no class)
+                const bool in = u0 < m_l;
+                const f2 far = {3.0e36f, 3.0e36f};
+                t01 = in ? t01 : far; t23 = in ? t23 : far;
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the previous step's epilogue read the plane the histogram shares)
 #pragma unroll
@@ -3025,7 +3057,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { c1[k] = d2v[k] < thA; c2[k] = !c1[k] && d2v[k] < thB; }
                 if (__any(c1[0] || c1[1] || c1[2] || c1[3] || c2[0] || c2[1] || c2[2] || c2[3])) {
-                    const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
+                    const f4 W = reinterpret_cast<const f4*>(stage_l + u0 * 4)[3];
                     const float wv[4] = {W.x, W.y, W.z, W.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -3095,7 +3127,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             n_fail += (unsigned int)__popcll(__ballot(valid && !ok));
             ++n_batches;
         }
-        }   // the cells of this visit
+        }   // the groups of this visit
     }
     if (lane == 0) {
         if (n_ok) atomicAdd(&header[34], n_ok);
