@@ -440,6 +440,7 @@ def main():
         n_fl = max(1, n_fl)
         sel_timing, ev, errs, icp_it = [[] for _ in range(n_fl)], [[] for _ in range(n_fl)], [[] for _ in range(n_fl)], [[] for _ in range(n_fl)]
         done = [[] for _ in range(n_fl)]
+        waiting = [None for _ in range(n_fl)]
         sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
         ref_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
         streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
@@ -470,16 +471,29 @@ def main():
                                                                    timing=sel_timing[w] if timed else None, prepared=prep,
                                                                    return_tform=True)                               # :258-296
             stamps[2].record()
-            nxt = draws(i_next) if i_next is not None else None      # host work in the shadow of the score kernels
-            # the ICP starts from the selected transform on the device: enqueued behind the scores, no host read in between
-            reg = ops.icp_point_to_point(e.src_pts[0], e.tgt_pts[0], T_sel[0], 0.2, 200)                            # :63-109
+            # the ICP starts from the selected transform on the device: its whole chain is enqueued behind the scores (ops.IcpJob: the
+            # stop test lives on the device) and its result is read when the NEXT pair has been enqueued -- evaluate.py:301 refines after
+            # the loop, nothing on the host needs it earlier.  The GPU still works through one pair after the other on this stream.
+            job = ops.IcpJob(e.src_pts[0], e.tgt_pts[0], T_sel[0].contiguous(), 0.2, 200)                            # :63-109
             stamps[3].record()
+            nxt = draws(i_next) if i_next is not None else None      # host work in the shadow of the score kernels
+            collect(w)
             if timed:
                 # (the metrics of :301-309 are computed after the loop, as in the reference: nothing of them sits between two pairs)
-                done[w].append((T_sel, reg.transformation, e.gt))
+                waiting[w] = (job, T_sel, e.gt, stamps)
+            else:
+                job.result()
+            return nxt
+
+        def collect(w):
+            """the previous pair's refined transform (its ICP ran behind its scores; by now it is waiting in pinned memory)"""
+            if waiting[w] is not None:
+                job, T_sel, gt_, stamps = waiting[w]
+                waiting[w] = None
+                reg = job.result()
+                done[w].append((T_sel, reg.transformation, gt_))
                 ev[w].append(stamps)
                 icp_it[w].append(reg.iterations)
-            return nxt
 
         def metrics(w):
             """RRE / RTE and the recall gates of this worker's timed pairs (evaluate.py:301-309), after its loop -- inside the timed
@@ -498,6 +512,7 @@ def main():
                 pre = None
                 for k, i in enumerate(mine):
                     pre = one(i, timed, w, pre, mine[k + 1] if k + 1 < len(mine) else None)
+                collect(w)
                 if timed:
                     metrics(w)
                 streams[w].synchronize()
@@ -590,8 +605,9 @@ def main():
                 "note": "evaluate.evaluate_pairs over the same pairs on ONE host thread and ONE host RNG stream consumed in the "
                         "reference's order (keypoint draws, weighted draw, two sub-sampling draws, pair after pair); pair i + 1 is "
                         "prepared on a second HIP stream while the correlation scores of pair i are computed, and the ICP of a pair "
-                        "(evaluate.py:301 runs it after the loop; it draws nothing) runs when its hypothesis is read back, beside "
-                        "the next pair's scores -- results identical to one pair at a time "
+                        "(evaluate.py:301 runs it after the loop; it draws nothing) is enqueued right behind its hypothesis selection "
+                        "(ops.IcpJob: start transform and stop test on the device) and read one pair later -- results identical to "
+                        "one pair at a time "
                         "(test_evaluate_pairs_overlapped_equals_one_pair_at_a_time)"}
 
     if not a.no_e2e and a.e2e_pairs > 0:
@@ -609,6 +625,7 @@ def main():
                                             "sigma = 2 cm point noise, 20 % corrupted features", a.e2e_in_flight)
         if a.e2e_side_by_side > a.e2e_in_flight:
             result["end_to_end_hard"]["side_by_side"] = side_by_side(e2e_leg(hard_pool, a.e2e_hard_pairs, 600000, "", a.e2e_side_by_side))
+        result["end_to_end_hard"]["evaluate_pairs_loop"] = api_loop(hard_pool, a.e2e_hard_pairs, 610000)
         hard_pool_first = hard_pool[0]
         del hard_pool
 
@@ -666,7 +683,8 @@ def main():
     result["config"]["end_to_end_pairs_per_s"] = {
         "plain_pair_by_pair": e2e and e2e["pairs_per_s"], "plain_evaluate_pairs": e2e and e2e.get("evaluate_pairs_loop", {}).get("pairs_per_s"),
         "plain_side_by_side": e2e and e2e.get("side_by_side", {}).get("pairs_per_s"),
-        "hard_pair_by_pair": e2h and e2h["pairs_per_s"], "hard_side_by_side": e2h and e2h.get("side_by_side", {}).get("pairs_per_s"),
+        "hard_pair_by_pair": e2h and e2h["pairs_per_s"], "hard_evaluate_pairs": e2h and e2h.get("evaluate_pairs_loop", {}).get("pairs_per_s"),
+        "hard_side_by_side": e2h and e2h.get("side_by_side", {}).get("pairs_per_s"),
         "f1_ms_plain": f1s.get("plain", {}).get("stage_ms", {}).get("total"), "f1_ms_hard": f1s.get("hard", {}).get("stage_ms", {}).get("total"),
         "what": "a1-a7 + raw-cloud prep + f1 hypothesis selection + f2 ICP per pair (evaluate.py:195-309), whole job"}
     # the dominant kernel of a REGISTRATION (not of the named path): the consensus pass of f1

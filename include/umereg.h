@@ -480,6 +480,19 @@ int umereg_icp_point_to_point_dev_f32(const float* src, const float* tgt, int n_
                                       int max_iteration, double relative_fitness, double relative_rmse,
                                       double* T_out_host, double* fitness_host, double* inlier_rmse_host,
                                       int* iterations_host, void* workspace, size_t workspace_bytes, void* stream);
+/* The same in pieces that never wait, for a loop that keeps several pairs in flight (evaluate.py:301 refines after the loop: nothing
+ * on the host needs a refined transform before the metrics).  umereg_icp_enqueue_f32 enqueues [first != 0: the target's search grid
+ * and the initial state from T_init_dev] + `iterations` evaluation / update pairs (the stop test lives on the device: iterations
+ * beyond it find the flag set and return) + an asynchronous copy of the state to state_host (umereg_icp_state_bytes() bytes of
+ * PINNED host memory) and returns.  Once the caller has waited for the stream (an event recorded behind the call),
+ * umereg_icp_state_decode reads that copy: *done_host = 0 means "enqueue more" (first = 0, same workspace, untouched in between). */
+size_t umereg_icp_state_bytes(void);
+int umereg_icp_enqueue_f32(const float* src, const float* tgt, int n_src, int n_tgt, const float* T_init_dev,
+                           float max_correspondence_distance, int max_iteration, double relative_fitness,
+                           double relative_rmse, int first, int iterations, void* state_host, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int umereg_icp_state_decode(const void* state_host, double* T_out_host, double* fitness_host, double* inlier_rmse_host,
+                            int* iterations_host, int* done_host);
 
 #ifdef __cplusplus
 }

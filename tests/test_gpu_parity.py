@@ -1406,6 +1406,29 @@ def test_icp_edge_cases(gpu):
     assert out.iterations == ref[3] and abs(out.fitness - ref[1]) < 1e-12 and np.abs(out.transformation - ref[0]).max() < 1e-9
 
 
+def test_icp_job_equals_the_synchronous_call(gpu):
+    """ops.IcpJob (the chain enqueued without a wait, collected later) returns what ops.icp_point_to_point returns: same transform bit
+    for bit, same fitness / rmse / iteration count -- also when four updates are not enough (a continuation batch), with two jobs in
+    flight on one stream (a workspace each) and with the start transform still being written when the job is created."""
+    from umeregrobust_amd import ops
+    jobs, refs = [], []
+    for seed, max_it in ((3, 30), (5, 2), (8, 200)):
+        src, tgt, gt, T0 = _icp_case(seed, ang_deg=2.5, shift=0.15) if seed == 8 else _icp_case(seed)
+        s_, t_ = T_(src, gpu), T_(tgt, gpu)
+        T0d = torch.zeros((4, 4), dtype=torch.float32, device=gpu)
+        T0d.copy_(torch.from_numpy(T0.astype(np.float32)), non_blocking=True)
+        jobs.append(ops.IcpJob(s_, t_, T0d, 0.2, max_it))
+        refs.append((s_, t_, T0d, max_it))
+    for job, (s_, t_, T0d, max_it) in zip(jobs, refs):
+        out = job.result()
+        ref = ops.icp_point_to_point(s_, t_, T0d, 0.2, max_it)
+        assert np.array_equal(out.transformation, ref.transformation)
+        assert out.iterations == ref.iterations and out.fitness == ref.fitness and out.inlier_rmse == ref.inlier_rmse
+        assert job.result() is out
+    with pytest.raises(ValueError):
+        ops.IcpJob(refs[0][0], refs[0][1], torch.eye(4), 0.2, 30)             # (a host transform: the synchronous call takes those)
+
+
 def test_refine_registration_mirror(gpu):
     """evaluate.refine_registration (reference evaluate.py:63-109): ICP from the selected transform + RRE / RTE."""
     from umeregrobust_amd.evaluate import refine_registration

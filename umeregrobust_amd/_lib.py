@@ -66,6 +66,10 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_icp_point_to_point_dev_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_double, c_double,
                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_icp_state_bytes": (c_size_t, []),
+    "umereg_icp_enqueue_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_double, c_double, c_int, c_int,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_icp_state_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "umereg_host_choice_round": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "umereg_host_choice_check": (c_int, [c_void_p, c_int, c_void_p]),
     "umereg_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

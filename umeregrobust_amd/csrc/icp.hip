@@ -273,50 +273,67 @@ UMEREG_API int umereg_icp_point_to_point_dev_f32(const float* src, const float* 
                    T_out_host, fitness_host, inlier_rmse_host, iterations_host, workspace, workspace_bytes, stream);
 }
 
-static int icp_run(const float* src, const float* tgt, int n_src, int n_tgt, const double* T_init_host, const float* T_init_dev,
-                   float max_correspondence_distance, int max_iteration, double relative_fitness, double relative_rmse,
-                   double* T_out_host, double* fitness_host, double* inlier_rmse_host, int* iterations_host, void* workspace,
-                   size_t workspace_bytes, void* stream)
+// enqueue only: [first: the target's grid, the initial state] + `iterations` evaluation / update pairs; nothing is waited for
+static int icp_enqueue(const float* src, const float* tgt, int n_src, int n_tgt, const double* T_init_host, const float* T_init_dev,
+                       float max_correspondence_distance, int max_iteration, double relative_fitness, double relative_rmse,
+                       bool first, int iterations, void* workspace, size_t workspace_bytes, hipStream_t st, IcpState** state_out)
 {
-    UMEREG_REQUIRE(src && tgt && T_out_host, "icp_point_to_point: null pointer");
+    UMEREG_REQUIRE(src && tgt, "icp_point_to_point: null pointer");
     UMEREG_REQUIRE(n_src > 0 && n_tgt > 0, "icp_point_to_point: empty cloud (n_src %d, n_tgt %d)", n_src, n_tgt);
-    UMEREG_REQUIRE(max_correspondence_distance > 0.f && max_iteration >= 0, "icp_point_to_point: bad distance / iteration limit");
+    UMEREG_REQUIRE(max_correspondence_distance > 0.f && max_iteration >= 0 && iterations >= 0, "icp_point_to_point: bad distance / iteration limit");
     if (int rc = check_device()) return rc;
     const size_t need = umereg_icp_workspace_bytes(n_src, n_tgt);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
         set_error("icp_point_to_point: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
         return UMEREG_EWORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const GridWs w = grid_ws(n_tgt);
     IcpState* state = (IcpState*)(ws + w.total);
     double* partial = (double*)(ws + w.total + align_up(sizeof(IcpState), 256));
-    if (int rc = launch_prep(tgt, ws, 1, n_tgt, -1.0f, st)) return rc;   // kNN-mode grid for K = 1
-    IcpState h;
-    memset(&h, 0, sizeof(h));
-    if (T_init_dev) {
-        hipLaunchKernelGGL(icp_init_dev_kernel, dim3(1), dim3(64), 0, st, state, T_init_dev);
-        UMEREG_CHECK_LAUNCH("icp_init_dev_kernel");
-    } else {
-        IcpInit init;
-        for (int k = 0; k < 16; ++k) init.T[k] = T_init_host[k];
-        hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, st, state, init);
-        UMEREG_CHECK_LAUNCH("icp_init_kernel");
+    if (first) {
+        if (int rc = launch_prep(tgt, ws, 1, n_tgt, -1.0f, st)) return rc;   // kNN-mode grid for K = 1
+        if (T_init_dev) {
+            hipLaunchKernelGGL(icp_init_dev_kernel, dim3(1), dim3(64), 0, st, state, T_init_dev);
+            UMEREG_CHECK_LAUNCH("icp_init_dev_kernel");
+        } else {
+            UMEREG_REQUIRE(T_init_host, "icp_point_to_point: null T_init");
+            IcpInit init;
+            for (int k = 0; k < 16; ++k) init.T[k] = T_init_host[k];
+            hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, st, state, init);
+            UMEREG_CHECK_LAUNCH("icp_init_kernel");
+        }
     }
     const int n_blocks = (n_src + kIcpBlock - 1) / kIcpBlock;
+    for (int b = 0; b < iterations; ++b) {
+        hipLaunchKernelGGL(icp_eval_kernel, dim3(n_blocks), dim3(kIcpThreads), 0, st, src, n_src, ws, n_tgt,
+                           max_correspondence_distance, state, partial);
+        hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(kIcpWG), 0, st, partial, n_blocks, n_src, max_iteration,
+                           relative_fitness, relative_rmse, state);
+    }
+    if (iterations) UMEREG_CHECK_LAUNCH("icp kernels");
+    *state_out = state;
+    return UMEREG_OK;
+}
+
+static int icp_run(const float* src, const float* tgt, int n_src, int n_tgt, const double* T_init_host, const float* T_init_dev,
+                   float max_correspondence_distance, int max_iteration, double relative_fitness, double relative_rmse,
+                   double* T_out_host, double* fitness_host, double* inlier_rmse_host, int* iterations_host, void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(T_out_host, "icp_point_to_point: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    IcpState h;
+    memset(&h, 0, sizeof(h));
     int launched = 0;
     while (true) {
         // the first batch is short: most registrations that start from a selected hypothesis converge in 2-3 updates, and every
         // iteration enqueued beyond the stop is a pair of launches that only finds the flag set
         const int batch = launched == 0 ? 4 : 8;
-        for (int b = 0; b < batch; ++b) {
-            hipLaunchKernelGGL(icp_eval_kernel, dim3(n_blocks), dim3(kIcpThreads), 0, st, src, n_src, ws, n_tgt,
-                               max_correspondence_distance, state, partial);
-            hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(kIcpWG), 0, st, partial, n_blocks, n_src, max_iteration,
-                               relative_fitness, relative_rmse, state);
-        }
-        UMEREG_CHECK_LAUNCH("icp kernels");
+        IcpState* state = nullptr;
+        if (int rc = icp_enqueue(src, tgt, n_src, n_tgt, T_init_host, T_init_dev, max_correspondence_distance, max_iteration, relative_fitness,
+                                 relative_rmse, launched == 0, batch, workspace, workspace_bytes, st, &state))
+            return rc;
         launched += batch;
         if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
@@ -329,5 +346,40 @@ static int icp_run(const float* src, const float* tgt, int n_src, int n_tgt, con
     if (fitness_host) *fitness_host = h.fitness;
     if (inlier_rmse_host) *inlier_rmse_host = h.rmse;
     if (iterations_host) *iterations_host = h.iters;
+    return UMEREG_OK;
+}
+
+UMEREG_API size_t umereg_icp_state_bytes(void) { return sizeof(IcpState); }
+
+UMEREG_API int umereg_icp_enqueue_f32(const float* src, const float* tgt, int n_src, int n_tgt, const float* T_init_dev,
+                                      float max_correspondence_distance, int max_iteration, double relative_fitness,
+                                      double relative_rmse, int first, int iterations, void* state_host, void* workspace,
+                                      size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(state_host, "icp_enqueue: null state_host");
+    UMEREG_REQUIRE(!first || T_init_dev, "icp_enqueue: null T_init");
+    hipStream_t st = (hipStream_t)stream;
+    IcpState* state = nullptr;
+    if (int rc = icp_enqueue(src, tgt, n_src, n_tgt, nullptr, T_init_dev, max_correspondence_distance, max_iteration, relative_fitness,
+                             relative_rmse, first != 0, iterations, workspace, workspace_bytes, st, &state))
+        return rc;
+    if (hipMemcpyAsync(state_host, state, sizeof(IcpState), hipMemcpyDeviceToHost, st) != hipSuccess) {
+        set_error("icp_enqueue: state download failed");
+        return UMEREG_ELAUNCH;
+    }
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_icp_state_decode(const void* state_host, double* T_out_host, double* fitness_host, double* inlier_rmse_host,
+                                       int* iterations_host, int* done_host)
+{
+    UMEREG_REQUIRE(state_host && T_out_host && done_host, "icp_state_decode: null pointer");
+    IcpState h;
+    memcpy(&h, state_host, sizeof(h));
+    for (int k = 0; k < 16; ++k) T_out_host[k] = h.T[k];
+    if (fitness_host) *fitness_host = h.fitness;
+    if (inlier_rmse_host) *inlier_rmse_host = h.rmse;
+    if (iterations_host) *iterations_host = h.iters;
+    *done_host = h.done;
     return UMEREG_OK;
 }

@@ -699,19 +699,22 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
     # stream only.  overlap=False: one pair at a time on the caller's stream.
     streams, pending, k = None, None, 0
 
-    refined = []      # per pair (T_est [1,4,4], rre [1], rte [1]) when the ICP runs inside the loop
+    refined = []      # per pair: T_est [4,4] (host) when the ICP runs inside the loop
+    max_corr = float(getattr(args, "icp_max_correspondence_distance", 0.2))
+    max_it = int(getattr(args, "icp_max_iteration", 200))
 
     def read_back(p):
-        R_hat, t_hat, st, _keep, T_dev = p     # _keep: the pair's input tensors stay alive until its last kernel is done
+        R_hat, t_hat, st, _keep, T_dev, job = p     # _keep: the pair's input tensors stay alive until its last kernel is done
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-            if refine and st is not None:
-                # The reference refines all pairs after the loop (:301).  The ICP consumes no random numbers and touches
-                # nothing but its own pair, so running it here -- on the pair's stream, while the NEXT pair's correlation
-                # scores keep the GPU busy on the other one -- gives the same registrations with its host round trips hidden.
-                # It starts from the selected transform ON THE DEVICE: its kernels are enqueued right behind the selection.
-                refined.append(refine_registration(R_hat, t_hat, args, [raw[len(R_sel)]], tform_dev=T_dev))
-            R_sel.append(R_hat.cpu())
-            t_sel.append(t_hat.cpu())
+            if job is not None:
+                # The reference refines all pairs after the loop (:301).  The ICP consumes no random numbers and touches nothing but
+                # its own pair: its whole chain was enqueued right behind the pair's hypothesis selection (ops.IcpJob: it starts from
+                # the selected transform ON THE DEVICE and stops by a flag on the device), so by now -- one pair later -- its result
+                # is waiting in pinned memory and the refinement has cost the host no round trip.
+                refined.append(torch.from_numpy(job.result().transformation).float())
+            T_host = T_dev.cpu()                   # (one read for R_hat and t_hat: they are views of it)
+            R_sel.append(T_host[:, :3, :3])
+            t_sel.append(T_host[:, :3, 3])
 
     for pair in pairs:
         dev = pair["src_pts"].device
@@ -734,10 +737,13 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
             _, _, R_hat, t_hat, T_dev = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
                                                           pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng,
                                                           prepared=getattr(out, "side", None), return_tform=True)       # :258-296
+            job = None
+            if refine and st is not None and src_raw.is_cuda and src_raw.dtype == torch.float32 and tgt_raw.dtype == torch.float32:
+                job = ops.IcpJob(src_raw, tgt_raw, T_dev[0].contiguous(), max_corr, max_it)                              # :63-96
         raw.append((src_raw, tgt_raw, pair["gt_tform"]))
         if pending is not None:
             read_back(pending)        # the previous pair's result: its scores ran beside everything above
-        pending = (R_hat, t_hat, st, pair, T_dev)
+        pending = (R_hat, t_hat, st, pair, T_dev, job)
         if st is None:
             read_back(pending)
             pending = None
@@ -748,13 +754,14 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
         for st in streams:
             torch.cuda.current_stream(streams[0].device).wait_stream(st)
     R_sel, t_sel = torch.cat(R_sel, dim=0), torch.cat(t_sel, dim=0)
-    if refine and len(refined) == R_sel.shape[0]:
-        T_est, rre, rte = (torch.cat([r[i] for r in refined]) for i in range(3))
-    elif refine:
+    if refine and len(refined) != R_sel.shape[0]:
         T_est, rre, rte = refine_registration(R_sel, t_sel, args, raw)                                             # :301
     else:
-        T_est = torch.eye(4)[None].repeat(R_sel.shape[0], 1, 1)
-        T_est[:, :3, :3], T_est[:, :3, 3] = R_sel, t_sel
+        if refine:
+            T_est = torch.stack(refined)                                                                           # (refined inside the loop)
+        else:
+            T_est = torch.eye(4)[None].repeat(R_sel.shape[0], 1, 1)
+            T_est[:, :3, :3], T_est[:, :3, 3] = R_sel, t_sel
         gts = torch.stack([g.detach().cpu().float() if isinstance(g, torch.Tensor) else torch.as_tensor(g).float() for _, _, g in raw])
         dev = raw[0][0].device
         rre = relative_rotation_error(T_est[:, :3, :3].to(dev).contiguous(), gts[:, :3, :3].to(dev).contiguous()).cpu()

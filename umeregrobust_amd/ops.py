@@ -639,6 +639,80 @@ def icp_point_to_point(src_pts, tgt_pts, T_init, max_correspondence_distance=0.2
     return SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
 
 
+_icp_pinned = []      # pinned state buffers of finished IcpJobs, for reuse (a pinned allocation costs more than an ICP evaluation)
+_icp_inflight = {}    # (device index, stream) -> workspace tags of the jobs in flight there
+
+
+class IcpJob:
+    """icp_point_to_point without the wait: the constructor enqueues the whole chain on the current stream (search grid, initial state
+    read from T_init ON THE DEVICE when its first kernel runs, four evaluation / update pairs -- the stop test lives on the device --,
+    an asynchronous copy of the state to pinned host memory) and returns; result() waits for that copy, enqueues further batches in
+    the rare case that four updates were not enough, and returns what icp_point_to_point returns.  A loop that keeps two pairs in
+    flight (evaluate.evaluate_pairs) starts a pair's ICP right behind its hypothesis selection and collects it one pair later: the
+    refinement costs the host no round trip (reference evaluate.py:301 refines after the loop -- nothing needs it earlier)."""
+
+    def __init__(self, src_pts, tgt_pts, T_init_dev, max_correspondence_distance=0.2, max_iteration=30, relative_fitness=1e-6,
+                 relative_rmse=1e-6):
+        lib = _lib.load()
+        self.sp = _dev(src_pts, "src_pts"); self.tp = _dev(tgt_pts, "tgt_pts")
+        if self.sp.dim() != 2 or self.tp.dim() != 2 or self.sp.shape[1] != 3 or self.tp.shape[1] != 3:
+            raise ValueError(f"IcpJob: expected [n,3] clouds, got {tuple(self.sp.shape)}, {tuple(self.tp.shape)}")
+        if not (isinstance(T_init_dev, torch.Tensor) and T_init_dev.is_cuda and T_init_dev.dtype == torch.float32
+                and T_init_dev.is_contiguous() and tuple(T_init_dev.shape) == (4, 4) and T_init_dev.device == self.sp.device):
+            raise ValueError("IcpJob: T_init_dev must be a contiguous float32 [4,4] tensor on the clouds' device")
+        if self.sp.shape[0] == 0 or self.tp.shape[0] == 0:
+            raise ValueError("IcpJob: empty cloud")
+        self.T0 = T_init_dev
+        self.par = (float(max_correspondence_distance), int(max_iteration), float(relative_fitness), float(relative_rmse))
+        dev = self.dev = self.sp.device
+        self.stream = torch.cuda.current_stream(dev)
+        self.key = (dev.index, _stream_ptr(dev))
+        used = _icp_inflight.setdefault(self.key, set())
+        self.slot = next(k for k in range(len(used) + 1) if k not in used)     # a workspace of its own among the jobs in flight on this stream
+        used.add(self.slot)
+        n, m = self.sp.shape[0], self.tp.shape[0]
+        self.ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp" if self.slot == 0 else f"icp{self.slot}")
+        self.state = _icp_pinned.pop() if _icp_pinned else torch.empty(int(lib.umereg_icp_state_bytes()), dtype=torch.uint8, pin_memory=True)
+        self.event = torch.cuda.Event()
+        self.launched = 0
+        self._res = None
+        self._enqueue(True, 4)
+
+    def _enqueue(self, first, iterations):
+        lib = _lib.load()
+        d, it, rf, rr = self.par
+        with torch.cuda.device(self.dev):
+            rc = lib.umereg_icp_enqueue_f32(_ptr(self.sp), _ptr(self.tp), self.sp.shape[0], self.tp.shape[0], _ptr(self.T0), d, it, rf, rr,
+                                            1 if first else 0, int(iterations), self.state.data_ptr(), _ptr(self.ws), self.ws.numel(),
+                                            self.stream.cuda_stream)
+        _lib.check(rc, "umereg_icp_enqueue_f32")
+        self.launched += iterations
+        self.event.record(self.stream)
+
+    def result(self):
+        if self._res is not None:
+            return self._res
+        import numpy as np
+        from types import SimpleNamespace
+        lib = _lib.load()
+        T = np.empty((4, 4), dtype=np.float64)
+        out = np.zeros(2, dtype=np.float64)
+        iters = np.zeros(2, dtype=np.int32)
+        while True:
+            self.event.synchronize()
+            rc = lib.umereg_icp_state_decode(self.state.data_ptr(), T.ctypes.data, out.ctypes.data, out.ctypes.data + 8, iters.ctypes.data,
+                                             iters.ctypes.data + 4)
+            _lib.check(rc, "umereg_icp_state_decode")
+            if iters[1] or self.launched > self.par[1] + 1:
+                break
+            self._enqueue(False, 8)
+        _icp_inflight[self.key].discard(self.slot)
+        _icp_pinned.append(self.state)
+        self.state = None
+        self._res = SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
+        return self._res
+
+
 def ume_svdvals(ume):
     """torch.linalg.svdvals of 32x4 UME matrices (reference utils/eval_utils.py:31-32): ume [...,32,4] -> [...,4]."""
     lib = _lib.load()
