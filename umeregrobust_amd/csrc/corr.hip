@@ -3513,6 +3513,7 @@ struct FlatWs {
     unsigned int* rbase;   // [records] first query slot of the record
     unsigned int* qlist;   // [slots] record << 6 | lane
     float* qval;           // [slots]
+    unsigned int* qsel;    // [slots] positions (in qlist) of the entries flat_bound_kernel left to the search (header word 44: how many)
     unsigned int slots;
 };
 // (capacity: 2^21 queries, or half of the job's if that is more -- a nuScenes-size job of 1.5e8 queries with outlier hypotheses
@@ -3524,7 +3525,7 @@ __host__ __device__ inline size_t flat_slots(long n_queries)
 }
 __host__ __device__ inline size_t flat_bytes(size_t n_records, long n_queries)
 {
-    return align_up(n_records * 4, 256) + 2 * align_up(flat_slots(n_queries) * 4, 256);
+    return align_up(n_records * 4, 256) + 3 * align_up(flat_slots(n_queries) * 4, 256);
 }
 __host__ __device__ inline FlatWs flat_ws(char* base, size_t n_records, long n_queries)
 {
@@ -3532,6 +3533,7 @@ __host__ __device__ inline FlatWs flat_ws(char* base, size_t n_records, long n_q
     f.rbase = reinterpret_cast<unsigned int*>(base);
     f.qlist = reinterpret_cast<unsigned int*>(base + align_up(n_records * 4, 256));
     f.qval = reinterpret_cast<float*>(base + align_up(n_records * 4, 256) + align_up(flat_slots(n_queries) * 4, 256));
+    f.qsel = reinterpret_cast<unsigned int*>(base + align_up(n_records * 4, 256) + 2 * align_up(flat_slots(n_queries) * 4, 256));
     f.slots = (unsigned int)flat_slots(n_queries);
     return f;
 }
@@ -3587,51 +3589,39 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict_
     }
 }
 
+// The bookkeeping of the bounded mode, one listed query per LANE (it used to sit in corr_score_flat_kernel's visits of four queries per
+// wavefront: 30 M outside queries of a nuScenes-size half-overlapping pair = 7.5 M visits of dependent loads for four lanes' worth of
+// arithmetic, 3.5 ms).  kMode 1 (first pass): a query outside the lattice adds its bound to the slack of its hypothesis and gets the value
+// 0; every other query is left to the search.  kMode 2 (second pass): the outside queries of the surviving hypotheses are left to the
+// search, every other value is 0 (leftover_sum_kernel ADDS the second pass to the first).  "Left to the search" = its position in the
+// flat list is appended to f.qsel (header word 44 counts; bound_survivors_kernel resets it between the passes).
 template <int kMode>
-__global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
-                                                                       const float* __restrict__ src_pts, const float4* __restrict__ vp4,
-                                                                       const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
-                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f,
-                                                                       const float* __restrict__ vpn, const unsigned int* __restrict__ vq_max_bits,
-                                                                       unsigned long long* __restrict__ slack, const unsigned int* __restrict__ surv)
+__global__ __launch_bounds__(256) void flat_bound_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
+                                                         const float* __restrict__ T, int Ns, int Nt, int K, float sigma, char* __restrict__ lat, unsigned int c_max,
+                                                         FlatWs f, const float* __restrict__ vpn, const unsigned int* __restrict__ vq_max_bits,
+                                                         unsigned long long* __restrict__ slack, const unsigned int* __restrict__ surv)
 {
-    __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
-    __shared__ unsigned int chist[kCoopWaves][kWave];
-    __shared__ float4 visit[kCoopWaves][4];            // the queries of a visit (image, source point): parked here, not in registers -- the
-                                                       // search needs 56 of the 64 a wavefront may hold at eight per SIMD
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = lane_id();
+    static_assert(kMode == 1 || kMode == 2, "first or second pass");
     const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
     const LatWs lw = lat_ws(c_max);
-    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
     if (header[11] != 0u) return;                      // too many queries: the record kernel serves them
     if (kMode == 2 && header[40] == 0u) return;        // no hypothesis needs its bounded queries
     const unsigned int n_q = header[10];
     const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
-    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
-    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
-    unsigned long long* la = lists[wave][0];
-    unsigned long long* lb = lists[wave][1];
-    const int grp = lane >> 3, sub = lane & 7;
-    const float inv_sigma = 1.0f / sigma;
-    const unsigned int n_waves = gridDim.x * kCoopWaves;
-    Lattice Lt;
-    float bmn[3] = {0.f, 0.f, 0.f}, bmx[3] = {0.f, 0.f, 0.f}, vq_max = 0.f;
-    if (kMode != 0) {
-        const unsigned int* bbox = reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox);
-        Lt = load_lattice(bbox, lattice_budget(lat, c_max));
+    const unsigned int* bbox = reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox);
+    const Lattice Lt = load_lattice(bbox, lattice_budget(lat, c_max));
+    float bmn[3], bmx[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { bmn[k] = dec_ord(~bbox[k]); bmx[k] = dec_ord(bbox[3 + k]); }
-        vq_max = __uint_as_float(*vq_max_bits);
-    }
-    // kFlatVisit consecutive entries per visit, one per lane for the bookkeeping (transform, bound); the searches one after the other, the
-    // whole wavefront on each.  (4, not 64: a KITTI-test pair leaves 2e5 queries, and 3 000 visits of 64 do not fill the chip -- 16 per visit
-    // measured 0.23 ms slower on that pair than one query per visit; the bookkeeping is ~1 % of a search either way.)
-    constexpr unsigned int kFlatVisit = 4;
-    for (unsigned int blk = blockIdx.x * kCoopWaves + wave; (unsigned long long)blk * kFlatVisit < n_q; blk += n_waves) {
-        const unsigned int q_l = blk * kFlatVisit + (unsigned int)lane;
-        const bool valid = lane < (int)kFlatVisit && q_l < n_q;
+    for (int k = 0; k < 3; ++k) { bmn[k] = dec_ord(~bbox[k]); bmx[k] = dec_ord(bbox[3 + k]); }
+    const float vq_max = __uint_as_float(*vq_max_bits);
+    const float inv_sigma = 1.0f / sigma;
+    const int lane = lane_id();
+    const unsigned long long n_round = ((unsigned long long)n_q + 63ull) & ~63ull;       // whole wavefronts stay in the loop (ballots)
+    for (unsigned long long q0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < n_round; q0 += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned int q_l = (unsigned int)q0;
+        const bool valid = q0 < (unsigned long long)n_q;
         const unsigned int ent = f.qlist[valid ? q_l : 0u];
         const uint4 rec = queue[ent >> 6];
         const int h_l = (int)rec.x, slot_l = (int)rec.y * kWave + (int)(ent & 63u);
@@ -3643,28 +3633,104 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
         const float qx_l = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
         const float qy_l = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
         const float qz_l = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-        bool exact = in_cloud;
-        if (kMode != 0) {
-            // outside the lattice (NaN images are not: they go through the search as always)
-            const bool outside = in_cloud && qx_l == qx_l && qy_l == qy_l && qz_l == qz_l && lattice_cell(Lt, qx_l, qy_l, qz_l) < 0;
-            if (kMode == 1) {
-                exact = in_cloud && !outside;
-                if (outside) {
-                    const float dx = fmaxf(fmaxf(bmn[0] - qx_l, qx_l - bmx[0]), 0.f), dy = fmaxf(fmaxf(bmn[1] - qy_l, qy_l - bmx[1]), 0.f);
-                    const float dz = fmaxf(fmaxf(bmn[2] - qz_l, qz_l - bmx[2]), 0.f);
-                    const float dB = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) * 0.9999f - 1e-5f, 0.f);
-                    const float r = dB * inv_sigma * 0.9999f;
-                    const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[qs_l] * vq_max * 1.0001f;
-                    // (an infinite, NaN or absurdly large bound -- NaN features -- sets the sticky top bit: the hypothesis then needs its
-                    // queries whatever the scores.  Finite terms are < 2^34 each, so even 2^20 of them cannot carry into that bit, and any
-                    // number of saturated queries leaves it set -- an added 2^62 per query wrapped to 0 at the fourth.)
-                    if (eps < 1.0e3f) atomicAdd(&slack[h_l], (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull);
-                    else atomicOr(&slack[h_l], 1ull << 63);
-                }
-            } else {
-                exact = outside && surv[h_l] != 0u;
+        // outside the lattice (NaN images are not: they go through the search as always)
+        const bool outside = in_cloud && qx_l == qx_l && qy_l == qy_l && qz_l == qz_l && lattice_cell(Lt, qx_l, qy_l, qz_l) < 0;
+        bool exact;
+        if (kMode == 1) {
+            exact = in_cloud && !outside;
+            unsigned long long fx = 0ull;
+            bool sat = false;
+            if (outside) {
+                const float dx = fmaxf(fmaxf(bmn[0] - qx_l, qx_l - bmx[0]), 0.f), dy = fmaxf(fmaxf(bmn[1] - qy_l, qy_l - bmx[1]), 0.f);
+                const float dz = fmaxf(fmaxf(bmn[2] - qz_l, qz_l - bmx[2]), 0.f);
+                const float dB = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) * 0.9999f - 1e-5f, 0.f);
+                const float r = dB * inv_sigma * 0.9999f;
+                const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[qs_l] * vq_max * 1.0001f;
+                // (an infinite, NaN or absurdly large bound -- NaN features -- sets the sticky top bit: the hypothesis then needs its
+                // queries whatever the scores.  Finite terms are < 2^34 each, so even 2^20 of them cannot carry into that bit, and any
+                // number of saturated queries leaves it set -- an added 2^62 per query wrapped to 0 at the fourth.)
+                sat = !(eps < 1.0e3f);
+                fx = sat ? 0ull : (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull;
             }
+            // one atomic per (wavefront, hypothesis), not per query: the entries of a record -- one hypothesis -- are consecutive in the list,
+            // and 30 M queries of a nuScenes-size pair on the slack words of 2 000 hypotheses serialised on those words (3 ms)
+            unsigned long long todo = __ballot(outside);
+            while (todo != 0ull) {
+                const int h0 = __builtin_amdgcn_readlane(h_l, __ffsll((long long)todo) - 1);
+                const bool mine = outside && h_l == h0;
+                const unsigned long long m = __ballot(mine);
+                todo &= ~m;
+                unsigned long long part = mine ? fx : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += (unsigned long long)__shfl_xor((long long)part, o, kWave);     // (integers: any order)
+                const bool any_sat = __any(mine && sat);
+                if (lane == 0) {
+                    if (part != 0ull) atomicAdd(&slack[h0], part);
+                    if (any_sat) atomicOr(&slack[h0], 1ull << 63);
+                }
+            }
+        } else {
+            exact = outside && surv[h_l] != 0u;
         }
+        if (valid && !exact) f.qval[q_l] = 0.f;
+        const unsigned long long b = __ballot(exact);
+        if (b != 0ull) {
+            unsigned int base = 0u;
+            if (lane == 0) base = atomicAdd(&header[44], (unsigned int)__popcll(b));
+            base = (unsigned int)__shfl((int)base, 0, kWave);
+            if (exact) f.qsel[base + (unsigned int)mbcnt(b)] = q_l;
+        }
+    }
+}
+
+// kMode 0: every entry of the flat list; kMode 3: the entries flat_bound_kernel left to the search (f.qsel, header word 44)
+template <int kMode>
+__global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
+                                                                       const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+                                                                       const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
+                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f)
+{
+    static_assert(kMode == 0 || kMode == 3, "the whole list or the selected entries");
+    __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
+    __shared__ unsigned int chist[kCoopWaves][kWave];
+    __shared__ float4 visit[kCoopWaves][4];            // the queries of a visit (image, source point): parked here, not in registers -- the
+                                                       // search needs 56 of the 64 a wavefront may hold at eight per SIMD
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const LatWs lw = lat_ws(c_max);
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    if (header[11] != 0u) return;                      // too many queries: the record kernel serves them
+    const unsigned int n_q = kMode == 3 ? header[44] : header[10];
+    const uint4* queue = reinterpret_cast<const uint4*>(lat + lw.total);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
+    unsigned long long* la = lists[wave][0];
+    unsigned long long* lb = lists[wave][1];
+    const int grp = lane >> 3, sub = lane & 7;
+    const float inv_sigma = 1.0f / sigma;
+    const unsigned int n_waves = gridDim.x * kCoopWaves;
+    // kFlatVisit consecutive entries per visit, one per lane for the bookkeeping (transform); the searches one after the other, the
+    // whole wavefront on each.  (4, not 64: a KITTI-test pair leaves 2e5 queries, and 3 000 visits of 64 do not fill the chip -- 16 per visit
+    // measured 0.23 ms slower on that pair than one query per visit; the bookkeeping is ~1 % of a search either way.)
+    constexpr unsigned int kFlatVisit = 4;
+    for (unsigned int blk = blockIdx.x * kCoopWaves + wave; (unsigned long long)blk * kFlatVisit < n_q; blk += n_waves) {
+        const unsigned int i_l = blk * kFlatVisit + (unsigned int)lane;
+        const bool valid = lane < (int)kFlatVisit && i_l < n_q;
+        const unsigned int q_l = kMode == 3 ? f.qsel[valid ? i_l : 0u] : i_l;
+        const unsigned int ent = f.qlist[valid ? q_l : 0u];
+        const uint4 rec = queue[ent >> 6];
+        const int h_l = (int)rec.x, slot_l = (int)rec.y * kWave + (int)(ent & 63u);
+        const bool in_cloud = valid && slot_l < Ns;
+        const int qs_l = __float_as_int(S4s[in_cloud ? slot_l : 0].w);
+        const float sx = src_pts[(size_t)qs_l * 3], sy = src_pts[(size_t)qs_l * 3 + 1], sz = src_pts[(size_t)qs_l * 3 + 2];
+        const float* Th = T + (size_t)h_l * 16;
+        // (the same arithmetic as the record kernel and corr_score_kernel)
+        const float qx_l = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
+        const float qy_l = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
+        const float qz_l = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
+        const bool exact = in_cloud;
         if (valid && !exact) f.qval[q_l] = 0.f;
         static_assert(kFlatVisit == 4, "visit[][4]");
         if (lane < (int)kFlatVisit) visit[wave][lane] = make_float4(qx_l, qy_l, qz_l, __int_as_float(qs_l));
@@ -3689,7 +3755,8 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
                 part += e < cnt ? wgt * d : 0.f;
             }
             part = wave_sum_f(part);
-            if (lane == 0) f.qval[blk * kFlatVisit + (unsigned int)l] = part;
+            const unsigned int q_out = kMode == 3 ? (unsigned int)__builtin_amdgcn_readlane((int)q_l, l) : blk * kFlatVisit + (unsigned int)l;
+            if (lane == 0) f.qval[q_out] = part;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
@@ -3728,7 +3795,7 @@ __global__ __launch_bounds__(1024) void bound_survivors_kernel(const float* __re
         if (need) atomicAdd(&cnt[0], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { header[40] = cnt[0]; header[41] = cnt[1]; }
+    if (threadIdx.x == 0) { header[40] = cnt[0]; header[41] = cnt[1]; header[44] = 0u; }      // (44: flat_bound_kernel's selection starts over)
 }
 
 // ---- the same queries, first one wavefront per RECORD (round 3) --------------------------------------------------------
@@ -4446,13 +4513,14 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                 hipLaunchKernelGGL(row_norm_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, (const float4*)src_wfeat, Ns, b_vpn, (unsigned int*)nullptr);
                 hipLaunchKernelGGL(row_norm_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const float4*)tgt_wfeat, Nt, (float*)nullptr, b_vqmax);
                 UMEREG_CHECK_LAUNCH("row_norm_kernel");
-                hipLaunchKernelGGL(corr_score_flat_kernel<1>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
-                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
-                                   (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
+                hipLaunchKernelGGL(flat_bound_kernel<1>, dim3(2048), dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, K, sigma,
+                                   lat, c_max, fw, (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
+                UMEREG_CHECK_LAUNCH("flat_bound_kernel");
+                hipLaunchKernelGGL(corr_score_flat_kernel<3>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
+                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
             } else {
                 hipLaunchKernelGGL(corr_score_flat_kernel<0>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
-                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
-                                   (const float*)nullptr, (const unsigned int*)nullptr, (unsigned long long*)nullptr, (const unsigned int*)nullptr);
+                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
             }
             UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
             hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial, 0);
@@ -4488,9 +4556,11 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("bound_survivors_kernel");
         char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes(queue_records(M, n_chunks_sz), (long)M * Ns);
         const FlatWs fw = flat_ws(flat_base, queue_records(M, n_chunks_sz), (long)M * Ns);
-        hipLaunchKernelGGL(corr_score_flat_kernel<2>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
-                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
-                           (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
+        hipLaunchKernelGGL(flat_bound_kernel<2>, dim3(2048), dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, K, sigma,
+                           lat, c_max, fw, (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
+        UMEREG_CHECK_LAUNCH("flat_bound_kernel");
+        hipLaunchKernelGGL(corr_score_flat_kernel<3>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
+                           src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
         UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
         hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial, 1);
         UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
