@@ -3290,7 +3290,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             cnt = __any(near_q) ? knn_wave(c, qx, qy, qz, near_q, K, cap, L.hist, L.list, lane) : 0;
             cnt = near_q ? cnt : 0;
         }
-        const float acc = score_epilogue(L.list, cnt, valid, sidx, vp4, vq4, K, sigma, lane);
+        // (behind the cell pass most steps of this kernel only sort queries into records -- no lane has neighbours: the epilogue's eight rounds of
+        // row reads for nothing were a third of its time)
+        const float acc = __any(cnt > 0) ? score_epilogue(L.list, cnt, valid, sidx, vp4, vq4, K, sigma, lane) : 0.f;
         if (LAT) {
             // lanes the lattice could not serve: one record per (hypothesis, chunk) for corr_score_fallback_kernel, which adds
             // their terms to this partial sum afterwards (one writer per record: the result stays deterministic)
