@@ -2833,8 +2833,8 @@ __host__ __device__ inline size_t cell_lds_per_wave(int K, bool lng)
 {
     // tie list (16-bit index plane) | stage (256 or 512 slots x 16 B) | the lane's K keys (d2 plane -- the histogram lives there until
     // the second sweep starts --, 16-bit index plane)
-    // | the cells of the current group (kCellFetch x 8 words)
-    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : 256) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256 + (size_t)kCellFetch * 32;
+    // (14.5 KiB: eleven wavefronts per CU; 128 bytes more are ten)
+    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : 256) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256;
 }
 
 // kLong = false: the cells whose list has <= kCellCap entries (byte counters, 256 stage slots: 14.5 KiB of LDS per wavefront);
@@ -2865,7 +2865,6 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + (kLong ? 512 : 256) * 16);
     unsigned int* hist = list.d2;                    // (dead before the first key is written: see cell_lds_per_wave)
     list.ix = reinterpret_cast<IdxT*>(reinterpret_cast<char*>(list.d2) + cell_d2_plane(K, kLong));
-    unsigned int* tab = reinterpret_cast<unsigned int*>(lds + cell_lds_per_wave(K, kLong) - (size_t)kCellFetch * 32);
     constexpr unsigned int kStageQuads = kLong ? 128u : 64u;
     constexpr int kHW = kLong ? kHist16Words : kCons2HistWords;
     auto h_add = [&](int t) __attribute__((always_inline)) { if (kLong) hist16_add(hist, lane, t); else cons2_hist_add(hist, lane, t); };
@@ -2912,6 +2911,8 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
         while (ci < fetch) {
         int g = 0;
         unsigned int Q = 0u, N = 0u;
+        // the group's cells: lane k holds cell k (id, first entry, d_K^2 bits | first list word, first stage quad, quads, first query of the group)
+        uint4 ga = make_uint4(0u, 0u, 0u, 0u), gb = make_uint4(0u, 0u, 0u, 0u);
         while (ci < fetch) {
             const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
             const unsigned int cell_first = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
@@ -2927,19 +2928,22 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             if (!take) { ++ci; continue; }
             if (g > 0 && Q + quads > kStageQuads) break;
             const unsigned int n_e = min(cell_ne - chunk0, kCellChunk);
-            if (lane == 0) {
-                unsigned int* t = tab + g * 8;
-                t[0] = (unsigned int)id; t[1] = cell_first + chunk0; t[2] = dk2b; t[3] = lfirst; t[4] = Q; t[5] = quads; t[6] = N; t[7] = n_e;
+            if (lane == g) {
+                ga = make_uint4((unsigned int)id, cell_first + chunk0, dk2b, 0u);
+                gb = make_uint4(lfirst, Q, quads, N);
             }
             Q += quads; N += n_e; ++g; ++ci;
         }
         if (g == 0) break;
         // ---- the group's lists into the stage: quad q of the stage = the four positions of a list word (padding = a far point) ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (unsigned int q = (unsigned int)lane; q < Q; q += kWave) {
+        for (unsigned int q0 = 0u; q0 < Q; q0 += kWave) {
+            const unsigned int q = q0 + (unsigned int)lane;
             int c = 0;
-            for (int k = 1; k < g; ++k) c += q >= tab[k * 8 + 4] ? 1 : 0;
-            const unsigned long long w = pool[(size_t)tab[c * 8 + 3] + (q - tab[c * 8 + 4])];
+            for (int k = 1; k < g; ++k) c += q >= (unsigned int)__builtin_amdgcn_readlane((int)gb.y, k) ? 1 : 0;
+            const unsigned int lf_c = (unsigned int)__shfl((int)gb.x, c, kWave), qb_c = (unsigned int)__shfl((int)gb.y, c, kWave);
+            if (q >= Q) continue;
+            const unsigned long long w = pool[(size_t)lf_c + (q - qb_c)];
             float* q4 = stage + q * 16;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2952,8 +2956,10 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             const unsigned int qi = b0e + (unsigned int)lane;
             const bool valid = qi < N;
             int c = 0;
-            for (int k = 1; k < g; ++k) c += qi >= tab[k * 8 + 6] ? 1 : 0;
-            const uint4 t0 = *reinterpret_cast<const uint4*>(tab + c * 8), t1 = *reinterpret_cast<const uint4*>(tab + c * 8 + 4);
+            for (int k = 1; k < g; ++k) c += qi >= (unsigned int)__builtin_amdgcn_readlane((int)gb.w, k) ? 1 : 0;
+            uint4 t0, t1;
+            t0.x = (unsigned int)__shfl((int)ga.x, c, kWave); t0.y = (unsigned int)__shfl((int)ga.y, c, kWave); t0.z = (unsigned int)__shfl((int)ga.z, c, kWave);
+            t1.x = (unsigned int)__shfl((int)gb.y, c, kWave); t1.y = (unsigned int)__shfl((int)gb.z, c, kWave); t1.z = (unsigned int)__shfl((int)gb.w, c, kWave);
             const float* stage_l = stage + t1.x * 16u;          // this lane's cell: its part of the stage,
             const int m_l = valid ? (int)t1.y * 4 : 0;          // its list (entries, padded to quads),
             const int m_use = wave_max_nonneg(m_l);             // the longest list of the step
