@@ -15,7 +15,7 @@ dst = sys.argv[2] if len(sys.argv) > 2 else None
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 N_SIMD, N_XCD = 1024, 8
 KERNELS = ("corr_consensus2_kernel", "corr_consensus_kernel", "corr_score_flat_kernel", "corr_score_kernel", "corr_score_record2_kernel",
-           "lattice_dk_kernel", "lattice_fill_kernel", "lattice_count_kernel", "lattice_mark_kernel", "lattice_compact_kernel")
+           "lattice_list_kernel", "lattice_mark_kernel", "lattice_compact_kernel")
 out = {"_comment": "per-launch averages of rocprofv3 --pmc passes over tools/exp_f1_prod.py (corr_scores alone, default flags, KT pair: "
                    "2 500 hypotheses x 10 000 points), one pass per counter set (tools/f1_pmc.sh).  SQ_WAVE_CYCLES / SQ_WAIT_* / "
                    "SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts; GRBM_GUI_ACTIVE = duration in shader clocks summed over "

@@ -565,7 +565,7 @@ struct Lattice {
 };
 
 struct LatWs {
-    size_t off_header, off_marks, off_wave_tot, off_cids, off_cells, off_dk2, off_pool, total;
+    size_t off_header, off_marks, off_wave_tot, off_posof, off_cids, off_cells, off_dk2, off_pool, total;
     unsigned int c_max;
     size_t pool_quads;
 };
@@ -584,6 +584,7 @@ __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
     w.off_marks = o;    o += ((size_t)c_max + 255) / 256 * 256;          // one byte per cell: some query lands in it
     w.off_wave_tot = o; o += ((size_t)c_max / kLatLanes + 64) * 4;       // list quads per build wavefront, then their prefix sums
     o = (o + 255) / 256 * 256;
+    w.off_posof = o;    o += (size_t)65536 * 2;                          // position in the cell-sorted table of every target point, by original index
     w.off_cids = o;     o += (size_t)c_max * 4 + 256;                    // marked cells, ascending
     w.off_cells = o;    o += (size_t)c_max * 16;
     w.off_dk2 = o;      o += (size_t)c_max * 4;                          // d_K^2 of the cell centres (float bits), for the cell pass
@@ -2347,12 +2348,9 @@ __global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n
 // ---- lattice build ---------------------------------------------------------------------------------------------------
 // (1) lattice_mark_kernel: marks[cell] = 1 for every cell some (hypothesis, source point) query lands in (~1/4 of them);
 // (2) lattice_compact_kernel: the marked cells in ascending order (one workgroup);
-// (3) lattice_count_kernel: one lane per marked cell: d_K of the centre, list radius, number of list entries;
-//     cells[id] = {-, quads, bits(r^2), flags}, quads per wavefront -> wave_tot;
-// (4) lattice_scan_kernel: exclusive prefix sums of wave_tot (one workgroup): every wavefront's first quad in the pool
-//     -- in cell order, so WHICH cells get a list when the pool runs out does not depend on timing;
-// (5) lattice_fill_kernel: the lists (positions in the cell-sorted table, four to a 64-bit word, padded with the
-//     position of a padding point).
+// (3) lattice_list_kernel: one wavefront per marked cell: d_K of the centre, list radius, the list (positions in the cell-sorted
+//     table, four to a 64-bit word, padded with the position of a padding point) into the wavefront's slice of the pool;
+//     cells[id] = {first quad, quads, bits(r^2), flags}.  (Until round 4: d_K, count, scan and fill as four kernels.)
 // cells[id].w != 0 or quads == 0: no list (the query is left to corr_score_fallback_kernel).
 __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
                                                            const float* __restrict__ T, int Ns, int Nt, int M, int hyp_per_thread,
@@ -2495,173 +2493,118 @@ __device__ __forceinline__ bool lattice_in_list(const Lattice& L, const float4& 
     return ax * ax + ay * ay + az * az <= r2;
 }
 
-// d_K of every marked cell's centre, one WAVEFRONT per cell (coop_knn): cells[id] = (0, neighbours found, bits(d_K^2), 0).
-// (As one lane per cell inside lattice_count_kernel -- 16 grid searches in lock-step -- this step took 6.7 of that
-// kernel's 7.0 ms on a half-overlapping pair: the marked cells of such a pair lie in the empty part of the target, 5-15 m
-// from its nearest points, exactly the queries a per-lane search is worst at.)
-__global__ __launch_bounds__(8 * 64) void lattice_dk_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt, int K)
+// ---- lattice build, one WAVEFRONT per marked cell: d_K of the centre AND the list (round 4) ------------------------------------
+// lattice_dk_kernel + lattice_count_kernel + lattice_scan_kernel + lattice_fill_kernel walked every marked cell's neighbourhood three
+// times (the cooperative search for d_K, then two per-lane grid walks -- 16 lanes of 64 at work -- to count and to write the list): 1.7
+// of the 16 ms of a nuScenes-test job, 3.5 of 22 on a half-overlapping one.  Here the wavefront that has just found d_K(c) collects the
+// list itself: the chunks of the Hilbert-ordered copy whose box comes within the list radius of the cell box (the same pruning as the
+// search: a box distance formed like a point's, with a margin), every point of those tested with lattice_in_list -- the SAME predicate,
+// so the same set as before --, positions in the cell-sorted table through the inverse order (lattice_posof_kernel), the list built in
+// LDS and written once.  No count, no scan: a wavefront owns a fixed slice of the pool (its cells are i = w, w + W, ...: a static
+// assignment, so WHICH cells go without a list when a slice runs out does not depend on timing either).
+__global__ __launch_bounds__(256) void lattice_posof_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt)
+{
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= Nt || reinterpret_cast<const unsigned int*>(lat + lat_ws(c_max).off_header)[8] != 0u) return;     // (the queue takes the leftovers: no lattice)
+    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + grid_ws(Nt).off_p4s);
+    unsigned short* posof = reinterpret_cast<unsigned short*>(lat + lat_ws(c_max).off_posof);
+    const unsigned int orig = (unsigned int)__float_as_int(P4s[pos].w);
+    if (orig < 65536u) posof[orig] = (unsigned short)pos;
+}
+
+constexpr int kLatListCap = 4 * kLatMaxQuads;            // entries of the longest list
+__global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __restrict__ ws_coop, const char* __restrict__ ws_tgt, char* __restrict__ lat,
+                                                              unsigned int c_max, int Nt, int K)
 {
     __shared__ unsigned long long lists[8][2][kCoopCap];
     __shared__ unsigned int chist[8][kWave];
+    __shared__ unsigned short entries[8][kLatListCap + 4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
-    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lw.off_header);
+    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
     if (header[8] != 0u) return;
     const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
     uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
+    unsigned int* dk2 = reinterpret_cast<unsigned int*>(lat + lw.off_dk2);
+    const unsigned short* posof = reinterpret_cast<const unsigned short*>(lat + lw.off_posof);
+    unsigned long long* pool = reinterpret_cast<unsigned long long*>(lat + lw.off_pool);
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
-    const float4* P4s = reinterpret_cast<const float4*>(ws_tgt + wt.off_p4s);
-    const float4* box = reinterpret_cast<const float4*>(ws_tgt + wt.off_box);
+    const float4* P4c = reinterpret_cast<const float4*>(ws_coop + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_coop + wt.off_box);
     const unsigned int n_marked = header[3];
+    const int n_tch = (Nt + kWave - 1) / kWave;
     unsigned long long* la = lists[wave][0];
     unsigned long long* lb = lists[wave][1];
-    for (unsigned int i = blockIdx.x * 8 + wave; i < n_marked; i += gridDim.x * 8) {
+    unsigned short* ent = entries[wave];
+    // this wavefront's slice of the pool
+    const unsigned int n_waves = gridDim.x * 8u, w_id = blockIdx.x * 8u + (unsigned int)wave;
+    const unsigned long long slice = (unsigned long long)lw.pool_quads / n_waves;
+    unsigned long long cur = slice * w_id;
+    const unsigned long long end = cur + slice;
+    unsigned int n_nolist = 0u, n_quads = 0u;
+    for (unsigned int i = w_id; i < n_marked; i += n_waves) {
         const int id = (int)cids[i];
         float ccx, ccy, ccz;
         lattice_cell_centre(L, id, ccx, ccy, ccz);
-        const int cnt = coop_knn(P4s, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane);
+        const int cnt = coop_knn(P4c, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane);
         const unsigned int d2k = cnt > 0 ? (unsigned int)(la[cnt - 1] >> 32) : 0u;       // keys ascend: the last one is the K-th
-        if (lane == 0) cells[id] = make_uint4(0u, (unsigned int)cnt, d2k, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float r = (sqrtf(__uint_as_float(d2k)) + L.hd) * 1.0001f + 1e-6f;
+        const float r2 = r * r;
+        int n = 0;
+        if (cnt >= K) {
+            const float r2p = r2 * 1.0002f + 1e-6f;            // (pruning margin: the box distance below and lattice_in_list round differently)
+            for (int c0 = 0; c0 < n_tch; c0 += kWave) {
+                const int ch = c0 + lane;
+                float t = 3.0e38f;
+                if (ch < n_tch) {
+                    const float4 blo = box[2 * ch], bhi = box[2 * ch + 1];
+                    const float gx = fmaxf(fmaxf(blo.x - (ccx + 0.5f * L.h), (ccx - 0.5f * L.h) - bhi.x), 0.f);
+                    const float gy = fmaxf(fmaxf(blo.y - (ccy + 0.5f * L.h), (ccy - 0.5f * L.h) - bhi.y), 0.f);
+                    const float gz = fmaxf(fmaxf(blo.z - (ccz + 0.5f * L.hz), (ccz - 0.5f * L.hz) - bhi.z), 0.f);
+                    t = gx * gx + gy * gy + gz * gz;
+                }
+                unsigned long long pend = __ballot(t <= r2p);
+                while (pend != 0ull) {
+                    const int l = __ffsll((long long)pend) - 1;
+                    pend &= pend - 1ull;
+                    const int j = (c0 + l) * kWave + lane;
+                    const float4 p = P4c[j];                         // (the padded table makes reads up to Nt + 63 safe)
+                    const bool in = j < Nt && lattice_in_list(L, p, ccx, ccy, ccz, r2);
+                    const unsigned long long b = __ballot(in);
+                    const int at = n + mbcnt(b);
+                    if (in && at < kLatListCap) ent[at] = posof[(unsigned int)__float_as_int(p.w) & 0xffffu];
+                    n += __popcll(b);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int quads = (n + 3) >> 2;
+        const bool has = cnt >= K && quads <= kLatMaxQuads && cur + (unsigned long long)quads <= end;
+        if (has) {
+            for (int q = lane; q < quads; q += kWave) {
+                unsigned long long word = 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * q + k;
+                    word |= (unsigned long long)(e < n ? (unsigned int)ent[e] : (unsigned int)Nt) << (16 * k);     // padding = the position of a padding point
+                }
+                pool[cur + (unsigned long long)q] = word;
+            }
+        }
+        if (lane == 0) {
+            cells[id] = has ? make_uint4((unsigned int)cur, (unsigned int)quads, __float_as_uint(r2), 0u) : make_uint4(0u, 0u, __float_as_uint(r2), 1u);
+            dk2[id] = d2k;
+        }
+        if (has) { cur += (unsigned long long)quads; n_quads += (unsigned int)quads; } else ++n_nolist;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-}
-
-// one lane per marked cell (64 consecutive entries of cids per wavefront: neighbouring cells)
-template <class IdxT>
-__global__ __launch_bounds__(256) void lattice_count_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max,
-                                                            int Nt, int K, int cap)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = lane_id();
-    const GridWs wt = grid_ws(Nt);
-    const LatWs lw = lat_ws(c_max);
-    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
-    const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
-    unsigned int* wave_tot = reinterpret_cast<unsigned int*>(lat + lw.off_wave_tot);
-    uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
-    const unsigned int n_marked = header[3];
-    const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (blockIdx.x * (blockDim.x >> 6) * kLatLanes >= n_marked) return;          // the whole workgroup is beyond the list
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
-    const bool valid = lane < kLatLanes && wid * kLatLanes + lane < n_marked;
-    const int id = (int)cids[valid ? wid * kLatLanes + lane : 0];
-    KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
-    {
-        // the walks of far cells cross hundreds of (mostly empty) grid rows, two dependent table reads each: keep the
-        // cell-start table in LDS (16 KiB per workgroup).  Whole workgroups leave above or stay: the barrier is safe.
-        int* start_lds = reinterpret_cast<int*>(lds);
-        for (int i = threadIdx.x; i <= kMaxCells; i += blockDim.x) start_lds[i] = c.start[i];
-        __syncthreads();
-        c.start = start_lds;
+    if (lane == 0) {
+        if (n_nolist) atomicAdd(&header[2], n_nolist);
+        if (n_quads) atomicAdd(&header[0], n_quads);
     }
-    float ccx, ccy, ccz;
-    lattice_cell_centre(L, id, ccx, ccy, ccz);
-    // d_K of the cell centre: found by lattice_dk_kernel (one wavefront per cell), left in the cell record
-    const uint4 pre = cells[id];
-    const int cnt = valid ? (int)pre.y : 0;
-    const unsigned int d2k_bits = pre.z;
-    if (valid) {
-        reinterpret_cast<unsigned int*>(lat + lw.off_dk2)[id] = d2k_bits;
-    }
-    const float r = (sqrtf(__uint_as_float(d2k_bits)) + L.hd) * 1.0001f + 1e-6f;
-    const float r2 = r * r;
-    const float rw = r + L.hd;                       // ball around the centre that contains {dist(p, box) <= r}
-    int n = (UMEREG_F1_ABLATE & 4096) ? 40 : 0;
-    if (!(UMEREG_F1_ABLATE & 4096))
-    walk_ball<true>(c, ccx, ccy, ccz, valid, rw * rw * 1.001f, lane,
-                    [&](float, const float4& p, int, bool in_run) { n += in_run && lattice_in_list(L, p, ccx, ccy, ccz, r2) ? 1 : 0; });
-    int quads = (n + 3) >> 2;
-    const bool has = valid && cnt >= K && quads <= kLatMaxQuads;
-    quads = has ? quads : 0;
-    if (valid) cells[id] = make_uint4(0u, (unsigned int)quads, __float_as_uint(r2), has ? 0u : 1u);
-    int tot = quads;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m, kWave);
-    const unsigned long long n_nolist = __ballot(valid && !has);
-    if (lane == 0 && wid * kLatLanes < n_marked) {
-        wave_tot[wid] = (unsigned int)tot;
-        if (n_nolist != 0ull) atomicAdd(&header[2], (unsigned int)__popcll(n_nolist));
-    }
-}
-
-// exclusive prefix sums of the per-wavefront list sizes: every wavefront's first quad in the pool, in cell order
-__global__ __launch_bounds__(1024) void lattice_scan_kernel(char* __restrict__ lat, unsigned int c_max)
-{
-    __shared__ unsigned int part[1024];
-    const LatWs lw = lat_ws(c_max);
-    unsigned int* wave_tot = reinterpret_cast<unsigned int*>(lat + lw.off_wave_tot);
-    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
-    const int n = (int)((header[3] + kLatLanes - 1) / kLatLanes);
-    const int per = (n + 1023) / 1024;
-    const int a = threadIdx.x * per, b = min(a + per, n);
-    unsigned int s = 0u;
-    for (int i = a; i < b; ++i) s += wave_tot[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {         // Hillis-Steele inclusive scan of the 1024 partial sums
-        const unsigned int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned int run = part[threadIdx.x] - s;          // exclusive
-    for (int i = a; i < b; ++i) { const unsigned int t = wave_tot[i]; wave_tot[i] = run; run += t; }
-    if (threadIdx.x == 1023) header[0] = part[1023];
-}
-
-__global__ __launch_bounds__(256) void lattice_fill_kernel(const char* __restrict__ ws_tgt, char* __restrict__ lat, unsigned int c_max, int Nt, int K)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = lane_id();
-    const GridWs wt = grid_ws(Nt);
-    const LatWs lw = lat_ws(c_max);
-    const unsigned int* wave_tot = reinterpret_cast<const unsigned int*>(lat + lw.off_wave_tot);
-    const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
-    unsigned int* header = reinterpret_cast<unsigned int*>(lat + lw.off_header);
-    uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
-    unsigned long long* pool = reinterpret_cast<unsigned long long*>(lat + lw.off_pool);
-    const unsigned int n_marked = header[3];
-    const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (wid * kLatLanes >= n_marked) return;
-    const bool valid = lane < kLatLanes && wid * kLatLanes + lane < n_marked;
-    const int id = (int)cids[valid ? wid * kLatLanes + lane : wid * kLatLanes];
-    const uint4 ce = valid ? cells[id] : make_uint4(0u, 0u, 0u, 1u);
-    const int quads = ce.w == 0u ? (int)ce.y : 0;
-    if (!__any(quads > 0)) return;
-    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
-    const KnnCtx c = make_ctx(ws_tgt, wt, K, Nt);
-    int incl = quads;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); incl += lane >= m ? o : 0; }
-    const unsigned long long first = (unsigned long long)wave_tot[wid] + (unsigned long long)(incl - quads);
-    bool has = quads > 0;
-    if (has && first + (unsigned long long)quads > (unsigned long long)lw.pool_quads) {      // pool exhausted: from this cell on, no lists
-        has = false;
-        cells[id] = make_uint4(0u, 0u, ce.z, 1u);
-    }
-    const unsigned long long n_lost = __ballot(quads > 0 && !has);
-    if (lane == 0 && n_lost != 0ull) atomicAdd(&header[2], (unsigned int)__popcll(n_lost));
-    float ccx, ccy, ccz;
-    lattice_cell_centre(L, id, ccx, ccy, ccz);
-    const float r2 = __uint_as_float(ce.z);
-    const float rw = sqrtf(r2) + L.hd;
-    unsigned long long word = 0ull;
-    int k = 0;
-    walk_ball<true>(c, ccx, ccy, ccz, has, rw * rw * 1.001f, lane, [&](float, const float4& p, int pos, bool in_run) {
-        if (in_run && lattice_in_list(L, p, ccx, ccy, ccz, r2)) {
-            word |= (unsigned long long)(unsigned int)pos << ((k & 3) * 16);
-            if ((k & 3) == 3) { pool[first + (unsigned long long)(k >> 2)] = word; word = 0ull; }
-            ++k;
-        }
-    });
-    if (has && (k & 3)) {
-        for (int e = k & 3; e < 4; ++e) word |= (unsigned long long)(unsigned int)Nt << (e * 16);
-        pool[first + (unsigned long long)(k >> 2)] = word;
-    }
-    if (has) cells[id] = make_uint4((unsigned int)first, (unsigned int)quads, ce.z, 0u);
 }
 
 // ---- cell pass: the consensus pass's leftovers, when they are MANY, grouped by the lattice cell they land in ---------------------
@@ -4436,14 +4379,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(lattice_mark_kernel, dim3((Ns + 255) / 256, (M + hpt - 1) / hpt), dim3(256), 0, st, (const char*)ws_tgt, src_pts, T,
                                Ns, Nt, M, hpt, lat, c_max, (const unsigned long long*)served, n_words, (const int*)inv, (const int*)chunk_of, cw.cnt);
         UMEREG_CHECK_LAUNCH("lattice_mark_kernel");
-        int bcap, bwaves;
-        size_t blds;
-        bool b16;
-        knn_lds_plan(K, Nt, &bcap, &bwaves, &blds, 4, &b16);
-        const unsigned int per_block = (unsigned int)bwaves * kWave;
         hipLaunchKernelGGL(lattice_compact_kernel, dim3(1), dim3(1024), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
         UMEREG_CHECK_LAUNCH("lattice_compact_kernel");
-        const unsigned int build_blocks = (c_max / kLatLanes + (unsigned int)bwaves - 1) / (unsigned int)bwaves;
         if (!coop_copy) {
             hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
             UMEREG_CHECK_LAUNCH("chunk_box_kernel");
@@ -4452,15 +4389,9 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // workgroup that returns at once still costs its launch, 50 us for 1 024 x 512 threads with 33 KiB of LDS each)
         // (idle on jobs whose leftovers go to the queue -- every KITTI-test pair --, where its launch alone was 60 us of a pair's 3.7 ms
         // beside other streams' kernels: the full grid only where the lattice is the likely path)
-        hipLaunchKernelGGL(lattice_dk_kernel, dim3((long)M * Ns >= kCellMinQueries ? 512 : 256), dim3(8 * kWave), 0, st, ws_coop, lat, c_max, Nt, K);
-        UMEREG_CHECK_LAUNCH("lattice_dk_kernel");
-        hipLaunchKernelGGL(lattice_count_kernel<unsigned short>, dim3(build_blocks), dim3(per_block), (size_t)(kMaxCells + 64) * 4, st,
-                           (const char*)ws_tgt, lat, c_max, Nt, K, bcap);
-        UMEREG_CHECK_LAUNCH("lattice_count_kernel");
-        hipLaunchKernelGGL(lattice_scan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max);
-        UMEREG_CHECK_LAUNCH("lattice_scan_kernel");
-        hipLaunchKernelGGL(lattice_fill_kernel, dim3((c_max / kLatLanes + 3) / 4), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt, K);
-        UMEREG_CHECK_LAUNCH("lattice_fill_kernel");
+        hipLaunchKernelGGL(lattice_posof_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
+        hipLaunchKernelGGL(lattice_list_kernel, dim3((long)M * Ns >= kCellMinQueries ? 512 : 256), dim3(8 * kWave), 0, st, ws_coop, (const char*)ws_tgt, lat, c_max, Nt, K);
+        UMEREG_CHECK_LAUNCH("lattice_list_kernel");
         if (cell_pass) {
             // the unserved queries of cells with a list, sorted by cell (counted by lattice_mark_kernel), one wavefront per cell (see corr_cell_kernel)
             const unsigned int nb = (c_max + 1023u) / 1024u;
