@@ -1744,6 +1744,25 @@ def test_corr_scores_cell_pass_equals_the_list_path(gpu):
     assert float((g2 - r2).abs().max()) <= 1e-5 * float(r2.abs().max())
 
 
+def test_corr_scores_routing_variants_agree(gpu):
+    """Every way a call can be routed gives the reference's scores: the consensus pass in its first form (UMEREG_CORR_CONSENSUS_V1) and its
+    second, source rows instead of the Hilbert order, the leftovers through the queue (one wavefront per query), through the candidate
+    lattice's list kernel, through the cell pass -- same arg-max, scores equal to rounding, each repeatable bit for bit."""
+    from umeregrobust_amd import ops
+    src, tgt, sf, tf, Ts = _garbage_hypotheses_case(seed=31)
+    a_ = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    base = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS
+    ref = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base)
+    want = orc.pc_corr_cost(Ts[:6, :3, :3], Ts[:6, :3, 3], src, tgt, 20, sf, tf, 1.5)
+    assert np.abs(N_(ref)[:6] - want).max() <= 2e-4 * np.abs(want).max() + 1e-6
+    for extra in (ops.CORR_CONSENSUS_V1, ops.CORR_SRC_ROWS, ops.CORR_LEFT_COOP, ops.CORR_LEFT_LATTICE, ops.CORR_LEFT_LATTICE | ops.CORR_CELL_PASS,
+                  ops.CORR_LEFT_LATTICE | ops.CORR_NO_FLAT, ops.CORR_NO_CONSENSUS):
+        got = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base | extra)
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), extra
+        assert int(got.argmax()) == int(ref.argmax()), extra
+        assert torch.equal(got, ops.corr_scores(*a_, K=20, sigma=1.5, flags=base | extra)), extra
+
+
 def test_corr_scores_bound_outside_keeps_the_arg_max(gpu):
     """UMEREG_CORR_BOUND_OUTSIDE: listed queries whose image lies outside the candidate lattice are bounded instead of searched, and
     only hypotheses whose score + bound reaches the best score - bound get them computed after all.  The arg-max and its score are

@@ -2651,7 +2651,12 @@ struct CellWs {
     unsigned int cap;
 };
 __host__ __device__ inline size_t cell_cap(long queries) { return (size_t)(queries < (long)kCellMaxEntries ? queries : (long)kCellMaxEntries); }
-__host__ __device__ inline size_t cell_items(unsigned int c_max, long queries) { return (size_t)c_max + cell_cap(queries) / kCellChunk + 64; }
+#ifndef UMEREG_CELL_CHUNK_LONG
+#define UMEREG_CELL_CHUNK_LONG 256
+#endif
+constexpr unsigned int kCellChunkLong = UMEREG_CELL_CHUNK_LONG;   // the same for the long-list instance: its steps cost three times a short one's, its cells hold thousands of
+                                                                  // queries, and its items are few -- with 512 per item the kernel lasted as long as its slowest two items
+__host__ __device__ inline size_t cell_items(unsigned int c_max, long queries) { return (size_t)c_max + cell_cap(queries) / (kCellChunk < kCellChunkLong ? kCellChunk : kCellChunkLong) + 64; }
 __host__ inline size_t cell_bytes(unsigned int c_max, long queries)
 {
     return 2 * align_up(((size_t)c_max + 64) * 4, 256) + 2 * align_up(cell_items(c_max, queries) * 8, 256) + align_up((1024 + 64) * 4, 256) +
@@ -2717,7 +2722,8 @@ __global__ __launch_bounds__(1024) void cell_apply_kernel(char* __restrict__ lat
     const bool lng = ce.y * 4u > (unsigned int)kCellCap;
     // (the short-list instance walks the marked list itself, in brick order, for every cell of up to kCellChunk queries: only the bigger cells go
     // through its item list -- an item per cell cost the ordinary pair 5 %: one more dependent load per visit, and the atomics' order is not the bricks')
-    const unsigned int n_it = (!lng && n_e <= kCellChunk) ? 0u : (n_e + kCellChunk - 1u) / kCellChunk;
+    const unsigned int chunk = lng ? kCellChunkLong : kCellChunk;
+    const unsigned int n_it = (!lng && n_e <= kCellChunk) ? 0u : (n_e + chunk - 1u) / chunk;
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
         const unsigned int mine = lng == (kind == 1) ? n_it : 0u;
@@ -2860,7 +2866,8 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
             const unsigned int cell_first = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
             const unsigned int cell_ne = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
-            const unsigned int chunk0 = (unsigned int)__builtin_amdgcn_readlane((int)it.y, 2 * ci) * kCellChunk;
+            constexpr unsigned int kChunk = kLong ? kCellChunkLong : kCellChunk;
+            const unsigned int chunk0 = (unsigned int)__builtin_amdgcn_readlane((int)it.y, 2 * ci) * kChunk;
             const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
             const unsigned int lfirst = (unsigned int)__builtin_amdgcn_readlane((int)rl.x, 2 * ci + 1);
             const unsigned int quads = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci + 1);
@@ -2870,7 +2877,7 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
                               quads <= kStageQuads;
             if (!take) { ++ci; continue; }
             if (g > 0 && Q + quads > kStageQuads) break;
-            const unsigned int n_e = min(cell_ne - chunk0, kCellChunk);
+            const unsigned int n_e = min(cell_ne - chunk0, kChunk);
             if (lane == g) {
                 ga = make_uint4((unsigned int)id, cell_first + chunk0, dk2b, 0u);
                 gb = make_uint4(lfirst, Q, quads, N);
