@@ -2632,7 +2632,14 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
 constexpr int kCellCap = 252;                       // list entries (byte counters: see corr_consensus2_kernel)
 constexpr size_t kCellMaxEntries = (size_t)1 << 26; // queries the pass can list (512 MiB of entries)
 constexpr long kCellMinQueries = 1l << 25;          // jobs below this never enqueue the pass (a KITTI-test pair: 2.5e7 queries, leftovers <= 2 M go to the queue)
-constexpr int kCellFetch = 4;                       // work items a wavefront takes per visit of the work counter
+#ifndef UMEREG_CELL_FETCH
+#define UMEREG_CELL_FETCH 4
+#endif
+#ifndef UMEREG_CELL_STAGE
+#define UMEREG_CELL_STAGE 256
+#endif
+constexpr int kCellFetch = UMEREG_CELL_FETCH;       // work items a wavefront takes per visit of the work counter
+constexpr int kCellStage = UMEREG_CELL_STAGE;       // stage slots of the short-list instance (a group of cells shares them)
 #ifndef UMEREG_CELL_CHUNK
 #define UMEREG_CELL_CHUNK 512
 #endif
@@ -2783,7 +2790,7 @@ __host__ __device__ inline size_t cell_lds_per_wave(int K, bool lng)
     // tie list (16-bit index plane) | stage (256 or 512 slots x 16 B) | the lane's K keys (d2 plane -- the histogram lives there until
     // the second sweep starts --, 16-bit index plane)
     // (14.5 KiB: eleven wavefronts per CU; 128 bytes more are ten)
-    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : 256) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256;
+    return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : kCellStage) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256;
 }
 
 // kLong = false: the cells whose list has <= kCellCap entries (byte counters, 256 stage slots: 14.5 KiB of LDS per wavefront);
@@ -2811,10 +2818,10 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
     tie.ix = reinterpret_cast<IdxT*>(tie.d2 + kCons2Tie * kWave);
     float* stage = reinterpret_cast<float*>(lds + (size_t)kCons2Tie * kWave * 6);
     KeyList<IdxT> list;
-    list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + (kLong ? 512 : 256) * 16);
+    list.d2 = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(stage) + (kLong ? 512 : kCellStage) * 16);
     unsigned int* hist = list.d2;                    // (dead before the first key is written: see cell_lds_per_wave)
     list.ix = reinterpret_cast<IdxT*>(reinterpret_cast<char*>(list.d2) + cell_d2_plane(K, kLong));
-    constexpr unsigned int kStageQuads = kLong ? 128u : 64u;
+    constexpr unsigned int kStageQuads = kLong ? 128u : (unsigned int)kCellStage / 4u;
     constexpr int kHW = kLong ? kHist16Words : kCons2HistWords;
     auto h_add = [&](int t) __attribute__((always_inline)) { if (kLong) hist16_add(hist, lane, t); else cons2_hist_add(hist, lane, t); };
     auto h_scan = [&](int base, int& bstar, int& before, int& inbin) __attribute__((always_inline)) {
