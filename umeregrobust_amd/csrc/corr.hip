@@ -1745,6 +1745,10 @@ constexpr int kC2Tie = UMEREG_CONS2_TIE; // the same in the consensus pass (its 
 constexpr int kC2Slots = (kCons2Cap + 4 + 3) & ~3;   // stage slots: the points + one quad of far-point padding
 static_assert(kCons2Cap <= 252 && kCons2Cap % 4 == 0, "byte counters; quad-aligned cap");
 constexpr int kCons2Zone = 12;           // zone size up to which the rank-counting path is taken
+#ifndef UMEREG_CONS2_DCACHE
+#define UMEREG_CONS2_DCACHE 12
+#endif
+constexpr int kC2DCache = UMEREG_CONS2_DCACHE;   // quads of the zone whose distances stay in registers between the two sweeps of a histogram step
 constexpr int kCons2HistWords = 9;       // 36 byte counters per lane: bin t = 0 below the range, 1..32, 33 at or beyond it
 constexpr size_t kC2MinWork = (size_t)kCoopCap * 8 * 2 + 256 > (size_t)kCons2Cap * 16 ? (size_t)kCoopCap * 8 * 2 + 256 : (size_t)kCons2Cap * 16;
 constexpr size_t kC2ListWork = (size_t)kCons2HistWords * kWave * 4 + (size_t)kC2Tie * kWave * 8;
@@ -2185,7 +2189,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
             const float sc = __builtin_amdgcn_rcpf(width);
 #pragma unroll
             for (int i = 0; i < kCons2HistWords; ++i) hist[i * kWave + lane] = 0u;
-            for (int u0 = s_min; u0 < m_use; u0 += 4) {
+            // The distances of the zone's first kC2DCache quads stay in registers between the two sweeps (12: 152 of the 168
+            // registers a wavefront may use at three per SIMD): the second sweep's 16 packed instructions and three stage reads per quad
+            // are half of what a candidate costs it.
+            f2 dca[kC2DCache > 0 ? kC2DCache : 1], dcb[kC2DCache > 0 ? kC2DCache : 1];
+            const int nq1_c = min(kC2DCache, (m_use - s_min) >> 2);
+#pragma unroll
+            for (int qq = 0; qq < kC2DCache; ++qq) {
+                if (qq < nq1_c) {
+                    quad_d2(s_min + 4 * qq, dca[qq], dcb[qq]);
+                    cons2_hist_add(hist, lane, cons2_bin(dca[qq].x, lo, sc));
+                    cons2_hist_add(hist, lane, cons2_bin(dca[qq].y, lo, sc));
+                    cons2_hist_add(hist, lane, cons2_bin(dcb[qq].x, lo, sc));
+                    cons2_hist_add(hist, lane, cons2_bin(dcb[qq].y, lo, sc));
+                }
+            }
+            for (int u0 = s_min + 4 * kC2DCache; u0 < m_use; u0 += 4) {
                 f2 t01, t23;
                 quad_d2(u0, t01, t23);
                 cons2_hist_add(hist, lane, cons2_bin(t01.x, lo, sc));
@@ -2255,9 +2274,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
                     thB = fmaxf(thA, fminf(e1, f1));
                 }
             }
-            for (int u0 = s_min; u0 < m2; u0 += 4) {
-                f2 t01, t23;
-                quad_d2(u0, t01, t23);
+            auto sweep2_quad = [&](int u0, const f2& t01, const f2& t23) __attribute__((always_inline)) {
                 const float d2v[4] = {t01.x, t01.y, t23.x, t23.y};
                 bool c1[4], c2[4];
 #pragma unroll
@@ -2290,6 +2307,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
                         }
                     }
                 }
+            };
+            const int nq2_c = min(kC2DCache, (m2 - s_min) >> 2);
+#pragma unroll
+            for (int qq = 0; qq < kC2DCache; ++qq)
+                if (qq < nq2_c) sweep2_quad(s_min + 4 * qq, dca[qq], dcb[qq]);
+            for (int u0 = s_min + 4 * kC2DCache; u0 < m2; u0 += 4) {
+                f2 t01, t23;
+                quad_d2(u0, t01, t23);
+                sweep2_quad(u0, t01, t23);
             }
             {
                 // (the bin function is monotone in d2, so every key of the K-th neighbour's bin is at or above everything the second
