@@ -421,7 +421,9 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
 #define UMEREG_CORR_CELL_PASS (1 << 19)    /* the cell pass (leftovers sorted by lattice cell, one wavefront per cell) also on jobs below 2^25 queries (tests, tuning) */
 #define UMEREG_CORR_NO_CELL_PASS (1 << 20) /* never (the round-3-start path: list kernel + one wavefront per query) */
 #define UMEREG_CORR_BOUND_OUTSIDE (1 << 21) /* arg-max mode: a listed query whose image lies outside the candidate lattice (beyond its margin around the target's bounding
-                                               box: max(20 % of the x/y extent, 3 m) in x / y, max(6 %, 3 m) in z) is BOUNDED by its distance dB to that box (K w(dist to the box) |vp| max|vq|) instead of searched; hypotheses whose score + bound reaches the best
+                                               box: max(20 % of the x/y extent, 3 m) in x / y, max(6 %, 3 m) in z) is BOUNDED by its distance dB to that box (K w(dist to the box) |vp| max|vq|) instead of searched,
+                                               and so is (round 4) a listed query of the one-wavefront-per-query search with no target point within 2.5 sigma of its image (dB = the
+                                               smallest distance to a 64-point chunk box of the target, known before anything is scanned); hypotheses whose score + bound reaches the best
                                                score - bound get those queries computed exactly in a second pass.  scores[h] is then exact for every hypothesis that can be the
                                                arg-max; for the others it lacks the bounded terms (it is within the bound of the exact score, and the exact score is below the
                                                arg-max's): umereg_corr_select_best_f32 returns the same hypothesis */

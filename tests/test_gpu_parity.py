@@ -1795,6 +1795,39 @@ def test_corr_scores_bound_outside_keeps_the_arg_max(gpu):
     assert abs(float(got[am]) - float(want[0])) <= 2e-4 * abs(float(want[0])) + 1e-6
 
 
+def test_corr_scores_bound_far_queries_inside_the_lattice(gpu):
+    """Round 4: in arg-max mode the one-wavefront-per-query search also bounds a listed query with NO target point within 2.5 sigma of its
+    image (the smallest chunk-box distance, known before anything is scanned).  A target with a hole in the middle and hypotheses that
+    shift the source by up to 10 m -- every image stays inside the candidate lattice, so nothing is bounded for lying outside it: the
+    arg-max and its score are those of the exact run, some other scores lack their far terms, the run repeats bit for bit, and a second
+    case in which the BEST hypothesis itself owns far queries gets them recomputed."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(5)
+    tgt = (rng.uniform(-30, 30, (9000, 3)) * np.array([1, 1, 0.1])).astype(np.float32)
+    tgt = tgt[(np.abs(tgt[:, 0]) > 9) | (np.abs(tgt[:, 1]) > 9)]                       # an 18 m x 18 m hole
+    src = (tgt[rng.randint(0, len(tgt), 4000)] + rng.standard_normal((4000, 3)) * 0.05).astype(np.float32)
+    sf = rng.standard_normal((4000, 32)).astype(np.float32); tf = rng.standard_normal((len(tgt), 32)).astype(np.float32)
+    M = 300
+    Ts = np.tile(np.eye(4, dtype=np.float32), (M, 1, 1))
+    Ts[1:, 0, 3] = rng.uniform(-10, 10, M - 1); Ts[1:, 1, 3] = rng.uniform(-10, 10, M - 1)
+    a_ = (T_(src, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts, gpu))
+    base = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS | ops.CORR_LEFT_COOP
+    ref = ops.corr_scores(*a_, K=20, sigma=1.5, flags=base)
+    got, _, hdr = ops.corr_scores_profile(*a_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE)
+    am = int(ref.argmax())
+    assert int(got.argmax()) == am and abs(float(got[am] - ref[am])) <= 1e-6 * abs(float(ref[am]))
+    assert int(hdr[41]) > 0 and int((got != ref).sum()) > 0                          # hypotheses with slack; scores without their far terms
+    assert torch.equal(got, ops.corr_scores(*a_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE))
+    # the winner itself throws a third of the source into the hole: its far queries are searched after all (header word 40)
+    src2 = src.copy(); src2[::3, :2] = rng.uniform(-3, 3, (len(src2[::3]), 2))
+    b_ = (T_(src2, gpu), T_(tgt, gpu), T_(sf, gpu), T_(tf, gpu), T_(Ts[:40].copy(), gpu))
+    ref2 = ops.corr_scores(*b_, K=20, sigma=1.5, flags=base)
+    got2, _, hdr2 = ops.corr_scores_profile(*b_, K=20, sigma=1.5, flags=base | ops.CORR_BOUND_OUTSIDE)
+    am2 = int(ref2.argmax())
+    assert int(hdr2[40]) >= 1, int(hdr2[40])
+    assert int(got2.argmax()) == am2 and abs(float(got2[am2] - ref2[am2])) <= 2e-6 * abs(float(ref2[am2])) + 1e-7
+
+
 def test_corr_bound_saturates_and_nan_scores_win_like_torch(gpu):
     """Two degenerate-input behaviours of the arg-max mode (advisor, round 3):
     (1) a NaN target feature row makes every outside query's bound infinite.  The saturation is a STICKY bit: any number of such

@@ -1270,7 +1270,8 @@ __global__ __launch_bounds__(256) void chunk_box_kernel(char* __restrict__ ws, s
 //   * final cut: histogram, then exact rank counting: la[0 .. returned count) = the K smallest keys in ascending order.
 // la / lb: two kCoopCap-key LDS lists of this wavefront (swapped as cuts go), hist: 64 words.
 __device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const float4* __restrict__ box, int Nt, int K, float qx, float qy,
-                                        float qz, unsigned long long*& la, unsigned long long*& lb, unsigned int* hist, int lane)
+                                        float qz, unsigned long long*& la, unsigned long long*& lb, unsigned int* hist, int lane,
+                                        float* box_min2 = nullptr, float stop_at2 = 3.0e38f)
 {
     const int n_tch = (Nt + kWave - 1) / kWave;
     auto dist2 = [&](const float4& p) __attribute__((always_inline)) {
@@ -1308,20 +1309,29 @@ __device__ __forceinline__ int coop_knn(const float4* __restrict__ P4s, const fl
     //     registers for step (2).
     constexpr int kKeepT = 4;
     float tk[kKeepT];
-    float best = 3.0e38f;
+    float best = 3.0e38f, any_min = 3.0e38f;
     int best_c = 0;
 #pragma unroll
     for (int r = 0; r < kKeepT; ++r) {
         const int c = r * kWave + lane;
         tk[r] = c < n_tch ? box2(c) : 3.0e38f;
+        any_min = fminf(any_min, tk[r]);
         if (c < n_tch && min(kWave, Nt - c * kWave) >= K && tk[r] < best) { best = tk[r]; best_c = c; }
     }
     for (int c0 = kKeepT * kWave; c0 < n_tch; c0 += kWave) {
         const int c = c0 + lane;
-        if (c < n_tch && min(kWave, Nt - c * kWave) >= K) {
+        if (c < n_tch) {
             const float t = box2(c);
-            if (t < best) { best = t; best_c = c; }
+            any_min = fminf(any_min, t);
+            if (min(kWave, Nt - c * kWave) >= K && t < best) { best = t; best_c = c; }
         }
+    }
+    if (box_min2) {
+        // a lower bound of the distance^2 to ANY table point: the smallest box distance (a box distance never exceeds the d2 of a point in the
+        // box).  A caller that only needs the neighbours of queries nearer than stop_at2 gets -1 for the others, before anything is scanned.
+        const float bm = wave_minmax_f<false>(any_min);
+        *box_min2 = bm;
+        if (bm >= stop_at2) return -1;
     }
     int seed;
     {
@@ -3505,6 +3515,7 @@ struct FlatWs {
     unsigned int* qlist;   // [slots] record << 6 | lane
     float* qval;           // [slots]
     unsigned int* qsel;    // [slots] positions (in qlist) of the entries flat_bound_kernel left to the search (header word 44: how many)
+    unsigned char* qfar;   // [slots] 1 = the search bounded this entry instead (nothing within kBoundBoxSigmas sigma of its image: see corr_score_flat_kernel)
     unsigned int slots;
 };
 // (capacity: 2^21 queries, or half of the job's if that is more -- a nuScenes-size job of 1.5e8 queries with outlier hypotheses
@@ -3516,7 +3527,7 @@ __host__ __device__ inline size_t flat_slots(long n_queries)
 }
 __host__ __device__ inline size_t flat_bytes(size_t n_records, long n_queries)
 {
-    return align_up(n_records * 4, 256) + 3 * align_up(flat_slots(n_queries) * 4, 256);
+    return align_up(n_records * 4, 256) + 3 * align_up(flat_slots(n_queries) * 4, 256) + align_up(flat_slots(n_queries), 256);
 }
 __host__ __device__ inline FlatWs flat_ws(char* base, size_t n_records, long n_queries)
 {
@@ -3525,6 +3536,7 @@ __host__ __device__ inline FlatWs flat_ws(char* base, size_t n_records, long n_q
     f.qlist = reinterpret_cast<unsigned int*>(base + align_up(n_records * 4, 256));
     f.qval = reinterpret_cast<float*>(base + align_up(n_records * 4, 256) + align_up(flat_slots(n_queries) * 4, 256));
     f.qsel = reinterpret_cast<unsigned int*>(base + align_up(n_records * 4, 256) + 2 * align_up(flat_slots(n_queries) * 4, 256));
+    f.qfar = reinterpret_cast<unsigned char*>(base + align_up(n_records * 4, 256) + 3 * align_up(flat_slots(n_queries) * 4, 256));
     f.slots = (unsigned int)flat_slots(n_queries);
     return f;
 }
@@ -3562,6 +3574,10 @@ __global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict_
 // bounded terms (it is within E_h of the exact one, which is below the arg-max's) -- corr_select_best / FeatureCorrelator return what
 // they return without the flag.
 constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
+#ifndef UMEREG_BOUND_BOX_SIGMAS
+#define UMEREG_BOUND_BOX_SIGMAS 2.5f
+#endif
+constexpr float kBoundBoxSigmas = UMEREG_BOUND_BOX_SIGMAS;    // a listed query with no target point within this many sigma is bounded, not searched.  Measured on KITTI-test pairs at 3 / 2 / 1 sigma: 36 / 46 / 59 % of the listed queries of a half-overlapping pair are bounded; on the bench's half-overlapping pairs 0 / 18 / 156 hypotheses have to be recomputed after all and the call takes 5.74 / 5.86 / 6.46 ms (6.5 without), on plain pairs 1.72 / 1.68 / 1.67 (1.70)
 
 __global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict__ v4, int N, float* __restrict__ out, unsigned int* __restrict__ max_bits)
 {
@@ -3660,8 +3676,9 @@ __global__ __launch_bounds__(256) void flat_bound_kernel(const char* __restrict_
                     if (any_sat) atomicOr(&slack[h0], 1ull << 63);
                 }
             }
+            if (valid) f.qfar[q_l] = 0;
         } else {
-            exact = outside && surv[h_l] != 0u;
+            exact = in_cloud && (outside || f.qfar[q_l] != 0) && surv[h_l] != 0u;
         }
         if (valid && !exact) f.qval[q_l] = 0.f;
         const unsigned long long b = __ballot(exact);
@@ -3679,11 +3696,19 @@ template <int kMode>
 __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void corr_score_flat_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                        const float* __restrict__ src_pts, const float4* __restrict__ vp4,
                                                                        const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt,
-                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f)
+                                                                       int K, float sigma, const char* __restrict__ lat, unsigned int c_max, FlatWs f,
+                                                                       const float* __restrict__ vpn = nullptr, const unsigned int* __restrict__ vq_max_bits = nullptr,
+                                                                       unsigned long long* __restrict__ slack = nullptr)
 {
     static_assert(kMode == 0 || kMode == 3, "the whole list or the selected entries");
+    // Bounded mode, first pass (kMode 3 with `slack`): a query whose image has NO target point within kBoundBoxSigmas sigma -- known after the box
+    // tests of the search, before anything is scanned: the smallest chunk-box distance is a lower bound dB of every neighbour's distance -- is
+    // bounded like a query outside the lattice: value 0, K w(dB) |vp_n| max_j |vq_j| added to its hypothesis' slack, flag f.qfar set so that the
+    // second pass finds it if the hypothesis survives.  These are the most expensive searches (a query 10 m from the cloud scans twice the
+    // chunks of one inside it) of the queries that matter least: 36-45 % of the listed queries of a KITTI-test pair (`UMEREG_FLAT_STATS`).
     __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
     __shared__ unsigned int chist[kCoopWaves][kWave];
+    __shared__ int visit_h[kCoopWaves][4];
     __shared__ float4 visit[kCoopWaves][4];            // the queries of a visit (image, source point): parked here, not in registers -- the
                                                        // search needs 56 of the 64 a wavefront may hold at eight per SIMD
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3724,7 +3749,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
         const bool exact = in_cloud;
         if (valid && !exact) f.qval[q_l] = 0.f;
         static_assert(kFlatVisit == 4, "visit[][4]");
-        if (lane < (int)kFlatVisit) visit[wave][lane] = make_float4(qx_l, qy_l, qz_l, __int_as_float(qs_l));
+        if (lane < (int)kFlatVisit) { visit[wave][lane] = make_float4(qx_l, qy_l, qz_l, __int_as_float(qs_l)); visit_h[wave][lane] = h_l; }
         unsigned int todo = (unsigned int)__ballot(exact);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         while (todo != 0u) {
@@ -3733,7 +3758,59 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
             const float4 v = visit[wave][l];
             const float qx = v.x, qy = v.y, qz = v.z;
             const int qs = __float_as_int(v.w);
+            if (kMode == 3 && slack != nullptr) {
+                float bm2 = 0.f;
+                const float stop = kBoundBoxSigmas * sigma;
+                const bool finite = qx == qx && qy == qy && qz == qz;                 // (NaN images go through the search as always)
+                const int c0 = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane, &bm2, finite ? stop * stop : 3.0e38f);
+                if (c0 < 0) {
+                    if (lane == 0) {
+                        const unsigned int q_far = (unsigned int)__builtin_amdgcn_readlane((int)q_l, l);
+                        const float dB = fmaxf(sqrtf(bm2) * 0.9999f - 1e-5f, 0.f);
+                        const float r = dB * inv_sigma * 0.9999f;
+                        const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[qs] * __uint_as_float(*vq_max_bits) * 1.0001f;
+                        const int h = visit_h[wave][l];
+                        if (eps < 1.0e3f) atomicAdd(&slack[h], (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull);
+                        else atomicOr(&slack[h], 1ull << 63);
+                        f.qval[q_far] = 0.f;
+                        f.qfar[q_far] = 1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    continue;
+                }
+                const float4 a = vp4[(size_t)qs * 8 + sub];
+                float part = 0.f;
+                for (int e0 = 0; e0 < c0; e0 += 8) {
+                    const int e = e0 + grp;
+                    const unsigned long long k = la[e < c0 ? e : 0];
+                    const float wgt = cauchy_weight_hw(__uint_as_float((unsigned int)(k >> 32)), inv_sigma);   // :593, :588-589
+                    const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
+                    float d = a.x * o.x;
+                    d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                    part += e < c0 ? wgt * d : 0.f;
+                }
+                part = wave_sum_f(part);
+                const unsigned int q_o = (unsigned int)__builtin_amdgcn_readlane((int)q_l, l);
+                if (lane == 0) f.qval[q_o] = part;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                continue;
+            }
+#ifdef UMEREG_FLAT_STATS
+            float bm2 = 0.f;
+            const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane, &bm2);
+            if (lane == 0) {
+                unsigned int* hs = const_cast<unsigned int*>(header);
+                const float r = sqrtf(bm2) * inv_sigma;
+                atomicAdd(&hs[48], 1u);
+                if (r >= 1.f) atomicAdd(&hs[49], 1u);
+                if (r >= 2.f) atomicAdd(&hs[50], 1u);
+                if (r >= 3.f) atomicAdd(&hs[51], 1u);
+                if (r >= 4.f) atomicAdd(&hs[52], 1u);
+                if (r >= 6.f) atomicAdd(&hs[53], 1u);
+            }
+#else
             const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
+#endif
             const float4 a = vp4[(size_t)qs * 8 + sub];
             float part = 0.f;
             for (int e0 = 0; e0 < cnt; e0 += 8) {
@@ -4496,7 +4573,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                                    lat, c_max, fw, (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
                 UMEREG_CHECK_LAUNCH("flat_bound_kernel");
                 hipLaunchKernelGGL(corr_score_flat_kernel<3>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
-                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);
+                                   src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw,
+                                   (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack);
             } else {
                 hipLaunchKernelGGL(corr_score_flat_kernel<0>, dim3(kFlatBlocks), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src,
                                    src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, K, sigma, (const char*)lat, c_max, fw);

@@ -531,7 +531,7 @@ CORR_CONSENSUS_V1, CORR_DEBUG_STATS, CORR_FAR_MARGIN_SHIFT = 32, 64, 8      # in
 CORR_SRC_ROWS, CORR_RECORD_STAGE = 128, 1 << 18
 CORR_LEFT_COOP, CORR_LEFT_LATTICE = 1 << 16, 1 << 17
 CORR_CELL_PASS, CORR_NO_CELL_PASS, CORR_BOUND_OUTSIDE = 1 << 19, 1 << 20, 1 << 21
-CORR_BOUND_MIN_QUERIES = 1 << 25      # jobs from this size on: FeatureCorrelator bounds the queries outside the lattice (and the library runs its cell pass)
+CORR_BOUND_MIN_QUERIES = 1 << 24      # jobs from this size on (a KITTI-test pair: 2.5e7 queries): FeatureCorrelator runs in arg-max mode -- listed queries outside the lattice or with nothing within 3 sigma of their image are bounded, not searched
 
 
 def corr_scores(src_pts, tgt_pts, src_wfeat, tgt_wfeat, T, K=20, sigma=0.05, timing=None, flags=0):

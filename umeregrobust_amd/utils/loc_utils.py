@@ -219,11 +219,12 @@ class FeatureCorrelator:
             src_feat_weight = feature_spatial_var(source_pc, source_feat, knn=50)       # :662
             tgt_feat_weight = feature_spatial_var(target_pc, target_feat, knn=50)       # :663
         wsf, wtf = ops.corr_weighted_features(source_feat[0], target_feat[0], src_feat_weight[0], tgt_feat_weight[0])
-        # Only the arg-max leaves this method (:676-680).  On big jobs (nuScenes / LoKITTI sizes: 5 000 hypotheses x 30 000 points) the
-        # queries of outlier hypotheses that land far outside the target are therefore BOUNDED instead of searched, and searched after
-        # all only for hypotheses the bound cannot rule out (include/umereg.h, UMEREG_CORR_BOUND_OUTSIDE): the same hypothesis wins,
-        # with its exact score; `last_scores` of hypotheses that were ruled out lack those (tiny) terms.  self.exact_scores = True
-        # computes every score exactly, whatever the size.
+        # Only the arg-max leaves this method (:676-680).  On jobs of >= 2^24 queries (a KITTI-test pair: 2 500 hypotheses x 10 000 points;
+        # nuScenes / LoKITTI sizes: 5 000 x 30 000) the queries of outlier hypotheses that land outside the target or with no target point
+        # within 2.5 sigma of their image are therefore BOUNDED instead of searched, and searched after all only for hypotheses the bound
+        # cannot rule out (include/umereg.h, UMEREG_CORR_BOUND_OUTSIDE): the same hypothesis wins, with its exact score; `last_scores` of
+        # hypotheses that were ruled out lack those terms (`last_scores_exact` says which mode ran).  self.exact_scores = True computes every
+        # score exactly, whatever the size.
         big = int(T_kp.shape[0]) * int(source_pc.shape[1]) >= ops.CORR_BOUND_MIN_QUERIES
         flags = ops.CORR_BOUND_OUTSIDE if (big and not self.exact_scores) else 0
         mmf_score = ops.corr_scores(source_pc[0], target_pc[0], wsf, wtf, T_kp, K=self.corr_num_nn, sigma=self.sigma,
