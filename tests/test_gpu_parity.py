@@ -1826,6 +1826,17 @@ def test_corr_scores_bound_far_queries_inside_the_lattice(gpu):
     am2 = int(ref2.argmax())
     assert int(hdr2[40]) >= 1, int(hdr2[40])
     assert int(got2.argmax()) == am2 and abs(float(got2[am2] - ref2[am2])) <= 2e-6 * abs(float(ref2[am2])) + 1e-7
+    # the same through the candidate lattice + cell pass: there the queries of FAR CELLS (every point of the cell at least 2.5 sigma from every
+    # target point: header word 45 counts such cells) are bounded by the scatter and recomputed by far_recompute_kernel for a surviving hypothesis
+    lat_ = ops.CORR_FORCE_LATTICE | ops.CORR_FORCE_CONSENSUS | ops.CORR_LEFT_LATTICE | ops.CORR_CELL_PASS
+    for args_, ref_, need in ((a_, ref, 0), (b_, ref2, 1)):
+        g, _, h_ = ops.corr_scores_profile(*args_, K=20, sigma=1.5, flags=lat_ | ops.CORR_BOUND_OUTSIDE)
+        am_ = int(ref_.argmax())
+        assert int(h_[45]) > 0 and int(h_[40]) >= need, (int(h_[45]), int(h_[40]))
+        assert int(g.argmax()) == am_ and abs(float(g[am_] - ref_[am_])) <= 2e-6 * abs(float(ref_[am_])) + 1e-7
+        assert torch.equal(g, ops.corr_scores(*args_, K=20, sigma=1.5, flags=lat_ | ops.CORR_BOUND_OUTSIDE))
+        exact = ops.corr_scores(*args_, K=20, sigma=1.5, flags=lat_)
+        assert float((exact - ref_).abs().max()) <= 1e-5 * float(ref_.abs().max())
 
 
 def test_corr_bound_saturates_and_nan_scores_win_like_torch(gpu):

@@ -1135,6 +1135,13 @@ __global__ __launch_bounds__(1024) void hyp_order_chunk_kernel(const float* __re
 }
 
 constexpr int kCoopCap = 256;       // cooperative key list (keys)
+constexpr int kCoopWaves = 8;       // wavefronts per record
+// (the bounded mode, UMEREG_CORR_BOUND_OUTSIDE: see flat_bound_kernel)
+constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
+#ifndef UMEREG_BOUND_BOX_SIGMAS
+#define UMEREG_BOUND_BOX_SIGMAS 2.5f
+#endif
+constexpr float kBoundBoxSigmas = UMEREG_BOUND_BOX_SIGMAS;    // a listed query with no target point within this many sigma is bounded, not searched.  Measured on KITTI-test pairs at 3 / 2 / 1 sigma: 36 / 46 / 59 % of the listed queries of a half-overlapping pair are bounded; on the bench's half-overlapping pairs 0 / 18 / 156 hypotheses have to be recomputed after all and the call takes 5.74 / 5.86 / 6.46 ms (6.5 without), on plain pairs 1.72 / 1.68 / 1.67 (1.70)
 
 // keep the K smallest of list[0 .. cnt) (cnt <= SLOTS * 64 <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
 // Rank counting: keys are unique, so ranks are a permutation.  cnt * SLOTS compare-and-adds per lane.
@@ -2423,7 +2430,8 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
 // time = ONE served word per lane, and a word that is all ones costs nothing more.  (By source index and hypothesis number -- the first
 // form of lattice_mark_kernel / cell_scatter_kernel -- every (point, hypothesis) pair paid for its transform, an inverse-order look-up
 // and a scattered 8-byte read of its served word: 1.5e8 of each on a nuScenes-size pair.)  f(n, pos, h, qx, qy, qz) per unserved query.
-template <class F>
+// (kAll: f(mine, n, pos, h, qx, qy, qz) on EVERY lane of a step with at least one unserved query, for callers that reduce over the wavefront)
+template <bool kAll = false, class F>
 __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float* __restrict__ T,
                                                   int Ns, int M, const unsigned long long* __restrict__ served, int n_words,
                                                   const int* __restrict__ perm, F&& f)
@@ -2433,9 +2441,9 @@ __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_sr
     for (long item = blockIdx.x; item < (long)n_pb * n_words; item += gridDim.x) {
         const int slot = (int)(item % n_pb) * 256 + threadIdx.x;
         const int w = (int)(item / n_pb);
-        if (slot >= Ns) continue;
-        const int n = __float_as_int(S4s[slot].w);
-        unsigned long long todo = ~served[(size_t)n * n_words + w];
+        if (!kAll && slot >= Ns) continue;
+        const int n = __float_as_int(S4s[slot < Ns ? slot : 0].w);
+        unsigned long long todo = slot < Ns ? ~served[(size_t)n * n_words + w] : 0ull;
         if (w == n_words - 1 && (M & 63)) todo &= (1ull << (M & 63)) - 1ull;
         if (!__any(todo != 0ull)) continue;
         const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
@@ -2449,7 +2457,8 @@ __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_sr
             const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
             const float qy = fmaf(Th[6], sz, fmaf(Th[5], sy, Th[4] * sx)) + Th[7];
             const float qz = fmaf(Th[10], sz, fmaf(Th[9], sy, Th[8] * sx)) + Th[11];
-            if (mine) f(n, w * 64 + b, h, qx, qy, qz);
+            if constexpr (kAll) f(mine, n, w * 64 + b, h, qx, qy, qz);
+            else if (mine) f(n, w * 64 + b, h, qx, qy, qz);
         }
     }
 }
@@ -2550,7 +2559,7 @@ __global__ __launch_bounds__(256) void lattice_posof_kernel(const char* __restri
 
 constexpr int kLatListCap = 4 * kLatMaxQuads;            // entries of the longest list
 __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __restrict__ ws_coop, const char* __restrict__ ws_tgt, char* __restrict__ lat,
-                                                              unsigned int c_max, int Nt, int K)
+                                                              unsigned int c_max, int Nt, int K, float sigma, int far_mode)
 {
     __shared__ unsigned long long lists[8][2][kCoopCap];
     __shared__ unsigned int chist[8][kWave];
@@ -2579,14 +2588,30 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
     const unsigned long long slice = (unsigned long long)lw.pool_quads / n_waves;
     unsigned long long cur = slice * w_id;
     const unsigned long long end = cur + slice;
-    unsigned int n_nolist = 0u, n_quads = 0u;
+    unsigned int n_nolist = 0u, n_quads = 0u, n_far = 0u;
     for (unsigned int i = w_id; i < n_marked; i += n_waves) {
         const int id = (int)cids[i];
         float ccx, ccy, ccz;
         lattice_cell_centre(L, id, ccx, ccy, ccz);
-        const int cnt = coop_knn(P4c, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane);
+        // Bounded mode (far_mode): a cell every point of which is at least kBoundBoxSigmas sigma from every target point gets no list -- its queries
+        // are bounded (cell_scatter_kernel).  The distance: the centre's nearest neighbour (or, before anything is scanned, the smallest
+        // chunk-box distance) less the half diagonal.
+        const float hd_m = L.hd * 1.0001f + 1e-5f, far_thr = kBoundBoxSigmas * sigma;
+        float bm2 = 0.f;
+        const int cnt = far_mode ? coop_knn(P4c, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane, &bm2, (far_thr + hd_m) * (far_thr + hd_m) * 1.0001f)
+                                 : coop_knn(P4c, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane);
         const unsigned int d2k = cnt > 0 ? (unsigned int)(la[cnt - 1] >> 32) : 0u;       // keys ascend: the last one is the K-th
+        const float d_near = cnt < 0 ? sqrtf(bm2) : (cnt > 0 ? sqrtf(__uint_as_float((unsigned int)(la[0] >> 32))) : 0.f);
+        const float d_low = fmaxf(d_near * 0.9999f - hd_m, 0.f);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (far_mode && (cnt < 0 || (cnt > 0 && d_low >= far_thr))) {
+            if (lane == 0) {
+                cells[id] = make_uint4(0u, 0u, __float_as_uint(d_low), 2u);
+                dk2[id] = d2k;
+            }
+            ++n_far;
+            continue;
+        }
         const float r = (sqrtf(__uint_as_float(d2k)) + L.hd) * 1.0001f + 1e-6f;
         const float r2 = r * r;
         int n = 0;
@@ -2631,7 +2656,12 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
             }
         }
         if (lane == 0) {
-            cells[id] = has ? make_uint4((unsigned int)cur, (unsigned int)quads, __float_as_uint(r2), 0u) : make_uint4(0u, 0u, __float_as_uint(r2), 1u);
+#ifdef UMEREG_FAR_STATS
+            const unsigned int cls = (d_low >= sigma ? 1u : 0u) | (d_low >= 2.f * sigma ? 2u : 0u) | (d_low >= 2.5f * sigma ? 4u : 0u) | (d_low >= 3.f * sigma ? 8u : 0u) | (d_low >= 4.f * sigma ? 16u : 0u);
+#else
+            const unsigned int cls = 0u; (void)d_low; (void)sigma;
+#endif
+            cells[id] = has ? make_uint4((unsigned int)cur, (unsigned int)quads, __float_as_uint(r2), cls << 8) : make_uint4(0u, 0u, __float_as_uint(r2), 1u);
             dk2[id] = d2k;
         }
         if (has) { cur += (unsigned long long)quads; n_quads += (unsigned int)quads; } else ++n_nolist;
@@ -2640,6 +2670,7 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
     if (lane == 0) {
         if (n_nolist) atomicAdd(&header[2], n_nolist);
         if (n_quads) atomicAdd(&header[0], n_quads);
+        if (n_far) atomicAdd(&header[45], n_far);               // (statistics: far cells)
     }
 }
 
@@ -2723,7 +2754,7 @@ __host__ inline CellWs cell_ws(char* base, unsigned int c_max, long queries)
 #define UMEREG_CELL_LONG 1
 #endif
 constexpr int kCellCapLong = UMEREG_CELL_LONG ? 4 * kLatMaxQuads : kCellCap;      // the long-list instance of the kernel (16-bit counters, 512 stage slots)
-__device__ __forceinline__ bool cell_usable(const uint4& ce) { return ce.w == 0u && ce.y != 0u && ce.y * 4u <= (unsigned int)kCellCapLong; }
+__device__ __forceinline__ bool cell_usable(const uint4& ce) { return (ce.w & 0xffu) == 0u && ce.y != 0u && ce.y * 4u <= (unsigned int)kCellCapLong; }
 
 // exclusive prefix sums of the marked cells' counts (cells without a usable list count as empty), in the order of the marked list:
 // phase 0: per-block sums; cell_blockscan_kernel: their offsets; phase 1: cnt[cell] = first entry, cur[cell] = 0, the cell's record
@@ -2754,6 +2785,13 @@ __global__ __launch_bounds__(1024) void cell_apply_kernel(char* __restrict__ lat
     }
     const unsigned int first = cw.bsum[blockIdx.x] + base + (unsigned int)incl - v;
     const unsigned int n_e = (i >= n || first >= cw.cap) ? 0u : min(v, cw.cap - first);
+#ifdef UMEREG_FAR_STATS
+    if (n_e) {
+        unsigned int* hs = const_cast<unsigned int*>(header);
+        atomicAdd(&hs[54], n_e >> 4);
+        for (int k = 0; k < 5; ++k) if ((ce.w >> (8 + k)) & 1u) atomicAdd(&hs[55 + k], n_e >> 4);
+    }
+#endif
     if (i < n) {
         cw.cnt[id] = first;
         cw.cur[id] = 0u;
@@ -2799,21 +2837,133 @@ __global__ __launch_bounds__(1024) void cell_blockscan_kernel(char* __restrict__
 }
 
 // the entries: every unserved query whose cell has a usable list, at cnt[cell] (= first) + cur[cell]++
+// Bounded mode (slack != nullptr): a query in a FAR cell (cells[].w == 2: every point of the cell is at least cells[].z >= kBoundBoxSigmas sigma
+// from every target point, lattice_list_kernel) is not listed: K w(that distance) |vp_n| max_j |vq_j| goes to its hypothesis' slack (one atomic per
+// wavefront and step: the lanes of a step share the hypothesis), it counts as served with the value 0, and its bit in `farq` lets
+// far_recompute_kernel find it if the hypothesis survives.  Measured (UMEREG_FAR_STATS): 12-15 % of the listed queries of a plain nuScenes-size
+// job, 61-84 % of a half-overlapping one's -- the images outlier hypotheses throw into the empty half of the scene.
 __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
                                                            const float* __restrict__ T, int Ns, int Nt, int M, const char* __restrict__ lat, unsigned int c_max,
-                                                           const unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm, CellWs cw)
+                                                           unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm, CellWs cw,
+                                                           int K, float sigma, const float* __restrict__ vpn, const unsigned int* __restrict__ vq_max_bits,
+                                                           unsigned long long* __restrict__ slack, unsigned long long* __restrict__ farq)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // few leftovers: the queue takes them
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const uint4* cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
-    for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int n, int pos, int h, float qx, float qy, float qz) {
-        const int cell = lattice_cell(L, qx, qy, qz);
-        if (cell < 0 || !cell_usable(cells[cell])) return;
-        const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
-        if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+    if (slack == nullptr) {
+        for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int n, int pos, int h, float qx, float qy, float qz) {
+            const int cell = lattice_cell(L, qx, qy, qz);
+            if (cell < 0 || !cell_usable(cells[cell])) return;
+            const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
+            if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+        });
+        return;
+    }
+    const float vq_max = __uint_as_float(*vq_max_bits);
+    const float inv_sigma = 1.0f / sigma;
+    const int lane = lane_id();
+    for_each_unserved<true>(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](bool mine, int n, int pos, int h, float qx, float qy, float qz) {
+        const int cell = mine ? lattice_cell(L, qx, qy, qz) : -1;
+        const uint4 ce = cells[cell >= 0 ? cell : 0];
+        const bool far = cell >= 0 && ce.w == 2u;
+        if (__any(far)) {
+            unsigned long long fx = 0ull;
+            bool sat = false;
+            if (far) {
+                const float r = __uint_as_float(ce.z) * inv_sigma * 0.9999f;
+                const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[n] * vq_max * 1.0001f;
+                sat = !(eps < 1.0e3f);
+                fx = sat ? 0ull : (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull;
+                const unsigned long long bit = 1ull << (pos & 63);
+                atomicOr(&served[(size_t)n * n_words + (pos >> 6)], bit);            // (its value stays the 0 the consensus pass wrote)
+                atomicOr(&farq[(size_t)n * n_words + (pos >> 6)], bit);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) fx += (unsigned long long)__shfl_xor((long long)fx, o, kWave);                 // (integers: any order)
+            const bool any_sat = __any(sat);
+            if (lane == 0) {
+                if (fx != 0ull) atomicAdd(&slack[h], fx);
+                if (any_sat) atomicOr(&slack[h], 1ull << 63);
+            }
+        }
+        if (cell >= 0 && !far && cell_usable(ce)) {
+            const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
+            if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+        }
     });
+}
+
+// second pass of the bounded mode: the queries cell_scatter_kernel bounded for lying in far cells, for the hypotheses that survived
+// (bound_survivors_kernel), exactly -- one wavefront per query, the value into the query's own slot of the consensus pass's plane
+// (the slice sums and scores are formed once more behind it).  Returns at once when no hypothesis needs its bounded queries.
+__global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void far_recompute_kernel(
+    const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float4* __restrict__ vp4,
+    const float4* __restrict__ vq4, const float* __restrict__ T, int Ns, int Nt, int M, int K, float sigma, const char* __restrict__ lat,
+    unsigned int c_max, const unsigned long long* __restrict__ farq, int n_words, const int* __restrict__ perm,
+    const unsigned int* __restrict__ surv, float* __restrict__ val)
+{
+    __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
+    __shared__ unsigned int chist[kCoopWaves][kWave];
+    const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lat_ws(c_max).off_header);
+    if (header[8] != 0u || header[40] == 0u) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
+    const float4* S4s = reinterpret_cast<const float4*>(ws_src + wsr.off_p4s);
+    const float4* P4s = reinterpret_cast<const float4*>(ws_coop + wt.off_p4s);
+    const float4* box = reinterpret_cast<const float4*>(ws_coop + wt.off_box);
+    unsigned long long* la = lists[wave][0];
+    unsigned long long* lb = lists[wave][1];
+    const int grp = lane >> 3, sub = lane & 7;
+    const float inv_sigma = 1.0f / sigma;
+    const int n_chunks = (Ns + kWave - 1) / kWave;
+    const long n_items = (long)n_chunks * n_words;
+    for (long item = (long)blockIdx.x * kCoopWaves + wave; item < n_items; item += (long)gridDim.x * kCoopWaves) {
+        const int chunk = (int)(item / n_words), w = (int)(item % n_words);
+        const int slot = chunk * kWave + lane;
+        const int n = __float_as_int(S4s[slot < Ns ? slot : 0].w);
+        const unsigned long long word = slot < Ns ? farq[(size_t)n * n_words + w] : 0ull;
+        if (!__any(word != 0ull)) continue;
+        const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
+        const int* perm_c = perm + (size_t)chunk * M + (size_t)w * 64;
+        for (int b = 0; b < 64 && w * 64 + b < M; ++b) {
+            unsigned long long m = __ballot((word >> b) & 1ull);
+            if (m == 0ull) continue;
+            const int h = perm_c[b];                                 // uniform
+            if (surv[h] == 0u) continue;
+            const float* Th = T + (size_t)h * 16;
+            while (m != 0ull) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), l));
+                const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), l));
+                const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), l));
+                const int qs = __builtin_amdgcn_readlane(n, l);
+                // (the arithmetic of corr_score_kernel)
+                const float qx = fmaf(Th[2], pz, fmaf(Th[1], py, Th[0] * px)) + Th[3];
+                const float qy = fmaf(Th[6], pz, fmaf(Th[5], py, Th[4] * px)) + Th[7];
+                const float qz = fmaf(Th[10], pz, fmaf(Th[9], py, Th[8] * px)) + Th[11];
+                const int cnt = coop_knn(P4s, box, Nt, K, qx, qy, qz, la, lb, chist[wave], lane);
+                const float4 a = vp4[(size_t)qs * 8 + sub];
+                float part = 0.f;
+                for (int e0 = 0; e0 < cnt; e0 += 8) {
+                    const int e = e0 + grp;
+                    const unsigned long long k = la[e < cnt ? e : 0];
+                    const float wgt = cauchy_weight_hw(__uint_as_float((unsigned int)(k >> 32)), inv_sigma);   // :593, :588-589
+                    const float4 o = vq4[(size_t)(unsigned int)(k & 0xffffffffull) * 8 + sub];
+                    float d = a.x * o.x;
+                    d = fmaf(a.y, o.y, d); d = fmaf(a.z, o.z, d); d = fmaf(a.w, o.w, d);
+                    part += e < cnt ? wgt * d : 0.f;
+                }
+                part = wave_sum_f(part);
+                if (lane == 0) val[(size_t)qs * M + (size_t)(w * 64 + b)] = part;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+    }
 }
 
 __host__ __device__ inline size_t cell_d2_plane(int K, bool lng)
@@ -3234,7 +3384,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const uint4 ce = cells[cell >= 0 ? cell : 0];
             // (after the cell pass what is left in cells WITH a list are the queries of lists longer than that pass stages -- dense spots:
             // 9 ns each here on a nuScenes-size pair, but 12 ns one wavefront per query (measured), so they stay)
-            const bool use = cell >= 0 && ce.w == 0u && ce.y != 0u && !(after_cell_pass & 2);
+            const bool use = cell >= 0 && (ce.w & 0xffu) == 0u && ce.y != 0u && !(after_cell_pass & 2);
             const unsigned int first = ce.x;
             const int nquads = use ? (int)ce.y : 0;
             LaneSel S;
@@ -3426,7 +3576,6 @@ __global__ __launch_bounds__(8 * 64) void spatial_var_coop_kernel(const char* __
 // samples that admitted hundreds of keys: 2.6 ms for 170 k queries, now 0.94 ms), a workgroup of 8 wavefronts shares the
 // queries of one record, and the K keys are scored with 8 lanes per neighbour's feature row.
 // The record's sum is formed by wavefront 0 from the per-query values in lane order: deterministic.
-constexpr int kCoopWaves = 8;       // wavefronts per record
 
 __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                   const float* __restrict__ src_pts, const float4* __restrict__ vp4,
@@ -3573,11 +3722,6 @@ __global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict_
 // Result: the score of every hypothesis that can be the arg-max is exact (same neighbours, same terms); every other score lacks its
 // bounded terms (it is within E_h of the exact one, which is below the arg-max's) -- corr_select_best / FeatureCorrelator return what
 // they return without the flag.
-constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
-#ifndef UMEREG_BOUND_BOX_SIGMAS
-#define UMEREG_BOUND_BOX_SIGMAS 2.5f
-#endif
-constexpr float kBoundBoxSigmas = UMEREG_BOUND_BOX_SIGMAS;    // a listed query with no target point within this many sigma is bounded, not searched.  Measured on KITTI-test pairs at 3 / 2 / 1 sigma: 36 / 46 / 59 % of the listed queries of a half-overlapping pair are bounded; on the bench's half-overlapping pairs 0 / 18 / 156 hypotheses have to be recomputed after all and the call takes 5.74 / 5.86 / 6.46 ms (6.5 without), on plain pairs 1.72 / 1.68 / 1.67 (1.70)
 
 __global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict__ v4, int N, float* __restrict__ out, unsigned int* __restrict__ max_bits)
 {
@@ -4284,7 +4428,11 @@ static bool cell_pass_on(unsigned int c_max, int Ns, int M, int flags, const voi
 
 // bounding of the queries outside the lattice (corr_score_flat_kernel<1>): slack (u64 per hypothesis), survivor flags, |vp_n|, max |vq_j|
 static bool bound_on(unsigned int c_max, int flags) { return c_max != 0 && (flags & UMEREG_CORR_BOUND_OUTSIDE) && !(flags & UMEREG_CORR_NO_FLAT); }
-static size_t bound_bytes(int Ns, int M) { return align_up((size_t)M * 8, 256) + align_up((size_t)M * 4, 256) + align_up((size_t)Ns * 4, 256) + 256; }
+// ... and the plane of the queries bounded for lying in far cells (one bit per query, like `served`)
+static size_t bound_bytes(int Ns, int M)
+{
+    return align_up((size_t)M * 8, 256) + align_up((size_t)M * 4, 256) + align_up((size_t)Ns * 4, 256) + 256 + align_up((size_t)Ns * ((M + 63) / 64) * 8, 256);
+}
 
 UMEREG_API size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags)
 {
@@ -4402,6 +4550,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
     const bool bound = bound_on(c_max, flags);
     unsigned long long* b_slack = nullptr;
     unsigned int* b_surv = nullptr;
+    unsigned long long* b_farq = nullptr;
     float* b_vpn = nullptr;
     unsigned int* b_vqmax = nullptr;
     float* val = nullptr;
@@ -4482,6 +4631,24 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         char* flat_base = (char*)workspace + umereg_corr_workspace_bytes_ex(Ns, Nt, M, flags) - flat_bytes(queue_records(M, n_chunks_sz), (long)M * Ns);
         const bool cell_pass = cell_pass_on(c_max, Ns, M, flags, T);
         CellWs cw = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        if (bound) {
+            // the bound's slack / survivor flags / norms / far-query plane, and what every bounding kernel needs before it runs
+            char* bb = flat_base - (cell_pass ? cell_bytes(c_max, (long)M * Ns) : 0) - bound_bytes(Ns, M);
+            b_slack = (unsigned long long*)bb;
+            b_surv = (unsigned int*)(bb + align_up((size_t)M * 8, 256));
+            b_vpn = (float*)((char*)b_surv + align_up((size_t)M * 4, 256));
+            b_vqmax = (unsigned int*)((char*)b_vpn + align_up((size_t)Ns * 4, 256));
+            b_farq = (unsigned long long*)((char*)b_vqmax + 256);
+            if (hipMemsetAsync(b_slack, 0, (size_t)M * 8, st) != hipSuccess || hipMemsetAsync(b_vqmax, 0, 4, st) != hipSuccess ||
+                (cell_pass && served && hipMemsetAsync(b_farq, 0, (size_t)Ns * n_words * 8, st) != hipSuccess)) {
+                set_error("hipMemsetAsync(slack) failed");
+                return UMEREG_ELAUNCH;
+            }
+            hipLaunchKernelGGL(row_norm_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, (const float4*)src_wfeat, Ns, b_vpn, (unsigned int*)nullptr);
+            hipLaunchKernelGGL(row_norm_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const float4*)tgt_wfeat, Nt, (float*)nullptr, b_vqmax);
+            UMEREG_CHECK_LAUNCH("row_norm_kernel");
+        }
+        const bool far_cells = bound && cell_pass && served != nullptr;      // queries in far lattice cells are bounded by the scatter (see cell_scatter_kernel)
         if (cell_pass) {
             cw = cell_ws(flat_base - cell_bytes(c_max, (long)M * Ns), c_max, (long)M * Ns);
             if (hipMemsetAsync(cw.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) { set_error("hipMemsetAsync(cell counters) failed"); return UMEREG_ELAUNCH; }
@@ -4507,7 +4674,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // (idle on jobs whose leftovers go to the queue -- every KITTI-test pair --, where its launch alone was 60 us of a pair's 3.7 ms
         // beside other streams' kernels: the full grid only where the lattice is the likely path)
         hipLaunchKernelGGL(lattice_posof_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
-        hipLaunchKernelGGL(lattice_list_kernel, dim3((long)M * Ns >= kCellMinQueries ? 512 : 256), dim3(8 * kWave), 0, st, ws_coop, (const char*)ws_tgt, lat, c_max, Nt, K);
+        hipLaunchKernelGGL(lattice_list_kernel, dim3((long)M * Ns >= kCellMinQueries ? 512 : 256), dim3(8 * kWave), 0, st, ws_coop, (const char*)ws_tgt, lat, c_max, Nt, K, sigma, far_cells ? 1 : 0);
         UMEREG_CHECK_LAUNCH("lattice_list_kernel");
         if (cell_pass) {
             // the unserved queries of cells with a list, sorted by cell (counted by lattice_mark_kernel), one wavefront per cell (see corr_cell_kernel)
@@ -4517,7 +4684,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(cell_apply_kernel<1>, dim3(nb), dim3(1024), 0, st, lat, c_max, cw);
             UMEREG_CHECK_LAUNCH("cell_apply_kernel");
             hipLaunchKernelGGL(cell_scatter_kernel, order_grid, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M,
-                               (const char*)lat, c_max, (const unsigned long long*)served, n_words, (const int*)perm, cw);
+                               (const char*)lat, c_max, served, n_words, (const int*)perm, cw, K, sigma, (const float*)b_vpn, (const unsigned int*)b_vqmax,
+                               far_cells ? b_slack : (unsigned long long*)nullptr, b_farq);
             UMEREG_CHECK_LAUNCH("cell_scatter_kernel");
             hipLaunchKernelGGL(corr_cell_kernel<false>, dim3(2816), dim3(kWave), cell_lds_per_wave(K, false), st, (const char*)ws_tgt, src_pts,
                                (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw, val, served,
@@ -4537,13 +4705,6 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         // the records either score kernel queued: queries outside the lattice / in cells without a list, far-off chunks
         // ... as a flat list of queries when they fit (header word 12 marks that the flat path ran), record by record otherwise
         const FlatWs fw = flat_ws(flat_base, queue_records(M, n_chunks_sz), (long)M * Ns);
-        if (bound) {
-            char* bb = flat_base - (cell_pass ? cell_bytes(c_max, (long)M * Ns) : 0) - bound_bytes(Ns, M);
-            b_slack = (unsigned long long*)bb;
-            b_surv = (unsigned int*)(bb + align_up((size_t)M * 8, 256));
-            b_vpn = (float*)((char*)b_surv + align_up((size_t)M * 4, 256));
-            b_vqmax = (unsigned int*)((char*)b_vpn + align_up((size_t)Ns * 4, 256));
-        }
         if ((flags & UMEREG_CORR_RECORD_STAGE) && !(flags & UMEREG_CORR_NO_FLAT)) {
             // first one wavefront per record (a staged set of the record's neighbours, one lane per query); the records keep the lanes it could not serve
             int rcap, rwaves;
@@ -4565,10 +4726,6 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(leftover_flatten_kernel, dim3(256), dim3(256), 0, st, lat, c_max, fw);
             UMEREG_CHECK_LAUNCH("leftover_flatten_kernel");
             if (bound) {
-                if (hipMemsetAsync(b_slack, 0, (size_t)M * 8, st) != hipSuccess || hipMemsetAsync(b_vqmax, 0, 4, st) != hipSuccess) { set_error("hipMemsetAsync(slack) failed"); return UMEREG_ELAUNCH; }
-                hipLaunchKernelGGL(row_norm_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, (const float4*)src_wfeat, Ns, b_vpn, (unsigned int*)nullptr);
-                hipLaunchKernelGGL(row_norm_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const float4*)tgt_wfeat, Nt, (float*)nullptr, b_vqmax);
-                UMEREG_CHECK_LAUNCH("row_norm_kernel");
                 hipLaunchKernelGGL(flat_bound_kernel<1>, dim3(2048), dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, K, sigma,
                                    lat, c_max, fw, (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, (const unsigned int*)b_surv);
                 UMEREG_CHECK_LAUNCH("flat_bound_kernel");
@@ -4621,6 +4778,14 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         UMEREG_CHECK_LAUNCH("corr_score_flat_kernel");
         hipLaunchKernelGGL(leftover_sum_kernel, dim3(256), dim3(256), 0, st, (const char*)lat, c_max, fw, n_chunks, partial, 1);
         UMEREG_CHECK_LAUNCH("leftover_sum_kernel");
+        if (val && served && cell_pass_on(c_max, Ns, M, flags, T)) {
+            // ... and the queries bounded for lying in far lattice cells (their values go to the consensus pass's plane)
+            char* bb = flat_base - cell_bytes(c_max, (long)M * Ns) - bound_bytes(Ns, M);
+            const unsigned long long* farq = (const unsigned long long*)(bb + align_up((size_t)M * 8, 256) + align_up((size_t)M * 4, 256) + align_up((size_t)Ns * 4, 256) + 256);
+            hipLaunchKernelGGL(far_recompute_kernel, dim3(1024), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat,
+                               (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, (const char*)lat, c_max, farq, n_words, (const int*)perm, (const unsigned int*)b_surv, val);
+            UMEREG_CHECK_LAUNCH("far_recompute_kernel");
+        }
     }
     if (val) {
         hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, (const char*)ws_src, slices);
