@@ -1141,6 +1141,13 @@ constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
 #ifndef UMEREG_BOUND_BOX_SIGMAS
 #define UMEREG_BOUND_BOX_SIGMAS 2.5f
 #endif
+#ifndef UMEREG_BOUND_CELL_SIGMAS
+#define UMEREG_BOUND_CELL_SIGMAS 6.0f
+#endif
+constexpr float kBoundCellSigmas = UMEREG_BOUND_CELL_SIGMAS;  // the same for a lattice cell as a whole (lattice_list_kernel, cell_scatter_kernel)
+// (measured on the bench's nuScenes-test pairs, as fed, 2.5 / 4 / 5 / 6 / 8 sigma: plain 13.6 / 14.1 / 14.4 / 14.6 / 14.7 ms with no hypothesis recomputed;
+// half-overlapping 25.0 / 23.6 / 18.7 / 14.4 / 15.0 with 177 / 115 / 46 / 2 / 1 hypotheses recomputed -- the near-identical good hypotheses of such a pair
+// are a few thousandths of a score apart, and every one the slack cannot separate from the best pays one wavefront per far query in the second pass)
 constexpr float kBoundBoxSigmas = UMEREG_BOUND_BOX_SIGMAS;    // a listed query with no target point within this many sigma is bounded, not searched.  Measured on KITTI-test pairs at 3 / 2 / 1 sigma: 36 / 46 / 59 % of the listed queries of a half-overlapping pair are bounded; on the bench's half-overlapping pairs 0 / 18 / 156 hypotheses have to be recomputed after all and the call takes 5.74 / 5.86 / 6.46 ms (6.5 without), on plain pairs 1.72 / 1.68 / 1.67 (1.70)
 
 // keep the K smallest of list[0 .. cnt) (cnt <= SLOTS * 64 <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
@@ -2596,7 +2603,7 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
         // Bounded mode (far_mode): a cell every point of which is at least kBoundBoxSigmas sigma from every target point gets no list -- its queries
         // are bounded (cell_scatter_kernel).  The distance: the centre's nearest neighbour (or, before anything is scanned, the smallest
         // chunk-box distance) less the half diagonal.
-        const float hd_m = L.hd * 1.0001f + 1e-5f, far_thr = kBoundBoxSigmas * sigma;
+        const float hd_m = L.hd * 1.0001f + 1e-5f, far_thr = kBoundCellSigmas * sigma;
         float bm2 = 0.f;
         const int cnt = far_mode ? coop_knn(P4c, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane, &bm2, (far_thr + hd_m) * (far_thr + hd_m) * 1.0001f)
                                  : coop_knn(P4c, box, Nt, K, ccx, ccy, ccz, la, lb, chist[wave], lane);
@@ -2605,8 +2612,28 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
         const float d_low = fmaxf(d_near * 0.9999f - hd_m, 0.f);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (far_mode && (cnt < 0 || (cnt > 0 && d_low >= far_thr))) {
+            // what a query of this cell can collect at most: sum_k w(d_(k)(q)) <= sum_k w(max(d_(k)(c) - hd, 0)) -- the k-th nearest distance is
+            // 1-Lipschitz in the query, and the centre's K nearest are in la (ascending) -- or K w(d_low) when only the box bound is known
+            // (rounded up: 1.0002).  cell_scatter_kernel multiplies it with |vp_n| max_j |vq_j|.
+            float wsum = 0.f;
+            {
+                const float inv_s = 1.0f / sigma;
+                const int kk = cnt < 0 ? K : cnt;
+                float term = 0.f;
+                if (lane < kk) {
+                    const float dq = cnt < 0 ? d_low : fmaxf(sqrtf(__uint_as_float((unsigned int)(la[lane] >> 32))) * 0.9999f - hd_m, 0.f);
+                    const float rr = dq * inv_s * 0.9999f;
+                    term = 1.0f / (1.0f + rr * rr);
+                }
+                for (int k0 = kWave; k0 < kk; k0 += kWave) {              // (K > 64: the rest at the smallest bound)
+                    const float rr = d_low * inv_s * 0.9999f;
+                    if (k0 + lane < kk) term += 1.0f / (1.0f + rr * rr);
+                }
+                wsum = wave_sum_f(term) * 1.0002f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (lane == 0) {
-                cells[id] = make_uint4(0u, 0u, __float_as_uint(d_low), 2u);
+                cells[id] = make_uint4(0u, 0u, __float_as_uint(wsum), 2u);
                 dk2[id] = d2k;
             }
             ++n_far;
@@ -2837,8 +2864,8 @@ __global__ __launch_bounds__(1024) void cell_blockscan_kernel(char* __restrict__
 }
 
 // the entries: every unserved query whose cell has a usable list, at cnt[cell] (= first) + cur[cell]++
-// Bounded mode (slack != nullptr): a query in a FAR cell (cells[].w == 2: every point of the cell is at least cells[].z >= kBoundBoxSigmas sigma
-// from every target point, lattice_list_kernel) is not listed: K w(that distance) |vp_n| max_j |vq_j| goes to its hypothesis' slack (one atomic per
+// Bounded mode (slack != nullptr): a query in a FAR cell (cells[].w == 2: every point of the cell is at least kBoundCellSigmas sigma from every target
+// point, cells[].z = the most the weights of a query's K neighbours can add up to: lattice_list_kernel) is not listed: that sum x |vp_n| max_j |vq_j| goes to its hypothesis' slack (one atomic per
 // wavefront and step: the lanes of a step share the hypothesis), it counts as served with the value 0, and its bit in `farq` lets
 // far_recompute_kernel find it if the hypothesis survives.  Measured (UMEREG_FAR_STATS): 12-15 % of the listed queries of a plain nuScenes-size
 // job, 61-84 % of a half-overlapping one's -- the images outlier hypotheses throw into the empty half of the scene.
@@ -2863,8 +2890,8 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
         return;
     }
     const float vq_max = __uint_as_float(*vq_max_bits);
-    const float inv_sigma = 1.0f / sigma;
     const int lane = lane_id();
+    (void)K; (void)sigma;
     for_each_unserved<true>(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](bool mine, int n, int pos, int h, float qx, float qy, float qz) {
         const int cell = mine ? lattice_cell(L, qx, qy, qz) : -1;
         const uint4 ce = cells[cell >= 0 ? cell : 0];
@@ -2873,8 +2900,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
             unsigned long long fx = 0ull;
             bool sat = false;
             if (far) {
-                const float r = __uint_as_float(ce.z) * inv_sigma * 0.9999f;
-                const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[n] * vq_max * 1.0001f;
+                const float eps = __uint_as_float(ce.z) * vpn[n] * vq_max * 1.0001f;       // (cells[].z of a far cell: the most its queries' weights can add up to)
                 sat = !(eps < 1.0e3f);
                 fx = sat ? 0ull : (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull;
                 const unsigned long long bit = 1ull << (pos & 63);
