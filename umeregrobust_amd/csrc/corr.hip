@@ -565,7 +565,7 @@ struct Lattice {
 };
 
 struct LatWs {
-    size_t off_header, off_marks, off_wave_tot, off_posof, off_cids, off_cells, off_dk2, off_pool, total;
+    size_t off_header, off_marks, off_wave_tot, off_posof, off_cids, off_cells, off_dk2, off_wsum, off_pool, total;
     unsigned int c_max;
     size_t pool_quads;
 };
@@ -588,6 +588,7 @@ __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
     w.off_cids = o;     o += (size_t)c_max * 4 + 256;                    // marked cells, ascending
     w.off_cells = o;    o += (size_t)c_max * 16;
     w.off_dk2 = o;      o += (size_t)c_max * 4;                          // d_K^2 of the cell centres (float bits), for the cell pass
+    w.off_wsum = o;     o += (size_t)c_max * 4;                          // bounded mode: what a query of a NEAR-FAR cell (cells[].w bit 8) can collect at most
     w.off_pool = o;     o += w.pool_quads * 8 + 256;
     w.total = (o + 255) / 256 * 256;
     return w;
@@ -1145,6 +1146,21 @@ constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
 #define UMEREG_BOUND_CELL_SIGMAS 6.0f
 #endif
 constexpr float kBoundCellSigmas = UMEREG_BOUND_CELL_SIGMAS;  // the same for a lattice cell as a whole (lattice_list_kernel, cell_scatter_kernel)
+#ifndef UMEREG_BOUND_NEAR_SIGMAS
+#define UMEREG_BOUND_NEAR_SIGMAS 2.5f
+#endif
+#ifndef UMEREG_BOUND_NEAR_FROM
+#define UMEREG_BOUND_NEAR_FROM 0.3f
+#endif
+// Cells between kBoundNearSigmas and kBoundCellSigmas ("near-far") keep their list, and the scatter bounds only the queries of hypotheses in the
+// LATE part of the chunk's order (position >= kBoundNearFrom x M: the hypotheses that displace this neighbourhood most -- the outliers, whose
+// slack does not matter because they cannot win); the early part is listed as always, so the good hypotheses, which the slack of such cells
+// cannot separate from the best, stay out of the second pass.  The choice is a heuristic about COST only: whatever is bounded is accounted
+// for in the slack, and whoever the slack cannot rule out is recomputed.
+// (measured on the bench's nuScenes-test pairs, as fed, boundary at 0.05 / 0.15 / 0.3 / 0.5 / 0.7 M and without the tier: plain 14.15 / 14.31 / 14.17 / 14.17 / 14.13 / 14.72 ms,
+// half-overlapping 17.3 / 13.70 / 13.67 / 13.74 / 14.27 / 14.38 with 21 / 2 / 2 / 2 / 2 / 2 hypotheses recomputed)
+constexpr float kBoundNearSigmas = UMEREG_BOUND_NEAR_SIGMAS;
+constexpr float kBoundNearFrom = UMEREG_BOUND_NEAR_FROM;
 // (measured on the bench's nuScenes-test pairs, as fed, 2.5 / 4 / 5 / 6 / 8 sigma: plain 13.6 / 14.1 / 14.4 / 14.6 / 14.7 ms with no hypothesis recomputed;
 // half-overlapping 25.0 / 23.6 / 18.7 / 14.4 / 15.0 with 177 / 115 / 46 / 2 / 1 hypotheses recomputed -- the near-identical good hypotheses of such a pair
 // are a few thousandths of a score apart, and every one the slack cannot separate from the best pays one wavefront per far query in the second pass)
@@ -2580,6 +2596,7 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
     const unsigned int* cids = reinterpret_cast<const unsigned int*>(lat + lw.off_cids);
     uint4* cells = reinterpret_cast<uint4*>(lat + lw.off_cells);
     unsigned int* dk2 = reinterpret_cast<unsigned int*>(lat + lw.off_dk2);
+    float* wsum_arr = reinterpret_cast<float*>(lat + lw.off_wsum);
     const unsigned short* posof = reinterpret_cast<const unsigned short*>(lat + lw.off_posof);
     unsigned long long* pool = reinterpret_cast<unsigned long long*>(lat + lw.off_pool);
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
@@ -2611,7 +2628,24 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
         const float d_near = cnt < 0 ? sqrtf(bm2) : (cnt > 0 ? sqrtf(__uint_as_float((unsigned int)(la[0] >> 32))) : 0.f);
         const float d_low = fmaxf(d_near * 0.9999f - hd_m, 0.f);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (far_mode && (cnt < 0 || (cnt > 0 && d_low >= far_thr))) {
+        const bool is_far = far_mode && (cnt < 0 || (cnt > 0 && d_low >= far_thr));
+        float wsum_near = 0.f;
+        if (far_mode && !is_far && cnt >= K && d_low >= kBoundNearSigmas * sigma) {
+            // (near-far cell: the same bound, kept beside the list)
+            const float inv_s = 1.0f / sigma;
+            float term = 0.f;
+            if (lane < cnt) {
+                const float dq = fmaxf(sqrtf(__uint_as_float((unsigned int)(la[lane] >> 32))) * 0.9999f - hd_m, 0.f);
+                const float rr = dq * inv_s * 0.9999f;
+                term = 1.0f / (1.0f + rr * rr);
+            }
+            for (int k0 = kWave; k0 < cnt; k0 += kWave) {
+                const float rr = d_low * inv_s * 0.9999f;
+                if (k0 + lane < cnt) term += 1.0f / (1.0f + rr * rr);
+            }
+            wsum_near = wave_sum_f(term) * 1.0002f;
+        }
+        if (is_far) {
             // what a query of this cell can collect at most: sum_k w(d_(k)(q)) <= sum_k w(max(d_(k)(c) - hd, 0)) -- the k-th nearest distance is
             // 1-Lipschitz in the query, and the centre's K nearest are in la (ascending) -- or K w(d_low) when only the box bound is known
             // (rounded up: 1.0002).  cell_scatter_kernel multiplies it with |vp_n| max_j |vq_j|.
@@ -2688,7 +2722,9 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
 #else
             const unsigned int cls = 0u; (void)d_low; (void)sigma;
 #endif
-            cells[id] = has ? make_uint4((unsigned int)cur, (unsigned int)quads, __float_as_uint(r2), cls << 8) : make_uint4(0u, 0u, __float_as_uint(r2), 1u);
+            const bool near_far = far_mode && has && d_low >= kBoundNearSigmas * sigma;
+            cells[id] = has ? make_uint4((unsigned int)cur, (unsigned int)quads, __float_as_uint(r2), (cls << 9) | (near_far ? 256u : 0u)) : make_uint4(0u, 0u, __float_as_uint(r2), 1u);
+            if (near_far) wsum_arr[id] = wsum_near;
             dk2[id] = d2k;
         }
         if (has) { cur += (unsigned long long)quads; n_quads += (unsigned int)quads; } else ++n_nolist;
@@ -2816,7 +2852,7 @@ __global__ __launch_bounds__(1024) void cell_apply_kernel(char* __restrict__ lat
     if (n_e) {
         unsigned int* hs = const_cast<unsigned int*>(header);
         atomicAdd(&hs[54], n_e >> 4);
-        for (int k = 0; k < 5; ++k) if ((ce.w >> (8 + k)) & 1u) atomicAdd(&hs[55 + k], n_e >> 4);
+        for (int k = 0; k < 5; ++k) if ((ce.w >> (9 + k)) & 1u) atomicAdd(&hs[55 + k], n_e >> 4);
     }
 #endif
     if (i < n) {
@@ -2891,16 +2927,20 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
     }
     const float vq_max = __uint_as_float(*vq_max_bits);
     const int lane = lane_id();
+    const float* wsum_arr = reinterpret_cast<const float*>(lat + lw.off_wsum);
+    const int near_from = (int)(kBoundNearFrom * (float)M);
     (void)K; (void)sigma;
     for_each_unserved<true>(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](bool mine, int n, int pos, int h, float qx, float qy, float qz) {
         const int cell = mine ? lattice_cell(L, qx, qy, qz) : -1;
         const uint4 ce = cells[cell >= 0 ? cell : 0];
-        const bool far = cell >= 0 && ce.w == 2u;
+        const bool near_far = cell >= 0 && (ce.w & 0x1ffu) == 256u && pos >= near_from;     // (a listed cell 2.5-6 sigma away, an outlier hypothesis: see kBoundNearFrom)
+        const bool far = cell >= 0 && (ce.w == 2u || near_far);
         if (__any(far)) {
             unsigned long long fx = 0ull;
             bool sat = false;
             if (far) {
-                const float eps = __uint_as_float(ce.z) * vpn[n] * vq_max * 1.0001f;       // (cells[].z of a far cell: the most its queries' weights can add up to)
+                // (the most the weights of a query of this cell can add up to: cells[].z of a far cell, the wsum array for a near-far one)
+                const float eps = (near_far ? wsum_arr[cell] : __uint_as_float(ce.z)) * vpn[n] * vq_max * 1.0001f;
                 sat = !(eps < 1.0e3f);
                 fx = sat ? 0ull : (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull;
                 const unsigned long long bit = 1ull << (pos & 63);
@@ -3084,7 +3124,8 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
         while (ci < fetch) {
             const int id = __builtin_amdgcn_readlane((int)rl.x, 2 * ci);
             const unsigned int cell_first = (unsigned int)__builtin_amdgcn_readlane((int)rl.y, 2 * ci);
-            const unsigned int cell_ne = (unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci);
+            // (the scatter may have bounded some of the queries the marking counted: what it really listed is the cell's cursor)
+            const unsigned int cell_ne = min((unsigned int)__builtin_amdgcn_readlane((int)rl.z, 2 * ci), cw.cur[id < 0 ? 0 : id]);
             constexpr unsigned int kChunk = kLong ? kCellChunkLong : kCellChunk;
             const unsigned int chunk0 = (unsigned int)__builtin_amdgcn_readlane((int)it.y, 2 * ci) * kChunk;
             const unsigned int dk2b = (unsigned int)__builtin_amdgcn_readlane((int)rl.w, 2 * ci);
