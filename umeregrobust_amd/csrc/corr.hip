@@ -1143,7 +1143,7 @@ constexpr float kSlackUnit = 1.0f / 16777216.0f;     // 2^-24
 #define UMEREG_BOUND_BOX_SIGMAS 2.5f
 #endif
 #ifndef UMEREG_BOUND_CELL_SIGMAS
-#define UMEREG_BOUND_CELL_SIGMAS 6.0f
+#define UMEREG_BOUND_CELL_SIGMAS 2.5f
 #endif
 constexpr float kBoundCellSigmas = UMEREG_BOUND_CELL_SIGMAS;  // the same for a lattice cell as a whole (lattice_list_kernel, cell_scatter_kernel)
 #ifndef UMEREG_BOUND_NEAR_SIGMAS
@@ -1164,6 +1164,9 @@ constexpr float kBoundNearFrom = UMEREG_BOUND_NEAR_FROM;
 // (measured on the bench's nuScenes-test pairs, as fed, 2.5 / 4 / 5 / 6 / 8 sigma: plain 13.6 / 14.1 / 14.4 / 14.6 / 14.7 ms with no hypothesis recomputed;
 // half-overlapping 25.0 / 23.6 / 18.7 / 14.4 / 15.0 with 177 / 115 / 46 / 2 / 1 hypotheses recomputed -- the near-identical good hypotheses of such a pair
 // are a few thousandths of a score apart, and every one the slack cannot separate from the best pays one wavefront per far query in the second pass)
+// (that was with one wavefront per far query in the second pass; since the second pass goes through the lattice + cell pass again -- bound_pass2_gate_kernel --
+// 177-200 surviving hypotheses cost 1.6-2.8 ms instead of 13, and the threshold is 2.5 sigma: 6 / 4 / 2.5 on the same pairs, plain 14.1 / 13.8 / 13.5 ms,
+// half-overlapping 13.9 / 13.8 / 13.9; with it the near-far tier below is empty)
 constexpr float kBoundBoxSigmas = UMEREG_BOUND_BOX_SIGMAS;    // a listed query with no target point within this many sigma is bounded, not searched.  Measured on KITTI-test pairs at 3 / 2 / 1 sigma: 36 / 46 / 59 % of the listed queries of a half-overlapping pair are bounded; on the bench's half-overlapping pairs 0 / 18 / 156 hypotheses have to be recomputed after all and the call takes 5.74 / 5.86 / 6.46 ms (6.5 without), on plain pairs 1.72 / 1.68 / 1.67 (1.70)
 
 // keep the K smallest of list[0 .. cnt) (cnt <= SLOTS * 64 <= kCoopCap): out[rank] = key for rank < K.  Returns min(cnt, K).
@@ -2457,8 +2460,11 @@ __global__ __launch_bounds__(256) void lattice_mark_kernel(const char* __restric
 template <bool kAll = false, class F>
 __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_src, const float* __restrict__ src_pts, const float* __restrict__ T,
                                                   int Ns, int M, const unsigned long long* __restrict__ served, int n_words,
-                                                  const int* __restrict__ perm, F&& f)
+                                                  const int* __restrict__ perm, F&& f, bool todo_plane = false,
+                                                  const unsigned int* __restrict__ only = nullptr)
 {
+    // (todo_plane: `served` holds the bits to DO, not the bits done; only: hypotheses with only[h] == 0 are skipped -- the second pass of the
+    // bounded mode walks the far-query plane for the surviving hypotheses)
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s);
     const int n_pb = (Ns + 255) / 256;
     for (long item = blockIdx.x; item < (long)n_pb * n_words; item += gridDim.x) {
@@ -2466,7 +2472,7 @@ __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_sr
         const int w = (int)(item / n_pb);
         if (!kAll && slot >= Ns) continue;
         const int n = __float_as_int(S4s[slot < Ns ? slot : 0].w);
-        unsigned long long todo = slot < Ns ? ~served[(size_t)n * n_words + w] : 0ull;
+        unsigned long long todo = slot < Ns ? (todo_plane ? served[(size_t)n * n_words + w] : ~served[(size_t)n * n_words + w]) : 0ull;
         if (w == n_words - 1 && (M & 63)) todo &= (1ull << (M & 63)) - 1ull;
         if (!__any(todo != 0ull)) continue;
         const float sx = src_pts[(size_t)n * 3], sy = src_pts[(size_t)n * 3 + 1], sz = src_pts[(size_t)n * 3 + 2];
@@ -2475,6 +2481,7 @@ __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_sr
             const bool mine = (todo >> b) & 1ull;
             if (!__any(mine)) continue;
             const int h = perm_c[b];                                 // uniform
+            if (only != nullptr && only[h] == 0u) continue;
             const float* Th = T + (size_t)h * 16;                    // uniform: scalar loads
             // (the arithmetic of corr_score_kernel: the cell is the one every other kernel computes for this query)
             const float qx = fmaf(Th[2], sz, fmaf(Th[1], sy, Th[0] * sx)) + Th[3];
@@ -2489,7 +2496,7 @@ __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_sr
 __global__ __launch_bounds__(256) void lattice_mark_order_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
                                                                  const float* __restrict__ T, int Ns, int Nt, int M, char* __restrict__ lat, unsigned int c_max,
                                                                  const unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm,
-                                                                 unsigned int* __restrict__ cell_cnt)
+                                                                 unsigned int* __restrict__ cell_cnt, bool todo_plane = false, const unsigned int* __restrict__ only = nullptr)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
@@ -2502,7 +2509,7 @@ __global__ __launch_bounds__(256) void lattice_mark_order_kernel(const char* __r
             marks[cell] = 1;
             if (cell_cnt) atomicAdd(&cell_cnt[cell], 1u);       // (the cell pass's counting sort: see corr_cell_kernel)
         }
-    });
+    }, todo_plane, only);
 }
 
 // ascending list of the marked cells (one workgroup; deterministic order): cids[0 .. header[3])
@@ -2909,7 +2916,8 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
                                                            const float* __restrict__ T, int Ns, int Nt, int M, const char* __restrict__ lat, unsigned int c_max,
                                                            unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm, CellWs cw,
                                                            int K, float sigma, const float* __restrict__ vpn, const unsigned int* __restrict__ vq_max_bits,
-                                                           unsigned long long* __restrict__ slack, unsigned long long* __restrict__ farq)
+                                                           unsigned long long* __restrict__ slack, unsigned long long* __restrict__ farq,
+                                                           bool todo_plane = false, const unsigned int* __restrict__ only = nullptr)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
@@ -2922,7 +2930,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
             if (cell < 0 || !cell_usable(cells[cell])) return;
             const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
             if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
-        });
+        }, todo_plane, only);
         return;
     }
     const float vq_max = __uint_as_float(*vq_max_bits);
@@ -2962,7 +2970,17 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
     });
 }
 
-// second pass of the bounded mode: the queries cell_scatter_kernel bounded for lying in far cells, for the hypotheses that survived
+// The second pass of the bounded mode re-runs the lattice + cell pass on the far-cell queries of the surviving hypotheses (a list for
+// every cell they lie in, the same kernels: one wavefront per query, which it used to be, cost a pair with 200 survivors 13 ms).  Its
+// kernels are enqueued whatever happens; this gate resets the work counters they share with the first pass -- or, when no hypothesis
+// survived, sets header word 8 (= "the leftovers are not the lattice's"), on which every one of them returns at once.
+__global__ void bound_pass2_gate_kernel(unsigned int* __restrict__ header)
+{
+    if (header[40] == 0u) { header[8] = 2u; return; }
+    header[3] = 0u; header[33] = 0u; header[37] = 0u; header[38] = 0u; header[39] = 0u; header[43] = 0u;
+}
+
+// ... and what that leaves (cells whose list would be too long, ties by the dozen): the queries cell_scatter_kernel bounded for lying in far cells, for the hypotheses that survived
 // (bound_survivors_kernel), exactly -- one wavefront per query, the value into the query's own slot of the consensus pass's plane
 // (the slice sums and scores are formed once more behind it).  Returns at once when no hypothesis needs its bounded queries.
 __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void far_recompute_kernel(
@@ -2974,7 +2992,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
     __shared__ unsigned long long lists[kCoopWaves][2][kCoopCap];
     __shared__ unsigned int chist[kCoopWaves][kWave];
     const unsigned int* header = reinterpret_cast<const unsigned int*>(lat + lat_ws(c_max).off_header);
-    if (header[8] != 0u || header[40] == 0u) return;
+    if (header[40] == 0u) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const GridWs wt = grid_ws(Nt), wsr = grid_ws(Ns);
@@ -3052,7 +3070,8 @@ template <bool kLong>
 __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ ws_tgt, const float* __restrict__ src_pts,
                                                        const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T,
                                                        int Ns, int Nt, int M, int K, float sigma, char* __restrict__ lat, unsigned int c_max, CellWs cw,
-                                                       float* __restrict__ val, unsigned long long* __restrict__ served, int dbg)
+                                                       float* __restrict__ val, unsigned long long* __restrict__ served, int dbg,
+                                                       unsigned long long* __restrict__ farq_clear = nullptr)
 {
     typedef unsigned short IdxT;                     // (the lattice exists for targets of < 65 472 points only)
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -3338,6 +3357,8 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
             if (ok) {
                 val[e] = acc;
                 atomicOr(&served[(size_t)n * n_words + (ph >> 6)], 1ull << (ph & 63));
+                // (second pass of the bounded mode: what is served here is not far_recompute_kernel's business any more)
+                if (farq_clear) atomicAnd(&farq_clear[(size_t)n * n_words + (ph >> 6)], ~(1ull << (ph & 63)));
             }
             n_ok += (unsigned int)__popcll(__ballot(ok));
             n_fail += (unsigned int)__popcll(__ballot(valid && !ok));
@@ -4849,6 +4870,35 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             // ... and the queries bounded for lying in far lattice cells (their values go to the consensus pass's plane)
             char* bb = flat_base - cell_bytes(c_max, (long)M * Ns) - bound_bytes(Ns, M);
             const unsigned long long* farq = (const unsigned long long*)(bb + align_up((size_t)M * 8, 256) + align_up((size_t)M * 4, 256) + align_up((size_t)Ns * 4, 256) + 256);
+            // (through the lattice + cell pass once more, on the far-query plane and the surviving hypotheses only: see bound_pass2_gate_kernel)
+            unsigned long long* farq_rw = const_cast<unsigned long long*>(farq);
+            const LatWs lw2 = lat_ws(c_max);
+            CellWs cw2 = cell_ws(flat_base - cell_bytes(c_max, (long)M * Ns), c_max, (long)M * Ns);
+            hipLaunchKernelGGL(bound_pass2_gate_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat);
+            if (hipMemsetAsync(lat + 256, 0, lw2.off_wave_tot - 256, st) != hipSuccess || hipMemsetAsync(cw2.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) {
+                set_error("hipMemsetAsync(second pass) failed");
+                return UMEREG_ELAUNCH;
+            }
+            const long order_items2 = (long)((Ns + 255) / 256) * n_words;
+            const dim3 order_grid2((unsigned)(order_items2 < 16384 ? order_items2 : 16384));
+            hipLaunchKernelGGL(lattice_mark_order_kernel, order_grid2, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M, lat, c_max,
+                               (const unsigned long long*)farq, n_words, (const int*)perm, cw2.cnt, true, (const unsigned int*)b_surv);
+            hipLaunchKernelGGL(lattice_compact_kernel, dim3(1), dim3(1024), 0, st, (const char*)ws_tgt, lat, c_max, Nt);
+            hipLaunchKernelGGL(lattice_list_kernel, dim3(512), dim3(8 * kWave), 0, st, ws_coop, (const char*)ws_tgt, lat, c_max, Nt, K, sigma, 0);
+            UMEREG_CHECK_LAUNCH("lattice kernels (second pass)");
+            const unsigned int nb2 = (c_max + 1023u) / 1024u;
+            hipLaunchKernelGGL(cell_apply_kernel<0>, dim3(nb2), dim3(1024), 0, st, lat, c_max, cw2);
+            hipLaunchKernelGGL(cell_blockscan_kernel, dim3(1), dim3(1024), 0, st, lat, c_max, cw2);
+            hipLaunchKernelGGL(cell_apply_kernel<1>, dim3(nb2), dim3(1024), 0, st, lat, c_max, cw2);
+            hipLaunchKernelGGL(cell_scatter_kernel, order_grid2, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M,
+                               (const char*)lat, c_max, farq_rw, n_words, (const int*)perm, cw2, K, sigma, (const float*)nullptr, (const unsigned int*)nullptr,
+                               (unsigned long long*)nullptr, (unsigned long long*)nullptr, true, (const unsigned int*)b_surv);
+            UMEREG_CHECK_LAUNCH("cell_scatter_kernel (second pass)");
+            hipLaunchKernelGGL(corr_cell_kernel<false>, dim3(2816), dim3(kWave), cell_lds_per_wave(K, false), st, (const char*)ws_tgt, src_pts,
+                               (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw2, val, served, 0, farq_rw);
+            hipLaunchKernelGGL(corr_cell_kernel<true>, dim3(2048), dim3(kWave), cell_lds_per_wave(K, true), st, (const char*)ws_tgt, src_pts,
+                               (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, lat, c_max, cw2, val, served, 0, farq_rw);
+            UMEREG_CHECK_LAUNCH("corr_cell_kernel (second pass)");
             hipLaunchKernelGGL(far_recompute_kernel, dim3(1024), dim3(kCoopWaves * kWave), 0, st, ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat,
                                (const float4*)tgt_wfeat, T, Ns, Nt, M, K, sigma, (const char*)lat, c_max, farq, n_words, (const int*)perm, (const unsigned int*)b_surv, val);
             UMEREG_CHECK_LAUNCH("far_recompute_kernel");
