@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
     const char* __restrict__ ws_tgt, const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
     const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed,
     const int* __restrict__ perm, int Ns, int Nt, int M, int K, float sigma, float far_margin_cells, float* __restrict__ val,
-    unsigned long long* __restrict__ served, unsigned int* __restrict__ stats, int dbg)
+    unsigned long long* __restrict__ served, unsigned int* __restrict__ stats, int dbg, float act_frac)
 {
     typedef unsigned int IdxT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -2127,10 +2127,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
         // KITTI-test pair and 7 % fewer of a half-overlapping nuScenes-size one, and the call is 1 % / 15 % faster (2.01 -> 1.99 ms,
         // 73.8 -> 63.0; LoKITTI-size 69.5 -> 62.6); 80 is better still on plain big jobs (42.6 -> 41.0) but pushes a half-overlapping
         // KITTI-test pair's leftovers towards the 2 M where the lattice takes over (6.41 -> 6.52); 60 loses everywhere but there.
-#ifndef UMEREG_CONS_ACT
-#define UMEREG_CONS_ACT 100
-#endif
-        const bool act = pos_h < M && delta < D && dk <= D && (UMEREG_CONS_ACT == 0 || delta <= (D - dk) * (UMEREG_CONS_ACT * 0.01f));   // (NaN transforms: false)
+        // Round 4, with the leftovers of big jobs cheaper (arg-max mode: far cells bounded; lattice build as one kernel): the fraction is the
+        // caller's -- 1.0 on jobs without a cell pass (a KITTI-test pair: 0.8 costs it 1.81 -> 1.82 / 5.81 -> 6.04 ms), 0.8 on jobs with one
+        // (nuScenes-test as fed 12.67 -> 12.22 / 13.99 -> 13.53 ms, nuScenes-size 24.2 -> 23.0 / 30.0 -> 28.9, LoKITTI-size 12.25 -> 12.15 /
+        // 27.3 -> 25.9; 0.6: 12.44 / 13.25, 23.2 / 28.4, 12.25 / 25.1).
+        const bool act = pos_h < M && delta < D && dk <= D && delta <= (D - dk) * act_frac;   // (NaN transforms: false)
         if (!__any(act)) {
             if (pos_h < M) val[(size_t)n * M + pos_h] = 0.f;
             if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = 0ull;
@@ -4697,7 +4698,7 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(corr_consensus2_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons2_lds_per_wave(), st,
                                (const char*)ws_tgt, ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
                                (const int*)perm, Ns, Nt, M, K, sigma, far_margin, val, served, (unsigned int*)lat + 7,
-                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0);
+                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0, cell_pass_on(c_max, Ns, M, flags, T) ? 0.8f : 1.0f);
             UMEREG_CHECK_LAUNCH("corr_consensus2_kernel");
         }
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
