@@ -2928,13 +2928,23 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // few leftovers: the queue takes them
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     const uint4* cells = reinterpret_cast<const uint4*>(lat + lw.off_cells);
+    // A listed query counts as SERVED from here on (one plain store per walked word: the lane owns it); the cell pass takes the bit back for the
+    // rare lane it cannot select for (distance ties by the dozen).  It used to set the bit itself, one atomic per query: 10-60 M per call.
+    // (Second pass: the walked plane is the far-query plane, whose bits the cell pass CLEARS for what it serves; `served_out` is null.)
     if (slack == nullptr) {
+        unsigned long long listed = 0ull;
         for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int n, int pos, int h, float qx, float qy, float qz) {
             const int cell = lattice_cell(L, qx, qy, qz);
             if (cell < 0 || !cell_usable(cells[cell])) return;
             const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
-            if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
-        }, todo_plane, only);
+            if (at < cw.cap) {
+                cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+                listed |= 1ull << (pos & 63);
+            }
+        }, todo_plane, only, [&](bool in_cloud, int n, int w) {
+            if (in_cloud && listed != 0ull && !todo_plane) served[(size_t)n * n_words + w] |= listed;
+            listed = 0ull;
+        });
         return;
     }
     const float vq_max = __uint_as_float(*vq_max_bits);
@@ -2943,6 +2953,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
     const int near_from = (int)(kBoundNearFrom * (float)M);
     (void)K; (void)sigma;
     unsigned long long far_bits = 0ull;          // this lane's bounded positions of the word it is walking (written once behind the word)
+    unsigned long long listed = 0ull;            // ... and its listed ones
     for_each_unserved<true>(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](bool mine, int n, int pos, int h, float qx, float qy, float qz) {
         const int cell = mine ? lattice_cell(L, qx, qy, qz) : -1;
         const uint4 ce = cells[cell >= 0 ? cell : 0];
@@ -2968,17 +2979,21 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
         }
         if (cell >= 0 && !far && cell_usable(ce)) {
             const unsigned int at = cw.cnt[cell] + atomicAdd(&cw.cur[cell], 1u);
-            if (at < cw.cap) cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+            if (at < cw.cap) {
+                cw.ent[at] = make_uint2((unsigned int)n * (unsigned int)M + (unsigned int)pos, (unsigned int)h);
+                listed |= 1ull << (pos & 63);
+            }
         }
     }, false, nullptr, [&](bool in_cloud, int n, int w) {
         // the word's bounded positions: served (their value stays the 0 the consensus pass wrote) and marked for the second pass.  Plain
         // stores: nobody else touches this word while this kernel runs (two atomics per far query were a third of the kernel: 40 M of them
         // on a half-overlapping nuScenes-test job).
-        if (in_cloud && far_bits != 0ull) {
-            served[(size_t)n * n_words + w] |= far_bits;
-            farq[(size_t)n * n_words + w] = far_bits;
+        if (in_cloud && (far_bits | listed) != 0ull) {
+            served[(size_t)n * n_words + w] |= far_bits | listed;
+            if (far_bits != 0ull) farq[(size_t)n * n_words + w] = far_bits;
         }
         far_bits = 0ull;
+        listed = 0ull;
     });
 }
 
@@ -3367,10 +3382,11 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
                 }
             }
             if (ok) {
-                val[e] = acc;
-                atomicOr(&served[(size_t)n * n_words + (ph >> 6)], 1ull << (ph & 63));
+                val[e] = acc;                       // (the scatter marked the query served when it listed it)
                 // (second pass of the bounded mode: what is served here is not far_recompute_kernel's business any more)
                 if (farq_clear) atomicAnd(&farq_clear[(size_t)n * n_words + (ph >> 6)], ~(1ull << (ph & 63)));
+            } else if (valid && farq_clear == nullptr) {
+                atomicAnd(&served[(size_t)n * n_words + (ph >> 6)], ~(1ull << (ph & 63)));      // listed, not selected for: back to the other structures
             }
             n_ok += (unsigned int)__popcll(__ballot(ok));
             n_fail += (unsigned int)__popcll(__ballot(valid && !ok));
