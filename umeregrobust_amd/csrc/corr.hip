@@ -1787,7 +1787,12 @@ constexpr int kCons2Tie = 8;             // list entries per lane for the candid
 constexpr int kC2Tie = UMEREG_CONS2_TIE; // the same in the consensus pass (its LDS budget decides the wavefronts per SIMD)
 constexpr int kC2Slots = (kCons2Cap + 4 + 3) & ~3;   // stage slots: the points + one quad of far-point padding
 static_assert(kCons2Cap <= 252 && kCons2Cap % 4 == 0, "byte counters; quad-aligned cap");
-constexpr int kCons2Zone = 12;           // zone size up to which the rank-counting path is taken
+#ifndef UMEREG_CONS2_ZONE
+#define UMEREG_CONS2_ZONE 8
+#endif
+constexpr int kCons2Zone = UMEREG_CONS2_ZONE;           // zone size up to which the rank-counting path is taken (a multiple of 4)
+// (the path always ranks kCons2Zone slots; its zones hold 5 points on average: 12 -> 8 slots, 66 -> 28 comparisons per step: a KITTI-test call 1.84 -> 1.78 ms,
+// LoKITTI-size 11.9 -> 11.8; 4 / 16 slots: 1.89 / 1.91)
 #ifndef UMEREG_CONS2_DCACHE
 #define UMEREG_CONS2_DCACHE 12
 #endif
