@@ -32,7 +32,12 @@ def _workspace(device, nbytes, tag):
     key = (device.index, _stream_ptr(device), tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        # a quarter of headroom: the sizes of a loop's pairs differ by a few per cent (voxel counts), and every new maximum would otherwise
+        # be a fresh device allocation in the middle of the loop -- 1.5 GB for a nuScenes-test pair's correlation workspace, ~25 ms each
+        # (seen as 10 ms per pair OUTSIDE the kernels on the first pass over a pool of pairs); the old buffer is dropped first
+        _workspaces.pop(key, None)
+        buf = None
+        buf = torch.empty(max(int(nbytes) + int(nbytes) // 4, 256), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
 
