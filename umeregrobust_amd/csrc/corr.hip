@@ -565,7 +565,7 @@ struct Lattice {
 };
 
 struct LatWs {
-    size_t off_header, off_marks, off_wave_tot, off_posof, off_cids, off_cells, off_dk2, off_wsum, off_pool, total;
+    size_t off_header, off_marks, off_wave_tot, off_posof, off_cids, off_cells, off_dk2, off_wsum, off_fartab, off_pool, total;
     unsigned int c_max;
     size_t pool_quads;
 };
@@ -589,6 +589,7 @@ __host__ __device__ inline LatWs lat_ws(unsigned int c_max)
     w.off_cells = o;    o += (size_t)c_max * 16;
     w.off_dk2 = o;      o += (size_t)c_max * 4;                          // d_K^2 of the cell centres (float bits), for the cell pass
     w.off_wsum = o;     o += (size_t)c_max * 4;                          // bounded mode: what a query of a NEAR-FAR cell (cells[].w bit 8) can collect at most
+    w.off_fartab = o;   o += (size_t)c_max * 4;                          // bounded mode: per lattice cell, the distance every point of it keeps from every chunk box of the target (0: not far)
     w.off_pool = o;     o += w.pool_quads * 8 + 256;
     w.total = (o + 255) / 256 * 256;
     return w;
@@ -2502,16 +2503,106 @@ __device__ __forceinline__ void for_each_unserved(const char* __restrict__ ws_sr
     }
 }
 
+__device__ __forceinline__ void lattice_cell_centre(const Lattice& L, int id, float& ccx, float& ccy, float& ccz)
+{
+    const int brick = id >> 6, loc = id & 63;
+    const int bxi = brick % L.bx, byi = (brick / L.bx) % L.by, bzi = brick / (L.bx * L.by);
+    ccx = L.lox + ((float)(bxi * 4 + (loc & 3)) + 0.5f) * L.h;
+    ccy = L.loy + ((float)(byi * 4 + ((loc >> 2) & 3)) + 0.5f) * L.h;
+    ccz = L.loz + ((float)(bzi * 4 + (loc >> 4)) + 0.5f) * L.hz;
+}
+
+// Bounded mode: which lattice cells are far from the target as a whole -- one lane per cell, the smallest box-to-box distance over the target's
+// 64-point chunk boxes (a lower bound of the distance between any point of the cell and any target point).  fartab[cell] = that distance
+// (rounded down) if it is at least kBoundCellSigmas sigma, else 0.  A wavefront = a 4 x 4 x 4 brick: it leaves the loop as soon as none of
+// its cells can be far any more, so only the bricks in empty parts of the scene see all the boxes (0.1 ms for 2^19 cells).
+__global__ __launch_bounds__(256) void lattice_far_table_kernel(const char* __restrict__ ws_coop, const char* __restrict__ ws_tgt, char* __restrict__ lat,
+                                                                unsigned int c_max, int Nt, float sigma)
+{
+    const GridWs wt = grid_ws(Nt);
+    const LatWs lw = lat_ws(c_max);
+    if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;
+    const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= (unsigned int)L.n_cells) return;
+    const float4* box = reinterpret_cast<const float4*>(ws_coop + wt.off_box);
+    float* fartab = reinterpret_cast<float*>(lat + lw.off_fartab);
+    const int n_tch = (Nt + kWave - 1) / kWave;
+    float ccx, ccy, ccz;
+    lattice_cell_centre(L, id < L.n_cells ? id : 0, ccx, ccy, ccz);
+    const float thr = kBoundCellSigmas * sigma, thr2 = thr * thr * 1.0002f + 1e-6f;
+    float best = id < L.n_cells ? 3.0e38f : 0.f;
+    for (int ch = 0; ch < n_tch; ++ch) {
+        const float4 blo = box[2 * ch], bhi = box[2 * ch + 1];           // (uniform: scalar loads)
+        const float gx = fmaxf(fmaxf(blo.x - (ccx + 0.5f * L.h), (ccx - 0.5f * L.h) - bhi.x), 0.f);
+        const float gy = fmaxf(fmaxf(blo.y - (ccy + 0.5f * L.h), (ccy - 0.5f * L.h) - bhi.y), 0.f);
+        const float gz = fmaxf(fmaxf(blo.z - (ccz + 0.5f * L.hz), (ccz - 0.5f * L.hz) - bhi.z), 0.f);
+        best = fminf(best, gx * gx + gy * gy + gz * gz);
+        if (!__any(best >= thr2)) break;
+    }
+    const bool far = id < L.n_cells && best >= thr2 && best < 1.0e37f;
+    if (id < L.n_cells) fartab[id] = far ? fmaxf(sqrtf(best) * 0.9999f - 1e-5f, 0.f) : 0.f;
+    const unsigned long long fb = __ballot(far);
+    if (fb != 0ull && lane_id() == 0) atomicAdd(reinterpret_cast<unsigned int*>(lat + lw.off_header) + 45, (unsigned int)__popcll(fb));      // (statistics: far cells)
+}
+
 __global__ __launch_bounds__(256) void lattice_mark_order_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
                                                                  const float* __restrict__ T, int Ns, int Nt, int M, char* __restrict__ lat, unsigned int c_max,
                                                                  const unsigned long long* __restrict__ served, int n_words, const int* __restrict__ perm,
-                                                                 unsigned int* __restrict__ cell_cnt, bool todo_plane = false, const unsigned int* __restrict__ only = nullptr)
+                                                                 unsigned int* __restrict__ cell_cnt, bool todo_plane = false, const unsigned int* __restrict__ only = nullptr,
+                                                                 int K = 0, float sigma = 1.f, const float* __restrict__ vpn = nullptr,
+                                                                 const unsigned int* __restrict__ vq_max_bits = nullptr, unsigned long long* __restrict__ slack = nullptr,
+                                                                 unsigned long long* __restrict__ farq = nullptr, unsigned long long* __restrict__ served_rw = nullptr)
 {
     const GridWs wt = grid_ws(Nt);
     const LatWs lw = lat_ws(c_max);
     if (reinterpret_cast<const unsigned int*>(lat + lw.off_header)[8] != 0u) return;     // the compacted path takes the leftovers
     const Lattice L = load_lattice(reinterpret_cast<const unsigned int*>(ws_tgt + wt.off_bbox), lattice_budget(lat, c_max));
     unsigned char* marks = reinterpret_cast<unsigned char*>(lat + lw.off_marks);
+    if (slack != nullptr) {
+        // Bounded mode: a query in a cell that lattice_far_table_kernel found far from every chunk box of the target is bounded HERE -- it is not
+        // marked, not counted, builds no list and is not walked again by the scatter (which bounds the cells only the centre's nearest neighbour
+        // shows to be far): K w(that distance) |vp_n| max_j |vq_j| to the slack, served with the value 0, its bit in the far-query plane.
+        const float* fartab = reinterpret_cast<const float*>(lat + lw.off_fartab);
+        const float vq_max = __uint_as_float(*vq_max_bits);
+        const float inv_sigma = 1.0f / sigma;
+        const int lane = lane_id();
+        unsigned long long far_bits = 0ull;
+        for_each_unserved<true>(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](bool mine, int n, int pos, int h, float qx, float qy, float qz) {
+            const int cell = mine ? lattice_cell(L, qx, qy, qz) : -1;
+            const float d_low = cell >= 0 ? fartab[cell] : 0.f;
+            const bool far = d_low > 0.f;
+            if (__any(far)) {
+                unsigned long long fx = 0ull;
+                bool sat = false;
+                if (far) {
+                    const float r = d_low * inv_sigma * 0.9999f;
+                    const float eps = (float)K * (1.0f / (1.0f + r * r)) * vpn[n] * vq_max * 1.0001f;
+                    sat = !(eps < 1.0e3f);
+                    fx = sat ? 0ull : (unsigned long long)(eps * (1.0f / kSlackUnit)) + 1ull;
+                    far_bits |= 1ull << (pos & 63);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) fx += (unsigned long long)__shfl_xor((long long)fx, o, kWave);                 // (integers: any order)
+                const bool any_sat = __any(sat);
+                if (lane == 0) {
+                    if (fx != 0ull) atomicAdd(&slack[h], fx);
+                    if (any_sat) atomicOr(&slack[h], 1ull << 63);
+                }
+            }
+            if (cell >= 0 && !far) {
+                marks[cell] = 1;
+                if (cell_cnt) atomicAdd(&cell_cnt[cell], 1u);
+            }
+        }, false, nullptr, [&](bool in_cloud, int n, int w) {
+            if (in_cloud && far_bits != 0ull) {
+                served_rw[(size_t)n * n_words + w] |= far_bits;
+                farq[(size_t)n * n_words + w] = far_bits;
+            }
+            far_bits = 0ull;
+        });
+        return;
+    }
     for_each_unserved(ws_src, src_pts, T, Ns, M, served, n_words, perm, [&](int, int, int, float qx, float qy, float qz) {
         const int cell = lattice_cell(L, qx, qy, qz);
         if (cell >= 0) {
@@ -2582,14 +2673,6 @@ __global__ __launch_bounds__(1024) void lattice_compact_kernel(const char* __res
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) { header[3] = before + part[1023]; header[1] = (unsigned int)L.n_cells; }
 }
 
-__device__ __forceinline__ void lattice_cell_centre(const Lattice& L, int id, float& ccx, float& ccy, float& ccz)
-{
-    const int brick = id >> 6, loc = id & 63;
-    const int bxi = brick % L.bx, byi = (brick / L.bx) % L.by, bzi = brick / (L.bx * L.by);
-    ccx = L.lox + ((float)(bxi * 4 + (loc & 3)) + 0.5f) * L.h;
-    ccy = L.loy + ((float)(byi * 4 + ((loc >> 2) & 3)) + 0.5f) * L.h;
-    ccz = L.loz + ((float)(bzi * 4 + (loc >> 4)) + 0.5f) * L.hz;
-}
 
 // is target point p a candidate of the cell (centre cc, list radius^2 r2)?  dist(p, cell box) <= r
 __device__ __forceinline__ bool lattice_in_list(const Lattice& L, const float4& p, float ccx, float ccy, float ccz, float r2)
@@ -3017,7 +3100,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
         // on a half-overlapping nuScenes-test job).
         if (in_cloud && (far_bits | listed) != 0ull) {
             served[(size_t)n * n_words + w] |= far_bits | listed;
-            if (far_bits != 0ull) farq[(size_t)n * n_words + w] = far_bits;
+            if (far_bits != 0ull) farq[(size_t)n * n_words + w] |= far_bits;       // (the marking may have put bits there)
         }
         far_bits = 0ull;
         listed = 0ull;
@@ -4799,7 +4882,16 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         const int hpt = 16;
         const long order_items = (long)((Ns + 255) / 256) * n_words;
         const dim3 order_grid((unsigned)(order_items < 16384 ? order_items : 16384));
-        if (served)
+        if (served && far_cells) {
+            if (!coop_copy) {
+                hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
+                UMEREG_CHECK_LAUNCH("chunk_box_kernel");
+            }
+            hipLaunchKernelGGL(lattice_far_table_kernel, dim3((c_max + 255) / 256), dim3(256), 0, st, ws_coop, (const char*)ws_tgt, lat, c_max, Nt, sigma);
+            hipLaunchKernelGGL(lattice_mark_order_kernel, order_grid, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M, lat, c_max,
+                               (const unsigned long long*)served, n_words, (const int*)perm, cw.cnt, false, (const unsigned int*)nullptr, K, sigma,
+                               (const float*)b_vpn, (const unsigned int*)b_vqmax, b_slack, b_farq, served);
+        } else if (served)
             hipLaunchKernelGGL(lattice_mark_order_kernel, order_grid, dim3(256), 0, st, (const char*)ws_tgt, (const char*)ws_src, src_pts, T, Ns, Nt, M, lat, c_max,
                                (const unsigned long long*)served, n_words, (const int*)perm, cw.cnt);
         else
