@@ -2408,7 +2408,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
 #endif
 constexpr unsigned int kLeftMax = UMEREG_LEFT_MAX;      // (2^21 until the end of round 3: over 32 half-overlapping KITTI-test pairs, whose leftovers straddle
                                                         // 2 M, f1 averages 7.5 ms with 2^21 and 6.4 with 3 M or 4.5 M -- the flat list holds half the job's queries now)   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
-__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force, unsigned int c_max)
+#ifndef UMEREG_LEFT_MAX_BOUND
+#define UMEREG_LEFT_MAX_BOUND 1000000u
+#endif
+constexpr unsigned int kLeftMaxBound = UMEREG_LEFT_MAX_BOUND;      // the same where the cell pass rides in arg-max mode on a job below 2^25 queries
+__global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force, unsigned int c_max, unsigned int left_max = kLeftMax)
 {
     const long left = n_queries - (long)header[7];
     header[9] = (unsigned int)(left < 0xffffffffl ? left : 0xffffffffl);
@@ -2418,7 +2422,7 @@ __global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n
         const long lo = (long)c_max < UMEREG_LAT_MINBUDGET ? (long)c_max : UMEREG_LAT_MINBUDGET;
         header[42] = (unsigned int)(want < lo ? lo : (want > (long)c_max ? (long)c_max : want));
     }
-    header[8] = force == 1 ? 1u : (force == 2 ? 0u : (left <= (long)kLeftMax ? 1u : 0u));   // force: UMEREG_CORR_LEFT_COOP / _LATTICE (tuning)
+    header[8] = force == 1 ? 1u : (force == 2 ? 0u : (left <= (long)left_max ? 1u : 0u));   // force: UMEREG_CORR_LEFT_COOP / _LATTICE (tuning)
 }
 
 // ---- lattice build ---------------------------------------------------------------------------------------------------
@@ -3949,10 +3953,18 @@ __global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict_
 // bounded terms (it is within E_h of the exact one, which is below the arg-max's) -- corr_select_best / FeatureCorrelator return what
 // they return without the flag.
 
-__global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict__ v4, int N, float* __restrict__ out, unsigned int* __restrict__ max_bits)
+__global__ __launch_bounds__(256) void row_norm_kernel(const float4* __restrict__ va4, int Na, float* __restrict__ out_a, const float4* __restrict__ vb4, int Nb,
+                                                       unsigned int* __restrict__ max_bits_b)
 {
-    // |v_n| of every 32-float row, rounded up; max_bits (optional) = the largest, as the bits of a non-negative float
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    // |v_n| of every 32-float row, rounded up: the rows of a to out_a; of the rows of b the largest, as the bits of a non-negative float
+    // (the first ceil(Na / 256) workgroups take a, the others b)
+    const int blocks_a = (Na + 255) / 256;
+    const bool is_a = (int)blockIdx.x < blocks_a;
+    const float4* __restrict__ v4 = is_a ? va4 : vb4;
+    const int N = is_a ? Na : Nb;
+    float* __restrict__ out = is_a ? out_a : nullptr;
+    unsigned int* __restrict__ max_bits = is_a ? nullptr : max_bits_b;
+    const int n = (is_a ? blockIdx.x : blockIdx.x - blocks_a) * blockDim.x + threadIdx.x;
     float s = 0.f;
     if (n < N) {
 #pragma unroll
@@ -4441,12 +4453,16 @@ __global__ __launch_bounds__(256) void leftover_sum_kernel(const char* __restric
 // sums of the consensus pass's terms over slices of kValSlice source points (fixed order inside a slice)
 constexpr int kValSlice = 64;
 __global__ __launch_bounds__(256) void corr_val_slices_kernel(const float* __restrict__ val, int M, int Ns, const char* __restrict__ ws_src,
-                                                              float* __restrict__ slices)
+                                                              float* __restrict__ slices, const int* __restrict__ perm = nullptr,
+                                                              const unsigned int* __restrict__ only = nullptr)
 {
     // slice = chunk of 64 slots of the processing order: its points share one hypothesis order, so position `pos` means the
     // same hypothesis in every row summed here
+    // (`only`: the sums of the flagged hypotheses alone, every other one keeps what it has -- the arg-max mode's second pass changes the
+    // terms of the surviving hypotheses and of no other, and a full pass reads the whole plane: 26 us of a KITTI-test call, 150 at 5000 x 30000)
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= M) return;
+    if (only && only[perm[(size_t)blockIdx.y * M + pos]] == 0u) return;
     const float4* S4s = reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s);
     const int s0 = blockIdx.y * kValSlice, s1 = min(s0 + kValSlice, Ns);
     float s = 0.f;
@@ -4649,7 +4665,10 @@ static bool cell_pass_on(unsigned int c_max, int Ns, int M, int flags, const voi
 {
     if (!consensus_on(c_max, M, flags, T) || (flags & (UMEREG_CORR_NO_CELL_PASS | UMEREG_CORR_CONSENSUS_V1 | UMEREG_CORR_LEFT_COOP))) return false;
     if ((unsigned long long)Ns * (unsigned long long)M >= (1ull << 32)) return false;          // 32-bit entries
-    return (long)M * Ns >= kCellMinQueries || (flags & UMEREG_CORR_CELL_PASS);
+    // (round 4: in arg-max mode also from 2^24 queries on -- a KITTI-test pair --: with the far cells bounded, what is left of a half-overlapping
+    // pair's 2 M leftovers goes through the lattice + cell pass in 1.9 ms against 2.5 through the queue; leftover_decide_kernel routes them there
+    // from kLeftMaxBound leftovers on)
+    return (long)M * Ns >= kCellMinQueries || (flags & UMEREG_CORR_CELL_PASS) || ((flags & UMEREG_CORR_BOUND_OUTSIDE) && (long)M * Ns >= (1l << 24));
 }
 
 // bounding of the queries outside the lattice (corr_score_flat_kernel<1>): slack (u64 per hypothesis), survivor flags, |vp_n|, max |vq_j|
@@ -4835,12 +4854,13 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             hipLaunchKernelGGL(corr_consensus2_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons2_lds_per_wave(), st,
                                (const char*)ws_tgt, ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
                                (const int*)perm, Ns, Nt, M, K, sigma, far_margin, val, served, (unsigned int*)lat + 7,
-                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0, cell_pass_on(c_max, Ns, M, flags, T) ? 0.8f : 1.0f);
+                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0, (cell_pass_on(c_max, Ns, M, flags, T) && (long)M * Ns >= kCellMinQueries) ? 0.8f : 1.0f);
             UMEREG_CHECK_LAUNCH("corr_consensus2_kernel");
         }
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued
         hipLaunchKernelGGL(leftover_decide_kernel, dim3(1), dim3(1), 0, st, (unsigned int*)lat, (long)M * Ns,
-                           (flags & UMEREG_CORR_LEFT_COOP) ? 1 : ((flags & UMEREG_CORR_LEFT_LATTICE) ? 2 : 0), c_max);
+                           (flags & UMEREG_CORR_LEFT_COOP) ? 1 : ((flags & UMEREG_CORR_LEFT_LATTICE) ? 2 : 0), c_max,
+                           (cell_pass_on(c_max, Ns, M, flags, T) && (long)M * Ns < kCellMinQueries && !(flags & UMEREG_CORR_CELL_PASS)) ? kLeftMaxBound : kLeftMax);
         UMEREG_CHECK_LAUNCH("leftover_decide_kernel");
         if (hipMemsetAsync(partial, 0, (size_t)M * n_chunks_sz * 4, st) != hipSuccess) { set_error("hipMemsetAsync(partial) failed"); return UMEREG_ELAUNCH; }
         hipLaunchKernelGGL(leftover_queue_kernel, dim3((unsigned)(((long)n_chunks * n_words + 3) / 4)), dim3(256), 0, st, (const char*)ws_src, Ns, M,
@@ -4865,19 +4885,21 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
             b_vpn = (float*)((char*)b_surv + align_up((size_t)M * 4, 256));
             b_vqmax = (unsigned int*)((char*)b_vpn + align_up((size_t)Ns * 4, 256));
             b_farq = (unsigned long long*)((char*)b_vqmax + 256);
-            if (hipMemsetAsync(b_slack, 0, (size_t)M * 8, st) != hipSuccess || hipMemsetAsync(b_vqmax, 0, 4, st) != hipSuccess ||
-                (cell_pass && served && hipMemsetAsync(b_farq, 0, (size_t)Ns * n_words * 8, st) != hipSuccess)) {
+            // (one fill for the block -- slack, flags, norms, maximum, plane: the norms are written after it --, one launch for both sets of rows:
+            // every launch of this chain is 4-5 us of a KITTI-test call whether it finds work or not)
+            // (... and the cell pass's counters lie right behind the block)
+            if (hipMemsetAsync(bb, 0, (cell_pass && served) ? bound_bytes(Ns, M) + (size_t)c_max * 4 : (size_t)((char*)b_farq - bb), st) != hipSuccess) {
                 set_error("hipMemsetAsync(slack) failed");
                 return UMEREG_ELAUNCH;
             }
-            hipLaunchKernelGGL(row_norm_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, (const float4*)src_wfeat, Ns, b_vpn, (unsigned int*)nullptr);
-            hipLaunchKernelGGL(row_norm_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, (const float4*)tgt_wfeat, Nt, (float*)nullptr, b_vqmax);
+            hipLaunchKernelGGL(row_norm_kernel, dim3((Ns + 255) / 256 + (Nt + 255) / 256), dim3(256), 0, st, (const float4*)src_wfeat, Ns, b_vpn,
+                               (const float4*)tgt_wfeat, Nt, b_vqmax);
             UMEREG_CHECK_LAUNCH("row_norm_kernel");
         }
         const bool far_cells = bound && cell_pass && served != nullptr;      // queries in far lattice cells are bounded by the scatter (see cell_scatter_kernel)
         if (cell_pass) {
             cw = cell_ws(flat_base - cell_bytes(c_max, (long)M * Ns), c_max, (long)M * Ns);
-            if (hipMemsetAsync(cw.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) { set_error("hipMemsetAsync(cell counters) failed"); return UMEREG_ELAUNCH; }
+            if (!(bound && served) && hipMemsetAsync(cw.cnt, 0, (size_t)c_max * 4, st) != hipSuccess) { set_error("hipMemsetAsync(cell counters) failed"); return UMEREG_ELAUNCH; }
         }
         const int hpt = 16;
         const long order_items = (long)((Ns + 255) / 256) * n_words;
@@ -5052,7 +5074,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
         }
     }
     if (val) {
-        hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, (const char*)ws_src, slices);
+        hipLaunchKernelGGL(corr_val_slices_kernel, dim3((M + 255) / 256, n_slices), dim3(256), 0, st, (const float*)val, M, Ns, (const char*)ws_src, slices,
+                           (const int*)perm, bound ? (const unsigned int*)b_surv : (const unsigned int*)nullptr);
         UMEREG_CHECK_LAUNCH("corr_val_slices_kernel");
     }
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((M + 3) / 4), dim3(256), 0, st, partial, M, n_chunks, Ns, (const float*)slices, n_slices, (const int*)inv,
