@@ -750,7 +750,7 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
            "clouds": ("as evaluate.select_hypothesis hands them over (voxel thinning at corr_ds / 0.3 m, then the sub-sample)" if thinned
                       else "both clouds sub-sampled to pc_corr_max_size points"), "stage_ms": stages,
            "served_by_the_consensus_pass": int(h[7]), "served_frac": round(int(h[7]) / queries, 5),
-           "left_to": ("one_wavefront_per_query" if int(h[8]) == 1 else "candidate_lattice"), "left_queries": int(h[9]),
+           "left_to": ("one_wavefront_per_query" if int(h[8]) in (1, 3) else "candidate_lattice"), "left_queries": int(h[9]),
            "cell_pass_served": int(h[34]), "outside_lattice_bounded": bool(big),
            "hypotheses_with_bounded_queries": int(h[41]), "of_which_recomputed": int(h[40]),
            "consensus_pass": {"source_points_staged_near": int(h[16]), "source_points_staged_in_empty_regions": int(h[17]),

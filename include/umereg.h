@@ -428,7 +428,7 @@ int umereg_corr_scores_f32(const float* src_pts, const float* tgt_pts, const flo
                                                arg-max; for the others it lacks the bounded terms (it is within the bound of the exact score, and the exact score is below the
                                                arg-max's): umereg_corr_select_best_f32 returns the same hypothesis */
 /* The workspace depends on the flags (the cell pass's entry buffer, the bound's slack): query it with the flags of the call.  On jobs
- * of >= 2^25 queries (M x Ns) the cell pass is on by default: its entry buffer holds min(M x Ns, 2^26) entries of 8 bytes, the flat
+ * of >= 2^25 queries (M x Ns), and with UMEREG_CORR_BOUND_OUTSIDE from 2^24 on, the cell pass is on by default: its entry buffer holds min(M x Ns, 2^26) entries of 8 bytes, the flat
  * one-wavefront-per-query list half the job's queries at 8 bytes each. */
 size_t umereg_corr_workspace_bytes_ex(int Ns, int Nt, int M, int flags);
 int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_pts, const float* src_wfeat,

@@ -1879,16 +1879,18 @@ def test_corr_bound_saturates_and_nan_scores_win_like_torch(gpu):
         assert torch.equal(Tb, T[int(ib)])
 
 
-def test_feature_correlator_on_a_big_job_picks_the_exact_arg_max(gpu):
+@pytest.mark.parametrize("M", [3400, 2000])
+def test_feature_correlator_on_a_big_job_picks_the_exact_arg_max(gpu, M):
     """Jobs of >= 2^25 queries (the nuScenes-test / LoKITTI configs: 5 000 hypotheses x 30 000 points) run the cell pass by themselves and
     FeatureCorrelator bounds the queries outside the lattice: the transform it returns is the one the exact scores pick (here 3 400
-    hypotheses x 10 000 points, a third of them garbage, so that the leftovers go to the lattice and thousands of queries are bounded)."""
+    hypotheses x 10 000 points, a third of them garbage, so that the leftovers go to the lattice and thousands of queries are bounded).
+    M = 2 000: a job between 2^24 and 2^25 queries (a KITTI-test pair) -- in arg-max mode it enqueues the cell pass too, and its leftovers
+    go to the lattice from 1 M on instead of 3 M (here 6 M: header word 8 != 1, far cells bounded: word 45)."""
     from umeregrobust_amd import ops
     from umeregrobust_amd.utils.loc_utils import FeatureCorrelator
     rng = np.random.RandomState(5)
     Nt = Ns = 10000
-    M = 3400
-    assert M * Ns >= ops.CORR_BOUND_MIN_QUERIES
+    assert M * Ns >= ops.CORR_BOUND_MIN_QUERIES and (M != 2000 or M * Ns < (1 << 25))
     tgt = (rng.uniform(-40, 40, (Nt, 3)) * np.array([1, 1, 0.05])).astype(np.float32)
     src = (tgt[rng.permutation(Nt)[:Ns]] + rng.standard_normal((Ns, 3)) * 0.05).astype(np.float32)
     sf = rng.standard_normal((Ns, 32)).astype(np.float32); tf = rng.standard_normal((Nt, 32)).astype(np.float32)
@@ -1909,6 +1911,10 @@ def test_feature_correlator_on_a_big_job_picks_the_exact_arg_max(gpu):
     assert abs(float(scores[idx] - fx.last_scores[idx])) <= 2e-6 * abs(float(fx.last_scores[idx])) + 1e-7
     assert int((scores != fx.last_scores).sum()) > 0                      # some hypotheses were ruled out without their far queries
     assert float(fx.last_scores.max()) == float(fx.last_scores[idx])
+    if M == 2000:
+        got, _, hdr = ops.corr_scores_profile(a_[0][0], a_[1][0], a_[2][0], a_[3][0], a_[4], K=20, sigma=1.0, flags=ops.CORR_BOUND_OUTSIDE)
+        assert int(hdr[9]) > 1000000 and int(hdr[8]) in (0, 2) and int(hdr[45]) > 0, (int(hdr[9]), int(hdr[8]), int(hdr[45]))
+        assert int(got.argmax()) == idx
 
 
 def test_evaluate_pairs_overlapped_equals_one_pair_at_a_time(gpu):

@@ -106,7 +106,7 @@ for which in kinds:
                   f"{int((s - ref > 1e-5 * np.abs(ref).max()).sum())}; hypotheses with slack {int(hdr[41])}, needing their bounded queries {int(hdr[40])}; "
                   f"hypotheses whose score is not exact: {int((np.abs(s - ref) > 1e-5 * np.abs(ref).max()).sum())} of {M}", flush=True)
         print(f"{which:5s} {v:5s}: {ev[0].elapsed_time(ev[1]) / reps:7.3f} ms  max|d| {np.abs(s - ref).max():.2e} of {np.abs(ref).max():.3f} "
-              f"argmax {int(s.argmax())}  served {int(hdr[7])} left {int(hdr[9])} path {'coop' if hdr[8] == 1 else 'lattice'} marked {int(hdr[3])} "
+              f"argmax {int(s.argmax())}  served {int(hdr[7])} left {int(hdr[9])} path {'coop' if hdr[8] in (1, 3) else 'lattice'} marked {int(hdr[3])} "
               f"fb records {int(hdr[4])} queries {int(hdr[6])} | staged near {int(hdr[16])} far {int(hdr[17])} avg n_c {hdr[18] / max(hdr[16] + hdr[17], 1):.1f} | "
               f"A steps {steps_a} avg u {u_a / max(steps_a, 1):.1f}  B steps {steps_b} avg u {u_b / max(steps_b, 1):.1f}  zoom steps {int(hdr[23])} | records {int(hdr[24])} avg stage {hdr[25] / max(hdr[24], 1):.0f} pts, queries of staged records {int(hdr[26])} left {int(hdr[27])} | cell pass: listed {int(hdr[32])} served {int(hdr[34])} not selected {int(hdr[35])} batches {int(hdr[36])} cells taken {int(hdr[33])} (marked {int(hdr[3])}, without list {int(hdr[2])}, pool quads {int(hdr[0])})"
               + (f" | flat stats (UMEREG_FLAT_STATS build): searches {int(hdr[48])}, smallest box distance >= 1 / 2 / 3 / 4 / 6 sigma: {[int(x) for x in hdr[49:54]]}" if hdr[48] else "")

@@ -2886,7 +2886,7 @@ __global__ __launch_bounds__(8 * 64) void lattice_list_kernel(const char* __rest
 // pair (24.8 M leftovers, 22.2 M of them served here); on a half-overlapping one 68 -> 21 + 19.7 + 4.9.
 constexpr int kCellCap = 252;                       // list entries (byte counters: see corr_consensus2_kernel)
 constexpr size_t kCellMaxEntries = (size_t)1 << 26; // queries the pass can list (512 MiB of entries)
-constexpr long kCellMinQueries = 1l << 25;          // jobs below this never enqueue the pass (a KITTI-test pair: 2.5e7 queries, leftovers <= 2 M go to the queue)
+constexpr long kCellMinQueries = 1l << 25;          // jobs below this enqueue the pass in arg-max mode only, from 2^24 queries on (cell_pass_on; a KITTI-test pair: 2.5e7 queries)
 #ifndef UMEREG_CELL_FETCH
 #define UMEREG_CELL_FETCH 4
 #endif
@@ -3114,10 +3114,10 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const char* __restric
 // The second pass of the bounded mode re-runs the lattice + cell pass on the far-cell queries of the surviving hypotheses (a list for
 // every cell they lie in, the same kernels: one wavefront per query, which it used to be, cost a pair with 200 survivors 13 ms).  Its
 // kernels are enqueued whatever happens; this gate resets the work counters they share with the first pass -- or, when no hypothesis
-// survived, sets header word 8 (= "the leftovers are not the lattice's"), on which every one of them returns at once.
+// survived, sets header word 8 (!= 0: "the leftovers are not the lattice's"), on which every one of them returns at once.
 __global__ void bound_pass2_gate_kernel(unsigned int* __restrict__ header)
 {
-    if (header[40] == 0u) { header[8] = 2u; return; }
+    if (header[40] == 0u) { header[8] = header[8] == 1u ? 3u : 2u; return; }      // (2 / 3: the first pass's leftovers had gone to the lattice / the queue)
     header[3] = 0u; header[33] = 0u; header[37] = 0u; header[38] = 0u; header[39] = 0u; header[43] = 0u;
 }
 
