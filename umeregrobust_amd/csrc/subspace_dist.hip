@@ -343,13 +343,7 @@ __device__ __forceinline__ float group32_max(float v)
 #ifndef UMEREG_COARSE_ABLATE
 #define UMEREG_COARSE_ABLATE 0   // timing experiments only (tools/exp_coarse_ablate.sh; results are wrong by construction): 1 no squares, 2 no filter, 4 no MFMAs, 8 no LDS reads
 #endif
-#ifndef UMEREG_COARSE_TA
-#define UMEREG_COARSE_TA 2     // (4 -- half the LDS reads per MFMA, 238 VGPRs -- measured 174 us against 142 in tools/exp_f16r_stats.py)
-#endif
-constexpr int kCoarseTA = UMEREG_COARSE_TA;          // A tiles (8 source keypoints each) per wave
-#ifndef UMEREG_COARSE_LATE_FILTER
-#define UMEREG_COARSE_LATE_FILTER 0   // 1: a tile's filter runs one tile late, behind the first MFMAs of the next tile (measured round 3: 168 us against 143 -- worse)
-#endif
+constexpr int kCoarseTA = 2;   // A tiles (8 source keypoints each) per wave (4 -- half the LDS reads per MFMA, 238 VGPRs -- measured 174 us against 142)
 #ifndef UMEREG_COARSE_TPS
 #define UMEREG_COARSE_TPS 1   // (2: 140-146 us against 138-147, 4: 162 -- round-3 measurement: the barrier is not the bound either)
 #endif
@@ -458,11 +452,9 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
     // The filter of a tile -- limit updates, hit tests, candidate appends: a dependent chain of compares, ballots and scalar
     // branches.  The ablations of tools/exp_coarse_ablate.sh say the squares overlap with the MFMAs completely and the filter
     // not at all, so round 3 tried to run it ONE TILE LATE, right after the first MFMAs of the next tile have been issued
-    // (UMEREG_COARSE_LATE_FILTER=1; a limit that is one tile staler is still "some coarse score of that row - margin", the
-    // proof obligation is untouched): 168 us against 143 -- the scheduling fences and the eight score registers carried
-    // across the tile cost more than the shadow returns.  Kept as a compile-time variant, off.
-    float scp[kCoarseTA][4];   // scores of the tile whose filter is pending
-    int jprev = -1;
+    // (a limit that is one tile staler is still "some coarse score of that row - margin", the proof obligation is untouched):
+    // 168 us against 143 -- the scheduling fences and the eight score registers carried across the tile cost more than the
+    // shadow returns.  The variant is gone from the source (round 4); the measurement stays in DESIGN 3.3.
     auto filter = [&](const int jt, const float (&sc)[kCoarseTA][4]) __attribute__((always_inline)) {
         if (UMEREG_COARSE_ABLATE & 2) {
             // no limits, no ballots, no candidates: the scores are folded into one register that is stored once at the end
@@ -540,12 +532,6 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
 #pragma unroll
                 for (int t = 0; t < kCoarseTA; ++t) cc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][1], b1, cc[t], 0, 0, 0);
             }
-            if (UMEREG_COARSE_LATE_FILTER && b == 0 && jprev >= 0) {
-                // (scheduling fence on both sides: the four MFMAs above stay above, the filter's code stays here)
-                __builtin_amdgcn_sched_barrier(0);
-                filter(jprev, scp);
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int t = 0; t < kCoarseTA; ++t)
 #pragma unroll
@@ -561,15 +547,7 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
                     sc[t][g] = fmaf(cc[t][4 * g + 3], cc[t][4 * g + 3], acc);
                 }
         }
-        if (UMEREG_COARSE_LATE_FILTER) {
-#pragma unroll
-            for (int t = 0; t < kCoarseTA; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) scp[t][g] = sc[t][g];
-            jprev = jt;
-        } else {
-            filter(jt, sc);
-        }
+        filter(jt, sc);
     };
     for (int jg = jt0; jg < jt1; jg += kCoarseTPS) {
 #pragma unroll
@@ -581,7 +559,6 @@ __global__ __launch_bounds__(kWave* kDistWaves, 2) void ume_coarse_h_kernel(
         __syncthreads();
         cur ^= 1;
     }
-    if (UMEREG_COARSE_LATE_FILTER && jprev >= 0) filter(jprev, scp);      // the last tile's
     // publish what this split learned for the workgroups that start later
     share(false);
     if (lane == 0) ms.cnt[(size_t)blk * ms.splits + sp] = (unsigned int)qn;
