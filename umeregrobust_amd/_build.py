@@ -24,7 +24,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # host-side sampler in api.hip relies on the SLP vectoriser for its lock-step binary searches).
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Xarch_device", "-fno-slp-vectorize", "-fPIC",
           "-fvisibility=hidden"]
-LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"]
+# -z defs: a kernel declared in corr_kernels.h but defined with another signature (or not at all) is an undefined host stub --
+# a link error here instead of a load error on the GPU box
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-Wl,-z,defs"]
 FLAGS = CFLAGS + ["-shared", "-I", INCLUDE]      # (the one-command form of the same build; kept for the record in logs)
 
 HASH_MARKER = b"UMEREG_SRC_HASH="
