@@ -72,6 +72,9 @@ def parse():
                          "rounds 2-3, reported as config.resident_replay); 'none' = 12 plain launches per pair")
     ap.add_argument("--resident-steps", type=int, default=5,
                     help="steps of the additional 'pair'-mode leg over 4 resident pairs (config.resident_replay; 0 = skip)")
+    ap.add_argument("--hard-steps", type=int, default=3,
+                    help="steps of the named-path leg repeated over HARD pairs (partial overlap, noise, corrupted features: the matcher's "
+                         "filter has less to prune with); reported as config.named_path_on_hard_pairs, not part of `value` (0 = skip)")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=4,
@@ -217,7 +220,7 @@ def main():
     scratch_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(depth)]   # (the resident-replay leg's; not reported)
 
     def leg_counts(slot):
-        return counts[slot] if leg.pipe is pipe else scratch_counts[slot]
+        return counts[slot] if (leg.pipe is pipe and leg.pool is pool) else scratch_counts[slot]
     # per-kernel HIP-event samples: `timing` from pairs that run ALONE (the kernel's own duration: what `roofline` prices),
     # `timing_situ` from pairs inside the pipeline (what a profiler of this command sees: kernels of 4 pairs share the chip)
     timing = {"moments": [], "dist": ops.TimingList()}
@@ -309,6 +312,42 @@ def main():
                            "note": "phase A as one hipGraph per (slot, resident PairBatch), replayed in place: no input copies, the same four "
                                    "pairs' tables stay in L2 / MALL (how rounds 2-3 measured `value`)"}
         leg.pipe, leg.pool = pipe, pool
+
+    # ---- the same leg (same pipeline, same graphs, distinct pairs copied into the slots) on pairs that can FAIL: two 240-degree
+    # sectors 100 degrees apart, 2 cm point noise, 20 % corrupted features.  `value`'s pairs are exact rigid copies -- every keypoint
+    # has a twin at subspace distance ~0, the best case for the coarse filter's limits; here a third of the keypoints have no twin
+    # and the filter keeps more candidates for the fp64 refine.  Untimed by the driver's clock contract; on record beside `value`. ----
+    hard_named = None
+    hard_pool_shared = []
+    if a.hard_steps > 0 and a.config != "K1":
+        hard_pool_shared = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"])) for i in range(4)]
+        for e in hard_pool_shared:
+            e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
+                if a.batch_clouds else None
+            e.mom_bytes = []
+        leg.pool = hard_pool_shared
+        run(0, P, False)
+        torch.cuda.synchronize()
+        for c_ in scratch_counts:
+            c_.zero_()
+        fence()
+        t1 = time.perf_counter()
+        run(P, a.hard_steps * P, False)
+        fence()
+        el_h = time.perf_counter() - t1
+        hc = torch.stack(scratch_counts).sum(0).double()
+        if collective:
+            tmax = torch.tensor([el_h], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el_h = float(tmax.item())
+            dist.all_reduce(hc, op=dist.ReduceOp.SUM)
+        hc = hc.cpu().numpy()
+        hard_named = {"pairs_per_s": round(a.hard_steps * P * world / el_h, 1), "steps": a.hard_steps, "distinct_pairs": len(hard_pool_shared),
+                      "ms_per_pair": round(1e3 * el_h / (a.hard_steps * P), 4),
+                      "hypotheses_within_1.5deg_0.6m": round(float(hc[1]) / max(float(hc[0]), 1.0), 4),
+                      "note": "named path a1-a7 on KT-size HARD pairs (two 240-deg sectors 100 deg apart, sigma = 2 cm, 20 % corrupted "
+                              "features), same pipeline and graphs as `value`; `value` itself is measured on exact rigid copies"}
+        leg.pool = pool
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     def situ(lst):
@@ -416,7 +455,7 @@ def main():
                    "value_is": ("named path a1-a7, pairs/s, over a stream of DISTINCT resident pairs (each copied device to device into its "
                                 "pipeline slot's staging buffers, 14 MB, then one graph replay): what a loop like evaluate.py:175 gets"
                                 if graph_mode == "slot" else f"named path a1-a7, pairs/s, graph mode '{graph_mode}'"),
-                   "resident_replay": resident_replay,
+                   "resident_replay": resident_replay, "named_path_on_hard_pairs": hard_named,
                    "roofline_sampling": "one pair per step runs alone (pipeline drained before and after, inside the timed region): "
                                         "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per step "
                                         "timed inside the pipeline, beside the kernels of the other pairs in flight", "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
@@ -618,8 +657,9 @@ def main():
         result["end_to_end"]["evaluate_pairs_loop"] = api_loop(pool, a.e2e_pairs, 510000)
     hard_pool = hard_pool_first = None
     if not a.no_e2e and a.e2e_hard_pairs > 0:
-        hard_pool = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]))
-                     for i in range(min(4, a.e2e_hard_pairs))]
+        n_hard = min(4, a.e2e_hard_pairs)      # (the same pairs as the named-path leg's hard pool, when that ran)
+        hard_pool = hard_pool_shared[:n_hard] if len(hard_pool_shared) >= n_hard else \
+            [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"])) for i in range(n_hard)]
         result["end_to_end_hard"] = e2e_leg(hard_pool, a.e2e_hard_pairs, 600000,
                                             f"{a.config}-size HARD pairs: partial overlap (two 240-deg sectors 100 deg apart), "
                                             "sigma = 2 cm point noise, 20 % corrupted features", a.e2e_in_flight)
