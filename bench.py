@@ -314,9 +314,11 @@ def main():
         leg.pipe, leg.pool = pipe, pool
 
     # ---- the same leg (same pipeline, same graphs, distinct pairs copied into the slots) on pairs that can FAIL: two 240-degree
-    # sectors 100 degrees apart, 2 cm point noise, 20 % corrupted features.  `value`'s pairs are exact rigid copies -- every keypoint
-    # has a twin at subspace distance ~0, the best case for the coarse filter's limits; here a third of the keypoints have no twin
-    # and the filter keeps more candidates for the fp64 refine.  Untimed by the driver's clock contract; on record beside `value`. ----
+    # sectors 100 degrees apart, 2 cm point noise, 20 % corrupted features.  `value`'s pairs are exact rigid copies of one scan;
+    # these are what a registration benchmark feeds.  Measured (tools/exp_f16r_stats.py [hard], round 4): the matcher does not
+    # care (coarse filter 143.4 vs 143.0 us, refine 28.7 vs 31.7 us: the keypoints of the two clouds are drawn independently either
+    # way, median matched distance 0.13 vs 0.58), the moment kernel does (103 vs 121 us per cloud: off-lattice points, fuller
+    # balls), and the leg as a whole is 6-7 % slower.  Untimed by the driver's clock contract; on record beside `value`. ----
     hard_named = None
     hard_pool_shared = []
     if a.hard_steps > 0 and a.config != "K1":
