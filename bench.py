@@ -347,7 +347,7 @@ def main():
         hard_named = {"pairs_per_s": round(a.hard_steps * P * world / el_h, 1), "steps": a.hard_steps, "distinct_pairs": len(hard_pool_shared),
                       "ms_per_pair": round(1e3 * el_h / (a.hard_steps * P), 4),
                       "hypotheses_within_1.5deg_0.6m": round(float(hc[1]) / max(float(hc[0]), 1.0), 4),
-                      "note": "named path a1-a7 on KT-size HARD pairs (two 240-deg sectors 100 deg apart, sigma = 2 cm, 20 % corrupted "
+                      "note": f"named path a1-a7 on {a.config}-size HARD pairs (two 240-deg sectors 100 deg apart, sigma = 2 cm, 20 % corrupted "
                               "features), same pipeline and graphs as `value`; `value` itself is measured on exact rigid copies"}
         leg.pool = pool
 
