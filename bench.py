@@ -72,9 +72,10 @@ def parse():
                          "rounds 2-3, reported as config.resident_replay); 'none' = 12 plain launches per pair")
     ap.add_argument("--resident-steps", type=int, default=5,
                     help="steps of the additional 'pair'-mode leg over 4 resident pairs (config.resident_replay; 0 = skip)")
-    ap.add_argument("--hard-steps", type=int, default=3,
+    ap.add_argument("--hard-steps", type=int, default=None,
                     help="steps of the named-path leg repeated over HARD pairs (partial overlap, noise, corrupted features: the matcher's "
-                         "filter has less to prune with); reported as config.named_path_on_hard_pairs, not part of `value` (0 = skip)")
+                         "filter has less to prune with); reported as config.named_path_on_hard_pairs, not part of `value` (0 = skip; "
+                         "default 3, and 0 for the K1 toy shape)")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=4,
@@ -321,7 +322,9 @@ def main():
     # balls), and the leg as a whole is 6-7 % slower.  Untimed by the driver's clock contract; on record beside `value`. ----
     hard_named = None
     hard_pool_shared = []
-    if a.hard_steps > 0 and a.config != "K1":
+    if a.hard_steps is None:
+        a.hard_steps = 0 if a.config == "K1" else 3
+    if a.hard_steps > 0:
         hard_pool_shared = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"])) for i in range(4)]
         for e in hard_pool_shared:
             e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
@@ -346,7 +349,7 @@ def main():
         hc = hc.cpu().numpy()
         hard_named = {"pairs_per_s": round(a.hard_steps * P * world / el_h, 1), "steps": a.hard_steps, "distinct_pairs": len(hard_pool_shared),
                       "ms_per_pair": round(1e3 * el_h / (a.hard_steps * P), 4),
-                      "hypotheses_within_1.5deg_0.6m": round(float(hc[1]) / max(float(hc[0]), 1.0), 4),
+                      "hypotheses_within_1.5deg_0.6m": round(float(hc[1]) / max(float(hc[0]), 1.0), 4), "counts": [int(v) for v in hc],
                       "note": f"named path a1-a7 on {a.config}-size HARD pairs (two 240-deg sectors 100 deg apart, sigma = 2 cm, 20 % corrupted "
                               "features), same pipeline and graphs as `value`; `value` itself is measured on exact rigid copies"}
         leg.pool = pool

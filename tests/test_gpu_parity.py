@@ -924,7 +924,8 @@ def test_bench_two_ranks_equal_one_rank_over_the_same_pairs(gpu):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    common = ["--config", "K1", "--warmup", "1", "--steps", "2", "--no-cpu-baseline", "--e2e-hard-pairs", "0", "--e2e-side-by-side", "0"]
+    common = ["--config", "K1", "--warmup", "1", "--steps", "2", "--no-cpu-baseline", "--e2e-hard-pairs", "0", "--e2e-side-by-side", "0",
+              "--hard-steps", "1"]           # (the named-path leg over hard pairs: its own barrier + all-reduce pair)
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                          "127.0.0.1", "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
                          "--force-device", "0", "--pairs-per-step", "4", "--e2e-pairs", "3"] + common,
@@ -938,6 +939,8 @@ def test_bench_two_ranks_equal_one_rank_over_the_same_pairs(gpu):
     assert r1.returncode == 0, r1.stderr[-3000:]
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["hypothesis_quality"]["counts"] == j2["hypothesis_quality"]["counts"]      # 2 ranks x 2 steps x 4 pairs == 1 x 2 x 8
+    h1, h2 = j1["config"]["named_path_on_hard_pairs"], j2["config"]["named_path_on_hard_pairs"]
+    assert h1["counts"] == h2["counts"] and h1["counts"][0] == 8 * 2500                   # the hard leg shards the same way
     e1, e2 = j1["end_to_end"], j2["end_to_end"]
     assert e1["pairs"] == e2["pairs"] == 6
     for key in ("rr_1.5deg_0.6m", "rr_1.5deg_0.3m", "rr_1deg_0.1m"):
