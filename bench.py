@@ -318,8 +318,8 @@ def main():
     # sectors 100 degrees apart, 2 cm point noise, 20 % corrupted features.  `value`'s pairs are exact rigid copies of one scan;
     # these are what a registration benchmark feeds.  Measured (tools/exp_f16r_stats.py [hard], round 4): the matcher does not
     # care (coarse filter 143.4 vs 143.0 us, refine 28.7 vs 31.7 us: the keypoints of the two clouds are drawn independently either
-    # way, median matched distance 0.13 vs 0.58), the moment kernel does (103 vs 121 us per cloud: off-lattice points, fuller
-    # balls), and the leg as a whole is 6-7 % slower.  Untimed by the driver's clock contract; on record beside `value`. ----
+    # way, median matched distance 0.13 vs 0.58), the moment kernel does (103 vs 121 us per cloud: a sector cloud holds its N
+    # points on two thirds of the area, so a ball search scans 1.5x the points), and the leg as a whole is 6-7 % slower.  Untimed by the driver's clock contract; on record beside `value`. ----
     hard_named = None
     hard_pool_shared = []
     if a.hard_steps is None:
