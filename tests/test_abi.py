@@ -60,3 +60,30 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(root, f)).read().lower()
                 assert "oracle" not in text, f"{os.path.join(root, f)} references the oracle"
+
+
+def _kernels_of(path):
+    text = open(path).read()
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"__launch_bounds__\s*\([^)]*\)", "", text)
+    text = re.sub(r"__attribute__\s*\(\((?:[^()]|\([^()]*\))*\)\)", "", text)
+    return re.findall(r"__global__\s+void\s+(\w+)\s*\(", text)
+
+
+def test_corr_kernel_declarations_match_the_definitions():
+    """The hypothesis-selection sources are five translation units: every kernel is DEFINED in exactly one of
+    corr_knn / corr_consensus / corr_lattice / corr_leftover.hip and DECLARED exactly once in corr_kernels.h (what corr.hip,
+    the file with the one call, launches through); corr.hip and the two headers define none."""
+    csrc = os.path.join(REPO, "umeregrobust_amd", "csrc")
+    defined = []
+    for f in ("corr_knn.hip", "corr_consensus.hip", "corr_lattice.hip", "corr_leftover.hip"):
+        names = [n for n in _kernels_of(os.path.join(csrc, f))]
+        defined += [n for n in dict.fromkeys(names)]          # (explicit instantiations repeat a template's name in its own file)
+    declared = _kernels_of(os.path.join(csrc, "corr_kernels.h"))
+    assert len(defined) == len(set(defined)) >= 40, "a kernel is defined in two files"      # (42 names, 51 instantiations)
+    assert len(declared) == len(set(declared)), "a kernel is declared twice"
+    assert set(defined) == set(declared), (sorted(set(defined) ^ set(declared)))
+    assert _kernels_of(os.path.join(csrc, "corr.hip")) == [] and _kernels_of(os.path.join(csrc, "corr_dev.h")) == []
+    # ... and every launch in corr.hip names a declared kernel
+    launched = set(re.findall(r"hipLaunchKernelGGL\(\(?(\w+)", open(os.path.join(csrc, "corr.hip")).read()))
+    assert launched and launched <= set(declared), sorted(launched - set(declared))
