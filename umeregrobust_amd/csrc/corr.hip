@@ -52,35 +52,12 @@ __host__ inline unsigned int lattice_cells_for(long queries, int Nt, int flags)
     return (unsigned int)c;
 }
 
-// ---- consensus pass, second form (round 3) ----------------------------------------------------------------------------
-// Same contract as corr_consensus_kernel (val / served / stats, exact or left to the other structures), rebuilt around three
-// observations about where that kernel's ~2 900 VALU instructions per 64-hypothesis step went:
-//   (1) the K + 6 entry lists were trimmed to K by repeated arg-max sweeps (~1 000 instructions per step).  But the stage is
-//       sorted by distance from the consensus image, and |d_j(q) - d_j(q~)| <= delta, so for a whole step (delta <= dmax)
-//         * staged points with  d_j(q~) < d_K(q~) - 2 dmax  are among the K nearest of EVERY lane (there are < K of them and each
-//           is closer to q than d_K(q) >= d_K(q~) - delta):  "sure-in", summed without any selection;
-//         * staged points with  d_j(q~) > d_K(q~) + 2 dmax  are among the K nearest of NO lane;
-//       what is left to select from is a ZONE of u = m_use - s_min points around stage position K, of which every lane needs
-//       the same number  need = K - s_min.  Agreeing hypotheses (delta of centimetres) leave u <= 12: their d2 stay in
-//       registers and the `need` smallest are found by rank counting (66 key comparisons), no LDS list, no histogram;
-//   (2) wider steps (u > 12) histogram only the range the K-th distance can lie in, [(d_K(q~) - delta)^2, (d_K(q~) + delta)^2)
-//       (everything below it is sure-in by the query's own distance: the underflow bin), in 32 bins of BYTE counters (the
-//       stage holds <= 252 points, so a counter cannot wrap): 2.3 KiB per wavefront instead of 8.4.  Everything below the bin
-//       of the K-th neighbour is summed on the fly in the second sweep; only the candidates IN that bin go to a list
-//       (kCons2Tie entries) and are trimmed there.  A fuller bin is zoomed into once (x32); a lane whose finest bin still
-//       overflows the list (exact distance ties by the dozen) is left to the other structures, like any lane that fails
-//       the a-posteriori test;
-//   (3) with the 13.3 KiB list gone a wavefront needs 12.25 KiB of LDS: three wavefronts per SIMD instead of two.
-// And, new: source points whose consensus image lies in an EMPTY part of the target (partly overlapping clouds: 38 % of the
-// points of a half-overlapping pair) used to give up (< K targets within D); they now stage the points within
-// d_K(q~) + margin of the image, found through the chunk boxes of the sorted table (coop_knn for d_K, then one pruned sweep)
-// -- the fine range of (2) is what makes the thin shell their neighbours live in selectable in one histogram.
+// (consensus pass, second form: corr_consensus.hip; the far-point margin below is the caller's default)
 constexpr float kConsFarMarginCells = 2.5f;   // default margin of the far-point stage (see corr_consensus2_kernel), in grid cells
-                                                        // 2 M, f1 averages 7.5 ms with 2^21 and 6.4 with 3 M or 4.5 M -- the flat list holds half the job's queries now)   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
 #ifndef UMEREG_LEFT_MAX_BOUND
 #define UMEREG_LEFT_MAX_BOUND 1000000u
 #endif
-constexpr unsigned int kLeftMaxBound = UMEREG_LEFT_MAX_BOUND;      // the same where the cell pass rides in arg-max mode on a job below 2^25 queries
+constexpr unsigned int kLeftMaxBound = UMEREG_LEFT_MAX_BOUND;      // kLeftMax (corr_dev.h) where the cell pass rides in arg-max mode on a job below 2^25 queries
 
 // ascending list of the marked cells (deterministic order): cids[0 .. header[3])
 // (kCompactBlocks workgroups, each with a contiguous range of 16-cell groups; a workgroup counts the marks of the ranges before its own
@@ -89,7 +66,6 @@ constexpr int kCompactBlocks = 64;
 constexpr size_t kCellMaxEntries = (size_t)1 << 26; // queries the pass can list (512 MiB of entries)
 constexpr long kCellMinQueries = 1l << 25;          // jobs below this enqueue the pass in arg-max mode only, from 2^24 queries on (cell_pass_on; a KITTI-test pair: 2.5e7 queries)
 __host__ __device__ inline size_t cell_cap(long queries) { return (size_t)(queries < (long)kCellMaxEntries ? queries : (long)kCellMaxEntries); }
-                                                                  // queries, and its items are few -- with 512 per item the kernel lasted as long as its slowest two items
 __host__ __device__ inline size_t cell_items(unsigned int c_max, long queries) { return (size_t)c_max + cell_cap(queries) / (kCellChunk < kCellChunkLong ? kCellChunk : kCellChunkLong) + 64; }
 __host__ inline size_t cell_bytes(unsigned int c_max, long queries)
 {
@@ -118,14 +94,7 @@ __host__ __device__ inline size_t cell_lds_per_wave(int K, bool lng)
     return (size_t)kCons2Tie * kWave * 6 + (size_t)(lng ? 512 : kCellStage) * 16 + cell_d2_plane(K, lng) + ((size_t)K * kWave * 2 + 255) / 256 * 256;
 }
 
-// ---- the same queries as a FLAT list ---------------------------------------------------------------------------------
-// A record holds a dozen queries on average, and the eight wavefronts of corr_score_fallback_kernel meet at two barriers
-// per record: with 1 or 2 queries each they wait for the slowest (SQ counters: 63 % of the wavefronts' time is waiting).
-// Flattened, every wavefront takes queries of its own: leftover_flatten_kernel gives each record a contiguous range of
-// query slots (entry = record << 6 | lane, lanes ascending), corr_score_flat_kernel writes one value per slot, and
-// leftover_sum_kernel adds a record's values in lane order to its (hypothesis, chunk) partial sum -- the same additions
-// in the same order as the record kernel's, so the result is bit-identical.  More than flat_slots() queries (header word 11
-// set): the flat kernels return and the record kernel runs as before.
+// (the flat list of leftover queries: corr_leftover.hip)
 constexpr unsigned int kFlatMaxQ = 1u << 21;
 constexpr int kFlatBlocks = 6144;   // workgroups of corr_score_flat_kernel (8 wavefronts each, visits of 4 queries dealt round-robin; 768 .. 16 384 measured: 1.17 .. 1.10 ms)
 // (capacity: 2^21 queries, or half of the job's if that is more -- a nuScenes-size job of 1.5e8 queries with outlier hypotheses

@@ -48,6 +48,25 @@ __global__ __launch_bounds__(256) void rotate_points_kernel(const float* __restr
         out[(size_t)i * 3 + r] = v == v && fabsf(v) < 1e30f ? v : 0.f;
     }
 }
+
+// ---- consensus pass: one wavefront per SOURCE POINT, one lane per hypothesis -----------------------------------------
+// Most hypotheses of a pair agree (they are the output of the same matcher: ~85 % within a degree / half a metre of
+// each other), so for a fixed source point p_n the queries T_h p_n of most hypotheses fall within a metre or two of
+// ONE place q~_n = T~ p_n (T~ = component-wise median of the hypotheses).  Their neighbours all come from the same
+// ~100 target points -- and <vp_n, vq_j> does not depend on the hypothesis at all.  So:
+//   setup (per source point, cooperative): C_n = all target points within D of q~_n (grid walk, <= kConsCap points,
+//     sorted by original index so that ties keep resolving towards the lower index), staged in LDS with their
+//     feature dot products <vp_n, vq_j>, and d_K(q~_n);
+//   loop (64 hypotheses per step, one per lane): q = T_h p_n, delta = |q - q~_n|; the usual histogram + append
+//     selection over the STAGED points (broadcast LDS reads: no gathers, no per-lane lists), range
+//     [0, (d_K(q~) + delta)^2) -- the K nearest of q~ are K candidates inside it;  score term from the kept keys and
+//     the staged dot products;
+//   exactness (a posteriori, per lane): the K-th distance d found inside C_n plus delta must stay below D: any point
+//     outside C_n is farther than D from q~_n, hence farther than D - delta >= d from q.  Lanes that fail (hypotheses
+//     away from the consensus, source points whose image has < K targets within D) are left to the lattice kernels:
+//     served[n][h] bit = 0.
+// The inner loop has no vector-memory instruction at all; the lattice path was bound by the L1's line rate
+// (gathers), this one by plain VALU issue.
 constexpr float kConsRadiusCells = 4.2f; // first D in grid cells (kNN-mode cell edge c: a disc of radius 2c holds ~2K points)
 
 // component-wise median of the hypotheses' rotation rows and translations: Tmed[12] = {r00 r01 r02 tx, r10 ..};
@@ -133,6 +152,14 @@ __global__ __launch_bounds__(256) void hyp_order_kernel(const float* __restrict_
     }
 }
 
+// ---- per-neighbourhood hypothesis orders -----------------------------------------------------------------------------
+// How far a hypothesis moves a source point from its consensus image depends on where the point is (a rotation error of
+// 0.5 degrees is 4 cm at 5 m and 45 cm at 50 m), so ONE order of the hypotheses serves no neighbourhood well: 64-hypothesis
+// steps that mix small and large displacements pay the large cut-off stage for every lane (CPU simulation,
+// tools/sim_consensus_order.py: -22 % candidate visits with an order per neighbourhood, -27 % with one per point).  The
+// source cloud's processing order is cell-sorted, so a chunk of 64 slots is a neighbourhood: every chunk gets its own order,
+// by the displacement of its centroid, and the positions (served bits, val rows) of a source point are positions in the order
+// of ITS chunk.  perm[chunk][pos] = h, inv[chunk][h] = pos.
 // slot -> chunk map by source index, and the centroid of every chunk
 __global__ __launch_bounds__(256) void chunk_centroid_kernel(const char* __restrict__ ws_src, const float* __restrict__ src_pts, int Ns,
                                                              int* __restrict__ chunk_of, float4* __restrict__ centroid)
@@ -526,6 +553,30 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
     if (lane == 0 && stats) atomicAdd(stats, n_served);
 }
+
+// ---- consensus pass, second form (round 3) ----------------------------------------------------------------------------
+// Same contract as corr_consensus_kernel (val / served / stats, exact or left to the other structures), rebuilt around three
+// observations about where that kernel's ~2 900 VALU instructions per 64-hypothesis step went:
+//   (1) the K + 6 entry lists were trimmed to K by repeated arg-max sweeps (~1 000 instructions per step).  But the stage is
+//       sorted by distance from the consensus image, and |d_j(q) - d_j(q~)| <= delta, so for a whole step (delta <= dmax)
+//         * staged points with  d_j(q~) < d_K(q~) - 2 dmax  are among the K nearest of EVERY lane (there are < K of them and each
+//           is closer to q than d_K(q) >= d_K(q~) - delta):  "sure-in", summed without any selection;
+//         * staged points with  d_j(q~) > d_K(q~) + 2 dmax  are among the K nearest of NO lane;
+//       what is left to select from is a ZONE of u = m_use - s_min points around stage position K, of which every lane needs
+//       the same number  need = K - s_min.  Agreeing hypotheses (delta of centimetres) leave u <= 12: their d2 stay in
+//       registers and the `need` smallest are found by rank counting (66 key comparisons), no LDS list, no histogram;
+//   (2) wider steps (u > 12) histogram only the range the K-th distance can lie in, [(d_K(q~) - delta)^2, (d_K(q~) + delta)^2)
+//       (everything below it is sure-in by the query's own distance: the underflow bin), in 32 bins of BYTE counters (the
+//       stage holds <= 252 points, so a counter cannot wrap): 2.3 KiB per wavefront instead of 8.4.  Everything below the bin
+//       of the K-th neighbour is summed on the fly in the second sweep; only the candidates IN that bin go to a list
+//       (kCons2Tie entries) and are trimmed there.  A fuller bin is zoomed into once (x32); a lane whose finest bin still
+//       overflows the list (exact distance ties by the dozen) is left to the other structures, like any lane that fails
+//       the a-posteriori test;
+//   (3) with the 13.3 KiB list gone a wavefront needs 12.25 KiB of LDS: three wavefronts per SIMD instead of two.
+// And, new: source points whose consensus image lies in an EMPTY part of the target (partly overlapping clouds: 38 % of the
+// points of a half-overlapping pair) used to give up (< K targets within D); they now stage the points within
+// d_K(q~) + margin of the image, found through the chunk boxes of the sorted table (coop_knn for d_K, then one pruned sweep)
+// -- the fine range of (2) is what makes the thin shell their neighbours live in selectable in one histogram.
 #ifndef UMEREG_CONS2_ZONE
 #define UMEREG_CONS2_ZONE 8
 #endif

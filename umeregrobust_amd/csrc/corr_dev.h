@@ -591,34 +591,10 @@ __device__ __forceinline__ float cauchy_weight_fast(float d2, float inv_sigma2)
     return __builtin_amdgcn_rcpf(fmaf(d2, inv_sigma2, 1.0f));
 }
 
-// ---- consensus pass: one wavefront per SOURCE POINT, one lane per hypothesis -----------------------------------------
-// Most hypotheses of a pair agree (they are the output of the same matcher: ~85 % within a degree / half a metre of
-// each other), so for a fixed source point p_n the queries T_h p_n of most hypotheses fall within a metre or two of
-// ONE place q~_n = T~ p_n (T~ = component-wise median of the hypotheses).  Their neighbours all come from the same
-// ~100 target points -- and <vp_n, vq_j> does not depend on the hypothesis at all.  So:
-//   setup (per source point, cooperative): C_n = all target points within D of q~_n (grid walk, <= kConsCap points,
-//     sorted by original index so that ties keep resolving towards the lower index), staged in LDS with their
-//     feature dot products <vp_n, vq_j>, and d_K(q~_n);
-//   loop (64 hypotheses per step, one per lane): q = T_h p_n, delta = |q - q~_n|; the usual histogram + append
-//     selection over the STAGED points (broadcast LDS reads: no gathers, no per-lane lists), range
-//     [0, (d_K(q~) + delta)^2) -- the K nearest of q~ are K candidates inside it;  score term from the kept keys and
-//     the staged dot products;
-//   exactness (a posteriori, per lane): the K-th distance d found inside C_n plus delta must stay below D: any point
-//     outside C_n is farther than D from q~_n, hence farther than D - delta >= d from q.  Lanes that fail (hypotheses
-//     away from the consensus, source points whose image has < K targets within D) are left to the lattice kernels:
-//     served[n][h] bit = 0.
-// The inner loop has no vector-memory instruction at all; the lattice path was bound by the L1's line rate
-// (gathers), this one by plain VALU issue.
+// (the consensus pass itself: corr_consensus.hip)
 constexpr int kConsCap = 256;            // staged target points per source point
 
-// ---- per-neighbourhood hypothesis orders -----------------------------------------------------------------------------
-// How far a hypothesis moves a source point from its consensus image depends on where the point is (a rotation error of
-// 0.5 degrees is 4 cm at 5 m and 45 cm at 50 m), so ONE order of the hypotheses serves no neighbourhood well: 64-hypothesis
-// steps that mix small and large displacements pay the large cut-off stage for every lane (CPU simulation,
-// tools/sim_consensus_order.py: -22 % candidate visits with an order per neighbourhood, -27 % with one per point).  The
-// source cloud's processing order is cell-sorted, so a chunk of 64 slots is a neighbourhood: every chunk gets its own order,
-// by the displacement of its centroid, and the positions (served bits, val rows) of a source point are positions in the order
-// of ITS chunk.  perm[chunk][pos] = h, inv[chunk][h] = pos.
+// (per-neighbourhood hypothesis orders: corr_consensus.hip)
 constexpr int kChunkOrderMax = 8192;        // hypotheses a chunk order can sort in LDS (beyond: the global order for every chunk)
 
 constexpr int kCoopCap = 256;       // cooperative key list (keys)
@@ -955,6 +931,7 @@ constexpr int kHist16Words = 18;
 #define UMEREG_LEFT_MAX 3000000u
 #endif
 constexpr unsigned int kLeftMax = UMEREG_LEFT_MAX;      // (2^21 until the end of round 3: over 32 half-overlapping KITTI-test pairs, whose leftovers straddle
+                                                        // 2 M, f1 averages 7.5 ms with 2^21 and 6.4 with 3 M or 4.5 M -- the flat list holds half the job's queries now)   // (measured round 3, with the Hilbert-ordered copy: 0.26 M leftovers 2.2 ms through the queue against 3.2 through the lattice, 1.6 M 7.8 against 8.1)
 #ifndef UMEREG_CELL_STAGE
 #define UMEREG_CELL_STAGE 256
 #endif
@@ -980,6 +957,7 @@ struct CellWs {
 #define UMEREG_CELL_CHUNK_LONG 256
 #endif
 constexpr unsigned int kCellChunkLong = UMEREG_CELL_CHUNK_LONG;   // the same for the long-list instance: its steps cost three times a short one's, its cells hold thousands of
+                                                                  // queries, and its items are few -- with 512 per item the kernel lasted as long as its slowest two items
 
 __host__ __device__ inline size_t cell_d2_plane(int K, bool lng)
 {
@@ -995,21 +973,7 @@ struct FlatWs {
     unsigned int slots;
 };
 
-// ---- the same queries, first one wavefront per RECORD (round 3) --------------------------------------------------------
-// A record = the queries of one 64-slot chunk of the source order under one hypothesis that nothing else served.  With the
-// source in Hilbert-curve order a chunk is a compact blob, and a rigid transform keeps it one: its queries lie in a box B of a few
-// metres and share their neighbours.  One cooperative search (coop_knn at the centre c of B) gives d_K(c); the target points
-// within R of ANY of the record's queries are staged in LDS (one sweep over the target's chunk boxes pruned against B, then
-// point against query), and every lane selects ITS K nearest from the stage with the histogram / append machinery of the
-// other structures (broadcast LDS reads).
-//   R = d_K(c) + min(hd, max(d_K(c) / 2, half a grid cell)),   hd = half diagonal of B.
-// Exactness is per lane and a posteriori, as in the consensus pass: a point that is not staged is farther than R from every
-// query of the record, so a lane whose K-th distance stays below R has its true K nearest.  (R = d_K(c) + hd and "within R of
-// the box" would be a superset for every query of B a priori -- the lattice's argument -- but for a rotated blob of 8 m in a
-// dense part of the target that is a thousand points; the union of balls stages ~250 and loses the few queries in sparser spots.)
-// Lanes that pass are summed into the record's partial sum here; the record's mask is REWRITTEN to the lanes that did not
-// (sparser spot, stage overflow, degenerate image) and the flat one-wavefront-per-query path that follows serves exactly
-// those -- one search per record instead of one per query for the rest (the flat kernel alone: 4 ns per query, 1.1 ms per pair).
+// (one wavefront per record: corr_leftover.hip)
 constexpr int kRecStage = 768;           // staged target points per record
 
 template <class IdxT>

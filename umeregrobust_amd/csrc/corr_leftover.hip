@@ -403,6 +403,14 @@ __global__ __launch_bounds__(kCoopWaves * 64) void corr_score_fallback_kernel(co
     }
 }
 
+// ---- the same queries as a FLAT list ---------------------------------------------------------------------------------
+// A record holds a dozen queries on average, and the eight wavefronts of corr_score_fallback_kernel meet at two barriers
+// per record: with 1 or 2 queries each they wait for the slowest (SQ counters: 63 % of the wavefronts' time is waiting).
+// Flattened, every wavefront takes queries of its own: leftover_flatten_kernel gives each record a contiguous range of
+// query slots (entry = record << 6 | lane, lanes ascending), corr_score_flat_kernel writes one value per slot, and
+// leftover_sum_kernel adds a record's values in lane order to its (hypothesis, chunk) partial sum -- the same additions
+// in the same order as the record kernel's, so the result is bit-identical.  More than flat_slots() queries (header word 11
+// set): the flat kernels return and the record kernel runs as before.
 __global__ __launch_bounds__(256) void leftover_flatten_kernel(char* __restrict__ lat, unsigned int c_max, FlatWs f)
 {
     unsigned int* header = reinterpret_cast<unsigned int*>(lat + lat_ws(c_max).off_header);
@@ -751,6 +759,21 @@ __global__ __launch_bounds__(1024) void bound_survivors_kernel(const float* __re
     if (threadIdx.x == 0) { header[40] = cnt[0]; header[41] = cnt[1]; header[44] = 0u; }      // (44: flat_bound_kernel's selection starts over)
 }
 
+// ---- the same queries, first one wavefront per RECORD (round 3) --------------------------------------------------------
+// A record = the queries of one 64-slot chunk of the source order under one hypothesis that nothing else served.  With the
+// source in Hilbert-curve order a chunk is a compact blob, and a rigid transform keeps it one: its queries lie in a box B of a few
+// metres and share their neighbours.  One cooperative search (coop_knn at the centre c of B) gives d_K(c); the target points
+// within R of ANY of the record's queries are staged in LDS (one sweep over the target's chunk boxes pruned against B, then
+// point against query), and every lane selects ITS K nearest from the stage with the histogram / append machinery of the
+// other structures (broadcast LDS reads).
+//   R = d_K(c) + min(hd, max(d_K(c) / 2, half a grid cell)),   hd = half diagonal of B.
+// Exactness is per lane and a posteriori, as in the consensus pass: a point that is not staged is farther than R from every
+// query of the record, so a lane whose K-th distance stays below R has its true K nearest.  (R = d_K(c) + hd and "within R of
+// the box" would be a superset for every query of B a priori -- the lattice's argument -- but for a rotated blob of 8 m in a
+// dense part of the target that is a thousand points; the union of balls stages ~250 and loses the few queries in sparser spots.)
+// Lanes that pass are summed into the record's partial sum here; the record's mask is REWRITTEN to the lanes that did not
+// (sparser spot, stage overflow, degenerate image) and the flat one-wavefront-per-query path that follows serves exactly
+// those -- one search per record instead of one per query for the rest (the flat kernel alone: 4 ns per query, 1.1 ms per pair).
 template <class IdxT>
 __global__ __launch_bounds__(128) void corr_score_record2_kernel(const char* __restrict__ ws_tgt, const char* __restrict__ ws_src,
                                                                  const float* __restrict__ src_pts, const float4* __restrict__ vp4,
