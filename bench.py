@@ -36,7 +36,14 @@ if REPO not in sys.path:
 # So, BEFORE numpy / torch exist in this process: the rank is pinned to its share (<= 8 cores) of the NUMA node its GPU hangs
 # off, and the BLAS / OpenMP pools are sized to it (umeregrobust_amd/hostpin.py; a world of 1 keeps every core -- the CPU-baseline
 # leg runs there).
+from umeregrobust_amd import benchline  # noqa: E402  (torch-free)
 from umeregrobust_amd.hostpin import pin_rank_from_env  # noqa: E402
+
+# `python bench.py --gpus N` as typed (N > 1, no launcher): this process becomes `python -m torch.distributed.run --nnodes=1
+# --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` -- one rank per GPU, as the
+# driver's own launch form.  Under a launcher (WORLD_SIZE set) or at N = 1 nothing happens here.
+if __name__ == "__main__":
+    benchline.maybe_self_launch(os.path.abspath(__file__))
 
 _fd = [sys.argv[i + 1] for i, v in enumerate(sys.argv[:-1]) if v == "--force-device"]
 HOST_PIN = pin_rank_from_env(force_device=_fd[0] if _fd else None)
@@ -108,6 +115,9 @@ def parse():
                     help="hard pairs of the CPU-vs-HIP recall check (the oracle costs ~1 s per reduced-size pair on a 256-core host; "
                          "stops after --cpu-rr-budget seconds of CPU time)")
     ap.add_argument("--cpu-rr-budget", type=float, default=400.0)
+    ap.add_argument("--detail", default=None,
+                    help="file the FULL result (notes, stage tables, per-kernel counters) is written to; the printed line is a bounded "
+                         "extract of it (umeregrobust_amd/benchline.py).  Default: gpurun_out/bench_detail.json under the repo")
     return ap.parse_args()
 
 
@@ -740,8 +750,18 @@ def main():
     if rr:
         result["cpu_baseline"]["rr_pairs"] = rr["pairs"]
         result["cpu_baseline"]["rr_pairs_with_a_different_gate_outcome"] = len(rr["pairs_with_a_different_gate_outcome_same_draws"])
+    result["world"]["launched_by"] = ("bench.py itself (torch.distributed.run re-exec)" if os.environ.get("UMEREG_BENCH_SELF_LAUNCHED")
+                                      else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python"))
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        # the full result goes to a file; the ONE line on stdout is a bounded extract (<= 4 KB: the driver keeps an 8 KB tail)
+        result = benchline.sanitize(result)
+        detail = a.detail or os.path.join(REPO, "gpurun_out", "bench_detail.json")
+        try:
+            detail = os.path.relpath(benchline.write_detail(result, detail), REPO)
+        except OSError as e:
+            print(f"[bench] could not write {detail}: {e}", file=sys.stderr)
+            detail = None
+        print(benchline.line(result, detail), flush=True)
     if collective:
         dist.barrier()
         dist.destroy_process_group()

@@ -597,7 +597,9 @@ def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_m
                        tau=0.05, filter_by_ume_dist_cond=True, corr_ds=0.6, pc_corr_max_size=10000, sigma=1.5,
                        icp_max_dist=0.2, icp_max_iteration=200):
     """evaluate.py:195-309 for one pair, RNG consumption in the reference's order (two keypoint draws, the weighted
-    match draw, two correlation sub-sampling draws).  -> dict(T_sel, T_est, rre, rte, rre_sel, rte_sel)."""
+    match draw, two correlation sub-sampling draws).  -> dict(T_sel, T_est, rre, rte, rre_sel, rte_sel, n_hyp, and the
+    intermediate results a stage-by-stage comparison needs: T_hyp [M,4,4] (every hypothesis), cond [M] (drawn matches), match [n_kp]
+    (row arg-min), sel_index (row of T_hyp that was selected))."""
     n_s, n_t = src_pts.shape[0], tgt_pts.shape[0]
     num_init_sel = min(10000, min(n_s, n_t)) if filter_by_ume_dist_cond else min(min(n_s, n_t), ume_n_samples)   # :195-198
     src_inds = rs.choice(n_s, num_init_sel, replace=False)                                 # :199
@@ -620,4 +622,6 @@ def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_m
                       float(np.linalg.norm(Tm[:3, 3] - gt[:3, 3])))
     rre, rte = err(T_est)                                                                   # :100-107
     rre_sel, rte_sel = err(T_sel)
-    return dict(T_sel=T_sel, T_est=T_est, rre=rre, rte=rte, rre_sel=rre_sel, rte_sel=rte_sel, n_hyp=int(T.shape[0]))
+    hit = np.flatnonzero((T.reshape(T.shape[0], -1) == T_sel.reshape(1, -1)).all(1))
+    return dict(T_sel=T_sel, T_est=T_est, rre=rre, rte=rte, rre_sel=rre_sel, rte_sel=rte_sel, n_hyp=int(T.shape[0]),
+                T_hyp=T, cond=np.asarray(cond), match=np.asarray(m), sel_index=int(hit[0]) if hit.size else -1)

@@ -5,6 +5,8 @@ translation gate sits at the fp32 reference's own noise floor -- SURVEY.md secti
 applied where the problem is well-conditioned and as a median elsewhere); distances within the
 reference's own fp32 noise (3e-3 abs near D ~ 0).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -884,6 +886,23 @@ def test_pipeline_slot_guard_and_per_pair_rng(gpu):
     assert not np.array_equal(np.asarray(o0.cond), np.asarray(o1.cond))
 
 
+def _run_bench(cmd, tmp_tag, env, repo, timeout):
+    """runs a bench.py command; -> (the printed line as a dict, the full result from its --detail file, the CompletedProcess).
+    The line is the bounded extract (umeregrobust_amd/benchline.py); the blocks the comparisons below need are in the file."""
+    import json
+    import subprocess
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="umereg_bench_"), f"{tmp_tag}.json")
+    r = subprocess.run(cmd + ["--detail", detail], capture_output=True, text=True, timeout=timeout, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, (len(lines), [len(l) for l in lines])     # ONE line, inside the driver's tail
+    line = json.loads(lines[0])
+    full = json.load(open(detail))
+    assert line["value"] == full["value"] and line["detail"]
+    return line, full, r
+
+
 def test_bench_collectives_on_rccl(gpu, tmp_path):
     """bench.py's distributed code path on RCCL (backend nccl): process-group init with a bound device, barrier placement,
     MAX / SUM all-reduces.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so on this 1-GPU box the
@@ -898,16 +917,12 @@ def test_bench_collectives_on_rccl(gpu, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     common = ["--config", "K1", "--warmup", "1", "--steps", "2", "--pairs-per-step", "8", "--no-cpu-baseline", "--e2e-pairs", "2",
               "--e2e-hard-pairs", "0"]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                         "127.0.0.1", "--master-port", "29631", os.path.join(repo, "bench.py"), "--gpus", "1", "--dist-backend", "nccl",
-                         "--force-dist"] + common, capture_output=True, text=True, timeout=600, env=env, cwd=repo)
-    assert r2.returncode == 0, r2.stderr[-3000:]
-    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    l2, j2, _ = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                            "127.0.0.1", "--master-port", "29631", os.path.join(repo, "bench.py"), "--gpus", "1", "--dist-backend", "nccl",
+                            "--force-dist"] + common, "rccl", env, repo, 600)
+    assert l2["config"]["world"] == {"ranks": 1, "backend": "nccl", "launched_by": "torch.distributed.run"}
     assert j2["n_gpus"] == 1 and j2["config"]["pairs_per_step_per_gpu"] == 8 and j2["end_to_end"]["pairs"] == 2
-    r1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"] + common,
-                        capture_output=True, text=True, timeout=600, env=env, cwd=repo)
-    assert r1.returncode == 0, r1.stderr[-3000:]
-    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    _, j1, _ = _run_bench([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"] + common, "plain", env, repo, 600)
     assert j1["hypothesis_quality"]["counts"] == j2["hypothesis_quality"]["counts"]
     assert j1["end_to_end"]["rr_1deg_0.1m"] == j2["end_to_end"]["rr_1deg_0.1m"]
 
@@ -926,18 +941,14 @@ def test_bench_two_ranks_equal_one_rank_over_the_same_pairs(gpu):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     common = ["--config", "K1", "--warmup", "1", "--steps", "2", "--no-cpu-baseline", "--e2e-hard-pairs", "0", "--e2e-side-by-side", "0",
               "--hard-steps", "1"]           # (the named-path leg over hard pairs: its own barrier + all-reduce pair)
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                         "127.0.0.1", "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
-                         "--force-device", "0", "--pairs-per-step", "4", "--e2e-pairs", "3"] + common,
-                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
-    assert r2.returncode == 0, r2.stderr[-3000:]
-    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    l2, j2, _ = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                            "--force-device", "0", "--pairs-per-step", "4", "--e2e-pairs", "3"] + common, "two", env, repo, 900)
+    assert l2["n_gpus"] == 2 and l2["cpu_baseline"] is None and l2["config"]["world"]["ranks"] == 2
     assert j2["n_gpus"] == 2 and j2["world"]["ranks"] == 2 and j2["world"]["backend"] == "gloo" and j2["scaling"] == "weak"
     assert j2["world"]["host_threads_per_rank"] <= 8                      # the ranks share the host: pools are pinned
-    r1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--pairs-per-step", "8", "--e2e-pairs", "6"] + common,
-                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
-    assert r1.returncode == 0, r1.stderr[-3000:]
-    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    _, j1, _ = _run_bench([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--pairs-per-step", "8", "--e2e-pairs", "6"] + common,
+                          "one", env, repo, 900)
     assert j1["hypothesis_quality"]["counts"] == j2["hypothesis_quality"]["counts"]      # 2 ranks x 2 steps x 4 pairs == 1 x 2 x 8
     h1, h2 = j1["config"]["named_path_on_hard_pairs"], j2["config"]["named_path_on_hard_pairs"]
     assert h1["counts"] == h2["counts"] and h1["counts"][0] == 8 * 2500                   # the hard leg shards the same way
@@ -953,7 +964,9 @@ def test_bench_eight_ranks_equal_one_rank_over_the_same_pairs(gpu):
     rank on device 0 (--force-device 0), collectives on gloo.  K1 shape, one step of one pair per rank: the eight ranks cover the
     global pairs 0..7 of the named path and 0..7 of the end-to-end leg, and the summed integer counts must EQUAL a 1-rank run over
     the same eight pairs.  Every rank is pinned to its own share of the host (hostpin) before numpy / torch exist.
-    Also: `--gpus 8` started without torch.distributed.run ends at once with a message (no rendezvous, no hang)."""
+    The eight ranks are started the way the command is TYPED -- `python bench.py --gpus 8 ...`, no launcher: bench.py re-executes itself
+    under torch.distributed.run (umeregrobust_amd/benchline.py); an inconsistent launch (WORLD_SIZE set to something else) still ends
+    at once with a message (no rendezvous, no hang)."""
     import json
     import os
     import subprocess
@@ -963,21 +976,18 @@ def test_bench_eight_ranks_equal_one_rank_over_the_same_pairs(gpu):
     common = ["--config", "K1", "--warmup", "1", "--steps", "1", "--no-cpu-baseline", "--e2e-hard-pairs", "0", "--e2e-side-by-side", "0",
               "--pool", "8"]
     bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8"] + common, capture_output=True, text=True,
-                         timeout=300, env=env, cwd=repo)
-    assert bad.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in bad.stderr and "torch.distributed.run" in bad.stderr
-    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
-                         "127.0.0.1", "--master-port", "29651", os.path.join(repo, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
-                         "--force-device", "0", "--pairs-per-step", "1", "--e2e-pairs", "1"] + common,
-                        capture_output=True, text=True, timeout=1500, env=env, cwd=repo)
-    assert r8.returncode == 0, r8.stderr[-3000:]
-    j8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+                         timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=repo)
+    assert bad.returncode != 0 and "--gpus 8 but WORLD_SIZE=2" in bad.stderr and "torch.distributed.run" in bad.stderr
+    env8 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    l8, j8, r8 = _run_bench([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
+                             "--force-device", "0", "--pairs-per-step", "1", "--e2e-pairs", "1"] + common, "eight", env8, repo, 1500)
+    assert "--nproc-per-node=8" in r8.stderr and l8["config"]["world"]["launched_by"].startswith("bench.py itself")
+    assert l8["n_gpus"] == 8 and l8["config"]["world"]["ranks"] == 8 and l8["config"]["world"]["backend"] == "gloo"
     assert j8["n_gpus"] == 8 and j8["world"]["ranks"] == 8 and j8["world"]["backend"] == "gloo" and j8["scaling"] == "weak"
     assert 1 <= j8["world"]["host_threads_per_rank"] <= 8 and j8["world"]["host_cpus_rank0"]
     assert j8["config"]["sharding"].startswith("pairs[rank::8]")
-    r1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--pairs-per-step", "8", "--e2e-pairs", "8"] + common,
-                        capture_output=True, text=True, timeout=900, env=env, cwd=repo)
-    assert r1.returncode == 0, r1.stderr[-3000:]
-    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    _, j1, _ = _run_bench([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--pairs-per-step", "8", "--e2e-pairs", "8"] + common,
+                          "one8", env, repo, 900)
     assert j1["hypothesis_quality"]["counts"] == j8["hypothesis_quality"]["counts"]      # 8 ranks x 1 pair == 1 rank x 8 pairs
     e1, e8 = j1["end_to_end"], j8["end_to_end"]
     assert e1["pairs"] == e8["pairs"] == 8
@@ -1973,3 +1983,65 @@ def test_full_pipeline_equals_the_oracle_on_replayed_draws(gpu):
         n_ok += int(rc["rre"] <= 1.5 and rc["rte"] <= 0.6)
     with pytest.raises(ValueError, match="does not fit"):
         ReplayRNG([np.arange(5)]).choice(4, 5, replace=False)
+
+
+@pytest.mark.parametrize("shape", ["KT", "NS"])
+def test_full_size_pair_equals_the_oracle_stage_by_stage(gpu, shape):
+    """One FULL-SIZE hard pair per benchmark shape through `evaluate_pairs` with the oracle's five host draws replayed
+    (reference evaluate.py:195-309), compared with `oracle.evaluate_pair_full` stage by stage:
+      KT  N = 50 000 points, 10 000 keypoints, M = 2 500 hypotheses, pc_corr_max_size 10 000 (test_kitti_config.yaml);
+      NS  N = 35 000 points, 5 000 keypoints = hypotheses, pc_corr_max_size 30 000, no match filtering (test_nuscenes_config.yaml:
+          the sizes at which f1 runs its cell pass and bounds the queries outside the lattice).
+    Same matches (row arg-min), every hypothesis' T against the oracle's (R <= 1e-4; t: median <= 1e-4 -- the bar of rows a6 / a8,
+    the fp32 reference's own reorder noise is 3e-4 --, maximum <= 2e-3), the SAME selected hypothesis, the same refined registration
+    (f2 bars).  The oracle's brute-force f1 costs ~25 s (KT) / ~110 s (NS) on the box's 256 host cores."""
+    import os
+    from types import SimpleNamespace
+    from umeregrobust_amd import evaluate
+    from umeregrobust_amd.host_rng import RecordingRNG, ReplayRNG
+    from umeregrobust_amd.synth import synth_pair_hard
+    from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml
+    if (os.cpu_count() or 1) < 32:
+        pytest.skip("the oracle's brute-force hypothesis selection at full size needs a many-core host (minutes on 256 cores)")
+    args = update_namespace_from_yaml(SimpleNamespace(), benchmark_config_path("kitti_test" if shape == "KT" else "nuscenes_test"))
+    N, n_kp, M = (50000, 10000, 2500) if shape == "KT" else (35000, 5000, 5000)
+    args.batch_size, args.ume_n_samples = 1, M
+    p = synth_pair_hard(seed=(9000 if shape == "KT" else 11000), N=N, n_kp=n_kp, voxel=0.3)
+    rec = RecordingRNG(np.random.RandomState(31))
+    rc = orc.evaluate_pair_full(p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.gt_tform, rec, ume_max_nn=args.ume_max_nn,
+                                ume_r_nn=args.ume_r_nn, ume_n_samples=M, tau=args.tau, filter_by_ume_dist_cond=args.filter_by_ume_dist_cond,
+                                corr_ds=args.corr_ds, pc_corr_max_size=args.pc_corr_max_size, sigma=args.corr_kernel_sigma)
+    assert len(rec.log) == (5 if args.filter_by_ume_dist_cond else 4) and rc["n_hyp"] == M and rc["sel_index"] >= 0
+    pair = dict(src_pts=T_(p.src_pts, gpu)[None], tgt_pts=T_(p.tgt_pts, gpu)[None], src_feat=T_(p.src_feat, gpu)[None],
+                tgt_feat=T_(p.tgt_feat, gpu)[None], gt_tform=T_(p.gt_tform, gpu))
+    got = []
+    with torch.no_grad():
+        rg = evaluate.evaluate_pairs([pair], args, rng=ReplayRNG(rec.log), refine=True, collect=got)
+    assert len(got) == 1
+    # a4 / a5: the same matches, the same drawn subset (the draw is replayed; the matches are this library's own)
+    match = N_(got[0]["match"]).reshape(-1)[:rc["match"].shape[0]]
+    agree = match == rc["match"]
+    assert agree.mean() >= 0.9995, agree.mean()                       # (fp32 near-ties of the reference's own cdist: rows a3 / a4)
+    if args.filter_by_ume_dist_cond:
+        assert np.array_equal(np.asarray(got[0]["cond"]), rc["cond"])
+    # a6: every hypothesis whose match is the same one
+    T_hip, T_orc = N_(got[0]["rtume_tform"]), rc["T_hyp"]
+    assert T_hip.shape == T_orc.shape == (M, 4, 4)
+    same = agree[rc["cond"]]
+    dR = np.abs(T_hip[same, :3, :3] - T_orc[same, :3, :3]).reshape(-1, 9).max(1)
+    dt = np.abs(T_hip[same, :3, 3] - T_orc[same, :3, 3]).max(1)
+    finite = np.isfinite(dR) & np.isfinite(dt)
+    assert finite.mean() > 0.999
+    assert np.median(dR[finite]) <= 1e-5 and np.quantile(dR[finite], 0.99) <= 1e-4, (np.median(dR[finite]), dR[finite].max())
+    assert np.median(dt[finite]) <= 1e-4 and np.quantile(dt[finite], 0.99) <= 2e-3, (np.median(dt[finite]), dt[finite].max())
+    # f1: the same selected hypothesis (index into the M hypotheses), hence the same selected transform to a6's bar
+    T_sel = np.eye(4, dtype=np.float32)
+    T_sel[:3, :3], T_sel[:3, 3] = N_(rg["R_sel"][0]), N_(rg["t_sel"][0])
+    hit = np.flatnonzero((T_hip.reshape(M, -1) == T_sel.reshape(1, -1)).all(1))
+    assert hit.size >= 1 and rc["sel_index"] in hit, (hit, rc["sel_index"])
+    assert np.abs(T_sel - rc["T_sel"]).max() <= 2e-3
+    # f2: the refined registration and its errors (ICP from the same basin ends in the same place)
+    assert np.abs(N_(rg["T_est"][0])[:3, :3] - rc["T_est"][:3, :3]).max() <= 1e-4
+    assert np.abs(N_(rg["T_est"][0])[:3, 3] - rc["T_est"][:3, 3]).max() <= 1e-3
+    assert abs(float(rg["rre"][0]) - rc["rre"]) <= 2e-2 and abs(float(rg["rte"][0]) - rc["rte"]) <= 1e-3
+    assert rc["rre"] <= 1.5 and rc["rte"] <= 0.6 and float(rg["rre"][0]) <= 1.5 and float(rg["rte"][0]) <= 0.6

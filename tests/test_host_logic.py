@@ -249,3 +249,93 @@ def test_host_cores_follow_the_gpus_numa_node():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     n = min(8, max(1, len(os.sched_getaffinity(0)) // 4))
     assert f"PIN {n} {n} False False {n}" in out.stdout, out.stdout + out.stderr
+
+
+def _canned_bench_result():
+    """a full bench.py result with every block at its round-4 size (prose notes, stage tables, per-kernel counters)"""
+    prose = "x" * 600
+    roof = lambda k, b, u: {"kernel": k, "bound": b, "achieved": 808.34, "peak": 2500.0, "unit": u, "frac": 0.3233,   # noqa: E731
+                            "traffic": 54902170, "avg_launch_ms": 0.1267, "launches": 20, "in_situ_avg_launch_ms": 0.2741,
+                            "note": prose, "sustained_note": prose, "traffic_source": prose, "counters_source": prose,
+                            "mfma_busy_frac": 0.3459, "valu_busy_frac": 0.6177, "counters_match_library": True}
+    rl = {"ume_moments_kernel": roof("ume_moments_kernel", "mfma", "TFLOP/s"),
+          "ume_coarse_h_kernel": roof("ume_coarse_h_kernel", "mfma", "TFLOP/s"),
+          "corr_consensus2_kernel": roof("corr_consensus2_kernel", "valu_issue", "Ginst/s (wave64 VALU)")}
+    e2e = {"workload": prose, "pairs_per_s": 335.4, "stage_ms": {"a": 1.0}, "note": prose, "stage_ms_note": prose, "rr_1.5deg_0.6m": 100.0,
+           "rr_1.5deg_0.3m": 100.0, "rr_1deg_0.1m": 100.0, "mRRE_deg": 0.01, "mRTE_m": float("nan")}
+    return {
+        "metric": "registration_pairs_per_s", "value": 3595.123, "unit": "pairs/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+        "ms_per_step": 17.8, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "world": {"ranks": 1, "backend": None, "note": prose, "launched_by": "python"},
+        "config": {"workload": "KT: named hot path a1-a7 on synthetic KITTI-shaped pairs (N=50000 pts/cloud, 10000 keypoints/cloud, K=750, "
+                               "r=5 m, d=32, M=2500 hypotheses, tau=0.05, kind=test)", "pairs_per_step_per_gpu": 64, "ms_per_pair": 0.2781,
+                   "sharding": "pairs[rank::1] (no data-path collective)", "value_is": prose, "roofline_sampling": prose,
+                   "excluded_from_value": prose, "resident_replay": {"pairs_per_s": 3700.0, "note": prose},
+                   "named_path_on_hard_pairs": {"pairs_per_s": 3313.0, "note": prose, "counts": [1, 2, 3, 4]},
+                   "end_to_end_pairs_per_s": {"plain_pair_by_pair": 335.43, "plain_evaluate_pairs": 431.05, "plain_side_by_side": 421.1,
+                                              "hard_pair_by_pair": 150.55, "hard_evaluate_pairs": 196.44, "hard_side_by_side": 198.61,
+                                              "f1_ms_plain": 1.6858, "f1_ms_hard": 5.18, "what": prose}},
+        "roofline": rl["ume_coarse_h_kernel"], "rooflines": rl,
+        "hypothesis_quality": {"note": prose}, "end_to_end": e2e, "end_to_end_hard": e2e,
+        "f1_selection": {"plain": {"kernels": {f"k{i}": {"note": prose} for i in range(12)}}},
+        "cpu_baseline": {"value": 1.965, "unit": "pairs/s", "cores": 256, "kind": "port", "sample": prose, "quality_check": {"note": prose},
+                         "rr_check": {"note": prose, "pairs_with_a_different_gate_outcome_same_draws": []}, "rr_pairs": 128,
+                         "rr_pairs_with_a_different_gate_outcome": 0},
+    }
+
+
+def test_bench_line_is_bounded_and_complete(tmp_path):
+    """the ONE line bench.py prints: < 4 KB whatever the full result holds (the driver keeps an 8 KB stdout tail; round 4's 22 KB
+    line did not parse), strict JSON, every key of the bench contract; the full result goes to the detail file"""
+    import json
+
+    from umeregrobust_amd import benchline
+    full = benchline.sanitize(_canned_bench_result())
+    assert len(json.dumps(full)) > 20000                         # (the canned result is as large as the one that broke)
+    path = benchline.write_detail(full, str(tmp_path / "d" / "bench_detail.json"))
+    s = benchline.line(full, "gpurun_out/bench_detail.json")
+    assert "\n" not in s and len(s.encode()) < benchline.LINE_LIMIT == 4096
+    d = json.loads(s, parse_constant=lambda c: pytest.fail(f"non-finite constant {c} in the line"))
+    for k in benchline.REQUIRED_KEYS:
+        assert k in d, k
+    assert d["value"] == 3595.123 and d["metric"] == "registration_pairs_per_s" and d["ms_per_step"] == 17.8
+    for k in ("workload", "pairs_per_step_per_gpu", "value_is", "end_to_end_pairs_per_s", "named_path_on_hard_pairs"):
+        assert k in d["config"], k
+    assert len(d["config"]["end_to_end_pairs_per_s"]) == 8 and d["config"]["named_path_on_hard_pairs"] == {"pairs_per_s": 3313.0}
+    for r in [d["roofline"]] + list(d["rooflines"].values()):
+        for k in benchline.ROOFLINE_KEYS:
+            assert k in r, k
+    assert set(d["rooflines"]) == {"ume_moments_kernel", "ume_coarse_h_kernel", "corr_consensus2_kernel"}
+    assert d["cpu_baseline"]["value"] == 1.965 and d["cpu_baseline"]["cores"] == 256 and d["cpu_baseline"]["kind"] == "port"
+    assert d["cpu_baseline"]["rr_pairs"] == 128 and d["cpu_baseline"]["rr_pairs_with_a_different_gate_outcome"] == 0
+    assert d["recall"]["mRTE_m"] is None                         # NaN -> null, not a bare NaN token
+    assert d["detail"] == "gpurun_out/bench_detail.json"
+    assert json.load(open(path))["f1_selection"]["plain"]["kernels"]["k3"]["note"]     # nothing is lost: it is in the file
+    # N > 1 (no CPU leg) and the tracked round-4 result (the one whose line was too long) go through as well
+    many = dict(full, cpu_baseline=None, n_gpus=8)
+    assert json.loads(benchline.line(many))["cpu_baseline"] is None
+    old = os.path.join(REPO, "profiles", "r04", "bench_default.json")
+    if os.path.exists(old):
+        raw = open(old).read()
+        assert len(raw) > 20000 and len(benchline.line(benchline.sanitize(json.loads(raw)))) < 4096
+
+
+def test_bench_gpus_n_launches_itself():
+    """`python bench.py --gpus N` as typed: N > 1 without WORLD_SIZE re-executes under torch.distributed.run (one process per
+    GPU, 127.0.0.1, a free port, same arguments); under a launcher, or at N = 1, it does not"""
+    from umeregrobust_amd import benchline
+    cmd = benchline.self_launch_command("/x/bench.py", ["--gpus", "8", "--steps", "20", "--warmup", "5"], {})
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
+    assert cmd[5:7] == ["--master-addr", "127.0.0.1"] and cmd[7] == "--master-port" and 1024 < int(cmd[8]) < 65536
+    assert cmd[9:] == ["/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert benchline.self_launch_command("/x/bench.py", ["--gpus=2"], {})[4] == "--nproc-per-node=2"
+    assert benchline.self_launch_command("/x/bench.py", ["--gpus", "8"], {"WORLD_SIZE": "8"}) is None
+    assert benchline.self_launch_command("/x/bench.py", ["--gpus", "1"], {}) is None
+    assert benchline.self_launch_command("/x/bench.py", ["--steps", "3"], {}) is None
+    # end to end on the CPU: the re-exec happens and every rank reaches bench.py's own launch checks (which refuse: no HIP device here)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert "starting -m torch.distributed.run --nnodes=1 --nproc-per-node=2" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a HIP device" in r.stderr

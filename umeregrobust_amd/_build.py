@@ -145,6 +145,10 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None):
     global OBJ_DIR
     out = out or LIB_PATH
     extra_flags = list(extra_flags)
+    if extra_flags and out == LIB_PATH:
+        # the embedded hash covers sources and the default flags only: a variant linked to the product's path would look current
+        # to is_stale() and be loaded silently by the next plain build_native()
+        raise ValueError("build_native(extra_flags=...) builds an A/B variant: give it its own `out` (e.g. tools/lib<name>.so), not the product library")
     if out == LIB_PATH and not extra_flags and not force and not is_stale():
         return LIB_PATH
     want = source_hash()

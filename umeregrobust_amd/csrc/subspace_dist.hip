@@ -1029,6 +1029,7 @@ static int resolve_opts(const umereg_match_opts* o, MatchOpts& m, const char* wh
     UMEREG_REQUIRE(o->variant == 0 || o->variant == 1, "%s: unknown matcher variant %d (0 = Q-form, 1 = P-form)", who, (int)o->variant);
     UMEREG_REQUIRE(o->splits >= 0 && o->force_exhaustive >= 0, "%s: negative matcher option", who);
     UMEREG_REQUIRE(o->share_mask <= 0xffffffffll, "%s: share_mask does not fit 32 bits", who);
+    UMEREG_REQUIRE(o->reserved == 0, "%s: umereg_match_opts.reserved must be 0 (got %d)", who, (int)o->reserved);
     m.variant = o->variant;
     m.splits = o->splits;
     m.share_mask = o->share_mask;

@@ -23,8 +23,8 @@ class _PinnedRing:
     each, five per pair) and the download of the match probabilities, through a small ring of PINNED buffers: a copy out of pageable
     numpy memory blocks the host for 50-100 us (staging + synchronisation), a pinned one is an asynchronous enqueue.  A buffer is
     reused only after the event recorded behind its last copy has completed (a no-op wait in practice: a pair passes several host
-    synchronisations before the ring comes round).  One ring per host thread (threading.local): the end-to-end legs run pairs on
-    several threads."""
+    synchronisations before the ring comes round).  One ring per host thread (threading.local: the end-to-end legs run pairs on
+    several threads) and per device (an event belongs to the device it was first recorded on)."""
     SLOTS = 8
 
     def __init__(self):
@@ -49,10 +49,15 @@ class _PinnedRing:
 _ring_tls = __import__("threading").local()
 
 
-def _ring():
-    r = getattr(_ring_tls, "ring", None)
+def _ring(dev):
+    rings = getattr(_ring_tls, "rings", None)
+    if rings is None:
+        rings = _ring_tls.rings = {}
+    idx = torch.device(dev).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    r = rings.get(idx)
     if r is None:
-        r = _ring_tls.ring = _PinnedRing()
+        r = rings[idx] = _PinnedRing()
     return r
 
 
@@ -64,7 +69,7 @@ def _index_tensor(idx, dev):
     dev = torch.device(dev)
     if dev.type != "cuda" or a.size < 256:
         return torch.as_tensor(a, dtype=torch.int64, device=dev)
-    ring = _ring()
+    ring = _ring(dev)
     k, buf = ring.slot(a.nbytes)
     host = buf[:a.nbytes].view(torch.int64).view(a.shape)
     host.numpy()[...] = a
@@ -79,7 +84,7 @@ def _to_host(t):
     the pageable path: tens of microseconds more per call)."""
     if not t.is_cuda:
         return t.detach().numpy()
-    ring = _ring()
+    ring = _ring(t.device)
     k, buf = ring.slot(t.numel() * t.element_size())
     host = buf[:t.numel() * t.element_size()].view(t.dtype).view(t.shape)
     host.copy_(t, non_blocking=True)
@@ -576,6 +581,10 @@ class RegistrationPipeline:
             a = SimpleNamespace(ume_src=graph.F[0:1], ume_tgt=graph.F[1:2], match=graph.m, match_d=graph.d, prob=graph.prob, D=None,
                                 src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=graph.F.shape[1], dev=self.dev, src_pts=src_pts,
                                 tgt_pts=tgt_pts, ready=ev, slot=k, rng=rng, draw=None, graph=graph)
+            # the device-to-device copies of launch_from read the caller's tensors on the SLOT's stream: the handle holds them until
+            # finish() has waited for `ready` (recorded behind those copies), so a caller that rebinds `pair` right after submit()
+            # cannot have the caching allocator hand the blocks out on its own stream while the copy is pending
+            a.keep = (pair, src_feat, tgt_feat)
             return a
         with torch.cuda.stream(st):
             a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, graph,
@@ -589,6 +598,7 @@ class RegistrationPipeline:
         a.slot = k
         a.rng = rng
         a.draw = None
+        a.keep = (pair, src_pts, tgt_pts, src_feat, tgt_feat)     # read on the slot's stream, possibly allocated on another: alive until finish()
         if self.pool is not None and self.args.filter_by_ume_dist_cond:
             a.draw = self.pool.submit(self._draw, a)
         return a
@@ -624,6 +634,15 @@ class RegistrationPipeline:
         injected = cond is not None
         if self.args.filter_by_ume_dist_cond and cond is None:
             cond = a.draw.result() if a.draw is not None else self._draw(a)
+        # the pair's inputs were read on the slot's stream: after a host draw the host has waited for `ready` (behind those reads) and
+        # the handle's hold on them can simply go; otherwise (no weighted draw, or an injected `cond`) the allocator is told
+        keep, a.keep = getattr(a, "keep", None), None
+        if keep and (injected or not self.args.filter_by_ume_dist_cond):
+            for t_ in keep:
+                for u_ in ((t_.pts, t_.feat, t_.inds) if isinstance(t_, PairBatch) else (t_,)):
+                    if isinstance(u_, torch.Tensor) and u_.is_cuda:
+                        u_.record_stream(st)
+        del keep
         graph = getattr(a, "graph", None)
         if graph is not None and not isinstance(cond, torch.Tensor):
             # graph fast path: index upload + SE(3) solve from the graph's own outputs in one native call
@@ -680,7 +699,7 @@ class RegistrationPipeline:
 _OVERLAP_STREAMS = {}
 
 
-def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overlap=True):
+def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overlap=True, collect=None):
     """The reference's evaluation loop (evaluate.py:175-309) over an iterable of registration pairs, with the
     reference's RNG consumption order per pair (keypoint draws, weighted match draw, correlation sub-sampling):
 
@@ -690,7 +709,9 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
     -> dict(R_sel, t_sel [P,...] (selected hypotheses), T_est [P,4,4], rre [P], rte [P], rr_np, rr_sp, mrre, mrte)
     where the last four are the numbers the reference prints (:304-309).  overlap (default): consecutive pairs overlap on
     two HIP streams (same results, same RNG consumption; see the loop).  Datasets and the feature network are the
-    caller's business (out of scope); everything between them and the printed metrics is here."""
+    caller's business (out of scope); everything between them and the printed metrics is here.
+    collect: a list that receives, per pair, dict(rtume_tform [M,4,4] (every hypothesis, a copy), cond, match) -- the intermediate
+    results a stage-by-stage comparison against a CPU checker needs (tests); costs one device copy per pair."""
     R_sel, t_sel, raw = [], [], []
     # Two pairs overlap on two HIP streams: while the correlation scores of pair i are computed (two thirds of a pair's GPU
     # time, and nothing on the host needs them before the read-back below), pair i + 1 goes through its keypoint draws,
@@ -737,6 +758,9 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
             _, _, R_hat, t_hat, T_dev = select_hypothesis(src_raw, tgt_raw, pair["src_pts"], pair["tgt_pts"], pair["src_feat"],
                                                           pair["tgt_feat"], out.rtume_tform, pair["gt_tform"], args, rng=rng,
                                                           prepared=getattr(out, "side", None), return_tform=True)       # :258-296
+            if collect is not None:
+                collect.append(dict(rtume_tform=out.rtume_tform[0].clone(), cond=out.cond,
+                                    match=out.match.clone() if isinstance(out.match, torch.Tensor) else out.match))
             job = None
             if refine and st is not None and src_raw.is_cuda and src_raw.dtype == torch.float32 and tgt_raw.dtype == torch.float32:
                 job = ops.IcpJob(src_raw, tgt_raw, T_dev[0].contiguous(), max_corr, max_it)                              # :63-96

@@ -633,7 +633,8 @@ def icp_point_to_point(src_pts, tgt_pts, T_init, max_correspondence_distance=0.2
     T = np.empty((4, 4), dtype=np.float64)
     out = np.zeros(2, dtype=np.float64)
     iters = np.zeros(1, dtype=np.int32)
-    ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp")
+    # (a workspace of its own: an IcpJob in flight on this stream keeps its search grid in "icp" / "icpN" across result())
+    ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp_sync")
     with torch.cuda.device(dev):
         fn = lib.umereg_icp_point_to_point_dev_f32 if on_dev else lib.umereg_icp_point_to_point_f32
         rc = fn(_ptr(sp), _ptr(tp), n, m, T_init.data_ptr() if on_dev else T0.ctypes.data, float(max_correspondence_distance),
@@ -676,12 +677,38 @@ class IcpJob:
         self.slot = next(k for k in range(len(used) + 1) if k not in used)     # a workspace of its own among the jobs in flight on this stream
         used.add(self.slot)
         n, m = self.sp.shape[0], self.tp.shape[0]
-        self.ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp" if self.slot == 0 else f"icp{self.slot}")
-        self.state = _icp_pinned.pop() if _icp_pinned else torch.empty(int(lib.umereg_icp_state_bytes()), dtype=torch.uint8, pin_memory=True)
-        self.event = torch.cuda.Event()
-        self.launched = 0
+        self.state = None
         self._res = None
-        self._enqueue(True, 4)
+        try:
+            self.ws = _workspace(dev, lib.umereg_icp_workspace_bytes(n, m), "icp" if self.slot == 0 else f"icp{self.slot}")
+            self.state = _icp_pinned.pop() if _icp_pinned else torch.empty(int(lib.umereg_icp_state_bytes()), dtype=torch.uint8, pin_memory=True)
+            self.event = torch.cuda.Event()
+            self.launched = 0
+            self._enqueue(True, 4)
+        except BaseException:
+            self._release(reuse_state=False)
+            raise
+
+    def _release(self, reuse_state=True):
+        """gives the workspace slot (and the pinned state buffer) back; idempotent.  A job that is dropped without result() -- an
+        exception left the caller's loop -- waits for its last enqueue first: the kernels still write to both."""
+        slot, self.slot = getattr(self, "slot", None), None
+        if slot is None:
+            return
+        _icp_inflight.get(self.key, set()).discard(slot)
+        if self.state is not None and reuse_state:
+            _icp_pinned.append(self.state)
+        self.state = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "slot", None) is not None:
+                ev = getattr(self, "event", None)
+                if ev is not None:
+                    ev.synchronize()
+                self._release()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _enqueue(self, first, iterations):
         lib = _lib.load()
@@ -703,17 +730,20 @@ class IcpJob:
         T = np.empty((4, 4), dtype=np.float64)
         out = np.zeros(2, dtype=np.float64)
         iters = np.zeros(2, dtype=np.int32)
-        while True:
+        try:
+            while True:
+                self.event.synchronize()
+                rc = lib.umereg_icp_state_decode(self.state.data_ptr(), T.ctypes.data, out.ctypes.data, out.ctypes.data + 8, iters.ctypes.data,
+                                                 iters.ctypes.data + 4)
+                _lib.check(rc, "umereg_icp_state_decode")
+                if iters[1] or self.launched > self.par[1] + 1:
+                    break
+                self._enqueue(False, 8)
+        except BaseException:
             self.event.synchronize()
-            rc = lib.umereg_icp_state_decode(self.state.data_ptr(), T.ctypes.data, out.ctypes.data, out.ctypes.data + 8, iters.ctypes.data,
-                                             iters.ctypes.data + 4)
-            _lib.check(rc, "umereg_icp_state_decode")
-            if iters[1] or self.launched > self.par[1] + 1:
-                break
-            self._enqueue(False, 8)
-        _icp_inflight[self.key].discard(self.slot)
-        _icp_pinned.append(self.state)
-        self.state = None
+            raise
+        finally:
+            self._release()
         self._res = SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
         return self._res
 
