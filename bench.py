@@ -427,25 +427,33 @@ def main():
                      "traffic": None, "avg_launch_ms": round(float(np.mean(dist_ms)), 4), "launches": len(dist_ms),
                      "algorithmic_flops_per_launch": dist_flops, "d_used": "512-equivalent (Q-form), fp32 MFMA"}
     # counters that only a profiler can read are taken from the tracked summaries of earlier rocprofv3 --pmc passes of
-    # this same command (tools/collect_profiles.sh), NOT measured in this run -- and labelled as such
-    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    # this same command (tools/collect_profiles.sh <tag> <config>), NOT measured in this run -- labelled as such, and with the
+    # answer to "was that the library that is being timed now": the summaries carry umereg_build_source_hash() of their run
+    lib_hash = umeregrobust_amd._lib.load().umereg_build_source_hash().decode()
+    suffix = "" if a.config == "KT" else "_" + a.config
+    counters_match = {}
+    pmc = os.path.join(REPO, "profiles", f"pmc_traffic{suffix}.json")
     if os.path.exists(pmc):
         tr = json.load(open(pmc))
+        counters_match[os.path.basename(pmc)] = tr.get("library_source_hash") == lib_hash
         for r_ in (roof_mom, roof_dist):
             r_["traffic"] = tr.get(r_["kernel"])
-            r_["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run " \
+            r_["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run " \
                                    "of this command; fabric bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)"
-    sq = os.path.join(REPO, "profiles", "sq_summary.json")
+    sq = os.path.join(REPO, "profiles", f"sq_summary{suffix}.json")
     if os.path.exists(sq):
         sqs = json.load(open(sq))
+        counters_match[os.path.basename(sq)] = sqs.get("library_source_hash") == lib_hash
         for r_ in (roof_mom, roof_dist):
             k_ = sqs.get(r_["kernel"])
             if k_:
                 for key in ("mfma_busy_frac", "valu_busy_frac", "valu_per_mfma", "vmem_busy_frac", "wait_any_frac", "issue_frac", "l2_hit_rate",
-                            "effective_clock_ghz"):
+                            "effective_clock_ghz", "ea_read_bytes", "ea_write_bytes"):
                     if key in k_:
                         r_[key] = k_[key]
-                r_["counters_source"] = "profiles/sq_summary.json (rocprofv3 --pmc SQ passes of an earlier run of this command)"
+                r_["counters_source"] = f"profiles/{os.path.basename(sq)} (rocprofv3 --pmc SQ passes of an earlier run of this command)"
+    for r_ in (roof_mom, roof_dist):
+        r_["counters_match_library"] = bool(counters_match) and all(counters_match.values())
     dominant = roof_mom if mom_total_ms >= dist_total_ms else roof_dist
 
     total_pairs = a.steps * P * world
@@ -476,6 +484,7 @@ def main():
                                         "timed inside the pipeline, beside the kernels of the other pairs in flight", "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
                    "excluded_from_value": "the two keypoint draws of evaluate.py:199-200 (indices pre-drawn with the pair; they are "
                                           "inside `end_to_end`), the feature network, hypothesis selection and ICP (see `end_to_end`)"},
+        "library_source_hash": lib_hash, "counters_match_library_by_file": counters_match,
         "roofline": dominant,
         "rooflines": {"ume_moments_kernel": roof_mom, roof_dist["kernel"]: roof_dist},
         "hypothesis_quality": {"hypotheses": int(c[0]), "within_1.5deg_0.6m": round(c[1] / max(c[0], 1), 4),
@@ -750,6 +759,11 @@ def main():
     if rr:
         result["cpu_baseline"]["rr_pairs"] = rr["pairs"]
         result["cpu_baseline"]["rr_pairs_with_a_different_gate_outcome"] = len(rr["pairs_with_a_different_gate_outcome_same_draws"])
+    cm = dict(result.get("counters_match_library_by_file") or {})
+    if (f1s.get("plain") or {}).get("counters_match_library") is not None:
+        cm["f1_sq_summary.json"] = f1s["plain"]["counters_match_library"]
+    result["counters_match_library_by_file"] = cm
+    result["counters_match_library"] = bool(cm) and all(cm.values())
     result["world"]["launched_by"] = ("bench.py itself (torch.distributed.run re-exec)" if os.environ.get("UMEREG_BENCH_SELF_LAUNCHED")
                                       else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python"))
     if rank == 0:
@@ -831,7 +845,11 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
     if os.path.exists(sq):
         res["kernels"] = {}
         which = "hard" if int(h[17]) > 0 else "plain"
-        tracked = json.load(open(sq)).get(which, {})
+        f1sq = json.load(open(sq))
+        tracked = f1sq.get(which, {})
+        from umeregrobust_amd import _lib as _l
+        f1_match = f1sq.get("library_source_hash") == _l.load().umereg_build_source_hash().decode()
+        res["counters_match_library"] = f1_match
         total_clk = sum(float(v.get("duration_shader_clocks") or 0.0) for v in tracked.values())
         for k, v in tracked.items():
             if float(v.get("duration_shader_clocks") or 0.0) < 0.02 * total_clk:
@@ -850,6 +868,7 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
                 "unit": "Ginst/s (wave64 VALU)", "frac": round(ginst / VALU_ISSUE_PEAK_GINST, 4), "traffic": None,
                 "avg_launch_ms": stages["consensus_pass"], "valu_instructions_per_launch": float(c2["sq_insts_valu"]),
                 "valu_busy_frac": c2.get("valu_busy_frac"), "avg_waves_per_simd": c2.get("avg_waves_per_simd"),
+                "counters_match_library": f1_match,
                 "note": f"{which} KT pair ({M} hypotheses x {Ns} points); duration live (HIP events inside the native call), instruction "
                         "count from profiles/f1_sq_summary.json (rocprofv3 --pmc pass of the same kernel on the same pair); the kernel "
                         "touches HBM for 2 M vector-memory instructions against 6e8 VALU: there is no memory roofline to quote"}}

@@ -16,7 +16,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 N_SIMD, N_XCD = 1024, 8
 KERNELS = ("corr_consensus2_kernel", "corr_consensus_kernel", "corr_score_flat_kernel", "corr_score_kernel", "corr_score_record2_kernel",
            "lattice_list_kernel", "lattice_mark_kernel", "lattice_compact_kernel")
-out = {"_comment": "per-launch averages of rocprofv3 --pmc passes over tools/exp_f1_prod.py (corr_scores alone, default flags, KT pair: "
+LIB_HASH = open(os.path.join(src, "library_hash.txt")).read().strip() if os.path.exists(os.path.join(src, "library_hash.txt")) else None
+out = {"library_source_hash": LIB_HASH, "_comment": "per-launch averages of rocprofv3 --pmc passes over tools/exp_f1_prod.py (corr_scores alone, default flags, KT pair: "
                    "2 500 hypotheses x 10 000 points), one pass per counter set (tools/f1_pmc.sh).  SQ_WAVE_CYCLES / SQ_WAIT_* / "
                    "SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts; GRBM_GUI_ACTIVE = duration in shader clocks summed over "
                    "the 8 XCDs.  valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (duration x 1024 SIMDs); issue_frac = SQ_ACTIVE_INST_ANY / "
