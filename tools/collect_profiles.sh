@@ -18,10 +18,12 @@ cd /tmp && export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0, '$ROOT'); from umeregrobust_amd import _lib; print(_lib.load().umereg_build_source_hash().decode())" > $OUT/library_hash.txt
 echo "$CFG" > $OUT/config.txt
 if [ "$CFG" = "KT" ]; then BENCH_ARGS=""; else BENCH_ARGS="--config $CFG --no-cpu-baseline --e2e-pairs 8 --e2e-hard-pairs 4"; fi
+if [ -z "$ONLY_PMC" ]; then    # (ONLY_PMC=1: the counter passes alone, for a look at a kernel between two builds)
 timeout -s KILL 1500 python $ROOT/bench.py $BENCH_ARGS --detail $OUT/bench_detail.json > $OUT/bench.log 2>&1; grep "^{" $OUT/bench.log | tail -1 > $OUT/bench.json
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python $ROOT/bench.py $BENCH_ARGS --no-cpu-baseline --detail $OUT/stats_detail.json > $OUT/stats.log 2>&1
 f=$(ls $OUT/stats/*/run_kernel_stats.csv $OUT/stats/run_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
 rm -rf $OUT/stats $OUT/stats_detail.json
+fi
 SMALL="--config $CFG --steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e --pool 4 --resident-steps 0 --hard-steps 0 --detail $OUT/small_detail.json"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py $SMALL > $OUT/pmc_$c.log 2>&1

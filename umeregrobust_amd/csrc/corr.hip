@@ -325,10 +325,21 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                 hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
                 UMEREG_CHECK_LAUNCH("chunk_box_kernel");
             }
-            hipLaunchKernelGGL(corr_consensus2_kernel, dim3((Ns + 1) / 2), dim3(2 * kWave), 2 * cons2_lds_per_wave(), st,
-                               (const char*)ws_tgt, ws_coop, (const char*)ws_src, src_pts, (const float4*)src_wfeat, (const float4*)tgt_wfeat, T, (const float*)Tmed,
-                               (const int*)perm, Ns, Nt, M, K, sigma, far_margin, val, served, (unsigned int*)lat + 7,
-                               (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0, (cell_pass_on(c_max, Ns, M, flags, T) && (long)M * Ns >= kCellMinQueries) ? 0.8f : 1.0f);
+            // persistent wavefronts (UMEREG_CONS2_PERSIST, default on): as many workgroups of kC2BlockWaves wavefronts as the chip holds at
+            // UMEREG_CONS2_WAVES per SIMD, each wavefront taking source points off header word kCons2NextWord; off: one wavefront per point
+            const int bw = kC2BlockWaves;
+            const int resident = 256 /* CUs of an MI355X */ * 4 * UMEREG_CONS2_WAVES / bw;
+            const bool persist = UMEREG_CONS2_PERSIST && c_max != 0;        // (the header is zeroed per call only when the lattice workspace exists)
+            const int want = (Ns + bw - 1) / bw, blocks = persist && want > resident ? resident : want;
+            Cons2Args ca;
+            ca.ws_tgt = (const char*)ws_tgt; ca.ws_coop = ws_coop; ca.ws_src = (const char*)ws_src; ca.src_pts = src_pts;
+            ca.vp4 = (const float4*)src_wfeat; ca.vq4 = (const float4*)tgt_wfeat; ca.T = T; ca.Tmed = (const float*)Tmed; ca.perm = (const int*)perm;
+            ca.val = val; ca.served = served; ca.stats = (unsigned int*)lat + 7;
+            ca.next_slot = persist ? (unsigned int*)lat + kCons2NextWord : (unsigned int*)nullptr;
+            ca.Ns = Ns; ca.Nt = Nt; ca.M = M; ca.K = K; ca.sigma = sigma; ca.far_margin_cells = far_margin;
+            ca.dbg = (flags & UMEREG_CORR_DEBUG_STATS) ? 1 : 0;
+            ca.act_frac = (cell_pass_on(c_max, Ns, M, flags, T) && (long)M * Ns >= kCellMinQueries) ? 0.8f : 1.0f;
+            hipLaunchKernelGGL(corr_consensus2_kernel, dim3(blocks), dim3(bw * kWave), bw * cons2_lds_per_wave(), st, ca);
             UMEREG_CHECK_LAUNCH("corr_consensus2_kernel");
         }
         // who takes its leftovers: the grid kernel (few) or the lattice (many); decided on the device, both enqueued

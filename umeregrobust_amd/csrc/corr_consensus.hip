@@ -588,22 +588,18 @@ constexpr int kCons2Zone = UMEREG_CONS2_ZONE;           // zone size up to which
 #endif
 constexpr int kC2DCache = UMEREG_CONS2_DCACHE;   // quads of the zone whose distances stay in registers between the two sweeps of a histogram step
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS2_WAVES, UMEREG_CONS2_WAVES))) void corr_consensus2_kernel(
+// One source point (slot `slot_n` of the processing order) on one wavefront; `my` = the wavefront's LDS region.
+__device__ __forceinline__ void cons2_point(
+    const int slot_n, char* const my, const int lane,
     const char* __restrict__ ws_tgt, const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
     const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed,
     const int* __restrict__ perm, int Ns, int Nt, int M, int K, float sigma, float far_margin_cells, float* __restrict__ val,
     unsigned long long* __restrict__ served, unsigned int* __restrict__ stats, int dbg, float act_frac)
 {
     typedef unsigned int IdxT;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = lane_id();
-    const int slot_n = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (slot_n >= Ns) return;
     const int n = __float_as_int(reinterpret_cast<const float4*>(ws_src + grid_ws(Ns).off_p4s)[slot_n].w);
     perm += (size_t)(slot_n >> 6) * M;
     const GridWs wt = grid_ws(Nt);
-    char* my = lds + (size_t)wave * cons2_lds_per_wave();
     unsigned int* hist = reinterpret_cast<unsigned int*>(my);
     KeyList<IdxT> tie;
     tie.d2 = reinterpret_cast<unsigned int*>(my + (size_t)kCons2HistWords * kWave * 4);
@@ -1075,6 +1071,52 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (lane == 0 && stats) atomicAdd(stats, n_served);
+}
+
+// The pass: one wavefront per source point.  The wavefronts of the launch are PERSISTENT: each takes the next slot of the processing order
+// from a counter in the call's header (word kCons2NextWord, zeroed with the header) until none is left.  A point costs between a tenth and
+// ten times the average (its stage, the width of its zones, how many of its steps go through the histogram), so with one workgroup per
+// pair of points the SIMDs held 2.3 wavefronts on average where three fit: a finished wavefront's registers and LDS stayed idle until
+// its workgroup partner was done too, and the last round of workgroups ran on a draining chip.
+// The arguments come as ONE struct and every point re-reads them from the kernel-argument segment (scalar loads, a few dozen per point):
+// kept in registers across the loop they cost 40 scalar registers more than the one-point kernel had, the allocator spilled them into vector
+// registers, and the kernel no longer fitted the 168 of three wavefronts per SIMD (188 + scratch).
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS2_WAVES, UMEREG_CONS2_WAVES))) void corr_consensus2_kernel(Cons2Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    unsigned int* const next_slot = args.next_slot;
+    const int Ns = args.Ns;
+    auto take = [&]() __attribute__((always_inline)) {
+        unsigned int s = 0u;
+        if (lane == 0) s = atomicAdd(next_slot, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(s);
+    };
+#if !UMEREG_CONS2_PERSIST
+    {
+        const int slot_n = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;      // one wavefront per source point, no loop (A/B builds)
+        if (slot_n < Ns)
+            cons2_point(slot_n, lds + (size_t)wave * cons2_lds_per_wave(), lane, args.ws_tgt, args.ws_coop, args.ws_src, args.src_pts, args.vp4, args.vq4,
+                        args.T, args.Tmed, args.perm, args.Ns, args.Nt, args.M, args.K, args.sigma, args.far_margin_cells, args.val, args.served,
+                        args.stats, args.dbg, args.act_frac);
+        return;
+    }
+#endif
+    int slot_n = next_slot ? take() : (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
+    while (slot_n < Ns) {                                                       // (one call site: the point's code exists once)
+        const Cons2Args* ap = reinterpret_cast<const Cons2Args*>(__builtin_amdgcn_kernarg_segment_ptr());
+        asm volatile("" : "+s"(ap));                                            // opaque: the loads below are this iteration's own
+        const Cons2Args a = *ap;
+        int lane_l = lane;
+        unsigned int my_off = (unsigned int)wave * (unsigned int)cons2_lds_per_wave();
+        asm volatile("" : "+v"(lane_l), "+s"(my_off));                           // (likewise: no per-lane address arithmetic carried across points)
+        cons2_point(slot_n, lds + my_off, lane_l, a.ws_tgt, a.ws_coop, a.ws_src, a.src_pts, a.vp4, a.vq4, a.T, a.Tmed, a.perm, a.Ns, a.Nt, a.M, a.K, a.sigma,
+                    a.far_margin_cells, a.val, a.served, a.stats, a.dbg, a.act_frac);
+        if (!next_slot) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                // the next point reuses this wavefront's LDS region
+        slot_n = take();
+    }
 }
 
 }  // namespace umereg

@@ -839,6 +839,14 @@ __host__ __device__ constexpr size_t cons_lds_per_wave(int cap)
 #ifndef UMEREG_CONS2_WAVES
 #define UMEREG_CONS2_WAVES 3
 #endif
+#ifndef UMEREG_CONS2_BLOCK_WAVES
+#define UMEREG_CONS2_BLOCK_WAVES 2
+#endif
+#ifndef UMEREG_CONS2_PERSIST
+#define UMEREG_CONS2_PERSIST 1
+#endif
+constexpr int kC2BlockWaves = UMEREG_CONS2_BLOCK_WAVES;   // wavefronts per workgroup of the consensus pass (1 or 2: __launch_bounds__(128))
+constexpr int kCons2NextWord = 48;       // header word: next slot of the processing order (persistent wavefronts of corr_consensus2_kernel)
 constexpr int kCons2Cap = UMEREG_CONS2_CAP;   // staged target points per source point (<= 252: byte counters, see above)
 constexpr int kCons2Tie = 8;             // list entries per lane for the candidates of the K-th neighbour's bin (cell pass)
 constexpr int kC2Tie = UMEREG_CONS2_TIE; // the same in the consensus pass (its LDS budget decides the wavefronts per SIMD)

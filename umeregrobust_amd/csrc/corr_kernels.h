@@ -44,11 +44,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed, const int* __restrict__ perm, int Ns, int Nt,
     int M, int K, int cap,
     float sigma, float* __restrict__ val, unsigned long long* __restrict__ served, unsigned int* __restrict__ stats);
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS2_WAVES, UMEREG_CONS2_WAVES))) void corr_consensus2_kernel(
-    const char* __restrict__ ws_tgt, const char* __restrict__ ws_coop, const char* __restrict__ ws_src, const float* __restrict__ src_pts,
-    const float4* __restrict__ vp4, const float4* __restrict__ vq4, const float* __restrict__ T, const float* __restrict__ Tmed,
-    const int* __restrict__ perm, int Ns, int Nt, int M, int K, float sigma, float far_margin_cells, float* __restrict__ val,
-    unsigned long long* __restrict__ served, unsigned int* __restrict__ stats, int dbg, float act_frac);
+// (its arguments as one struct: the kernel's persistent wavefronts re-read them from the kernel-argument segment per source point)
+struct Cons2Args {
+    const char* ws_tgt; const char* ws_coop; const char* ws_src; const float* src_pts; const float4* vp4; const float4* vq4; const float* T;
+    const float* Tmed; const int* perm; float* val; unsigned long long* served; unsigned int* stats; unsigned int* next_slot;
+    int Ns, Nt, M, K; float sigma, far_margin_cells; int dbg; float act_frac;
+};
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS2_WAVES, UMEREG_CONS2_WAVES))) void corr_consensus2_kernel(Cons2Args args);
 
 // ---- corr_lattice.hip ----------------------------------------------------------------------------------------------
 __global__ void leftover_decide_kernel(unsigned int* __restrict__ header, long n_queries, int force, unsigned int c_max, unsigned int left_max = kLeftMax);
