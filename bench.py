@@ -781,7 +781,26 @@ def main():
         dist.destroy_process_group()
 
 
-VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0     # wave64 VALU instructions per ns the chip can issue: 1024 SIMDs x 2.4 GHz / 4 cycles each
+def valu_issue_floor_s(counters, rates):
+    """The time the VALU instructions of one launch need at the MEASURED issue rate of their classes (tools/probe/valu_rate.hip ->
+    profiles/valu_rate.json; classes = the SQ_INSTS_VALU_* counters of the part): sum over classes of instructions / (chip rate of the
+    class, the best cell of its table row).  Packed fp32 instructions are counted once by ADD_F32 / MUL_F32 and twice by FLOPS_FP32:
+    pk = FLOPS_FP32 - (ADD + MUL + 2 FMA).  What no class counter names (moves, selects, compares, bit operations, cross-lane moves) is
+    priced at the rate of the fastest class -- the peak errs on the high side.  -> (seconds, {class: [instructions, Ginst/s]})"""
+    ops = rates["ops"]
+    n = lambda k: float(counters.get(k, 0.0))   # noqa: E731
+    add, mul, fma = n("SQ_INSTS_VALU_ADD_F32"), n("SQ_INSTS_VALU_MUL_F32"), n("SQ_INSTS_VALU_FMA_F32")
+    pk = min(max(n("SQ_INSTS_VALU_FLOPS_FP32") - (add + mul + 2.0 * fma), 0.0), add + mul)
+    fast = max(ops[k]["best"] for k in ("v_add_f32", "v_add_u32", "v_mov_b32", "v_and_b32"))
+    cls = {"packed_f32": [pk, max(ops["v_pk_add_f32"]["best"], ops["v_pk_mul_f32"]["best"])],
+           "add_mul_f32": [add + mul - pk, max(ops["v_add_f32"]["best"], ops["v_mul_f32"]["best"])],
+           "fma_f32": [fma, ops["v_fma_f32"]["best"]],
+           "transcendental": [n("SQ_INSTS_VALU_TRANS_F32"), max(ops["v_rcp_f32"]["best"], ops["v_sqrt_f32"]["best"])],
+           "convert": [n("SQ_INSTS_VALU_CVT"), ops["v_cvt_f32_i32"]["best"]],
+           "int32": [n("SQ_INSTS_VALU_INT32"), fast],
+           "int64": [n("SQ_INSTS_VALU_INT64"), ops.get("v_cmp_lt_u64", ops["v_fma_f64"])["best"]]}
+    cls["other"] = [max(n("SQ_INSTS_VALU") - sum(v[0] for v in cls.values()), 0.0), fast]
+    return sum(v[0] / (v[1] * 1e9) for v in cls.values()), cls
 
 
 def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
@@ -855,23 +874,31 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
             if float(v.get("duration_shader_clocks") or 0.0) < 0.02 * total_clk:
                 continue      # (the lattice's four idle early-outs and the like: their rows stay in the summary file)
             v = {kk: vv for kk, vv in v.items() if kk != "counters"}
-            res["kernels"][k] = dict(v, bound="valu_issue", peak_valu_ginst_per_s=round(VALU_ISSUE_PEAK_GINST, 1),
+            res["kernels"][k] = dict(v, bound="valu_issue",
                                      counters_source="profiles/f1_sq_summary.json (rocprofv3 --pmc SQ passes of tools/exp_f1_prod.py, "
                                                      "an earlier run of the same kernels; tools/f1_pmc.sh)")
-        # the dominant kernel of a registration, priced against its bound -- VALU issue: wave64 VALU instructions (tracked counter pass
-        # of the same kernel on the same pair) / (live duration of the consensus stage x 1 024 SIMDs x 2.4 GHz / 4 cycles)
+        # the dominant kernel of a registration, priced against its bound -- VALU issue, per instruction CLASS: the tracked counter pass
+        # of the same kernel on the same pair gives the instructions of every class, the issue-rate probe what the chip sustains for
+        # each; achieved = instructions / live duration of the consensus stage, peak = instructions / the time they need at those rates
         c2 = tracked.get("corr_consensus2_kernel")
-        if c2 and stages.get("consensus_pass"):
-            ginst = float(c2["sq_insts_valu"]) / (stages["consensus_pass"] * 1e-3) / 1e9
+        vr = os.path.join(REPO, "profiles", "valu_rate.json")
+        if c2 and stages.get("consensus_pass") and os.path.exists(vr) and "SQ_INSTS_VALU_FLOPS_FP32" in c2.get("counters", {}):
+            dur = stages["consensus_pass"] * 1e-3
+            floor_s, cls = valu_issue_floor_s(c2["counters"], json.load(open(vr)))
+            n_valu = float(c2["sq_insts_valu"])
             res["rooflines"] = {"corr_consensus2_kernel": {
-                "kernel": "corr_consensus2_kernel", "bound": "valu_issue", "achieved": round(ginst, 1), "peak": round(VALU_ISSUE_PEAK_GINST, 1),
-                "unit": "Ginst/s (wave64 VALU)", "frac": round(ginst / VALU_ISSUE_PEAK_GINST, 4), "traffic": None,
-                "avg_launch_ms": stages["consensus_pass"], "valu_instructions_per_launch": float(c2["sq_insts_valu"]),
-                "valu_busy_frac": c2.get("valu_busy_frac"), "avg_waves_per_simd": c2.get("avg_waves_per_simd"),
-                "counters_match_library": f1_match,
-                "note": f"{which} KT pair ({M} hypotheses x {Ns} points); duration live (HIP events inside the native call), instruction "
-                        "count from profiles/f1_sq_summary.json (rocprofv3 --pmc pass of the same kernel on the same pair); the kernel "
-                        "touches HBM for 2 M vector-memory instructions against 6e8 VALU: there is no memory roofline to quote"}}
+                "kernel": "corr_consensus2_kernel", "bound": "valu_issue", "achieved": round(n_valu / dur / 1e9, 1),
+                "peak": round(n_valu / floor_s / 1e9, 1), "peak_source": "profiles/valu_rate.json x the kernel's instruction-class mix",
+                "unit": "Ginst/s (wave64 VALU)", "frac": round(floor_s / dur, 4), "traffic": None,
+                "avg_launch_ms": stages["consensus_pass"], "valu_instructions_per_launch": n_valu,
+                "issue_time_floor_ms": round(floor_s * 1e3, 4),
+                "instruction_classes": {k: {"instructions": round(v[0]), "chip_rate_ginst_per_s": v[1]} for k, v in cls.items()},
+                "avg_waves_per_simd": c2.get("avg_waves_per_simd"), "counters_match_library": f1_match,
+                "note": f"{which} KT pair ({M} hypotheses x {Ns} points); duration live (HIP events inside the native call); instruction counts per "
+                        "class from profiles/f1_sq_summary.json (rocprofv3 --pmc passes of the same kernel on the same pair), chip rates per class "
+                        "from tools/probe/valu_rate.hip (simple fp32 / int ops issue in 2 cycles per SIMD, packed fp32, conversions, min / max "
+                        "and 3-operand integer ops in 4, transcendentals in 8); the kernel touches HBM for 2 M vector-memory instructions "
+                        "against 5e8 VALU: there is no memory roofline to quote"}}
     return res
 
 

@@ -1,4 +1,5 @@
-"""Moment-kernel time on the KT pair (both clouds in one launch), optionally with another build of the library (ALTLIB)."""
+"""Moment-kernel time on one pair of a config (both clouds in one launch; usage: python tools/exp_mom_time.py [KT|NS|SY]), optionally with
+another build of the library (ALTLIB=<file under tools/>), e.g. -DUMEREG_MOM_ABLATE=1: the search alone."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -10,11 +11,16 @@ if os.environ.get('ALTLIB'):
 from umeregrobust_amd import ops, evaluate
 from umeregrobust_amd.synth import synth_pair_cfg
 dev = torch.device("cuda:0")
-p = synth_pair_cfg(1, "KT")
+cfg = sys.argv[1] if len(sys.argv) > 1 else "KT"
+p = synth_pair_cfg(1, cfg)
 t = lambda a: torch.from_numpy(a).to(dev)
 pair = evaluate.PairBatch.from_clouds(t(p.src_pts)[None], t(p.tgt_pts)[None], t(p.src_feat)[None], t(p.tgt_feat)[None], t(p.src_inds), t(p.tgt_inds))
-tm = []
-for it in range(25):
-    ops.ume_moments(pair.pts, None, pair.feat, 750, 5.0, kp_index=pair.inds, timing=tm if it >= 5 else None)
-torch.cuda.synchronize()
-print(f"moments {np.mean([a.elapsed_time(b) for a, b in tm]) * 1e3:.1f} us per pair")
+searches = [int(x) if x.isdigit() else x for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["auto"])]
+for search in searches:
+  tm = []
+  for it in range(25):
+    F, cnt = ops.ume_moments(pair.pts, None, pair.feat, 750, 5.0, kp_index=pair.inds, timing=tm if it >= 5 else None, return_count=True, search=search)
+  torch.cuda.synchronize()
+  print(f"search={search}", end=" ")
+  print(f"{cfg}: N {pair.pts.shape[1]} keypoints {pair.inds.shape[1]} mean neighbours {float(cnt.float().mean()):.0f} checksum {float(F.double().abs().sum()):.6f}")
+  print(f"moments {np.mean([a.elapsed_time(b) for a, b in tm]) * 1e3:.1f} us per pair")

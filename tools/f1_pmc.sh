@@ -10,7 +10,9 @@ for which in plain hard; do
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" \
              "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
-             "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAVES_EQ_64 SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC"; do
+             "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAVES_EQ_64 SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC" \
+             "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" \
+             "SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_BRANCH SQ_IFETCH SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64"; do
     i=$((i+1))
     timeout -s KILL 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $ROOT/tools/exp_f1_prod.py $REPS $which > $OUT/p$i.log 2>&1
     f=$(ls $OUT/p$i/*/pmc_counter_collection.csv $OUT/p$i/pmc_counter_collection.csv 2>/dev/null | head -1)

@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS
 #endif
     int slot_n = next_slot ? take() : (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
     while (slot_n < Ns) {                                                       // (one call site: the point's code exists once)
-        const Cons2Args* ap = reinterpret_cast<const Cons2Args*>(__builtin_amdgcn_kernarg_segment_ptr());
+        const Cons2Args* ap = (const Cons2Args*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ap));                                            // opaque: the loads below are this iteration's own
         const Cons2Args a = *ap;
         int lane_l = lane;

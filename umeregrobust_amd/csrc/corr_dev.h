@@ -840,10 +840,10 @@ __host__ __device__ constexpr size_t cons_lds_per_wave(int cap)
 #define UMEREG_CONS2_WAVES 3
 #endif
 #ifndef UMEREG_CONS2_BLOCK_WAVES
-#define UMEREG_CONS2_BLOCK_WAVES 2
+#define UMEREG_CONS2_BLOCK_WAVES 1
 #endif
 #ifndef UMEREG_CONS2_PERSIST
-#define UMEREG_CONS2_PERSIST 1
+#define UMEREG_CONS2_PERSIST 0
 #endif
 constexpr int kC2BlockWaves = UMEREG_CONS2_BLOCK_WAVES;   // wavefronts per workgroup of the consensus pass (1 or 2: __launch_bounds__(128))
 constexpr int kCons2NextWord = 48;       // header word: next slot of the processing order (persistent wavefronts of corr_consensus2_kernel)
