@@ -118,11 +118,6 @@ int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const i
  *   slot: the kernel of rounds 1-3) instead of the matrix pipe (v_mfma_f64_4x4x4_4b_f64, the default: exact fp32 x fp32 products,
  *   fp64 accumulation -- the same arithmetic in another order, bit-identical results on every input tried, 13 % faster). */
 #define UMEREG_MOMENTS_ACC_VALU 8
-/*   flags bits 8..15 (measurement / A-B; 0 = default): which neighbour search serves a keypoint.  Balls that hold many more than K points
- *   (dense clouds) are served by an index-order walk of the cloud -- pytorch3d's own loop, wave-parallel: the first K hits ARE the result --
- *   when it is expected to read fewer than (bits / 4) times the entries the grid search would visit; 255 = never (grid search only).
- *   The neighbour set is the same either way, bit for bit. */
-#define UMEREG_MOMENTS_LINEAR_SHIFT 8
 int umereg_ume_keypoint_order(void* packed, const float* kpts, const int64_t* kp_index, int B, int N,
                               int n_kp, float radius, void* stream);
 /*   kp_index int64 [B,n_kp] (optional): keypoints given as indices into pts -- fuses the gathers

@@ -230,45 +230,6 @@ def test_moments_saturated_ball(gpu):
     assert (np.abs(N_(F[0]) - F64) / scale).max() < 3e-7
 
 
-@pytest.mark.parametrize("order", ["random", "sorted_by_x", "sy"])
-def test_moments_index_order_walk_equals_grid_search(gpu, order):
-    """Balls that hold many more than K points are served by an index-order walk of the cloud (pytorch3d's own loop, wave-parallel)
-    instead of the grid search + streaming top-K: the kept neighbours must be the SAME indices, bit for bit, whichever search runs
-    (forced either way through the flags), and equal the oracle's -- on a randomly permuted dense cloud (what the reference's collate
-    produces), on one whose index order is spatial (the walk's worst case: it reads far before it has K hits; still exact) and on a
-    config-5 cloud (200 000 points, balls of ~6 000: the case the walk was built for).  Mixed counts: some balls hold fewer than K."""
-    from umeregrobust_amd import ops
-    rng = np.random.RandomState(11)
-    if order == "sy":
-        from umeregrobust_amd.synth import synth_pair_cfg
-        p = synth_pair_cfg(3, "SY")
-        pts, f = p.src_pts, p.src_feat
-        kp = pts[p.src_inds[:96]]
-    else:
-        pts = np.concatenate([rng.uniform(-9, 9, (40000, 3)), rng.uniform(20, 60, (2000, 3))]).astype(np.float32)   # dense block + sparse far part
-        if order == "sorted_by_x":
-            pts = pts[np.argsort(pts[:, 0], kind="stable")]
-        else:
-            pts = pts[rng.permutation(pts.shape[0])]
-        f = rng.standard_normal((pts.shape[0], 32)).astype(np.float32)
-        f /= np.linalg.norm(f, axis=1, keepdims=True)
-        kp = np.concatenate([pts[rng.choice(pts.shape[0], 60, replace=False)], np.array([[40, 40, 40], [8.9, 8.9, 8.9], [100, 0, 0]], np.float32)])
-    P, Kp, Ft = T_(pts, gpu)[None], T_(kp, gpu)[None], T_(f, gpu)[None]
-    res = {s_: ops.ume_moments(P, Kp, Ft, 750, 5.0, return_count=True, return_idx=True, search=s_) for s_ in ("grid", "auto", 254)}
-    ref = orc.ball_query(kp[None], pts[None], K=750, radius=5.0, return_nn=False)
-    for s_, (F, cnt, idx) in res.items():
-        assert np.array_equal(N_(idx), ref.idx), s_
-        assert np.array_equal(N_(cnt)[0], (ref.idx[0] >= 0).sum(1)), s_
-    c = N_(res["grid"][1])[0]
-    assert c.max() == 750 and (order == "sy" or c.min() < 750)
-    Fg, Fw = N_(res["grid"][0]), N_(res[254][0])
-    scale = np.abs(Fg).max(axis=(2, 3), keepdims=True) + 1e-30
-    assert (np.abs(Fg - Fw) / scale).max() < 3e-7                        # (same neighbours in another order: fp64 sums, rounded once)
-    assert np.array_equal(N_(res["auto"][0]), Fg) or (np.abs(N_(res["auto"][0]) - Fg) / scale).max() < 3e-7
-    with pytest.raises(ValueError, match="search"):
-        ops.ume_moments(P, Kp, Ft, 750, 5.0, search="fast")
-
-
 # ------------------------------------------------------------------------------------------- a3
 def test_orthobasis(gpu):
     from umeregrobust_amd import ops

@@ -15,11 +15,10 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "KT"
 p = synth_pair_cfg(1, cfg)
 t = lambda a: torch.from_numpy(a).to(dev)
 pair = evaluate.PairBatch.from_clouds(t(p.src_pts)[None], t(p.tgt_pts)[None], t(p.src_feat)[None], t(p.tgt_feat)[None], t(p.src_inds), t(p.tgt_inds))
-searches = [int(x) if x.isdigit() else x for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["auto"])]
-for search in searches:
+for search in ["default"]:
   tm = []
   for it in range(25):
-    F, cnt = ops.ume_moments(pair.pts, None, pair.feat, 750, 5.0, kp_index=pair.inds, timing=tm if it >= 5 else None, return_count=True, search=search)
+    F, cnt = ops.ume_moments(pair.pts, None, pair.feat, 750, 5.0, kp_index=pair.inds, timing=tm if it >= 5 else None, return_count=True)
   torch.cuda.synchronize()
   print(f"search={search}", end=" ")
   print(f"{cfg}: N {pair.pts.shape[1]} keypoints {pair.inds.shape[1]} mean neighbours {float(cnt.float().mean()):.0f} checksum {float(F.double().abs().sum()):.6f}")

@@ -303,6 +303,55 @@ __device__ __forceinline__ int compact_le(int* lst, int cnt, int thr, int lane)
     return out;
 }
 
+// The same two steps with the list held in REGISTERS (lists of up to kSelRegs x 64 entries: K <= 768, every config of the reference).
+// select_kth walks the LDS list once per bit -- 18 passes x 24 dependent reads for a 200 000-point cloud, ~50 000 cycles of a wavefront's
+// life per selection -- and every saturated ball needs at least one (config 5: search 198 of the kernel's 248 us).  Here each lane
+// reads its <= kSelRegs entries once (the reads in flight together), the K-th smallest index is found by bisection on the VALUE with
+// one compare + ballot per entry and step (t = the largest value with fewer than K entries below it), and the survivors are written
+// back from the registers.  Same threshold, same kept set; their ORDER in the list is the one compact_le gives (ascending position).
+constexpr int kSelRegs = 25;
+__device__ __forceinline__ int select_compact_regs(int* lst, int cnt, int K, int nbits, int lane, int& thr_out)
+{
+    int v[kSelRegs];
+#pragma unroll
+    for (int i = 0; i < kSelRegs; ++i) {
+        const int e = i * kWave + lane;
+        v[i] = e < cnt ? lst[e] : 0x7fffffff;
+    }
+    const int n_i = (cnt + kWave - 1) / kWave;                   // (wave-uniform)
+    int t = 0;
+    for (int bit = nbits - 1; bit >= 0; --bit) {
+        const int trial = t | (1 << bit);
+        int below = 0;
+#pragma unroll
+        for (int i = 0; i < kSelRegs; ++i)
+            if (i < n_i) below += (int)__popcll(__ballot(v[i] < trial));
+        if (below < K) t = trial;                                // fewer than K entries below `trial`: the K-th smallest is >= trial
+    }
+    thr_out = t;
+    __builtin_amdgcn_wave_barrier();
+    int out = 0;
+#pragma unroll
+    for (int i = 0; i < kSelRegs; ++i) {
+        if (i < n_i) {
+            const bool keep = v[i] <= t;                         // (the padding, INT_MAX, never is)
+            const unsigned long long m = __ballot(keep);
+            if (keep) lst[out + mbcnt(m)] = v[i];
+            out += (int)__popcll(m);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return out;
+}
+
+// keep the K smallest entries of lst[0..cnt) (cnt > K), -> the new count (= K: the entries are distinct) and the threshold
+__device__ __forceinline__ int keep_k_smallest(int* lst, int cnt, int K, int nbits, int cap, int lane, int& thr)
+{
+    if (cap <= kSelRegs * kWave) return select_compact_regs(lst, cnt, K, nbits, lane, thr);
+    thr = select_kth(lst, cnt, K, nbits, lane);
+    return compact_le(lst, cnt, thr, lane);
+}
+
 // Grid search for one query.  Returns min(#hits, K); the kept ORIGINAL indices are in
 // lst[0..count) in unspecified (deterministic) order.  lst has capacity cap >= K + 2*64.
 __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, const int* __restrict__ start,
@@ -375,8 +424,7 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                         cnt += __popcll(m);
                         if (cnt > cap - kWave) {   // the next chunk might not fit: keep the K smallest
                             __builtin_amdgcn_wave_barrier();
-                            thr = select_kth(lst, cnt, K, nbits, lane);
-                            cnt = compact_le(lst, cnt, thr, lane);
+                            cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
                         }
                     }
                 }
@@ -387,99 +435,8 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (cnt > K) {
-        thr = select_kth(lst, cnt, K, nbits, lane);
-        cnt = compact_le(lst, cnt, thr, lane);
-    }
+    if (cnt > K) cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
     return cnt;
-}
-
-// The same neighbour set by pytorch3d's own route, wave-parallel: walk the ORIGINAL-order table from index 0 and keep the first K points
-// inside the ball.  No list management at all (hits arrive in index order; the walk stops at K), addresses known in advance (kLinUnroll
-// chunks in flight), and the four wavefronts of a workgroup -- neighbouring keypoints -- stream the same lines at about the same time.
-// It reads K N / n_ball points instead of the ~1.7 n_ball of the grid search, so it is the cheaper route exactly where the grid search
-// is at its worst: SATURATED balls (dense clouds: n_ball >> K), where that search keeps re-selecting the K smallest indices out of a
-// list that every chunk refills (SY: 750 kept of ~6 000 in the ball; search 198 of the kernel's 248 us).  Same arithmetic per point,
-// same strict test, same table values: the kept set is bit-identical to the grid search's (returned in ascending index order).
-constexpr int kLinUnroll = 8;
-#ifndef UMEREG_MOM_LINEAR_X4
-#define UMEREG_MOM_LINEAR_X4 12
-#endif
-constexpr int kLinDefaultX4 = UMEREG_MOM_LINEAR_X4;   // the walk is taken when it reads < 3 x the entries of the grid search (tools/exp_mom_time.py sweeps it)
-__device__ __forceinline__ int ball_search_linear(const float4* __restrict__ P4o, float qx, float qy, float qz, float r2, int K, int n_eff,
-                                                  int* lst, int lane)
-{
-    int cnt = 0;
-    for (int base = 0; base < n_eff && cnt < K; base += kWave * kLinUnroll) {
-        float4 pv[kLinUnroll];
-#pragma unroll
-        for (int u = 0; u < kLinUnroll; ++u) {
-            const int pos = base + u * kWave + lane;
-            pv[u] = P4o[pos < n_eff ? pos : n_eff - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < kLinUnroll; ++u) {
-            const int pos = base + u * kWave + lane;
-            const float dx = qx - pv[u].x;
-            const float dy = qy - pv[u].y;
-            const float dz = qz - pv[u].z;
-            float d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
-            const bool hit = (pos < n_eff) && (d2 < r2);
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull && cnt < K) {   // wave-uniform
-                const int at = cnt + mbcnt(m);
-                if (hit && at < K) lst[at] = pos;
-                cnt = min(K, cnt + (int)__popcll(m));
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return cnt;
-}
-
-// How many table entries the grid search would visit for this query (the clipped rows' runs, summed): its cost, and -- a ball holds
-// ~0.55 of its clipped rows -- an estimate of the points inside.  One lane per row, two dependent table reads.
-__device__ __forceinline__ int ball_candidates(const int* __restrict__ start, const Grid& g, float qx, float qy, float qz, float r2, int lane)
-{
-    const float rq = sqrtf(r2) * 1.0001f + 1e-20f;
-    const int y0 = cell_axis(qy - rq, g.miny, g.invy, g.ny), y1 = cell_axis(qy + rq, g.miny, g.invy, g.ny);
-    const int z0 = cell_axis(qz - rq, g.minz, g.invz, g.nz), z1 = cell_axis(qz + rq, g.minz, g.invz, g.nz);
-    const float csy = 1.0f / g.invy, csz = 1.0f / g.invz;
-    const float rq2 = rq * rq;
-    const int ny_r = y1 - y0 + 1, n_rows = ny_r * (z1 - z0 + 1);
-    int total = 0;
-    for (int r0 = 0; r0 < n_rows; r0 += kWave) {
-        const int r = r0 + lane;
-        const int z = z0 + r / ny_r, y = y0 + r % ny_r;
-        const float z_a = g.minz + (float)z * csz, z_b = z_a + csz;
-        const float dzc = fmaxf(fmaxf(z > 0 ? z_a - qz : 0.f, z < g.nz - 1 ? qz - z_b : 0.f), 0.f) * 0.9999f;
-        const float y_a = g.miny + (float)y * csy, y_b = y_a + csy;
-        const float dyc = fmaxf(fmaxf(y > 0 ? y_a - qy : 0.f, y < g.ny - 1 ? qy - y_b : 0.f), 0.f) * 0.9999f;
-        const float rem = rq2 - dyc * dyc - dzc * dzc;
-        int n = 0;
-        if (r < n_rows && rem > 0.f) {
-            const float sx = sqrtf(rem) * 1.0001f + 1e-20f;
-            const int cbase = (z * g.ny + y) * g.nx;
-            n = start[cbase + cell_axis(qx + sx, g.minx, g.invx, g.nx) + 1] - start[cbase + cell_axis(qx - sx, g.minx, g.invx, g.nx)];
-        }
-        total += n;
-    }
-#pragma unroll
-    for (int m = 1; m < kWave; m <<= 1) total += __shfl_xor(total, m, kWave);
-    return total;
-}
-
-// Which search serves a query: the index-order walk when it is expected to read fewer entries than `lin_x4 / 4` times what the grid
-// search visits (whose entries cost more: list appends, threshold re-selection).  Expected walk length: K N / n_ball with
-// n_ball ~ 0.55 n_cand; a ball that may hold fewer than K points (n_ball < 1.3 K) always takes the grid search -- the walk would run
-// to the end of the table.  Wave-uniform; either way the same K indices come back.
-__device__ __forceinline__ bool ball_use_linear(int n_cand, int K, int n_eff, int lin_x4)
-{
-    const float n_ball = 0.55f * (float)n_cand;
-    if (lin_x4 <= 0 || !(n_ball >= 1.3f * (float)K)) return false;
-    return (float)K * (float)n_eff / n_ball < 0.25f * (float)lin_x4 * (float)n_cand;
 }
 
 // ascending bitonic sort of lst[0..n_pow2) (entries beyond the live count must hold INT_MAX)
@@ -715,16 +672,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     }
     const int nbits = 32 - __clz(N > 1 ? N - 1 : 1);
 
-    // saturated balls take the index-order walk (see ball_search_linear); flags bits 8..15: the walk's price relative to a grid entry,
-    // in quarters (0 = the default kLinDefaultX4; 255 = never: the grid search for every query)
-    const int lin_req = (flags >> UMEREG_MOMENTS_LINEAR_SHIFT) & 0xff;
-    const int lin_x4 = lin_req == 0 ? kLinDefaultX4 : (lin_req == 0xff ? 0 : lin_req);
-    const float r2 = radius * radius;
-    int count;
-    if (lin_x4 > 0 && N >= 8 * K && ball_use_linear(ball_candidates(start, g, qx, qy, qz, r2, lane), K, N, lin_x4))
-        count = ball_search_linear(Pb, qx, qy, qz, r2, K, N, lst, lane);
-    else
-        count = ball_search_grid(P4s, start, g, qx, qy, qz, r2, K, N, nbits, lst, cap, lane);
+    const int count = ball_search_grid(P4s, start, g, qx, qy, qz, radius * radius, K, N, nbits, lst, cap, lane);
 
     if (nn_count && lane == 0) nn_count[(size_t)b * n_kp + kp] = count;
     if (nn_idx) {   // optional parity output, ascending like ball_query

@@ -118,11 +118,10 @@ def _timed_end(timing, ev, dev):
 
 
 MOMENTS_ORDERED, MOMENTS_RAW, MOMENTS_ACC_F32, MOMENTS_ACC_VALU = 1, 2, 4, 8      # include/umereg.h
-MOMENTS_LINEAR_SHIFT = 8      # bits 8..15: admission factor of the index-order walk (0 = default, 255 = grid search only)
 
 
 def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None, kp_index=None,
-                normalize=True, acc="f64", search="auto"):
+                normalize=True, acc="f64"):
     """Fused ball query + gather + UME moment matrix (reference evaluate.py:50-60).
     pts [B,N,3], kpts [B,n,3], feat [B,N,32] -> F [B,n,32,4] (+ nn_count i32 [B,n], nn_idx i64 [B,n,K]).
     timing: optional list; receives a (start, end) event pair bracketing the moment kernel alone.
@@ -131,18 +130,7 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
     normalize=False: the un-normalised matrix of generate_ume_from_keypoints2 (utils/loc_utils.py:160-162).
     acc: "f64" (default) -- every term accumulated in fp64, on the matrix pipe (v_mfma_f64_4x4x4_4b_f64); "f64valu" -- the same sums on the
     vector pipe (the kernel of rounds 1-3: bit-identical results, 13 % slower; kept for A/B); "f32" -- neighbour sums in packed fp32 on keypoint-centred
-    coordinates, everything after them in fp64 (UMEREG_MOMENTS_ACC_F32: 9 % faster, 2.6e-5 instead of correctly rounded).
-    search: "auto" (default) -- balls holding many more than K points are served by the index-order walk of the cloud, the others by the
-    grid search; "grid" -- the grid search for every keypoint; an int 1..254 -- the walk's admission factor in quarters (A/B).  The
-    neighbour sets are the same, bit for bit (tests/test_gpu_parity.py::test_moments_saturated_ball)."""
-    if search == "auto":
-        search_bits = 0
-    elif search == "grid":
-        search_bits = 0xff << MOMENTS_LINEAR_SHIFT
-    elif isinstance(search, int) and 1 <= search <= 254:
-        search_bits = search << MOMENTS_LINEAR_SHIFT
-    else:
-        raise ValueError(f"ume_moments: search must be 'auto', 'grid' or an int in 1..254 (got {search!r})")
+    coordinates, everything after them in fp64 (UMEREG_MOMENTS_ACC_F32: 9 % faster, 2.6e-5 instead of correctly rounded)."""
     if acc not in ("f32", "f64", "f64valu"):
         raise ValueError(f"ume_moments: acc must be 'f64' (default: fp64 sums on the matrix pipe), 'f64valu' (the same on the vector "
                          f"pipe) or 'f32' (got {acc!r})")
@@ -181,7 +169,7 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
                 _lib.check(rc, "umereg_ume_keypoint_order")
             ev = _timed(timing, dev)
             rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(kp_index), _ptr(feat), B, N, n, d, int(K),
-                                                   float(radius), ordered | search_bits | (0 if normalize else MOMENTS_RAW) |
+                                                   float(radius), ordered | (0 if normalize else MOMENTS_RAW) |
                                                    (MOMENTS_ACC_F32 if acc == "f32" else MOMENTS_ACC_VALU if acc == "f64valu" else 0), _ptr(F), _ptr(cnt), _ptr(nidx),
                                                    _stream_ptr(dev))
             _lib.check(rc, "umereg_ume_moments_packed_f32")
