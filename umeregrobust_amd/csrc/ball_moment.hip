@@ -309,7 +309,10 @@ __device__ __forceinline__ int compact_le(int* lst, int cnt, int thr, int lane)
 // reads its <= kSelRegs entries once (the reads in flight together), the K-th smallest index is found by bisection on the VALUE with
 // one compare + ballot per entry and step (t = the largest value with fewer than K entries below it), and the survivors are written
 // back from the registers.  Same threshold, same kept set; their ORDER in the list is the one compact_le gives (ascending position).
-constexpr int kSelRegs = 25;
+#ifndef UMEREG_SEL_REGS
+#define UMEREG_SEL_REGS 20
+#endif
+constexpr int kSelRegs = UMEREG_SEL_REGS;
 __device__ __forceinline__ int select_compact_regs(int* lst, int cnt, int K, int nbits, int lane, int& thr_out)
 {
     int v[kSelRegs];
@@ -353,7 +356,7 @@ __device__ __forceinline__ int keep_k_smallest(int* lst, int cnt, int K, int nbi
 }
 
 // Grid search for one query.  Returns min(#hits, K); the kept ORIGINAL indices are in
-// lst[0..count) in unspecified (deterministic) order.  lst has capacity cap >= K + 2*64.
+// lst[0..count) in unspecified (deterministic) order.  lst has capacity cap >= K + (kScanUnroll + 1) * 64 (lds_plan).
 __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, const int* __restrict__ start,
                                                 const Grid& g, float qx, float qy, float qz, float r2, int K,
                                                 int n_eff, int nbits, int* lst, int cap, int lane)
@@ -422,16 +425,20 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                     if (m != 0ull) {   // wave-uniform
                         if (hit) lst[cnt + mbcnt(m)] = oi;
                         cnt += __popcll(m);
-                        if (cnt > cap - kWave) {   // the next chunk might not fit: keep the K smallest
-                            __builtin_amdgcn_wave_barrier();
-                            cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
-                        }
                     }
                 }
             };
+            // room for a whole trip is made BEFORE its loads are issued (keep the K smallest; cap >= K + kScanUnroll chunks): the
+            // selection then runs with none of the trip's points in registers
+            auto make_room = [&](int chunks) __attribute__((always_inline)) {
+                if (cnt > cap - chunks * kWave) {
+                    __builtin_amdgcn_wave_barrier();
+                    cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
+                }
+            };
             int base = beg;
-            for (; end - base > 2 * kWave; base += kWave * kScanUnroll) scan(base, std::integral_constant<int, kScanUnroll>{});
-            if (base < end) scan(base, std::integral_constant<int, 2>{});
+            for (; end - base > 2 * kWave; base += kWave * kScanUnroll) { make_room(kScanUnroll); scan(base, std::integral_constant<int, kScanUnroll>{}); }
+            if (base < end) { make_room(2); scan(base, std::integral_constant<int, 2>{}); }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -885,7 +892,13 @@ int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int
 static void lds_plan(int K, int* cap, int* waves)
 {
     const int Kpad = (int)align_up((size_t)K, 64);
-    *cap = 2 * Kpad + 64;
+    // the list: >= K + a trip of kScanUnroll chunks + one (room is made before a trip's loads are issued); twice K + a chunk where that is
+    // more (fewer selections).  A list that can fit the in-register selection (kSelRegs entries per lane: K <= 768 -- the reference's 750 --
+    // with the default 20) is capped at what fits.  Measured (tools/exp_mom_time.py, us per pair SY / KT / NS; selection in LDS: 242 / 103 /
+    // 47): 25 registers (list 1 600) 149 / 108 / 50, 20 (1 280) 158 / 103 / 48 -- five registers more cost KT its eighth wavefront.
+    const int reg_cap = kSelRegs * kWave, cap_min = Kpad + (kScanUnroll + 1) * kWave;
+    const int cap_big = std::max(2 * Kpad + 64, cap_min);
+    *cap = cap_min <= reg_cap ? std::min(reg_cap, cap_big) : cap_big;
     *waves = (*cap) * 4 * 4 <= 48 * 1024 ? 4 : ((*cap) * 4 * 2 <= 64 * 1024 ? 2 : 1);
 }
 
