@@ -394,6 +394,12 @@ def main():
                         "64.6 measured for this instruction).  `survey_8d_*`: SURVEY 8(d)'s algorithmic bytes (140 n_i + 524 per "
                         "keypoint) / time -- gathers from 8 MB tables that L2 serves, so the ratio to the HBM peak can exceed 1 and is "
                         "not a utilisation; `l2_frac` = the same rate over the 34.5 TB/s aggregate L2 -> CU bandwidth"}
+    if a.config == "SY":
+        # config 5 (200 000-point clouds, saturated balls): the feature table (2 x 25.6 MB) no longer sits in an XCD's 4 MiB L2, the gathers are
+        # served by the fabric / Infinity Cache, and SURVEY 8(d)'s model -- algorithmic bytes against the HBM peak -- is a utilisation here
+        # (< 1).  This is BASELINE.json's "roofline run": the moment kernel is priced the way north_star asks (>= 50 % of the HBM roofline).
+        roof_mom.update({"bound": "hbm", "achieved": round(mom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4),
+                         "mfma_f64_tflops": round(mom_tfs, 2), "mfma_f64_frac": round(mom_tfs / MFMA_F64_PEAK_TFLOPS, 4)})
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
         # region is that kernel alone); the fp64 refine of the ~15 candidates per row is

@@ -184,6 +184,6 @@ int main(int argc, char** argv)
     SWEEP(FMA_F32); SWEEP(MUL_F32); SWEEP(ADD_F32); SWEEP(MUL_THEN_ADD_F32); SWEEP(ADD_U32); SWEEP(AND_B32); SWEEP(LSHL_ADD_U32);
     SWEEP(MAD_U32_U24); SWEEP(MIN_F32); SWEEP(MOV_B32); SWEEP(CMP_CNDMASK); SWEEP(CVT_F32_I32); SWEEP(RCP_F32); SWEEP(SQRT_F32);
     SWEEP(PK_FMA_F32); SWEEP(PK_MUL_F32); SWEEP(PK_ADD_F32); SWEEP(FMA_F64); SWEEP(DS_ADD_U32);
-    SWEEP(LSHLREV_B32); SWEEP(MED3_I32); SWEEP(CNDMASK_B32); SWEEP(CMP_LT_F32); SWEEP(CMP_LT_U64); SWEEP(MOV_DPP); SWEEP(SAD_U8); SWEEP(CVT_I32_F32);
+    SWEEP(LSHLREV_B32); SWEEP(MED3_I32); SWEEP(CMP_LT_F32); SWEEP(CMP_LT_U64); SWEEP(MOV_DPP); SWEEP(SAD_U8); SWEEP(CVT_I32_F32);
     return 0;
 }
