@@ -576,7 +576,7 @@ def sparse_quantize(coordinates, quantization_size):
 
 
 def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_feat, T_kp, rs, corr_ds, pc_corr_max_size,
-                      sigma, corr_num_nn=20):
+                      sigma, corr_num_nn=20, return_scores=False):
     """evaluate.py:258-296: voxel-thin the raw clouds, K=1 feature transfer, host-RNG sub-sampling, FeatureCorrelator.
     -> best T [4,4] fp32."""
     si = sparse_quantize(src_pts_raw, corr_ds)                                            # :261-262
@@ -588,9 +588,9 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     sraw, sfeat = sraw[r], sfeat[r]
     r = rs.choice(traw.shape[0], min(pc_corr_max_size, traw.shape[0]), replace=False)      # :282-285
     traw, tfeat = traw[r], tfeat[r]
-    best, _ = feature_corr_hypothesis_test(sraw[None], traw[None], sfeat[None], tfeat[None], T_kp, sigma=sigma,
-                                           corr_num_nn=corr_num_nn, n_hypotheses=10, fast=True)
-    return best
+    best, scores = feature_corr_hypothesis_test(sraw[None], traw[None], sfeat[None], tfeat[None], T_kp, sigma=sigma,
+                                                corr_num_nn=corr_num_nn, n_hypotheses=10, fast=True)
+    return (best, scores) if return_scores else best
 
 
 def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_max_nn=750, ume_r_nn=5.0, ume_n_samples=2500,
@@ -599,7 +599,7 @@ def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_m
     """evaluate.py:195-309 for one pair, RNG consumption in the reference's order (two keypoint draws, the weighted
     match draw, two correlation sub-sampling draws).  -> dict(T_sel, T_est, rre, rte, rre_sel, rte_sel, n_hyp, and the
     intermediate results a stage-by-stage comparison needs: T_hyp [M,4,4] (every hypothesis), cond [M] (drawn matches), match [n_kp]
-    (row arg-min), sel_index (row of T_hyp that was selected))."""
+    (row arg-min), sel_index (row of T_hyp that was selected), scores [M] (every hypothesis' correlation score))."""
     n_s, n_t = src_pts.shape[0], tgt_pts.shape[0]
     num_init_sel = min(10000, min(n_s, n_t)) if filter_by_ume_dist_cond else min(min(n_s, n_t), ume_n_samples)   # :195-198
     src_inds = rs.choice(n_s, num_init_sel, replace=False)                                 # :199
@@ -614,7 +614,8 @@ def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_m
     else:
         cond = np.arange(D.shape[0])
     T, _ = batch_estimate_transform_ume_old(ume_src[cond], ume_tgt[m[cond]], with_dist=False)   # :248-254
-    T_sel = select_hypothesis(src_pts, tgt_pts, src_pts, tgt_pts, src_feat, tgt_feat, T, rs, corr_ds, pc_corr_max_size, sigma)
+    T_sel, scores = select_hypothesis(src_pts, tgt_pts, src_pts, tgt_pts, src_feat, tgt_feat, T, rs, corr_ds, pc_corr_max_size, sigma,
+                                      return_scores=True)
     T_est, _, _, _ = icp_point_to_point(src_pts, tgt_pts, T_sel.astype(np.float64), icp_max_dist, icp_max_iteration)   # :93-96
     T_est = T_est.astype(np.float32)
     gt = _f32(gt_tform)
@@ -624,4 +625,4 @@ def evaluate_pair_full(src_pts, tgt_pts, src_feat, tgt_feat, gt_tform, rs, ume_m
     rre_sel, rte_sel = err(T_sel)
     hit = np.flatnonzero((T.reshape(T.shape[0], -1) == T_sel.reshape(1, -1)).all(1))
     return dict(T_sel=T_sel, T_est=T_est, rre=rre, rte=rte, rre_sel=rre_sel, rte_sel=rte_sel, n_hyp=int(T.shape[0]),
-                T_hyp=T, cond=np.asarray(cond), match=np.asarray(m), sel_index=int(hit[0]) if hit.size else -1)
+                T_hyp=T, cond=np.asarray(cond), match=np.asarray(m), sel_index=int(hit[0]) if hit.size else -1, scores=np.asarray(scores))
