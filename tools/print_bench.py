@@ -1,11 +1,17 @@
-"""usage: python tools/print_bench.py <bench log>  -- the headline numbers of a bench.py JSON line"""
+"""usage: python tools/print_bench.py <bench log | bench_detail.json>  -- the headline numbers of a bench.py run"""
 import json
+import os
 import sys
 
 d = None
-for l in open(sys.argv[1]):
-    if l.startswith("{"):
-        d = json.loads(l)
+if sys.argv[1].endswith(".json"):          # a bench_detail.json (the full result)
+    d = json.load(open(sys.argv[1]))
+else:
+    for l in open(sys.argv[1]):
+        if l.startswith("{"):
+            d = json.loads(l)
+    if d and d.get("detail") and os.path.exists(d["detail"]):   # the line is a bounded extract: the full result is in the file it names
+        d = json.load(open(d["detail"]))
 print("value", d["value"], d["unit"])
 for k in ("end_to_end", "end_to_end_hard"):
     if k in d:
