@@ -580,6 +580,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #ifndef UMEREG_CONS2_ZONE
 #define UMEREG_CONS2_ZONE 8
 #endif
+#ifndef UMEREG_C2_ABLATE
+#define UMEREG_C2_ABLATE 0   // timing experiments only (results wrong; tools/r05_cons2_ablate.sh): 1 no steps at all (set-up alone), 2 no rank-counting
+#endif                       // steps' work, 4 no histogram steps' sweeps, 8 no second sweep, 16 no sure-in prefix, 32 no first-sweep histogram adds
 constexpr int kCons2Zone = UMEREG_CONS2_ZONE;           // zone size up to which the rank-counting path is taken (a multiple of 4)
 // (the path always ranks kCons2Zone slots; its zones hold 5 points on average: 12 -> 8 slots, 66 -> 28 comparisons per step: a KITTI-test call 1.84 -> 1.78 ms,
 // LoKITTI-size 11.9 -> 11.8; 4 / 16 slots: 1.89 / 1.91)
@@ -817,6 +820,11 @@ __device__ __forceinline__ void cons2_point(
             if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = 0ull;
             continue;
         }
+        if (UMEREG_C2_ABLATE & 1) {
+            if (pos_h < M) val[(size_t)n * M + pos_h] = 0.f;
+            if (lane == 0) served[(size_t)n * n_words + (h0 >> 6)] = 0ull;
+            continue;
+        }
         const float dmax = wave_max_nonneg_f(act ? delta : 0.f);
         // the zone of the step: stage positions [s_min, m_use)
         int m_use, s_min;
@@ -849,7 +857,7 @@ __device__ __forceinline__ void cons2_point(
         };
         float acc = 0.f, d2m = 0.f;
         // the sure-in prefix: among the K nearest of every lane of the step
-        for (int u0 = 0; u0 < s_min; u0 += 4) {
+        for (int u0 = 0; u0 < ((UMEREG_C2_ABLATE & 16) ? 0 : s_min); u0 += 4) {
             f2 t01, t23;
             quad_d2(u0, t01, t23);
             const f4 dt = *reinterpret_cast<const f4*>(dots + u0);
@@ -858,7 +866,9 @@ __device__ __forceinline__ void cons2_point(
             d2m = fmaxf(fmaxf(d2m, fmaxf(t01.x, t01.y)), fmaxf(t23.x, t23.y));
         }
         bool sel_ok;
-        if (u_zone <= kCons2Zone) {
+        if ((UMEREG_C2_ABLATE & 2) && u_zone <= kCons2Zone) {
+            sel_ok = true;
+        } else if (u_zone <= kCons2Zone) {
             // ---- (A) the zone in registers, the `need` smallest keys by rank counting ----
             float z[kCons2Zone];
             unsigned int zi[kCons2Zone];
@@ -917,6 +927,7 @@ __device__ __forceinline__ void cons2_point(
             // registers a wavefront may use at three per SIMD): the second sweep's 16 packed instructions and three stage reads per quad
             // are half of what a candidate costs it.
             f2 dca[kC2DCache > 0 ? kC2DCache : 1], dcb[kC2DCache > 0 ? kC2DCache : 1];
+            if (UMEREG_C2_ABLATE & 4) m_use = s_min;
             const int nq1_c = min(kC2DCache, (m_use - s_min) >> 2);
 #pragma unroll
             for (int qq = 0; qq < kC2DCache; ++qq) {
@@ -981,6 +992,7 @@ __device__ __forceinline__ void cons2_point(
 #pragma unroll
                 for (int u = 0; u < kPer; ++u) cnt2 += __popcll(__ballot(u * kWave + lane < n_c && dc2[u * kWave + lane] <= reach2));
                 m2 = min(m_use, (cnt2 + 3) & ~3);
+                if (UMEREG_C2_ABLATE & 8) m2 = s_min;
             }
             int ntie = 0;
             // classes of the second sweep by comparison with the exact bin edges (cons2_edge): below the K-th neighbour's bin

@@ -888,6 +888,9 @@ __device__ __forceinline__ float cons2_edge(int b, float lo, float sc, float wid
 }
 __device__ __forceinline__ void cons2_hist_add(unsigned int* hist, int lane, int t)
 {
+#ifdef UMEREG_C2_ABLATE
+    if (UMEREG_C2_ABLATE & 32) { asm volatile("" :: "v"(t)); return; }       // (timing experiment: the bin is computed, the counter not touched)
+#endif
     atomicAdd(&hist[(t >> 2) * kWave + lane], 1u << ((t & 3) * 8));       // lane-private byte counter (ds_add_u32)
 }
 // first bin t (0..33) with  base + h[0] + .. + h[t] >= K:  bstar = t, before = base + h[0..t-1], inbin = h[t]; bstar = -1 if none
