@@ -325,8 +325,8 @@ UMEREG_API int umereg_corr_scores_ex_f32(const float* src_pts, const float* tgt_
                 hipLaunchKernelGGL(chunk_box_kernel, dim3(((Nt + kWave - 1) / kWave + 3) / 4, 1), dim3(256), 0, st, ws_tgt, (size_t)0, Nt);
                 UMEREG_CHECK_LAUNCH("chunk_box_kernel");
             }
-            // persistent wavefronts (UMEREG_CONS2_PERSIST, default on): as many workgroups of kC2BlockWaves wavefronts as the chip holds at
-            // UMEREG_CONS2_WAVES per SIMD, each wavefront taking source points off header word kCons2NextWord; off: one wavefront per point
+            // one wavefront per source point, kC2BlockWaves per workgroup.  (-DUMEREG_CONS2_PERSIST=1, A/B builds: as many workgroups as the chip
+            // holds at UMEREG_CONS2_WAVES per SIMD, each wavefront taking source points off header word kCons2NextWord: measured slower)
             const int bw = kC2BlockWaves;
             const int resident = 256 /* CUs of an MI355X */ * 4 * UMEREG_CONS2_WAVES / bw;
             const bool persist = UMEREG_CONS2_PERSIST && c_max != 0;        // (the header is zeroed per call only when the lattice workspace exists)

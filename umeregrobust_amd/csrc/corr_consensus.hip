@@ -1085,14 +1085,13 @@ __device__ __forceinline__ void cons2_point(
     if (lane == 0 && stats) atomicAdd(stats, n_served);
 }
 
-// The pass: one wavefront per source point.  The wavefronts of the launch are PERSISTENT: each takes the next slot of the processing order
-// from a counter in the call's header (word kCons2NextWord, zeroed with the header) until none is left.  A point costs between a tenth and
-// ten times the average (its stage, the width of its zones, how many of its steps go through the histogram), so with one workgroup per
-// pair of points the SIMDs held 2.3 wavefronts on average where three fit: a finished wavefront's registers and LDS stayed idle until
-// its workgroup partner was done too, and the last round of workgroups ran on a draining chip.
-// The arguments come as ONE struct and every point re-reads them from the kernel-argument segment (scalar loads, a few dozen per point):
-// kept in registers across the loop they cost 40 scalar registers more than the one-point kernel had, the allocator spilled them into vector
-// registers, and the kernel no longer fitted the 168 of three wavefronts per SIMD (188 + scratch).
+// The pass: one wavefront per source point, kC2BlockWaves (1) wavefronts per workgroup -- a finished wavefront's registers and LDS free at
+// once; with two per workgroup they stayed idle until the partner was done (1.175 -> 1.145 ms on a KITTI-test pair).
+// -DUMEREG_CONS2_PERSIST=1 (A/B builds, tools/r05_cons2_ab.sh; default 0): PERSISTENT wavefronts that take source points off a counter in the
+// call's header (word kCons2NextWord) -- three wavefronts per SIMD for the whole launch instead of 2.3 on average (a point costs between
+// a tenth and ten times the average), measured SLOWER: 1.21-1.22 ms (profiles/r05/cons2_schedule_ab.txt).  For that form the arguments come
+// as ONE struct and every point re-reads them from the kernel-argument segment: kept in registers across the loop they cost 40 scalar
+// registers more than the one-point kernel has, and the kernel no longer fits the 168 of three wavefronts per SIMD (it still spills 80 B).
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(UMEREG_CONS2_WAVES, UMEREG_CONS2_WAVES))) void corr_consensus2_kernel(Cons2Args args)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
