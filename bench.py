@@ -85,8 +85,9 @@ def parse():
                          "default 3, and 0 for the K1 toy shape)")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
-    ap.add_argument("--depth", type=int, default=4,
-                    help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial")
+    ap.add_argument("--depth", type=int, default=3,
+                    help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial.  Measured (round 5, "
+                         "same box, three repetitions, pairs/s): 2: 3 420, 3: 3 750-3 780, 4: 3 560-3 600, 5: 3 590-3 620, 8: 3 400")
     ap.add_argument("--stream-plan", default=None,
                     help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
                          "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
@@ -233,7 +234,7 @@ def main():
     def leg_counts(slot):
         return counts[slot] if (leg.pipe is pipe and leg.pool is pool) else scratch_counts[slot]
     # per-kernel HIP-event samples: `timing` from pairs that run ALONE (the kernel's own duration: what `roofline` prices),
-    # `timing_situ` from pairs inside the pipeline (what a profiler of this command sees: kernels of 4 pairs share the chip)
+    # `timing_situ` from pairs inside the pipeline (what a profiler of this command sees: kernels of several pairs share the chip)
     timing = {"moments": [], "dist": ops.TimingList()}
     timing_situ = {"moments": [], "dist": ops.TimingList()}
     mom_bytes_log = []
@@ -262,7 +263,7 @@ def main():
         for i in range(first, first + n):
             # per-kernel event pairs (the roofline leg) need the layered entry points; the other pairs go through the one-call
             # a1..a5 entry.  Once per step a pair runs ALONE (pipeline drained on both sides -- inside the timed region, it
-            # costs ~2 % of `value`): with 4 pairs in flight a kernel's wall duration is mostly time-sharing (coarse matcher
+            # costs ~2 % of `value`): with several pairs in flight a kernel's wall duration is mostly time-sharing (coarse matcher
             # 0.29 ms in situ, 0.135 ms alone), and a roofline fraction has to price the kernel, not its neighbours.  Once
             # per step another pair is timed in situ, for comparison with a profiler's summary of this command.
             k = (i - first) % P
