@@ -889,7 +889,9 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
         # each; achieved = instructions / live duration of the consensus stage, peak = instructions / the time they need at those rates
         c2 = tracked.get("corr_consensus2_kernel")
         vr = os.path.join(REPO, "profiles", "valu_rate.json")
-        if c2 and stages.get("consensus_pass") and os.path.exists(vr) and "SQ_INSTS_VALU_FLOPS_FP32" in c2.get("counters", {}):
+        # (the tracked instruction counts are those of the KITTI-test job -- 2 500 hypotheses x 10 000 x 10 000 points: other jobs are not priced)
+        if c2 and stages.get("consensus_pass") and os.path.exists(vr) and "SQ_INSTS_VALU_FLOPS_FP32" in c2.get("counters", {}) \
+                and (M, Ns, int(tp.shape[0])) == (2500, 10000, 10000) and not thinned:
             dur = stages["consensus_pass"] * 1e-3
             floor_s, cls = valu_issue_floor_s(c2["counters"], json.load(open(vr)))
             n_valu = float(c2["sq_insts_valu"])
