@@ -703,9 +703,10 @@ def main():
     # ---- f1 (hypothesis selection) on its own: stage times by HIP events inside the native call, the consensus pass's step
     # statistics, and the counters of the tracked rocprofv3 passes -- what DESIGN 3.6 quotes, recomputable from profiles/ ----
     if rank == 0 and not a.no_e2e and a.e2e_pairs > 0:
-        f1 = {"plain": f1_profile(evaluate, ops, torch, pool[0], args, dev)}
+        kt = a.config == "KT"       # (the tracked counter passes are those of the KITTI-test pairs)
+        f1 = {"plain": f1_profile(evaluate, ops, torch, pool[0], args, dev, price=kt)}
         if hard_pool_first is not None:
-            f1["hard"] = f1_profile(evaluate, ops, torch, hard_pool_first, args, dev)
+            f1["hard"] = f1_profile(evaluate, ops, torch, hard_pool_first, args, dev, price=kt)
         if a.config != "KT":      # (configs whose corr_ds thins the source: also the job the end-to-end leg really runs)
             f1["plain_as_fed"] = f1_profile(evaluate, ops, torch, pool[0], args, dev, thinned=True)
             if hard_pool_first is not None:
@@ -810,7 +811,7 @@ def valu_issue_floor_s(counters, rates):
     return sum(v[0] / (v[1] * 1e9) for v in cls.values()), cls
 
 
-def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
+def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False, price=True):
     """reference utils/loc_utils.py:656-681 on one resident pair (network points as raw clouds, weighted features): per-stage
     HIP-event times of the native call, the consensus pass's statistics (one extra, untimed call with UMEREG_CORR_DEBUG_STATS) and the
     tracked SQ counters.  thinned=False: both clouds sub-sampled to pc_corr_max_size points (the job size the configs allow: 2 500 x
@@ -891,7 +892,7 @@ def f1_profile(evaluate, ops, torch, e, args, dev, reps=5, thinned=False):
         vr = os.path.join(REPO, "profiles", "valu_rate.json")
         # (the tracked instruction counts are those of the KITTI-test job -- 2 500 hypotheses x 10 000 x 10 000 points: other jobs are not priced)
         if c2 and stages.get("consensus_pass") and os.path.exists(vr) and "SQ_INSTS_VALU_FLOPS_FP32" in c2.get("counters", {}) \
-                and (M, Ns, int(tp.shape[0])) == (2500, 10000, 10000) and not thinned:
+                and price and (M, Ns, int(tp.shape[0])) == (2500, 10000, 10000) and not thinned:
             dur = stages["consensus_pass"] * 1e-3
             floor_s, cls = valu_issue_floor_s(c2["counters"], json.load(open(vr)))
             n_valu = float(c2["sq_insts_valu"])
