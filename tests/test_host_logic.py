@@ -339,3 +339,30 @@ def test_bench_gpus_n_launches_itself():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs a HIP device" in r.stderr
+
+
+def test_valu_issue_floor_prices_every_instruction_once():
+    """bench.py's VALU-issue pricing of the consensus pass: every instruction of the launch lands in exactly one class (packed fp32 = the
+    flops the ADD / MUL / FMA counters do not explain), each class is priced at the measured chip rate of that class, and the tracked files
+    of the round give a floor below the kernel's duration"""
+    import json
+
+    import bench
+    rates = {"ops": {k: {"best": v} for k, v in (("v_add_f32", 1000.0), ("v_mul_f32", 1000.0), ("v_add_u32", 1000.0), ("v_mov_b32", 1000.0),
+                                                  ("v_and_b32", 1000.0), ("v_pk_add_f32", 500.0), ("v_pk_mul_f32", 500.0), ("v_fma_f32", 800.0),
+                                                  ("v_rcp_f32", 250.0), ("v_sqrt_f32", 250.0), ("v_cvt_f32_i32", 500.0), ("v_fma_f64", 500.0),
+                                                  ("v_cmp_lt_u64", 500.0))}}
+    c = {"SQ_INSTS_VALU": 1000.0, "SQ_INSTS_VALU_ADD_F32": 200.0, "SQ_INSTS_VALU_MUL_F32": 100.0, "SQ_INSTS_VALU_FMA_F32": 50.0,
+         "SQ_INSTS_VALU_FLOPS_FP32": 200.0 + 100.0 + 2 * 50.0 + 120.0,          # 120 of the 300 adds / muls are packed
+         "SQ_INSTS_VALU_TRANS_F32": 10.0, "SQ_INSTS_VALU_CVT": 20.0, "SQ_INSTS_VALU_INT32": 150.0, "SQ_INSTS_VALU_INT64": 30.0}
+    floor_s, cls = bench.valu_issue_floor_s(c, rates)
+    assert cls["packed_f32"][0] == 120.0 and cls["add_mul_f32"][0] == 180.0 and cls["other"][0] == 1000.0 - (300 + 50 + 10 + 20 + 150 + 30)
+    assert sum(v[0] for v in cls.values()) == 1000.0
+    want = (120 / 500 + 180 / 1000 + 50 / 800 + 10 / 250 + 20 / 500 + 150 / 1000 + 30 / 500 + 440 / 1000) * 1e-9
+    assert abs(floor_s - want) < 1e-15
+    sq, vr = os.path.join(REPO, "profiles", "f1_sq_summary.json"), os.path.join(REPO, "profiles", "valu_rate.json")
+    if os.path.exists(sq) and os.path.exists(vr):
+        k = json.load(open(sq))["plain"]["corr_consensus2_kernel"]
+        floor_s, cls = bench.valu_issue_floor_s(k["counters"], json.load(open(vr)))
+        dur_s = k["duration_shader_clocks"] / 2.4e9                              # (at most this long: the clock is <= 2.4 GHz)
+        assert 0.3 * dur_s < floor_s < dur_s and cls["packed_f32"][0] > 0
