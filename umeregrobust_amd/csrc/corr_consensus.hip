@@ -580,9 +580,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #ifndef UMEREG_CONS2_ZONE
 #define UMEREG_CONS2_ZONE 8
 #endif
+#ifndef UMEREG_CONS2_RANK_TRIM
+#define UMEREG_CONS2_RANK_TRIM 1
+#endif
+#ifndef UMEREG_CONS2_TIE_FAST
+#define UMEREG_CONS2_TIE_FAST 1
+#endif
 #ifndef UMEREG_C2_ABLATE
 #define UMEREG_C2_ABLATE 0   // timing experiments only (results wrong; tools/r05_cons2_ablate.sh): 1 no steps at all (set-up alone), 2 no rank-counting
-#endif                       // steps' work, 4 no histogram steps' sweeps, 8 no second sweep, 16 no sure-in prefix, 32 no first-sweep histogram adds
+#endif                       // steps' work, 4 no histogram steps' sweeps, 8 no second sweep, 16 no sure-in prefix, 32 no first-sweep histogram adds, 256 no trimming of the tie list
 constexpr int kCons2Zone = UMEREG_CONS2_ZONE;           // zone size up to which the rank-counting path is taken (a multiple of 4)
 // (the path always ranks kCons2Zone slots; its zones hold 5 points on average: 12 -> 8 slots, 66 -> 28 comparisons per step: a KITTI-test call 1.84 -> 1.78 ms,
 // LoKITTI-size 11.9 -> 11.8; 4 / 16 slots: 1.89 / 1.91)
@@ -1025,6 +1031,17 @@ __device__ __forceinline__ void cons2_point(
                 if (__any(c2[0] || c2[1] || c2[2] || c2[3])) {
                     const f4 W = reinterpret_cast<const f4*>(stage + u0 * 4)[3];
                     const float wv[4] = {W.x, W.y, W.z, W.w};
+                    // no lane's list overflows with this quad (the rule; ONE wave-wide test per quad instead of one per candidate): plain appends
+                    const int n_new = (c2[0] ? 1 : 0) + (c2[1] ? 1 : 0) + (c2[2] ? 1 : 0) + (c2[3] ? 1 : 0);
+                    if (UMEREG_CONS2_TIE_FAST && !__any(ntie + n_new > kC2Tie)) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
+                            if (c2[k]) tie.set(ntie, lane, key);
+                            ntie += c2[k] ? 1 : 0;
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
@@ -1059,7 +1076,47 @@ __device__ __forceinline__ void cons2_point(
                 // sweep summed on the fly: the K-th distance found is the largest key kept here or one of the sure-in prefix, whose
                 // maximum d2m already holds; the count is K iff need_t keys are kept)
                 const int bound = wave_max_nonneg(ntie);
+                if (UMEREG_C2_ABLATE & 256) ntie = min(ntie, need_t);           // (timing experiment: no trimming)
+#if UMEREG_CONS2_RANK_TRIM
+                // Which of a lane's <= kC2Tie listed keys are its need_t smallest: by rank counting in registers (one comparison per pair of
+                // slots, as the agreeing steps do it), summed in slot order -- instead of dropping the largest key one at a time (an arg-max
+                // sweep over the LDS list per dropped key, then a second pass over the list for the sum: 0.06 of the pass's 1.08 ms on a
+                // KITTI-test pair, 0.27 of 2.95 on a half-overlapping one).  Keys are unique (the index word holds the stage position).
+                if (__any(ntie > need_t)) {
+                    unsigned long long kk[kC2Tie];
+                    int below[kC2Tie], above[kC2Tie];
+#pragma unroll
+                    for (int e = 0; e < kC2Tie; ++e) {
+                        kk[e] = ~0ull;
+                        if (e < bound) kk[e] = e < ntie ? tie.get(e, lane) : ~0ull;
+                        below[e] = 0; above[e] = 0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < kC2Tie; ++i)
+#pragma unroll
+                        for (int j = i + 1; j < kC2Tie; ++j)
+                            if (j < bound) {                                     // (wave-uniform)
+                                const int lt = kk[i] < kk[j] ? 1 : 0;
+                                below[j] += lt;
+                                above[i] += lt;
+                            }
+#pragma unroll
+                    for (int e = 0; e < kC2Tie; ++e) {
+                        if (e < bound) {
+                            const int rank = below[e] + (bound - 1 - e) - above[e];     // keys below this one (absent slots rank last)
+                            const bool on = e < ntie && rank < need_t;
+                            const float d2 = __uint_as_float((unsigned int)(kk[e] >> 32));
+                            const float dv = dots[(unsigned int)kk[e] & ((1u << kConsIdxBits) - 1u)];
+                            const float term = wgt(d2) * dv;
+                            acc += on ? term : 0.f;
+                            d2m = on ? fmaxf(d2m, d2) : d2m;
+                        }
+                    }
+                    ntie = need_t >= 0 ? min(ntie, need_t) : ntie;
+                } else
+#else
                 while (__any(ntie > need_t)) drop_max(tie, ntie, ntie > need_t, bound, lane);
+#endif
 #pragma unroll
                 for (int e = 0; e < kC2Tie; ++e) {
                     if (e < bound) {
