@@ -1038,6 +1038,18 @@ __global__ __launch_bounds__(64) void corr_cell_kernel(const char* __restrict__ 
                 if (__any(c1[0] || c1[1] || c1[2] || c1[3] || c2[0] || c2[1] || c2[2] || c2[3])) {
                     const f4 W = reinterpret_cast<const f4*>(stage_l + u0 * 4)[3];
                     const float wv[4] = {W.x, W.y, W.z, W.w};
+                    // no lane's tie list overflows with this quad (the rule): plain appends, ONE wave-wide test per quad instead of one per candidate
+                    const int n_new = (c2[0] ? 1 : 0) + (c2[1] ? 1 : 0) + (c2[2] ? 1 : 0) + (c2[3] ? 1 : 0);
+                    if (!__any(ntie + n_new > kCons2Tie)) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
+                            if (c1[k] && cnt_l < K) { list.set(cnt_l, lane, key); ++cnt_l; }
+                            if (c2[k]) tie.set(ntie, lane, key);
+                            ntie += c2[k] ? 1 : 0;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const unsigned long long key = ((unsigned long long)__float_as_uint(d2v[k]) << 32) | (unsigned int)__float_as_int(wv[k]);
