@@ -116,6 +116,11 @@ def parse():
                     help="hard pairs of the CPU-vs-HIP recall check (the oracle costs ~1 s per reduced-size pair on a 256-core host; "
                          "stops after --cpu-rr-budget seconds of CPU time)")
     ap.add_argument("--cpu-rr-budget", type=float, default=400.0)
+    ap.add_argument("--roofline-every", type=int, default=None,
+                    help="steps between two roofline samples (a pair run ALONE with the pipeline drained around it, and one timed in situ).  "
+                         "Default: steps // 5, at least 1 -- five samples of each kind over the timed region (20 steps: every 4th).  A sample "
+                         "drains the pipeline inside the timed region: one per step cost 6-7 %% of `value` (3 665 against 3 916-3 944 pairs/s at "
+                         "every 4th, same box), more than the thing measured varies")
     ap.add_argument("--detail", default=None,
                     help="file the FULL result (notes, stage tables, per-kernel counters) is written to; the printed line is a bounded "
                          "extract of it (umeregrobust_amd/benchline.py).  Default: gpurun_out/bench_detail.json under the repo")
@@ -258,23 +263,27 @@ def main():
         with torch.cuda.stream(leg.pipe.stream_of(h)):          # a7 + recall gates, on the device
             ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, leg_counts(h.slot))
 
+    roofline_every = a.roofline_every if a.roofline_every else max(1, a.steps // 5)
+
     def run(first, n, record):
         pending = []
         for i in range(first, first + n):
             # per-kernel event pairs (the roofline leg) need the layered entry points; the other pairs go through the one-call
-            # a1..a5 entry.  Once per step a pair runs ALONE (pipeline drained on both sides -- inside the timed region, it
-            # costs ~2 % of `value`): with several pairs in flight a kernel's wall duration is mostly time-sharing (coarse matcher
+            # a1..a5 entry.  Once per sampled step (--roofline-every) a pair runs ALONE (pipeline drained on both sides -- inside the timed region, it
+            # costs 6-7 % of `value` when done every step, hence every steps // 5): with several pairs in flight a kernel's wall duration is mostly time-sharing (coarse matcher
             # 0.29 ms in situ, 0.135 ms alone), and a roofline fraction has to price the kernel, not its neighbours.  Once
             # per step another pair is timed in situ, for comparison with a profiler's summary of this command.
             k = (i - first) % P
-            if record and k == 0:
+            step = (i - first) // P
+            sample = record and step % roofline_every == 0
+            if sample and k == 0:
                 while pending:
                     finish(pending.pop(0))
                 torch.cuda.synchronize()
                 finish(submit(i, timing))
                 torch.cuda.synchronize()
                 continue
-            pending.append(submit(i, timing_situ if (record and k == P // 2) else None))
+            pending.append(submit(i, timing_situ if (sample and k == P // 2) else None))
             if len(pending) >= depth:
                 finish(pending.pop(0))
         while pending:
@@ -486,8 +495,9 @@ def main():
                                 "pipeline slot's staging buffers, 14 MB, then one graph replay): what a loop like evaluate.py:175 gets"
                                 if graph_mode == "slot" else f"named path a1-a7, pairs/s, graph mode '{graph_mode}'"),
                    "resident_replay": resident_replay, "named_path_on_hard_pairs": hard_named,
-                   "roofline_sampling": "one pair per step runs alone (pipeline drained before and after, inside the timed region): "
-                                        "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per step "
+                   "roofline_sampling_every_n_steps": roofline_every,
+                   "roofline_sampling": "one pair per sampled step runs alone (pipeline drained before and after, inside the timed region): "
+                                        "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per sampled step "
                                         "timed inside the pipeline, beside the kernels of the other pairs in flight", "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
                    "excluded_from_value": "the two keypoint draws of evaluate.py:199-200 (indices pre-drawn with the pair; they are "
                                           "inside `end_to_end`), the feature network, hypothesis selection and ICP (see `end_to_end`)"},
