@@ -4,6 +4,11 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from types import SimpleNamespace
+if os.environ.get("ALTLIB"):       # another build of the library (a file under tools/)
+    import umeregrobust_amd._build as _b
+    _b.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ["ALTLIB"])
+    import umeregrobust_amd._lib as _L
+    _L.LIB_PATH = _b.LIB_PATH
 from umeregrobust_amd import evaluate
 from umeregrobust_amd.synth import synth_pair_cfg
 from umeregrobust_amd.utils.general_utils import benchmark_config_path, update_namespace_from_yaml

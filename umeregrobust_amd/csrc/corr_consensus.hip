@@ -593,8 +593,12 @@ constexpr int kCons2Zone = UMEREG_CONS2_ZONE;           // zone size up to which
 // (the path always ranks kCons2Zone slots; its zones hold 5 points on average: 12 -> 8 slots, 66 -> 28 comparisons per step: a KITTI-test call 1.84 -> 1.78 ms,
 // LoKITTI-size 11.9 -> 11.8; 4 / 16 slots: 1.89 / 1.91)
 #ifndef UMEREG_CONS2_DCACHE
-#define UMEREG_CONS2_DCACHE 12
+#define UMEREG_CONS2_DCACHE 10
 #endif
+// (10 since round 5, was 12: 147 registers instead of 155-164.  Alone the pass runs as fast with 9-12 cached quads; what the registers decide
+// is what fits BESIDE it: three wavefronts of <= 160 allocated registers leave a SIMD's file room for the small kernels of the next pair,
+// which evaluate_pairs overlaps with this pass -- at 164 (168 allocated, the file full) that loop fell from 440 to 400 pairs/s, at 147 it
+// runs at 445-455: profiles/r05/cons2_registers.txt)
 constexpr int kC2DCache = UMEREG_CONS2_DCACHE;   // quads of the zone whose distances stay in registers between the two sweeps of a histogram step
 
 // One source point (slot `slot_n` of the processing order) on one wavefront; `my` = the wavefront's LDS region.
@@ -929,7 +933,7 @@ __device__ __forceinline__ void cons2_point(
             const float sc = __builtin_amdgcn_rcpf(width);
 #pragma unroll
             for (int i = 0; i < kCons2HistWords; ++i) hist[i * kWave + lane] = 0u;
-            // The distances of the zone's first kC2DCache quads stay in registers between the two sweeps (12: 152 of the 168
+            // The distances of the zone's first kC2DCache quads stay in registers between the two sweeps (ten since round 5; twelve were 152 of the 168
             // registers a wavefront may use at three per SIMD): the second sweep's 16 packed instructions and three stage reads per quad
             // are half of what a candidate costs it.
             f2 dca[kC2DCache > 0 ? kC2DCache : 1], dcb[kC2DCache > 0 ? kC2DCache : 1];
