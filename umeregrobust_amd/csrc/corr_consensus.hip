@@ -933,8 +933,8 @@ __device__ __forceinline__ void cons2_point(
             const float sc = __builtin_amdgcn_rcpf(width);
 #pragma unroll
             for (int i = 0; i < kCons2HistWords; ++i) hist[i * kWave + lane] = 0u;
-            // The distances of the zone's first kC2DCache quads stay in registers between the two sweeps (12: 152 of the 168
-            // registers a wavefront may use at three per SIMD): the second sweep's 16 packed instructions and three stage reads per quad
+            // The distances of the zone's first kC2DCache quads stay in registers between the two sweeps (ten; twelve were 152 of the 168
+            // registers a wavefront may use at three per SIMD -- see UMEREG_CONS2_DCACHE for why not): the second sweep's 16 packed instructions and three stage reads per quad
             // are half of what a candidate costs it.
             f2 dca[kC2DCache > 0 ? kC2DCache : 1], dcb[kC2DCache > 0 ? kC2DCache : 1];
             if (UMEREG_C2_ABLATE & 4) m_use = s_min;
