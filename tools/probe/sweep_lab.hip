@@ -16,7 +16,7 @@ constexpr int kWave = 64;
 constexpr int kQuads = 17;                 // mean zone of a KITTI-test histogram step: 67 candidates
 constexpr size_t kLdsPerWave = 12544;      // what the pass uses per wavefront (12.25 KiB): three wavefronts per SIMD
 
-enum { READS = 1, DIST_PK = 2, DIST_SCALAR = 4, BIN = 8, ADDR = 16, ADD = 32, SWEEP2 = 64, PRED = 128 };
+enum { READS = 1, DIST_PK = 2, DIST_SCALAR = 4, BIN = 8, ADDR = 16, ADD = 32, SWEEP2 = 64, PRED = 128, LANEMAJOR = 256 };
 
 template <int MASK>
 __global__ __launch_bounds__(64) void sweep_kernel(float* __restrict__ out, int iters, float lo, float sc, float thA)
@@ -83,7 +83,15 @@ __global__ __launch_bounds__(64) void sweep_kernel(float* __restrict__ out, int 
                 } else {
                     acc += d[k];
                 }
-                if (MASK & ADDR) {
+                if ((MASK & ADDR) && (MASK & LANEMAJOR)) {
+                    // lane-major byte counters: 36 bytes per lane, byte t -- the word is (lane * 36 + t) & ~3, the shift its low two bits x 8:
+                    // one variable shift less per candidate; lanes no longer hit distinct banks
+                    const unsigned int a = (unsigned int)lane * 36u + (unsigned int)t;
+                    unsigned int* w = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(hist) + (a & ~3u));
+                    const unsigned int inc = 1u << ((a << 3) & 31u);
+                    if (MASK & ADD) atomicAdd(w, inc);
+                    else acc += __uint_as_float((unsigned int)(size_t)w ^ inc);
+                } else if (MASK & ADDR) {
                     unsigned int* w = &hist[(t >> 2) * kWave + lane];
                     const unsigned int inc = 1u << ((t & 3) * 8);
                     if ((MASK & ADD) && (MASK & PRED)) {       // only candidates inside the range touch a counter; the others count in a register
@@ -150,5 +158,7 @@ int main(int argc, char** argv)
     run<READS | DIST_PK | BIN | ADDR | ADD>("first sweep, range holding ~half of the candidates", d_out, iters, ghz, 0.0f, 0.5f);
     run<READS | DIST_PK | BIN | ADDR | ADD | PRED>("  adds only for candidates inside the range (others counted in a register)", d_out, iters, ghz, 0.0f, 0.5f);
     run<READS | DIST_PK | BIN | ADDR | ADD | PRED>("  the same, range holding ~a tenth", d_out, iters, ghz);
+    run<READS | DIST_PK | BIN | ADDR | ADD | LANEMAJOR>("first sweep with lane-major byte counters (range ~half)", d_out, iters, ghz, 0.0f, 0.5f);
+    run<READS | DIST_PK | BIN | ADDR | ADD | LANEMAJOR>("  the same, range ~a tenth (most candidates in the overflow byte)", d_out, iters, ghz);
     return 0;
 }
