@@ -73,16 +73,20 @@ def parse():
                     help="distinct synthetic pairs resident in HBM (cycled; pair g uses pool[g %% pool]).  The reference's loop runs over "
                          "distinct pairs (evaluate.py:175): with the default graph mode every submitted pair is NEW to the pipeline")
     ap.add_argument("--graph-mode", default="slot", choices=["slot", "pair", "none"],
-                    help="phase A (a1-a5) as a hipGraph: 'slot' = one graph per pipeline slot over staging buffers it owns, every pair "
-                         "copied in device to device (any stream of distinct pairs; what `value` is measured on); 'pair' = one graph per "
-                         "(slot, resident PairBatch), replayed in place (callers that cycle through resident buffers; the headline of "
-                         "rounds 2-3, reported as config.resident_replay); 'none' = 12 plain launches per pair")
+                    help="phase A (a1-a5) as a hipGraph: 'slot' (= 'pair', kept as a synonym) = ONE graph per pipeline slot, captured at a "
+                         "capacity, whose kernels read every submitted pair's clouds where they lie through a device-side record (any stream "
+                         "of distinct pairs of any sizes that fit; what `value` is measured on); 'none' = 13 plain launches per pair")
     ap.add_argument("--resident-steps", type=int, default=5,
                     help="steps of the additional 'pair'-mode leg over 4 resident pairs (config.resident_replay; 0 = skip)")
     ap.add_argument("--hard-steps", type=int, default=None,
                     help="steps of the named-path leg repeated over HARD pairs (partial overlap, noise, corrupted features: the matcher's "
                          "filter has less to prune with); reported as config.named_path_on_hard_pairs, not part of `value` (0 = skip; "
                          "default 3, and 0 for the K1 toy shape)")
+    ap.add_argument("--ragged-steps", type=int, default=None,
+                    help="steps of the named-path leg repeated over RAGGED pairs -- N_src != N_tgt, both drawn per pair from U(0.7 N, N) "
+                         "independently, the shape the reference's collate produces (kitti_dataset.py:568-569) -- on the SAME pipeline and "
+                         "graphs as `value`; reported as config.named_path_on_ragged_pairs (0 = skip; default 3, and 0 for the K1 toy shape)")
+    ap.add_argument("--ragged-pool", type=int, default=16, help="distinct ragged pairs resident in HBM for that leg")
     ap.add_argument("--precision", default="f16r", choices=["f16r", "f16x2", "f32"],
                     help="distance GEMM: f16 filter + fp64 refine (default), split-f16 MFMA scan, or exact-fp32 MFMA scan")
     ap.add_argument("--depth", type=int, default=3,
@@ -135,18 +139,20 @@ def _synth_one(job):
 
 def synth_many(seeds, kw, workers):
     """The pool's synthetic pairs (0.4 s of numpy each at KITTI size), generated on a few worker processes: `spawn`, so that the
-    children never see this process's HIP context; they import numpy only (umeregrobust_amd.synth).  Serial on any failure."""
+    children never see this process's HIP context; they import numpy only (umeregrobust_amd.synth).  Serial on any failure.
+    kw: one dict for all seeds, or a list with one dict per seed (pairs of different shapes)."""
     seeds = list(seeds)
+    jobs = [(s_, kw[i] if isinstance(kw, (list, tuple)) else kw) for i, s_ in enumerate(seeds)]
     workers = max(1, min(8, int(workers), len(seeds)))
     if workers > 1 and len(seeds) >= 8:
         try:
             import multiprocessing as mp
             from concurrent.futures import ProcessPoolExecutor
             with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
-                return list(ex.map(_synth_one, [(s_, kw) for s_ in seeds], chunksize=max(1, len(seeds) // (4 * workers))))
+                return list(ex.map(_synth_one, jobs, chunksize=max(1, len(seeds) // (4 * workers))))
         except Exception as e:   # noqa: BLE001
             print(f"[bench] parallel pool generation failed ({e!r}); generating serially", file=sys.stderr)
-    return [_synth_one((s_, kw)) for s_ in seeds]
+    return [_synth_one(j_) for j_ in jobs]
 
 
 def gate_counts(rre, rte):
@@ -316,8 +322,6 @@ def main():
     # reported as config.resident_replay so that both modes are on record from the same box and run. ----
     resident_replay = None
     if a.resident_steps > 0 and graph_mode == "slot" and all(e.pair is not None for e in pool):
-        leg.pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs="pair",
-                                                 stream_plan=a.stream_plan, match_opts=match_opts)
         leg.pool = pool[:4]
         run(0, 2 * P, False)
         fence()
@@ -330,8 +334,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el_r = float(tmax.item())
         resident_replay = {"pairs_per_s": round(a.resident_steps * P * world / el_r, 1), "steps": a.resident_steps, "resident_pairs": len(leg.pool),
-                           "note": "phase A as one hipGraph per (slot, resident PairBatch), replayed in place: no input copies, the same four "
-                                   "pairs' tables stay in L2 / MALL (how rounds 2-3 measured `value`)"}
+                           "note": "the same pipeline and graphs cycling through FOUR resident pairs: their tables stay in L2 / MALL (how "
+                                   "rounds 2-3 measured `value`)"}
         leg.pipe, leg.pool = pipe, pool
 
     # ---- the same leg (same pipeline, same graphs, distinct pairs copied into the slots) on pairs that can FAIL: two 240-degree
@@ -373,6 +377,57 @@ def main():
                       "note": f"named path a1-a7 on {a.config}-size HARD pairs (two 240-deg sectors 100 deg apart, sigma = 2 cm, 20 % corrupted "
                               "features), same pipeline and graphs as `value`; `value` itself is measured on exact rigid copies"}
         leg.pool = pool
+
+    # ---- the same leg (same pipeline, same ONE graph per slot) on RAGGED pairs: N_src != N_tgt, both drawn per pair from
+    # U(0.7 N, N) independently -- the shape the reference's collate produces (datasets/kitti/kitti_dataset.py:568-569 dilutes source
+    # and target independently; evaluate.py:195-204), and which `value`'s equally large clouds are the special case of.  A pair of
+    # another shape costs a 64-byte record written on the device before the replay: `graphs_captured_during_the_leg` must be 0. ----
+    ragged_named = None
+    if a.ragged_steps is None:
+        a.ragged_steps = 0 if a.config == "K1" else 3
+    if a.ragged_steps > 0 and a.batch_clouds:
+        from umeregrobust_amd.synth import ragged_sizes
+        n_rag = max(1, a.ragged_pool)
+        sizes = [ragged_sizes(i, int(0.7 * cfg["N"]), cfg["N"]) for i in range(n_rag)]
+        rag_pool = []
+        for p_host in synth_many(range(7000, 7000 + n_rag),
+                                 [dict(n_src=s_[0], n_tgt=s_[1], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]) for s_ in sizes], host_threads):
+            e = resident(p_host)
+            e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds)
+            e.mom_bytes = []
+            rag_pool.append(e)
+        leg.pool = rag_pool
+        cap0 = pipe.captures
+        run(0, P, False)
+        torch.cuda.synchronize()
+        cap1 = pipe.captures
+        for c_ in scratch_counts:
+            c_.zero_()
+        fence()
+        t1 = time.perf_counter()
+        run(P, a.ragged_steps * P, False)
+        fence()
+        el_g = time.perf_counter() - t1
+        gc = torch.stack(scratch_counts).sum(0).double()
+        if collective:
+            tmax = torch.tensor([el_g], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el_g = float(tmax.item())
+            dist.all_reduce(gc, op=dist.ReduceOp.SUM)
+        gc = gc.cpu().numpy()
+        ragged_named = {"pairs_per_s": round(a.ragged_steps * P * world / el_g, 1), "steps": a.ragged_steps, "distinct_pairs": n_rag,
+                        "ms_per_pair": round(1e3 * el_g / (a.ragged_steps * P), 4),
+                        "ratio_to_value": round((a.ragged_steps * P * world / el_g) / (a.steps * P * world / elapsed), 4),
+                        "cloud_sizes": {"min": int(min(min(s_) for s_ in sizes)), "max": int(max(max(s_) for s_ in sizes)),
+                                        "mean": round(float(np.mean(sizes)), 0), "first_pairs": [list(s_) for s_ in sizes[:4]]},
+                        "graphs_captured_in_its_warm_up": cap1 - cap0, "graphs_captured_during_the_leg": pipe.captures - cap1,
+                        "hypotheses_within_1.5deg_0.6m": round(float(gc[1]) / max(float(gc[0]), 1.0), 4), "counts": [int(v) for v in gc],
+                        "note": f"named path a1-a7 on {a.config}-size RAGGED pairs (N_src, N_tgt ~ U({int(0.7 * cfg['N'])}, {cfg['N']}) independently, "
+                                "per pair; min(n_kp, N_src, N_tgt) keypoints per cloud): reference datasets/kitti/kitti_dataset.py:568-569, "
+                                "evaluate.py:195-204.  Same pipeline and per-slot graphs as `value` (captured once at the capacity "
+                                "args.max_pc_size; a pair of another shape = a 64-byte device record, no re-capture, no staging copy)"}
+        leg.pool = pool
+        del rag_pool
 
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     def situ(lst):
@@ -491,10 +546,11 @@ def main():
                    "sampler": "host numpy RNG (reference evaluate.py:238)", "distance_gemm": a.precision,
                    "pairs_in_flight": depth, "phase_a_as_hipgraph": graph_mode,
                    "distinct_pairs_in_the_pool": len(pool),
-                   "value_is": ("named path a1-a7, pairs/s, over a stream of DISTINCT resident pairs (each copied device to device into its "
-                                "pipeline slot's staging buffers, 14 MB, then one graph replay): what a loop like evaluate.py:175 gets"
-                                if graph_mode == "slot" else f"named path a1-a7, pairs/s, graph mode '{graph_mode}'"),
-                   "resident_replay": resident_replay, "named_path_on_hard_pairs": hard_named,
+                   "value_is": ("named path a1-a7, pairs/s, over a stream of DISTINCT resident pairs, each read where it lies by ONE hipGraph "
+                                "per pipeline slot (captured at the capacity max_pc_size; a pair = a 64-byte device record + a replay): "
+                                "what a loop like evaluate.py:175 gets" if graph_mode != "none" else "named path a1-a7, pairs/s, plain launches"),
+                   "resident_replay": resident_replay, "named_path_on_hard_pairs": hard_named, "named_path_on_ragged_pairs": ragged_named,
+                   "graphs_captured_total": pipe.captures,
                    "roofline_sampling_every_n_steps": roofline_every,
                    "roofline_sampling": "one pair per sampled step runs alone (pipeline drained before and after, inside the timed region): "
                                         "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per sampled step "
@@ -784,19 +840,20 @@ def main():
     result["counters_match_library"] = bool(cm) and all(cm.values())
     result["world"]["launched_by"] = ("bench.py itself (torch.distributed.run re-exec)" if os.environ.get("UMEREG_BENCH_SELF_LAUNCHED")
                                       else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "python"))
-    if rank == 0:
-        # the full result goes to a file; the ONE line on stdout is a bounded extract (<= 4 KB: the driver keeps an 8 KB tail)
-        result = benchline.sanitize(result)
-        detail = a.detail or os.path.join(REPO, "gpurun_out", "bench_detail.json")
-        try:
-            detail = os.path.relpath(benchline.write_detail(result, detail), REPO)
-        except OSError as e:
-            print(f"[bench] could not write {detail}: {e}", file=sys.stderr)
-            detail = None
-        print(benchline.line(result, detail), flush=True)
+    # (the collectives end BEFORE rank 0 formats anything: an exception in the formatting must not leave the other ranks in a barrier)
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the full result goes to a file; the ONE line on stdout is a bounded extract (<= 4 KB: the driver keeps an 8 KB tail)
+        detail = a.detail or os.path.join(REPO, "gpurun_out", "bench_detail.json")
+        try:
+            result = benchline.sanitize(result)
+            detail = os.path.relpath(benchline.write_detail(result, detail), REPO)
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] could not write {detail}: {e!r}", file=sys.stderr)
+            detail = None
+        print(benchline.safe_line(result, detail), flush=True)
 
 
 def valu_issue_floor_s(counters, rates):

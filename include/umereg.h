@@ -245,6 +245,21 @@ int umereg_pair_match_ex_f32(const float* pts, const float* feat, const int64_t*
                              float* prob, void* workspace, size_t workspace_bytes, const umereg_match_opts* opts,
                              void* stream);
 
+/* The same for a pair whose clouds DIFFER in size and live in separate buffers -- the shape real data has: the reference's
+ * collate dilutes source and target independently (datasets/kitti/kitti_dataset.py:568-569: src_num_pts = min(len(src),
+ * max_pc_size), tgt_num_pts = min(len(tgt), max_pc_size)), the loop takes num_init_sel = min(10000, N_src, N_tgt) keypoints from
+ * each (evaluate.py:195-204).  So N_src != N_tgt, both varying from pair to pair, with ONE keypoint count n_kp.
+ *   src_pts f32 [N_src,3], tgt_pts f32 [N_tgt,3], src_feat f32 [N_src,32], tgt_feat f32 [N_tgt,32] (16-byte aligned),
+ *   src_kp / tgt_kp int64 [n_kp]: keypoints as indices into their own cloud
+ *   -> F f32 [2,n_kp,32,4] (row 0 = source), match_idx, match_dist, prob as in umereg_pair_match_f32.
+ * Nothing is copied or stacked: the kernels read each cloud where it lies, through a 64-byte device record at the tail of the
+ * workspace.  Results are those of the per-cloud calls, bit for bit.
+ * workspace: umereg_pair_match_workspace_bytes_ex(max(N_src, N_tgt), n_kp, opts). */
+int umereg_pair_match_ragged_f32(const float* src_pts, const float* tgt_pts, const float* src_feat, const float* tgt_feat,
+                                 const int64_t* src_kp, const int64_t* tgt_kp, int N_src, int N_tgt, int n_kp, int K,
+                                 float radius, float tau, float* F, int64_t* match_idx, float* match_dist, float* prob,
+                                 void* workspace, size_t workspace_bytes, const umereg_match_opts* opts, void* stream);
+
 /* The same chain as ONE executable hipGraph, for callers that process many pairs out of the same buffers (an evaluation
  * loop with resident or double-buffered inputs): captured once on `stream` (a non-default stream; nothing is executed by
  * the capture), replayed with a single launch per pair -- ~0.015 ms of host time instead of ~0.10 ms for the 12
@@ -268,6 +283,20 @@ int umereg_pair_match_graph_launch_ex(void* graph, float* prob_host, void* strea
  * replayed and the probabilities downloaded as in _launch_ex.  NULL, or the captured pointer itself, skips that copy. */
 int umereg_pair_match_graph_launch_from(void* graph, const float* pts, const float* feat, const int64_t* kp_index,
                                         float* prob_host, void* stream);
+/* ONE graph for every pair that fits a capacity (the loop of evaluate.py:175 over pairs of varying size): the chain is captured
+ * with its kernels reading the clouds through the device record in the workspace, sized for clouds of up to N_cap points.
+ * umereg_pair_match_graph_launch_ragged replays it for ANY pair with N_src, N_tgt <= N_cap (arguments as in
+ * umereg_pair_match_ragged_f32): the record is rewritten by a one-thread kernel on `stream`, then the graph is launched and the
+ * probabilities downloaded as in _launch_ex.  A change of shape therefore costs a 64-byte record -- no staging copy of the
+ * clouds, no re-capture.  Baked in: N_cap, n_kp (10 000 for every pair of the KITTI benchmarks), K, radius, tau, the options.
+ * workspace (caller-owned, as are F / match_idx / match_dist / prob): umereg_pair_match_workspace_bytes_ex(N_cap, n_kp, opts).
+ * The clouds of a launch must stay valid until that launch has completed. */
+int umereg_pair_match_graph_create_cap(int N_cap, int n_kp, int K, float radius, float tau, float* F, int64_t* match_idx,
+                                       float* match_dist, float* prob, void* workspace, size_t workspace_bytes,
+                                       const umereg_match_opts* opts, void* stream, void** graph_out);
+int umereg_pair_match_graph_launch_ragged(void* graph, const float* src_pts, const float* tgt_pts, const float* src_feat,
+                                          const float* tgt_feat, const int64_t* src_kp, const int64_t* tgt_kp, int N_src,
+                                          int N_tgt, float* prob_host, void* stream);
 /* The continuation after the host draw (evaluate.py:238-254): upload the kept match indices (cond_host int64 [n_cond], pinned
  * host memory; NULL = every match) and solve one SE(3) per kept match from the graph's own outputs:
  * T_out[k] from (F_src[cond[k]], F_tgt[match[cond[k]]]).  cond_dev int64 [n_cond], T_out f32 [n_cond,4,4]: device buffers. */

@@ -96,6 +96,13 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "umereg_pair_match_graph_create_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "umereg_pair_match_ragged_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                             c_void_p]),
+    "umereg_pair_match_graph_create_cap": (c_int, [c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "umereg_pair_match_graph_launch_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                      c_int, c_void_p, c_void_p]),
     "umereg_voxel_first_index_workspace_bytes": (c_size_t, [c_int]),
     "umereg_voxel_first_index_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_host_permutation_mt19937": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p]),

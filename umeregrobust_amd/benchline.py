@@ -37,6 +37,7 @@ def compact(result, detail_path=None):
     """The bounded extract of bench.py's full result dict (see the module docstring) -> dict."""
     cfg = result.get("config") or {}
     hard = cfg.get("named_path_on_hard_pairs") or {}
+    rag = cfg.get("named_path_on_ragged_pairs") or {}
     e2e = dict(cfg.get("end_to_end_pairs_per_s") or {})
     e2e.pop("what", None)
     world = result.get("world") or {}
@@ -50,6 +51,7 @@ def compact(result, detail_path=None):
         "value_is": _short(cfg.get("value_is_short") or cfg.get("value_is", ""), 200),
         "end_to_end_pairs_per_s": e2e,
         "named_path_on_hard_pairs": {"pairs_per_s": hard.get("pairs_per_s")} if hard else None,
+        "named_path_on_ragged_pairs": {k: rag.get(k) for k in ("pairs_per_s", "ratio_to_value", "graphs_captured_during_the_leg")} if rag else None,
         "world": {"ranks": world.get("ranks"), "backend": world.get("backend"), "launched_by": world.get("launched_by")},
     }
     out["roofline"] = _roof(result.get("roofline"))
@@ -85,6 +87,23 @@ def line(result, detail_path=None):
     if len(s.encode()) > LINE_LIMIT:
         raise ValueError(f"bench line is {len(s.encode())} bytes (> {LINE_LIMIT}): move the new keys to bench_detail.json")
     return s
+
+
+def safe_line(result, detail_path=None):
+    """line(), and if that raises (a key that does not serialise, an oversized extract): the contract's keys alone -- a timed run must
+    not end without its line, and rank 0 must reach the barrier the other ranks wait in."""
+    try:
+        return line(result, detail_path)
+    except Exception as e:   # noqa: BLE001
+        print(f"[bench] full line failed ({e!r}); printing the required keys only", file=sys.stderr)
+        c = {k: result.get(k) for k in REQUIRED_KEYS}
+        cfg = result.get("config") or {}
+        c["config"] = {"workload": _short(cfg.get("workload", ""), 200)}
+        c["roofline"] = _roof(result.get("roofline"))
+        cb = result.get("cpu_baseline")
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind") if k in cb} if cb else None
+        c["detail"] = detail_path
+        return json.dumps(sanitize(c), allow_nan=False, separators=(", ", ": "), default=str)
 
 
 def sanitize(o):

@@ -38,18 +38,21 @@ constexpr int kPackWG = 1024;
 constexpr int kPackMaxBlocks = 32;
 
 __global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __restrict__ pts, char* __restrict__ ws,
-                                                              size_t ws_stride, int N)
+                                                              size_t ws_stride, int N, const PairDesc* __restrict__ desc)
 {
     __shared__ unsigned int red[kPackWG / 64][6];
     const GridWs w = grid_ws(N);
     const int b = blockIdx.y;
+    // (a ragged pair: cloud b where the caller left it, n_live <= N points of it; the table is padded to the capacity)
+    const int n_live = desc ? desc->n_pts[b] : N;
+    const float* __restrict__ src = desc ? desc->pts[b] : pts + (size_t)b * N * 3;
     float4* out = reinterpret_cast<float4*>(ws + b * ws_stride + w.off_p4o);
     unsigned int* bbox = reinterpret_cast<unsigned int*>(ws + b * ws_stride + w.off_bbox);
     unsigned int e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     for (int j = blockIdx.x * kPackWG + threadIdx.x; j < w.Npad; j += gridDim.x * kPackWG) {
         float4 v = make_float4(kFar, kFar, kFar, 0.f);
-        if (j < N) {
-            const float* p = pts + ((size_t)b * N + j) * 3;
+        if (j < n_live) {
+            const float* p = src + (size_t)j * 3;
             v = make_float4(p[0], p[1], p[2], 0.f);
             const unsigned int ex = enc_ord(v.x), ey = enc_ord(v.y), ez = enc_ord(v.z);
             e[0] = max(e[0], ~ex); e[1] = max(e[1], ~ey); e[2] = max(e[2], ~ez);
@@ -101,7 +104,7 @@ __device__ __forceinline__ int hilbert64(int x, int y)
 }
 
 __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ ws, size_t ws_stride, int N,
-                                                            float radius, int order_only)
+                                                            float radius, int order_only, const PairDesc* __restrict__ desc)
 {
     __shared__ int hist[kMaxCells];
     __shared__ Grid g_sh;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
     __syncthreads();
     const Grid g = g_sh;
     const int j = blockIdx.x * kSortWG + threadIdx.x;
-    if (j < N) {
+    if (j < (desc ? desc->n_pts[blockIdx.y] : N)) {
         const float4 p = P4o[j];
         int c = (cell_axis(p.z, g.minz, g.invz, g.nz) * g.ny + cell_axis(p.y, g.miny, g.invy, g.ny)) * g.nx +
                 cell_axis(p.x, g.minx, g.invx, g.nx);
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(char* __restrict__ ws, s
 }
 
 // ---- K3: stable scatter into cell-sorted order ------------------------------------------------
-__global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict__ ws, size_t ws_stride, int N)
+__global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict__ ws, size_t ws_stride, int N,
+                                                               const PairDesc* __restrict__ desc)
 {
     __shared__ int slot[kMaxCells];
     __shared__ int part[kSortWG / 64];
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict_
     }
     __syncthreads();
     const int j = blockIdx.x * kSortWG + threadIdx.x;
-    const bool valid = j < N;
+    const int n_live = desc ? desc->n_pts[blockIdx.y] : N;
+    const bool valid = j < n_live;
     const int c = valid ? cell_of[j] : -1;
     const int wave = threadIdx.x >> 6;
     // rank among the lanes of this wave with the same cell and a lower index
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(kSortWG) void grid_scatter_kernel(char* __restrict_
     }
     // tail padding of the sorted table (read, never accepted, by the last chunk of the last run)
     if (blockIdx.x == 0 && threadIdx.x < 64)
-        P4s[N + threadIdx.x] = make_float4(kFar, kFar, kFar, __int_as_float(0x7fffffff));
+        P4s[n_live + threadIdx.x] = make_float4(kFar, kFar, kFar, __int_as_float(0x7fffffff));
 }
 
 // ---- streaming top-K by original index ---------------------------------------------------------
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
 __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, size_t ws_stride,
                                                          const float* __restrict__ kpts,
                                                          const int64_t* __restrict__ kp_index, int N, int n_kp,
-                                                         float radius)
+                                                         float radius, const PairDesc* __restrict__ desc)
 {
     __shared__ int cnt[kMaxCells];
     __shared__ int part[1024 / 64];
@@ -547,10 +552,12 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
     const int* cell_of = reinterpret_cast<const int*>(wb + w.off_cell);
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) cnt[c] = 0;
     __syncthreads();
+    const int n_live = desc ? desc->n_pts[b] : N;
+    const int64_t* __restrict__ kpi = desc ? desc->kp[b] : (kp_index ? kp_index + (size_t)b * n_kp : nullptr);
     auto cell_of_kp = [&](int k) {
-        if (kp_index) {   // the point's cell, from the hist pass (an out-of-range index only affects the ORDER here: clamped)
-            const int64_t i = kp_index[(size_t)b * n_kp + k];
-            return cell_of[i < 0 ? 0 : (i >= N ? N - 1 : i)];
+        if (kpi) {   // the point's cell, from the hist pass (an out-of-range index only affects the ORDER here: clamped)
+            const int64_t i = kpi[k];
+            return cell_of[i < 0 ? 0 : (i >= n_live ? n_live - 1 : i)];
         }
         const float* q = kpts + ((size_t)b * n_kp + k) * 3;
         return (cell_axis(q[2], g.minz, g.invz, g.nz) * g.ny + cell_axis(q[1], g.miny, g.invy, g.ny)) * g.nx +
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
     float radius, int flags, float* __restrict__ F, int32_t* __restrict__ nn_count,
-    int64_t* __restrict__ nn_idx)
+    int64_t* __restrict__ nn_idx, const PairDesc* __restrict__ desc)
 {
     const bool ordered = flags & UMEREG_MOMENTS_ORDERED;
     extern __shared__ int lds[];
@@ -659,11 +666,14 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
     const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
-    const float4* fb = feat4 + (size_t)b * N * 8;
+    // a ragged pair (desc): this cloud's feature table and keypoint indices where the caller left them, n_live <= N points
+    const int n_live = desc ? desc->n_pts[b] : N;
+    const float4* fb = desc ? reinterpret_cast<const float4*>(desc->feat[b]) : feat4 + (size_t)b * N * 8;
+    const int64_t* __restrict__ kpi = desc ? desc->kp[b] : (kp_index ? kp_index + (size_t)b * n_kp : nullptr);
     float qx, qy, qz;
-    if (kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
-        const int64_t ki = kp_index[(size_t)b * n_kp + kp];
-        if (ki < 0 || ki >= N) {
+    if (kpi) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
+        const int64_t ki = kpi[kp];
+        if (ki < 0 || ki >= n_live) {
             // an index outside the cloud (stale, or the -1 padding the reference's own code produces) must not read out of
             // bounds: the keypoint's matrix is all NaN -- loud downstream, where torch indexing would have raised
             for (int e = lane; e < 128; e += kWave) F[((size_t)b * n_kp + kp) * 128 + e] = __int_as_float(0x7fc00000);
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     }
     const int nbits = 32 - __clz(N > 1 ? N - 1 : 1);
 
-    const int count = ball_search_grid(P4s, start, g, qx, qy, qz, radius * radius, K, N, nbits, lst, cap, lane);
+    const int count = ball_search_grid(P4s, start, g, qx, qy, qz, radius * radius, K, n_live, nbits, lst, cap, lane);
 
     if (nn_count && lane == 0) nn_count[(size_t)b * n_kp + kp] = count;
     if (nn_idx) {   // optional parity output, ascending like ball_query
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only)
+int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only, const PairDesc* desc)
 {
     const GridWs w = grid_ws(N);
     // the B bounding-box records (64 B each, one per cloud's workspace slice) in one call
@@ -868,22 +878,22 @@ int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStrea
     {
         int nb = (w.Npad + kPackWG - 1) / kPackWG;
         nb = nb > kPackMaxBlocks ? kPackMaxBlocks : nb;
-        hipLaunchKernelGGL(pack_points_kernel, dim3(nb, B), dim3(kPackWG), 0, st, pts, ws, w.total, N);
+        hipLaunchKernelGGL(pack_points_kernel, dim3(nb, B), dim3(kPackWG), 0, st, pts, ws, w.total, N, desc);
     }
     UMEREG_CHECK_LAUNCH("pack_points_kernel");
-    hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius, order_only);
+    hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius, order_only, desc);
     UMEREG_CHECK_LAUNCH("grid_hist_kernel");
     hipLaunchKernelGGL(grid_scan_kernel, dim3(kScanWGs, B), dim3(256), 0, st, ws, w.total, N, radius, order_only);
     UMEREG_CHECK_LAUNCH("grid_scan_kernel");
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, desc);
     UMEREG_CHECK_LAUNCH("grid_scatter_kernel");
     return UMEREG_OK;
 }
 
 int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,
-                       hipStream_t st)
+                       hipStream_t st, const PairDesc* desc)
 {
-    hipLaunchKernelGGL(kp_order_kernel, dim3(1, B), dim3(1024), 0, st, ws, grid_ws(N).total, kpts, kp_index, N, n_q, radius);
+    hipLaunchKernelGGL(kp_order_kernel, dim3(1, B), dim3(1024), 0, st, ws, grid_ws(N).total, kpts, kp_index, N, n_q, radius, desc);
     UMEREG_CHECK_LAUNCH("kp_order_kernel");
     return UMEREG_OK;
 }
@@ -967,10 +977,36 @@ UMEREG_API int umereg_ume_keypoint_order(void* packed, const float* kpts, const 
     UMEREG_REQUIRE(n_kp <= grid_ws(N).Npad, "keypoint_order: n_kp (%d) exceeds the order buffer (%d)", n_kp, grid_ws(N).Npad);
     if (int rc = check_device()) return rc;
     hipLaunchKernelGGL(kp_order_kernel, dim3(1, B), dim3(1024), 0, (hipStream_t)stream, (char*)packed, grid_ws(N).total,
-                       kpts, kp_index, N, n_kp, radius);
+                       kpts, kp_index, N, n_kp, radius, (const PairDesc*)nullptr);
     UMEREG_CHECK_LAUNCH("kp_order_kernel");
     return UMEREG_OK;
 }
+
+namespace umereg {
+// the moment kernel's launch; desc (device pointer, optional): the two clouds of a ragged pair (B = 2, N = the capacity)
+int launch_moments(const void* packed, const float* kpts, const int64_t* kp_index, const float* feat, int B, int N, int n_kp, int K,
+                   float radius, int flags, float* F, int32_t* nn_count, int64_t* nn_idx, hipStream_t st, const PairDesc* desc)
+{
+    int cap, waves;
+    lds_plan(K, &cap, &waves);
+    dim3 grid((n_kp + waves - 1) / waves, B);
+    UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_VALU)), "ume_moments: ACC_F32 and ACC_VALU exclude each other");
+    if (!(flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)))
+        hipLaunchKernelGGL(ume_moments_kernel<2>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+    else if (!(flags & UMEREG_MOMENTS_ACC_F32))
+        hipLaunchKernelGGL(ume_moments_kernel<1>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+    else
+        hipLaunchKernelGGL(ume_moments_kernel<0>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+    UMEREG_CHECK_LAUNCH("ume_moments_kernel");
+    return UMEREG_OK;
+}
+}  // namespace umereg
 
 UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kpts, const int64_t* kp_index,
                                              const float* feat, int B, int N, int n_kp, int feat_dim, int K,
@@ -986,24 +1022,7 @@ UMEREG_API int umereg_ume_moments_packed_f32(const void* packed, const float* kp
     UMEREG_REQUIRE(((uintptr_t)feat & 15) == 0 && ((uintptr_t)F & 15) == 0 && ((uintptr_t)packed & 15) == 0,
                    "ume_moments: packed, feat and F must be 16-byte aligned");
     if (int rc = check_device()) return rc;
-    int cap, waves;
-    lds_plan(K, &cap, &waves);
-    dim3 grid((n_kp + waves - 1) / waves, B);
-    UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_VALU)), "ume_moments: ACC_F32 and ACC_VALU exclude each other");
-    if (!(flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)))
-        hipLaunchKernelGGL(ume_moments_kernel<2>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
-    else if (!(flags & UMEREG_MOMENTS_ACC_F32))
-        hipLaunchKernelGGL(ume_moments_kernel<1>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
-    else
-        hipLaunchKernelGGL(ume_moments_kernel<0>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           (hipStream_t)stream, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx);
-    UMEREG_CHECK_LAUNCH("ume_moments_kernel");
-    return UMEREG_OK;
+    return launch_moments(packed, kpts, kp_index, feat, B, N, n_kp, K, radius, flags, F, nn_count, nn_idx, (hipStream_t)stream, nullptr);
 }
 
 UMEREG_API int umereg_ume_moments_f32(const float* pts, const float* kpts, const float* feat, int B,

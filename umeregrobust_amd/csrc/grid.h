@@ -13,6 +13,25 @@ constexpr int kCapX = 32, kCapY = 32, kCapZ = 4;
 constexpr int kSortWG = 1024;       // points per workgroup in the counting sort
 constexpr int kScanUnroll = 4;      // 64-point chunks in flight per wave in the grid search
 
+// ---- a registration pair whose two clouds differ in size and live where the caller left them ---------------------------
+// The reference dilutes source and target INDEPENDENTLY (datasets/kitti/kitti_dataset.py:568-569) and handles the two sizes with
+// min(...) (evaluate.py:195-204): N_src != N_tgt, both varying from pair to pair, is the shape real data has.  A batch of two
+// clouds is then not one [2,N,*] tensor.  The kernels of the search structure and the moment kernel take an optional pointer to
+// this DEVICE-side record: batch element b reads its cloud through pts[b] / feat[b] / kp[b] and stops at n_pts[b], while every
+// workspace offset and stride stays that of the CAPACITY N the launch was sized for (n_pts[b] <= N).  The record is read when the
+// kernel RUNS, so a chain captured once as a hipGraph serves every pair that fits the capacity: a new pair is 64 bytes written by
+// pair_desc_write_kernel, not a re-capture and not a 14 MB staging copy.  Results are those of a launch sized for the cloud itself:
+// the grid geometry comes from the bounding box of the live points, the counting sort is stable whatever the workgroup count.
+struct PairDesc {
+    const float* pts[2];        // [n_pts[b], 3]
+    const float* feat[2];       // [n_pts[b], 32], 16-byte aligned
+    const int64_t* kp[2];       // [n_kp] keypoints as indices into their cloud
+    int n_pts[2];
+    int n_kp;                   // (informative: the keypoint count is a launch parameter)
+    int reserved;
+};
+static_assert(sizeof(PairDesc) == 64, "PairDesc is a 64-byte device record");
+
 // ---- workspace carve-up (per batch element) ---------------------------------------------------
 struct GridWs {
     size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_tot, off_bbox, off_kperm, off_box, total;
@@ -157,9 +176,14 @@ __device__ __forceinline__ int cell_axis(float p, float mn, float inv, int n)
 // build the structure for `pts` [B,N,3] with cell edge >= 1.0001 * radius (pack, bbox, stable counting sort)
 // order_only: bit b set (-1: every bit) = the structure of batch element b only supplies a processing order (Hilbert-curve order of
 // the cells where the grid has one layer); it must not be searched (see grid_hist_kernel)
-int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only = 0);
+// desc (optional, device pointer): per-cloud sources and lengths of a ragged pair (B = 2; `pts` is then unused, N is the capacity)
+int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only = 0, const PairDesc* desc = nullptr);
 // cell-sorted processing order of n_q query points (kpts [B,n_q,3] or indices into pts) -> ws.off_kperm
 int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,
-                       hipStream_t st);
+                       hipStream_t st, const PairDesc* desc = nullptr);
+
+// the fused search + gather + moment kernel over a structure built by launch_prep (arguments as umereg_ume_moments_packed_f32)
+int launch_moments(const void* packed, const float* kpts, const int64_t* kp_index, const float* feat, int B, int N, int n_kp, int K,
+                   float radius, int flags, float* F, int32_t* nn_count, int64_t* nn_idx, hipStream_t st, const PairDesc* desc = nullptr);
 
 }  // namespace umereg

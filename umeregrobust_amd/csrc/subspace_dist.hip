@@ -1407,7 +1407,8 @@ UMEREG_API size_t umereg_pair_match_workspace_bytes_ex(int N, int n_kp, const um
 {
     if (N <= 0 || n_kp <= 0) return 0;
     const size_t m = umereg_ume_match_workspace_bytes_ex(1, n_kp, n_kp, opts);
-    return m ? align_up(umereg_ume_moments_workspace_bytes(2, N), 256) + m : 0;
+    // (+ the 64-byte device record of a ragged pair, umereg_pair_match_ragged_f32, behind everything else)
+    return m ? align_up(umereg_ume_moments_workspace_bytes(2, N), 256) + align_up(m, 256) + 256 : 0;
 }
 UMEREG_API size_t umereg_pair_match_workspace_bytes(int N, int n_kp) { return umereg_pair_match_workspace_bytes_ex(N, n_kp, nullptr); }
 
@@ -1419,38 +1420,99 @@ UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const 
                                     workspace_bytes, nullptr, stream);
 }
 
+// The chain itself.  desc_vals == nullptr: the stacked form (pts [2,N,3], feat [2,N,32], kp_index [2,n_kp]).  Otherwise the
+// clouds of a RAGGED pair (N = the capacity the workspace and the launches are sized for): the record at the tail of the
+// workspace is written first -- by a kernel that takes the values as arguments, so that nothing on the host has to outlive the call
+// -- and every kernel of a1/a2 reads its cloud through it.  write_desc = false: the chain only (a graph capture; the record is
+// written outside the graph, before every replay).
+static PairDesc* desc_of(void* workspace, size_t need) { return (PairDesc*)((char*)workspace + need - 256); }
+
+__global__ void pair_desc_write_kernel(PairDesc* __restrict__ d, PairDesc v) { *d = v; }
+
+static int write_pair_desc(PairDesc* dev, const PairDesc& v, hipStream_t st)
+{
+    hipLaunchKernelGGL(pair_desc_write_kernel, dim3(1), dim3(1), 0, st, dev, v);
+    UMEREG_CHECK_LAUNCH("pair_desc_write_kernel");
+    return UMEREG_OK;
+}
+
+static int ragged_args(const PairDesc& v, int N_cap, int n_kp, const char* who)
+{
+    UMEREG_REQUIRE(v.pts[0] && v.pts[1] && v.feat[0] && v.feat[1] && v.kp[0] && v.kp[1], "%s: null cloud pointer", who);
+    UMEREG_REQUIRE(v.n_pts[0] > 0 && v.n_pts[1] > 0 && v.n_pts[0] <= N_cap && v.n_pts[1] <= N_cap,
+                   "%s: cloud sizes (%d, %d) must be in [1, capacity %d]", who, v.n_pts[0], v.n_pts[1], N_cap);
+    UMEREG_REQUIRE(((uintptr_t)v.feat[0] & 15) == 0 && ((uintptr_t)v.feat[1] & 15) == 0 && ((uintptr_t)v.pts[0] & 3) == 0 &&
+                   ((uintptr_t)v.pts[1] & 3) == 0 && ((uintptr_t)v.kp[0] & 7) == 0 && ((uintptr_t)v.kp[1] & 7) == 0,
+                   "%s: misaligned cloud pointer (features: 16 bytes)", who);
+    (void)n_kp;
+    return UMEREG_OK;
+}
+
+static int pair_match_chain(const float* pts, const float* feat, const int64_t* kp_index, const PairDesc* desc_vals, bool write_desc,
+                            bool ragged, int N, int n_kp, int K, float radius, float tau, float* F, int64_t* match_idx,
+                            float* match_dist, float* prob, void* workspace, size_t workspace_bytes, const umereg_match_opts* opts,
+                            void* stream, const char* who)
+{
+    MatchOpts mo;
+    if (int rc = resolve_opts(opts, mo, who)) return rc;
+    UMEREG_REQUIRE(F && match_idx && match_dist, "%s: null output pointer", who);
+    UMEREG_REQUIRE(ragged || (pts && feat && kp_index), "%s: null pointer", who);
+    UMEREG_REQUIRE(N > 0 && n_kp > 0, "%s: N, n_kp must be positive (got %d, %d)", who, N, n_kp);
+    UMEREG_REQUIRE(K > 0 && K <= 7680, "%s: K must be in [1, 7680] (got %d)", who, K);
+    UMEREG_REQUIRE(radius > 0.f, "%s: radius must be positive", who);
+    UMEREG_REQUIRE(!prob || tau > 0.f, "%s: tau must be positive when prob is requested", who);
+    UMEREG_REQUIRE(((uintptr_t)F & 15) == 0 && (ragged || ((uintptr_t)feat & 15) == 0), "%s: feat and F must be 16-byte aligned", who);
+    if (int rc = check_device()) return rc;
+    const size_t need = umereg_pair_match_workspace_bytes_ex(N, n_kp, opts);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+        set_error("%s: workspace too small or misaligned (%zu < %zu)", who, workspace_bytes, need);
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws_mom = (char*)workspace;
+    const size_t mom_bytes = align_up(umereg_ume_moments_workspace_bytes(2, N), 256);
+    char* ws_match = ws_mom + mom_bytes;
+    const PairDesc* desc = ragged ? desc_of(workspace, need) : nullptr;
+    if (ragged && write_desc) {
+        if (int rc = ragged_args(*desc_vals, N, n_kp, who)) return rc;
+        if (int rc = write_pair_desc(desc_of(workspace, need), *desc_vals, st)) return rc;
+    }
+    if (int rc = launch_prep(pts, ws_mom, 2, N, radius, st, 0, desc)) return rc;
+    const int ordered = n_kp <= grid_ws(N).Npad && n_kp >= 64;
+    if (ordered)
+        if (int rc = launch_query_order(ws_mom, nullptr, kp_index, 2, N, n_kp, radius, st, desc)) return rc;
+    if (int rc = launch_moments(ws_mom, nullptr, kp_index, feat, 2, N, n_kp, K, radius, ordered ? UMEREG_MOMENTS_ORDERED : 0, F, nullptr,
+                                nullptr, st, desc))
+        return rc;
+    if (int rc = umereg_ume_match_f16r_ex(F, F + (size_t)n_kp * 128, 1, n_kp, n_kp, match_idx, match_dist, ws_match,
+                                          need - 256 - mom_bytes, opts, stream))
+        return rc;
+    if (prob)
+        if (int rc = umereg_match_prob_f32(match_dist, n_kp, tau, prob, stream)) return rc;
+    return UMEREG_OK;
+}
+
 UMEREG_API int umereg_pair_match_ex_f32(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
                                         float radius, float tau, float* F, int64_t* match_idx, float* match_dist,
                                         float* prob, void* workspace, size_t workspace_bytes, const umereg_match_opts* opts,
                                         void* stream)
 {
-    MatchOpts mo;
-    if (int rc = resolve_opts(opts, mo, "pair_match")) return rc;
-    UMEREG_REQUIRE(pts && feat && kp_index && F && match_idx && match_dist, "pair_match: null pointer");
-    UMEREG_REQUIRE(N > 0 && n_kp > 0, "pair_match: N, n_kp must be positive (got %d, %d)", N, n_kp);
-    UMEREG_REQUIRE(!prob || tau > 0.f, "pair_match: tau must be positive when prob is requested");
-    if (int rc = check_device()) return rc;
-    const size_t need = umereg_pair_match_workspace_bytes_ex(N, n_kp, opts);
-    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
-        set_error("pair_match: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
-        return UMEREG_EWORKSPACE;
-    }
-    char* ws_mom = (char*)workspace;
-    const size_t mom_bytes = align_up(umereg_ume_moments_workspace_bytes(2, N), 256);
-    char* ws_match = ws_mom + mom_bytes;
-    if (int rc = umereg_pack_points_f32(pts, 2, N, radius, ws_mom, mom_bytes, stream)) return rc;
-    const int ordered = n_kp <= grid_ws(N).Npad && n_kp >= 64;
-    if (ordered)
-        if (int rc = umereg_ume_keypoint_order(ws_mom, nullptr, kp_index, 2, N, n_kp, radius, stream)) return rc;
-    if (int rc = umereg_ume_moments_packed_f32(ws_mom, nullptr, kp_index, feat, 2, N, n_kp, UMEREG_FEAT_DIM, K, radius,
-                                               ordered ? UMEREG_MOMENTS_ORDERED : 0, F, nullptr, nullptr, stream))
-        return rc;
-    if (int rc = umereg_ume_match_f16r_ex(F, F + (size_t)n_kp * 128, 1, n_kp, n_kp, match_idx, match_dist, ws_match,
-                                          workspace_bytes - mom_bytes, opts, stream))
-        return rc;
-    if (prob)
-        if (int rc = umereg_match_prob_f32(match_dist, n_kp, tau, prob, stream)) return rc;
-    return UMEREG_OK;
+    return pair_match_chain(pts, feat, kp_index, nullptr, false, false, N, n_kp, K, radius, tau, F, match_idx, match_dist, prob, workspace,
+                            workspace_bytes, opts, stream, "pair_match");
+}
+
+// ---- the same for a pair whose clouds DIFFER in size and live in separate buffers --------------------------------------------
+// reference datasets/kitti/kitti_dataset.py:568-569 dilutes source and target independently; evaluate.py:195-204 draws
+// min(10000, N_src, N_tgt) keypoints from each: n_kp is common to both clouds, N is not.
+UMEREG_API int umereg_pair_match_ragged_f32(const float* src_pts, const float* tgt_pts, const float* src_feat, const float* tgt_feat,
+                                            const int64_t* src_kp, const int64_t* tgt_kp, int N_src, int N_tgt, int n_kp, int K,
+                                            float radius, float tau, float* F, int64_t* match_idx, float* match_dist, float* prob,
+                                            void* workspace, size_t workspace_bytes, const umereg_match_opts* opts, void* stream)
+{
+    UMEREG_REQUIRE(N_src > 0 && N_tgt > 0, "pair_match_ragged: cloud sizes must be positive (got %d, %d)", N_src, N_tgt);
+    const PairDesc v = {{src_pts, tgt_pts}, {src_feat, tgt_feat}, {src_kp, tgt_kp}, {N_src, N_tgt}, n_kp, 0};
+    return pair_match_chain(nullptr, nullptr, nullptr, &v, true, true, N_src > N_tgt ? N_src : N_tgt, n_kp, K, radius, tau, F, match_idx,
+                            match_dist, prob, workspace, workspace_bytes, opts, stream, "pair_match_ragged");
 }
 
 
@@ -1472,6 +1534,7 @@ struct PairMatchGraph {
     float* feat;               // [2, N, 32]
     int64_t* kp_index;         // [2, n_kp]
     int N;
+    PairDesc* desc;            // capacity form (umereg_pair_match_graph_create_cap): the record the captured kernels read; else NULL
 };
 
 UMEREG_API int umereg_pair_match_graph_create(const float* pts, const float* feat, const int64_t* kp_index, int N, int n_kp, int K,
@@ -1515,9 +1578,66 @@ UMEREG_API int umereg_pair_match_graph_create_ex(const float* pts, const float* 
         set_error("pair_match_graph_create: hipGraphInstantiate failed (%s)", hipGetErrorString(e_inst));
         return UMEREG_ELAUNCH;
     }
-    PairMatchGraph* h = new PairMatchGraph{g, ex, F, match_idx, prob, n_kp, (float*)pts, (float*)feat, (int64_t*)kp_index, N};
+    PairMatchGraph* h = new PairMatchGraph{g, ex, F, match_idx, prob, n_kp, (float*)pts, (float*)feat, (int64_t*)kp_index, N, nullptr};
     *graph_out = h;
     return UMEREG_OK;
+}
+
+// ---- ONE graph for every pair that fits a capacity -------------------------------------------------------------------------------
+// The chain captured with its kernels reading the clouds through the device record at the tail of the workspace (PairDesc, grid.h):
+// a replay for a NEW pair -- other buffers, other N_src / N_tgt -- is umereg_pair_match_graph_launch_ragged: one 64-byte record
+// written by a one-thread kernel, then the replay.  No staging copy, no re-capture; what stays baked in is the capacity (every
+// cloud must have <= N_cap points), the keypoint count n_kp (= min(10000, N_src, N_tgt) at evaluate.py:197: 10 000 for every pair of
+// the KITTI benchmarks) and K, radius, tau, the options.
+UMEREG_API int umereg_pair_match_graph_create_cap(int N_cap, int n_kp, int K, float radius, float tau, float* F, int64_t* match_idx,
+                                                  float* match_dist, float* prob, void* workspace, size_t workspace_bytes,
+                                                  const umereg_match_opts* opts, void* stream, void** graph_out)
+{
+    UMEREG_REQUIRE(graph_out, "pair_match_graph_create_cap: null graph_out");
+    UMEREG_REQUIRE(stream, "pair_match_graph_create_cap: capture needs a non-default stream");
+    *graph_out = nullptr;
+    if (int rc = check_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pair_match_graph_create_cap: hipStreamBeginCapture failed");
+        return UMEREG_ELAUNCH;
+    }
+    const int rc = pair_match_chain(nullptr, nullptr, nullptr, nullptr, false, true, N_cap, n_kp, K, radius, tau, F, match_idx, match_dist,
+                                    prob, workspace, workspace_bytes, opts, stream, "pair_match_graph_create_cap");
+    hipGraph_t g = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(st, &g);
+    if (rc != UMEREG_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e_end != hipSuccess || !g) {
+        (void)hipGetLastError();
+        set_error("pair_match_graph_create_cap: hipStreamEndCapture failed (%s)", hipGetErrorString(e_end));
+        return UMEREG_ELAUNCH;
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e_inst != hipSuccess || !ex) {
+        (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        set_error("pair_match_graph_create_cap: hipGraphInstantiate failed (%s)", hipGetErrorString(e_inst));
+        return UMEREG_ELAUNCH;
+    }
+    PairDesc* desc = desc_of(workspace, umereg_pair_match_workspace_bytes_ex(N_cap, n_kp, opts));
+    *graph_out = new PairMatchGraph{g, ex, F, match_idx, prob, n_kp, nullptr, nullptr, nullptr, N_cap, desc};
+    return UMEREG_OK;
+}
+
+UMEREG_API int umereg_pair_match_graph_launch_ragged(void* graph, const float* src_pts, const float* tgt_pts, const float* src_feat,
+                                                     const float* tgt_feat, const int64_t* src_kp, const int64_t* tgt_kp, int N_src,
+                                                     int N_tgt, float* prob_host, void* stream)
+{
+    UMEREG_REQUIRE(graph, "pair_match_graph_launch_ragged: null graph");
+    PairMatchGraph* h = (PairMatchGraph*)graph;
+    UMEREG_REQUIRE(h->desc, "pair_match_graph_launch_ragged: this graph was captured over fixed buffers (umereg_pair_match_graph_create), "
+                            "not at a capacity");
+    const PairDesc v = {{src_pts, tgt_pts}, {src_feat, tgt_feat}, {src_kp, tgt_kp}, {N_src, N_tgt}, h->n_kp, 0};
+    if (int rc = ragged_args(v, h->N, h->n_kp, "pair_match_graph_launch_ragged")) return rc;
+    if (int rc = write_pair_desc(h->desc, v, (hipStream_t)stream)) return rc;
+    return umereg_pair_match_graph_launch_ex(graph, prob_host, stream);
 }
 
 UMEREG_API int umereg_pair_match_graph_launch(void* graph, void* stream)
@@ -1558,6 +1678,7 @@ UMEREG_API int umereg_pair_match_graph_launch_from(void* graph, const float* pts
 {
     UMEREG_REQUIRE(graph, "pair_match_graph_launch_from: null graph");
     PairMatchGraph* h = (PairMatchGraph*)graph;
+    UMEREG_REQUIRE(!h->desc, "pair_match_graph_launch_from: this graph was captured at a capacity: use umereg_pair_match_graph_launch_ragged");
     hipStream_t st = (hipStream_t)stream;
     const struct { const void* src; void* dst; size_t bytes; } cp[3] = {
         {pts, h->pts, (size_t)2 * h->N * 3 * sizeof(float)},

@@ -247,15 +247,17 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
     t_dist = None if timing is None else timing.setdefault("dist", ops.TimingList())
     if pair is not None and timing is None and not materialize_D and ops.DEFAULT_MATCH_PRECISION == "f16r" \
             and not getattr(args, "hungarian_matching_flag", False):
-        # the whole of a1..a5 in one native call (same kernels as the layered path below)
-        F, m_tgt, ume_d, prob = ops.pair_match(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn,
-                                               args.tau if args.filter_by_ume_dist_cond else None, opts=match_opts)
+        # the whole of a1..a5 in one native call (same kernels as the layered path below), the two clouds read where they lie:
+        # N_src != N_tgt is the normal case (kitti_dataset.py:568-569), nothing is stacked
+        F, m_tgt, ume_d, prob = ops.pair_match_ragged(pair.src_pts, pair.tgt_pts, pair.src_feat, pair.tgt_feat, pair.inds[0], pair.inds[1],
+                                                      args.ume_max_nn, args.ume_r_nn,
+                                                      args.tau if args.filter_by_ume_dist_cond else None, opts=match_opts)
         return SimpleNamespace(ume_src=F[0:1], ume_tgt=F[1:2], match=m_tgt, match_d=ume_d, prob=prob, D=None,
                                src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=F.shape[1], dev=dev,
                                src_pts=src_pts, tgt_pts=tgt_pts)
-    if pair is not None:
-        # both clouds of the pair as ONE batch of 2 through every kernel (same arithmetic per cloud; half
-        # the launches, twice the parallelism for the small grid-building kernels)
+    if pair is not None and pair.pts is not None:
+        # (timed / layered calls) equally large clouds stacked by the caller: ONE batch of 2 through every kernel (same arithmetic
+        # per cloud; half the launches, twice the parallelism for the small grid-building kernels)
         ume_both = ops.ume_moments(pair.pts, None, pair.feat, args.ume_max_nn, args.ume_r_nn, timing=t_mom,
                                    kp_index=pair.inds)
         ume_src, ume_tgt = ume_both[0:1], ume_both[1:2]
@@ -292,18 +294,54 @@ def _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, mat
 
 
 class PairBatch:
-    """A registration pair laid out as a batch of two clouds: pts [2,N,3], feat [2,N,32], inds [2,n_kp]
-    (row 0 = source, row 1 = target).  Requires both clouds to have the same N and keypoint count, which
-    is what the reference's collate (`max_pc_size`) and keypoint draw (`num_init_sel`) produce."""
+    """A registration pair as the native a1-a5 entries take it: the two clouds WHERE THEY LIE -- src_pts [N_src,3], tgt_pts [N_tgt,3],
+    src_feat [N_src,32], tgt_feat [N_tgt,32], contiguous float32 on the device -- and the keypoint indices of both as the rows of
+    one int64 [2,n_kp] tensor (row 0 = source).  N_src != N_tgt is the NORMAL case: the reference's collate dilutes source and target
+    independently (datasets/kitti/kitti_dataset.py:568-569: min(len(cloud), max_pc_size) each, and the cached clouds are separately
+    voxelised reconstructions), and its loop draws num_init_sel = min(10000, N_src, N_tgt) keypoints from EACH cloud
+    (evaluate.py:195-204) -- so the sizes differ and vary pair to pair while the keypoint count is common to both.  Nothing is
+    stacked or copied: the kernels read each cloud through a device-side record (ops.pair_match_ragged, ops.PairMatchCapGraph).
+
+    PairBatch(pts, feat, inds) keeps the stacked form of earlier rounds -- pts [2,N,3], feat [2,N,32] -- for callers that hold
+    equally large clouds in one tensor (`.pts` / `.feat` are then set, the per-cloud attributes are views of them)."""
 
     def __init__(self, pts, feat, inds):
         assert pts.dim() == 3 and pts.shape[0] == 2 and feat.shape[:2] == pts.shape[:2] and inds.shape[0] == 2
         self.pts, self.feat, self.inds = pts.contiguous(), feat.contiguous(), inds.contiguous().to(torch.int64)
+        self.src_pts, self.tgt_pts, self.src_feat, self.tgt_feat = self.pts[0], self.pts[1], self.feat[0], self.feat[1]
+
+    @property
+    def sizes(self):
+        """(N_src, N_tgt, n_kp)"""
+        return self.src_pts.shape[0], self.tgt_pts.shape[0], self.inds.shape[1]
+
+    def tensors(self):
+        return (self.src_pts, self.tgt_pts, self.src_feat, self.tgt_feat, self.inds)
+
+    def native(self):
+        """(six device addresses, N_src, N_tgt) as umereg_pair_match_graph_launch_ragged takes them; cached -- a PairBatch is
+        immutable once built (rebinding its tensors afterwards is not supported)."""
+        na = getattr(self, "_native", None)
+        if na is None:
+            na = self._native = (self.src_pts.data_ptr(), self.tgt_pts.data_ptr(), self.src_feat.data_ptr(), self.tgt_feat.data_ptr(),
+                                 self.inds.data_ptr(), self.inds.data_ptr() + 8 * self.inds.shape[1],
+                                 self.src_pts.shape[0], self.tgt_pts.shape[0])
+        return na
 
     @classmethod
     def from_clouds(cls, src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds):
-        """Stacks two [1,N,*] clouds (one device copy); returns None if their shapes differ."""
-        if src_pts.shape != tgt_pts.shape or src_inds.shape != tgt_inds.shape:
+        """The pair over the caller's own tensors ([1,N,*] or [N,*] clouds of any two sizes; NO copy of the clouds).  Returns None
+        only for what the native entries cannot read in place (another dtype, a non-contiguous view, a host tensor) or for keypoint
+        sets of different length -- the layered per-cloud path handles those."""
+        cl = []
+        for t_, w_ in ((src_pts, 3), (tgt_pts, 3), (src_feat, 32), (tgt_feat, 32)):
+            if t_.dim() == 3 and t_.shape[0] == 1:
+                t_ = t_[0]
+            if not (t_.is_cuda and t_.dim() == 2 and t_.shape[1] == w_ and t_.dtype == torch.float32 and t_.is_contiguous()):
+                return None
+            cl.append(t_)
+        if cl[2].shape[0] != cl[0].shape[0] or cl[3].shape[0] != cl[1].shape[0] or src_inds.numel() != tgt_inds.numel() \
+                or src_inds.numel() == 0:
             return None
         base = getattr(src_inds, "_base", None)
         if base is not None and base is getattr(tgt_inds, "_base", None) and base.dim() == 2 and base.shape[0] == 2 \
@@ -311,7 +349,11 @@ class PairBatch:
             inds = base                   # the two index sets are the rows of one [2, n_kp] upload already (_draw_keypoints)
         else:
             inds = torch.stack([src_inds.view(-1), tgt_inds.view(-1)], 0)
-        return cls(torch.cat([src_pts, tgt_pts], 0), torch.cat([src_feat, tgt_feat], 0), inds)
+        self = cls.__new__(cls)
+        self.pts = self.feat = None
+        self.src_pts, self.tgt_pts, self.src_feat, self.tgt_feat = cl
+        self.inds = inds.contiguous().to(device=cl[0].device, dtype=torch.int64)
+        return self
 
 
 class PairResult(SimpleNamespace):
@@ -401,9 +443,8 @@ def register_pair(src_pts, tgt_pts, src_feat, tgt_feat, args, rng=np.random, src
     pair = None
     if timing is None and not materialize_D and src_pts.is_cuda and ops.DEFAULT_MATCH_PRECISION == "f16r" \
             and not getattr(args, "hungarian_matching_flag", False):
-        # equally large clouds (what the reference's collate produces): both through every kernel as ONE batch of two and a1..a5
-        # as one native call (the same kernels; one device copy of the clouds, 14 MB at KITTI size, instead of a second set of
-        # grid-build and keypoint-order launches)
+        # both clouds -- of whatever two sizes the collate produced (kitti_dataset.py:568-569) -- through every kernel as ONE batch
+        # of two and a1..a5 as one native call, read where they lie (no stacking copy)
         pair = PairBatch.from_clouds(src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds)
     a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, args, src_inds, tgt_inds, materialize_D, timing, pair=pair)
     if after_phase_a is not None:
@@ -428,27 +469,29 @@ class RegistrationPipeline:
     """
 
     def __init__(self, args, device, depth=2, rng=np.random, threaded_draw=False, use_graphs=False, stream_plan=None,
-                 match_opts=None):
+                 match_opts=None, capacity=None):
         """threaded_draw: run the host draw (event wait + choice) on one worker thread, in submission
         order, so it also overlaps the main thread's kernel enqueues (the native draw releases the GIL).
         Use depth >= 3 with it.  The worker is then the only consumer of `rng` between submit and finish,
         so inject the keypoint indices (or draw them from a different generator)."""
         self.args, self.rng, self.depth = args, rng, depth
         self.match_opts = match_opts       # ops.MatchOpts of THIS pipeline's matcher calls (per call, not process state)
-        # use_graphs: replay phase A (12 launches) as one hipGraph per (slot, PairBatch): for loops that keep submitting
-        # the same PairBatch objects (resident or double-buffered inputs).  The graph writes into buffers it owns, so the
-        # tensors of a pair are valid until the same (slot, PairBatch) is submitted again, its rtume_tform / g_index (slot
-        # buffers) until the slot's next finish(): consume or clone them before submitting `depth` more pairs.
-        # use_graphs = "slot": ONE graph per pipeline slot, captured over staging buffers the slot owns; every submitted pair of that
-        # shape is copied into them device to device (14 MB at KITTI size) and the graph replayed -- what a loop over DISTINCT pairs
-        # (reference evaluate.py:175: 1 475 of them) needs: no re-capture, no dependence on the caller keeping its tensors in place.
-        # use_graphs = True / "pair": the per-(slot, PairBatch) form above, for callers that cycle through resident PairBatch objects.
+        # use_graphs ("slot"; True / "pair" are accepted as the same thing): phase A (13 launches) as ONE hipGraph per pipeline slot,
+        # captured once at a CAPACITY -- clouds of up to `capacity` points (default: args.max_pc_size, the collate's bound,
+        # kitti_dataset.py:568-569; grown on demand) and the keypoint count of the first pair -- whose kernels read each submitted
+        # pair's clouds WHERE THEY LIE through a 64-byte device record (ops.PairMatchCapGraph).  What a loop over distinct pairs of
+        # varying size (reference evaluate.py:175: 1 475 of them, N_src != N_tgt) needs: a new pair, of whatever shape that fits, is
+        # a record write + a replay -- no re-capture, no staging copy, no dependence on where the caller keeps its tensors.  Only a
+        # cloud beyond the capacity or another keypoint count (min(10000, N_src, N_tgt): clouds below 10 000 points) captures anew.
+        # The graph writes into buffers it owns: a pair's phase-A outputs, rtume_tform and g_index (slot buffers) are valid until the
+        # slot's next submit / finish: consume or clone them before submitting `depth` more pairs.
         if use_graphs not in (False, True, "pair", "slot"):
             raise ValueError(f"use_graphs must be False, True / 'pair' or 'slot' (got {use_graphs!r})")
-        self.use_graphs = "pair" if use_graphs is True else use_graphs
-        self.graphs = {}                 # (slot, id(pair)) -> (PairMatchGraph, pair), least recently used first
-        self.slot_graphs = {}            # slot -> PairMatchGraph over the slot's own staging buffers ("slot" mode)
-        self.max_graphs = 64
+        self.use_graphs = "slot" if use_graphs else False
+        self.capacity = int(capacity) if capacity else int(getattr(args, "max_pc_size", 0) or 0)
+        self.graphs = {}                 # (kept empty: the per-(slot, PairBatch) graphs of rounds 2-5 are gone)
+        self.slot_graphs = {}            # slot -> [PairMatchCapGraph, ...] most recently used last (one per keypoint count; <= 2)
+        self.captures = 0                # graphs captured so far (a stream of pairs that fit the capacity: `depth`)
         self.pool = None
         if threaded_draw:
             from concurrent.futures import ThreadPoolExecutor
@@ -495,57 +538,31 @@ class RegistrationPipeline:
         self.n_submitted += 1
         return a
 
-    def _graph_for(self, k, pair):
-        """The captured phase A of `pair` on slot k.  A cached graph is replayed only if every buffer it was captured over
-        (address, shape, dtype of pts / feat / inds) and every baked-in parameter (K, radius, tau) is the one asked for now:
-        `id(pair)` alone is not an identity (CPython reuses ids, and a PairBatch's tensors can be reassigned)."""
+    def _slot_graph(self, k, pair):
+        """The slot's capacity graph for a pair of these sizes; captured when none of the slot's graphs fits (first use, a cloud
+        beyond the capacity, another keypoint count)."""
         args = self.args
         tau = args.tau if args.filter_by_ume_dist_cond else None
-        key = (k, id(pair))
-        entry = self.graphs.get(key)
-        if entry is not None:
-            graph, owner = entry
-            if owner is pair and graph.matches(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau, self.match_opts):
-                self.graphs[key] = self.graphs.pop(key)                 # most recently used last
-                return graph
-            self._retire(key)
-        if len(self.graphs) >= self.max_graphs:
-            # least recently used first; a graph whose slot has a pair in flight is still referenced by that pair's handle
-            # and may be running: only idle slots' graphs go, after their stream has drained
-            for old in list(self.graphs):
-                if len(self.graphs) < self.max_graphs:
-                    break
-                if not self.in_flight[old[0]]:
-                    self._retire(old)
+        n_src, n_tgt, n_kp = pair.sizes
+        lst = self.slot_graphs.setdefault(k, [])
+        for g in lst:
+            if g.fits(n_src, n_tgt, n_kp, args.ume_max_nn, args.ume_r_nn, tau, self.match_opts):
+                if g is not lst[-1]:
+                    lst.remove(g); lst.append(g)
+                return g
+        need = max(n_src, n_tgt)
+        if need > self.capacity:
+            self.capacity = (need + need // 8 + 1023) // 1024 * 1024       # (headroom: the next pair is a few per cent larger or smaller)
+        if len(lst) >= 2:
+            self.streams[k].synchronize()         # the old exec may still be running on the slot's stream
+            lst.pop(0)
         with torch.cuda.stream(self.streams[k]):
             # buffers owned by the graph are allocated under the slot's stream: that is the stream its kernels run on, so
             # the caching allocator cannot hand them to somebody else while a replay is in flight
-            graph = ops.PairMatchGraph(pair.pts, pair.feat, pair.inds, args.ume_max_nn, args.ume_r_nn, tau, opts=self.match_opts)
-        self.graphs[key] = (graph, pair)          # the strong reference keeps id(pair) from being reused while the entry lives
-        return graph
-
-    def _slot_graph(self, k, pair):
-        """"slot" mode: the slot's graph over its own staging buffers, (re)built when the shape or a baked-in parameter changes."""
-        args = self.args
-        tau = args.tau if args.filter_by_ume_dist_cond else None
-        g = self.slot_graphs.get(k)
-        if g is not None and g.pts.shape == pair.pts.shape and g.kp_index.shape == pair.inds.shape \
-                and g.matches(g.pts, g.feat, g.kp_index, args.ume_max_nn, args.ume_r_nn, tau, self.match_opts):
-            return g
-        if g is not None:
-            self.streams[k].synchronize()         # the old exec may still be running on the slot's stream
-        with torch.cuda.stream(self.streams[k]):
-            stage = (torch.empty_like(pair.pts), torch.empty_like(pair.feat), torch.empty_like(pair.inds))
-            for dst, src in zip(stage, (pair.pts, pair.feat, pair.inds)):
-                dst.copy_(src)                    # (valid inputs for the capture-time size checks; nothing runs during a capture)
-            g = ops.PairMatchGraph(*stage, args.ume_max_nn, args.ume_r_nn, tau, opts=self.match_opts)
-        self.slot_graphs[k] = g
+            g = ops.PairMatchCapGraph(self.dev, self.capacity, n_kp, args.ume_max_nn, args.ume_r_nn, tau, opts=self.match_opts)
+        lst.append(g)
+        self.captures += 1
         return g
-
-    def _retire(self, key):
-        entry = self.graphs.pop(key, None)
-        if entry is not None:
-            self.streams[key[0]].synchronize()    # the exec may still be running on its slot's stream
 
     def _submit_slot(self, k, src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds, timing, pair, rng):
         st = self.streams[k]
@@ -554,40 +571,39 @@ class RegistrationPipeline:
             src_inds, tgt_inds = pair.inds[0], pair.inds[1]
         else:
             src_inds, tgt_inds = _draw_keypoints(src_pts, tgt_pts, self.args, rng, src_inds, tgt_inds)
+            if timing is None:
+                # the pair over the caller's own tensors (no copy of the clouds, whatever their two sizes): the one-call / graph path
+                pair = PairBatch.from_clouds(src_pts, tgt_pts, src_feat, tgt_feat, src_inds, tgt_inds)
         st.wait_stream(torch.cuda.current_stream(self.dev))
         # (no ordering between the phase-A blocks of consecutive pairs: the single-workgroup kernels of one pair --
         # keypoint order, grid scan, softmax, RTUME -- then run beside the machine-filling kernels of the other:
         # 0.416 -> 0.36 ms per pair)
         graph = None
-        refill = False
         if self.use_graphs and pair is not None and timing is None and ops.DEFAULT_MATCH_PRECISION == "f16r" \
-                and not getattr(self.args, "hungarian_matching_flag", False):
-            refill = self.use_graphs == "slot" and self.pool is None and torch.cuda.current_device() == self.dev.index
-            graph = self._slot_graph(k, pair) if refill else self._graph_for(k, pair)
-        if graph is not None and self.pool is None and torch.cuda.current_device() == self.dev.index:
-            # graph fast path: replay + probability download in one native call on the slot's stream, no torch stream /
+                and not getattr(self.args, "hungarian_matching_flag", False) and self.pool is None \
+                and torch.cuda.current_device() == self.dev.index:
+            graph = self._slot_graph(k, pair)
+        if graph is not None:
+            # graph fast path: record write + replay + probability download in one native call on the slot's stream, no torch stream /
             # device contexts, a per-slot event (the host side of a pair is as long as its GPU side: every 10 us count)
             hp = None
             if graph.prob is not None:
                 hp = self.host_prob[k]
                 if hp is None or hp.numel() != graph.prob.numel():
                     hp = self.host_prob[k] = torch.empty(graph.prob.numel(), dtype=torch.float32, pin_memory=True)
-            if refill:
-                graph.launch_from(pair.pts, pair.feat, pair.inds, hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
-            else:
-                graph.launch_ex(hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
+            graph.launch_native(pair.native(), hp.data_ptr() if hp is not None else 0, self.stream_ptrs[k])
             ev = self.ready_ev[k]
             ev.record(st)
             a = SimpleNamespace(ume_src=graph.F[0:1], ume_tgt=graph.F[1:2], match=graph.m, match_d=graph.d, prob=graph.prob, D=None,
                                 src_inds=src_inds, tgt_inds=tgt_inds, num_kpts=graph.F.shape[1], dev=self.dev, src_pts=src_pts,
                                 tgt_pts=tgt_pts, ready=ev, slot=k, rng=rng, draw=None, graph=graph)
-            # the device-to-device copies of launch_from read the caller's tensors on the SLOT's stream: the handle holds them until
-            # finish() has waited for `ready` (recorded behind those copies), so a caller that rebinds `pair` right after submit()
-            # cannot have the caching allocator hand the blocks out on its own stream while the copy is pending
+            # the replay reads the caller's tensors on the SLOT's stream: the handle holds them until finish() has waited for `ready`
+            # (recorded behind the replay's last kernel), so a caller that rebinds `pair` right after submit() cannot have the
+            # caching allocator hand the blocks out on its own stream while the kernels are pending
             a.keep = (pair, src_feat, tgt_feat)
             return a
         with torch.cuda.stream(st):
-            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, graph,
+            a = _phase_a(src_pts, tgt_pts, src_feat, tgt_feat, self.args, src_inds, tgt_inds, False, timing, pair, None,
                          match_opts=self.match_opts)
             if a.prob is not None:
                 if self.host_prob[k] is None or self.host_prob[k].numel() != a.prob.numel():
@@ -613,8 +629,8 @@ class RegistrationPipeline:
         to wait for that stream (no host synchronisation), so the returned tensors can be consumed with ordinary torch
         semantics.  A caller that consumes them under `with torch.cuda.stream(pipe.stream_of(a))` only -- bench.py's loop --
         passes order_caller=False and saves the event record / wait and the allocator bookkeeping (~15 us of host time).
-        With use_graphs the phase-A outputs (ume_src/ume_tgt, match, match_d, prob) are buffers owned by the captured graph:
-        valid until the same (slot, pair) is submitted again."""
+        With use_graphs the phase-A outputs (ume_src/ume_tgt, match, match_d, prob) are buffers owned by the slot's graph:
+        valid until the slot's next submit."""
         st = self.streams[a.slot]
         if not order_caller:
             return self._finish_on_slot(a, cond, st)
@@ -639,7 +655,7 @@ class RegistrationPipeline:
         keep, a.keep = getattr(a, "keep", None), None
         if keep and (injected or not self.args.filter_by_ume_dist_cond):
             for t_ in keep:
-                for u_ in ((t_.pts, t_.feat, t_.inds) if isinstance(t_, PairBatch) else (t_,)):
+                for u_ in (t_.tensors() if isinstance(t_, PairBatch) else (t_,)):
                     if isinstance(u_, torch.Tensor) and u_.is_cuda:
                         u_.record_stream(st)
         del keep

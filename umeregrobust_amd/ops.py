@@ -793,6 +793,125 @@ def pair_match(pts, feat, kp_index, K, radius, tau=None, opts=None):
     return F, m, d, prob
 
 
+def _cloud2(t, name, width):
+    """a cloud as the ragged entries take it: contiguous f32 [N, width] on the device ([1,N,width] accepted), never copied"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the HIP device (no CPU fallback), got "
+                           f"{getattr(t, 'device', type(t).__name__)}")
+    if t.dim() == 3 and t.shape[0] == 1:
+        t = t[0]
+    if t.dim() != 2 or t.shape[1] != width or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float32 [N,{width}] tensor, got {t.dtype} {tuple(t.shape)} "
+                         f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def _kp2(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int64 or t.dim() != 1 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous int64 [n_kp] tensor on the HIP device")
+    return t
+
+
+def pair_match_ragged(src_pts, tgt_pts, src_feat, tgt_feat, src_kp, tgt_kp, K, radius, tau=None, opts=None):
+    """a1..a5 of one registration pair whose clouds may DIFFER in size (reference datasets/kitti/kitti_dataset.py:568-569 dilutes
+    source and target independently; evaluate.py:195-236), in one native call and without stacking or copying the clouds.
+    src_pts [N_src,3], tgt_pts [N_tgt,3], src_feat [N_src,32], tgt_feat [N_tgt,32] ([1,N,*] accepted), src_kp / tgt_kp int64 [n_kp]
+    -> (F [2,n_kp,32,4], match [1,n_kp] i64, match_d [1,n_kp] f32, prob [n_kp] f32 | None): the results of the per-cloud calls."""
+    lib = _lib.load()
+    sp, tp = _cloud2(src_pts, "src_pts", 3), _cloud2(tgt_pts, "tgt_pts", 3)
+    sf, tf = _cloud2(src_feat, "src_feat", 32), _cloud2(tgt_feat, "tgt_feat", 32)
+    sk, tk = _kp2(src_kp, "src_kp"), _kp2(tgt_kp, "tgt_kp")
+    if sf.shape[0] != sp.shape[0] or tf.shape[0] != tp.shape[0] or sk.shape != tk.shape or sk.numel() == 0:
+        raise ValueError("pair_match_ragged: features must match their cloud, both clouds need the same (non-zero) number of keypoints")
+    Ns, Nt, n = sp.shape[0], tp.shape[0], sk.shape[0]
+    dev = sp.device
+    F = torch.empty((2, n, 32, 4), dtype=torch.float32, device=dev)
+    m = torch.empty((1, n), dtype=torch.int64, device=dev)
+    d = torch.empty((1, n), dtype=torch.float32, device=dev)
+    prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
+    op = _lib.opts_ptr(opts)
+    need = lib.umereg_pair_match_workspace_bytes_ex(max(Ns, Nt), n, op)
+    if need == 0:
+        _lib.check(-1, "umereg_pair_match_workspace_bytes_ex")
+    ws = _workspace(dev, need, "pair")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_pair_match_ragged_f32(_ptr(sp), _ptr(tp), _ptr(sf), _ptr(tf), _ptr(sk), _ptr(tk), Ns, Nt, n, int(K), float(radius),
+                                              float(tau) if tau is not None else 0.0, _ptr(F), _ptr(m), _ptr(d), _ptr(prob),
+                                              _ptr(ws), ws.numel(), op, _stream_ptr(dev))
+    _lib.check(rc, "umereg_pair_match_ragged_f32")
+    return F, m, d, prob
+
+
+class PairMatchCapGraph:
+    """a1..a5 of a registration pair captured ONCE as a hipGraph at a capacity (clouds of up to `capacity` points, `n_kp` keypoints)
+    and replayed for any pair that fits: the captured kernels read the clouds through a 64-byte device record that launch() rewrites
+    (umereg_pair_match_graph_create_cap / _launch_ragged).  Outputs and workspace are owned by this object: F, m, d, prob are valid
+    until its next launch().  A pair's clouds must stay alive until its launch has completed."""
+
+    def __init__(self, device, capacity, n_kp, K, radius, tau=None, opts=None):
+        import ctypes
+        lib = _lib.load()
+        dev = self.dev = torch.device(device)
+        self.capacity, self.n_kp = int(capacity), int(n_kp)
+        self.params = (int(K), float(radius), None if tau is None else float(tau), None if opts is None else opts.key())
+        self.opts = opts
+        n = self.n_kp
+        self.F = torch.empty((2, n, 32, 4), dtype=torch.float32, device=dev)
+        self.m = torch.empty((1, n), dtype=torch.int64, device=dev)
+        self.d = torch.empty((1, n), dtype=torch.float32, device=dev)
+        self.prob = torch.empty((n,), dtype=torch.float32, device=dev) if tau is not None else None
+        op = _lib.opts_ptr(opts)
+        need = lib.umereg_pair_match_workspace_bytes_ex(self.capacity, n, op)
+        if need == 0:
+            _lib.check(-1, "umereg_pair_match_workspace_bytes_ex")
+        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self._lib = lib
+        handle = ctypes.c_void_p()
+        cap = torch.cuda.Stream(dev)                     # capture needs a non-default stream; nothing runs on it
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.device(dev):
+            rc = lib.umereg_pair_match_graph_create_cap(self.capacity, n, int(K), float(radius), float(tau) if tau is not None else 0.0,
+                                                        _ptr(self.F), _ptr(self.m), _ptr(self.d), _ptr(self.prob), _ptr(self.ws),
+                                                        self.ws.numel(), op, cap.cuda_stream, ctypes.byref(handle))
+        _lib.check(rc, "umereg_pair_match_graph_create_cap")
+        self.handle = handle
+
+    def fits(self, n_src, n_tgt, n_kp, K, radius, tau, opts=None):
+        """True if a replay of this graph computes a1..a5 of a pair of these sizes with these parameters."""
+        return self.handle is not None and max(n_src, n_tgt) <= self.capacity and n_kp == self.n_kp and \
+            self.params == (int(K), float(radius), None if tau is None else float(tau), None if opts is None else opts.key())
+
+    def launch(self, src_pts, tgt_pts, src_feat, tgt_feat, src_kp, tgt_kp, prob_host_ptr, stream_ptr):
+        """Replay for this pair on an explicit stream (+ asynchronous copy of the probabilities into pinned host memory: address or
+        0).  Tensors as pair_match_ragged takes them; nothing is copied, no torch stream / device context is touched."""
+        rc = self._lib.umereg_pair_match_graph_launch_ragged(self.handle, src_pts.data_ptr(), tgt_pts.data_ptr(), src_feat.data_ptr(),
+                                                             tgt_feat.data_ptr(), src_kp.data_ptr(), tgt_kp.data_ptr(),
+                                                             src_pts.shape[0], tgt_pts.shape[0], prob_host_ptr or None, stream_ptr)
+        if rc:
+            _lib.check(rc, "umereg_pair_match_graph_launch_ragged")
+
+    def launch_native(self, na, prob_host_ptr, stream_ptr):
+        """launch() from a pre-marshalled argument tuple (evaluate.PairBatch.native(): six device addresses, N_src, N_tgt)."""
+        rc = self._lib.umereg_pair_match_graph_launch_ragged(self.handle, *na, prob_host_ptr or None, stream_ptr)
+        if rc:
+            _lib.check(rc, "umereg_pair_match_graph_launch_ragged")
+
+    def solve(self, cond_host_ptr, n_cond, cond_dev, T_out, stream_ptr):
+        """evaluate.py:238-254 after the host draw, from this graph's outputs (see umereg_pair_match_graph_solve)."""
+        rc = self._lib.umereg_pair_match_graph_solve(self.handle, cond_host_ptr or None, int(n_cond), cond_dev.data_ptr() if cond_dev is not None else None,
+                                                     T_out.data_ptr(), stream_ptr)
+        if rc:
+            _lib.check(rc, "umereg_pair_match_graph_solve")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.umereg_pair_match_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class PairMatchGraph:
     """a1..a5 of one registration pair (pair_match) captured as ONE hipGraph over fixed buffers: the inputs given here,
     and outputs / workspace owned by this object.  launch() replays it on the current stream and returns the same
