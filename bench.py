@@ -210,6 +210,19 @@ def main():
                                tgt_feat=t(p.tgt_feat)[None], src_inds=t(p.src_inds), tgt_inds=t(p.tgt_inds),
                                gt=t(p.gt_tform).contiguous())
 
+    def pair_of(e):
+        """the entry's PairBatch.  Equally large clouds are kept as ONE [2,N,*] tensor per quantity (the entry's per-cloud tensors become
+        views of it): the roofline samples go through the layered entry points, and their moment launch then covers both clouds like the
+        production launch does.  Ragged entries stay where they are -- the one-call / graph path reads either form in place."""
+        if not a.batch_clouds:
+            return None
+        if e.src_pts.shape != e.tgt_pts.shape:
+            return evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds)
+        pb = evaluate.PairBatch(torch.cat([e.src_pts, e.tgt_pts]), torch.cat([e.src_feat, e.tgt_feat]), torch.stack([e.src_inds, e.tgt_inds]))
+        e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat = pb.pts[0:1], pb.pts[1:2], pb.feat[0:1], pb.feat[1:2]
+        e.src_inds, e.tgt_inds = pb.inds[0], pb.inds[1]
+        return pb
+
     # ---- synthetic inputs, resident in HBM before the timed region ---------------------------------
     # the pool and every pair's RNG seed depend on the pair's GLOBAL index g = rank + world * i only, so the integer
     # results of an N-GPU run equal those of a 1-GPU run over the same number of pairs
@@ -217,8 +230,7 @@ def main():
     pool = []
     for p_host in synth_many(range(max(1, a.pool)), dict(N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]), host_threads):
         e = resident(p_host)
-        e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
-            if a.batch_clouds else None
+        e.pair = pair_of(e)
         pool.append(e)
     # neighbour counts (for the algorithmic-bytes roofline), outside the timed region
     for e in pool:
@@ -351,8 +363,7 @@ def main():
     if a.hard_steps > 0:
         hard_pool_shared = [resident(synth_pair_hard(seed=9000 + i, N=cfg["N"], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"])) for i in range(4)]
         for e in hard_pool_shared:
-            e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds) \
-                if a.batch_clouds else None
+            e.pair = pair_of(e)
             e.mom_bytes = []
         leg.pool = hard_pool_shared
         run(0, P, False)
@@ -393,7 +404,7 @@ def main():
         for p_host in synth_many(range(7000, 7000 + n_rag),
                                  [dict(n_src=s_[0], n_tgt=s_[1], n_kp=n_kp, kind=a.kind, voxel=cfg["voxel"]) for s_ in sizes], host_threads):
             e = resident(p_host)
-            e.pair = evaluate.PairBatch.from_clouds(e.src_pts, e.tgt_pts, e.src_feat, e.tgt_feat, e.src_inds, e.tgt_inds)
+            e.pair = pair_of(e)
             e.mom_bytes = []
             rag_pool.append(e)
         leg.pool = rag_pool

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
     // (the geometry -- divisions and, in kNN mode, the cell-edge search loop -- by the first wavefront only: sixteen wavefronts doing
     // it side by side share four SIMDs)
     if (threadIdx.x < 64) {
-        const Grid g0 = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
+        const Grid g0 = load_grid_compute(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, desc ? desc->n_pts[blockIdx.y] : N);
         if (threadIdx.x == 0) g_sh = g0;
     }
     for (int c = threadIdx.x; c < kMaxCells; c += kSortWG) hist[c] = 0;
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(kSortWG) void grid_hist_kernel(char* __restrict__ w
 // agent-scope fence writes the XCD's L2 back on this part).  (One workgroup did all of it in round 2: 3 MB through one CU for a
 // 50 000-point cloud, 22 us.)
 constexpr int kScanWGs = kMaxCells / 256;
-__global__ __launch_bounds__(256) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius, int order_only)
+__global__ __launch_bounds__(256) void grid_scan_kernel(char* __restrict__ ws, size_t ws_stride, int N, float radius, int order_only,
+                                                        const PairDesc* __restrict__ desc)
 {
     const GridWs w = grid_ws(N);
     char* wb = ws + blockIdx.y * ws_stride;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(char* __restrict__ ws, s
     int* __restrict__ bases = reinterpret_cast<int*>(wb + w.off_bases);
     int* __restrict__ tot = reinterpret_cast<int*>(wb + w.off_tot);
     unsigned int* bbox = reinterpret_cast<unsigned int*>(wb + w.off_bbox);
-    const Grid gg = load_grid_compute(bbox, radius, N);
+    const Grid gg = load_grid_compute(bbox, radius, desc ? desc->n_pts[blockIdx.y] : N);      // (the density of the LIVE points, kNN mode)
     if (blockIdx.x == 0 && threadIdx.x == 0) store_grid(bbox, gg);     // for every later kernel
     // cells beyond this are never populated (curve positions of an order-only structure: any of the 4096)
     const int n_cells = ((order_only >> blockIdx.y) & 1) ? kMaxCells : gg.nx * gg.ny * gg.nz;
@@ -883,7 +884,7 @@ int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStrea
     UMEREG_CHECK_LAUNCH("pack_points_kernel");
     hipLaunchKernelGGL(grid_hist_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, radius, order_only, desc);
     UMEREG_CHECK_LAUNCH("grid_hist_kernel");
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(kScanWGs, B), dim3(256), 0, st, ws, w.total, N, radius, order_only);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(kScanWGs, B), dim3(256), 0, st, ws, w.total, N, radius, order_only, desc);
     UMEREG_CHECK_LAUNCH("grid_scan_kernel");
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, desc);
     UMEREG_CHECK_LAUNCH("grid_scatter_kernel");
