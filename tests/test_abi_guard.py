@@ -351,7 +351,7 @@ def case_pair_match_graphs(G):
                     fn + ".cond": tcd, fn + ".T": tT, fn + ".T_all": tTa})
         G.call("umereg_pair_match_graph_destroy", h)
     # the capacity graph: one capture, pairs of other sizes read where they lie
-    cap_N = 2400
+    cap_N = N
     F, tF = G.out((2, n, 32, 4), torch.float32, "F")
     m, tm = G.out((n,), torch.int64, "match_idx")
     d, td = G.out((n,), torch.float32, "match_dist")
@@ -359,7 +359,7 @@ def case_pair_match_graphs(G):
     ws, nws = G.ws(G.lib.umereg_pair_match_workspace_bytes_ex(cap_N, n, None))
     h = ctypes.c_void_p()
     G.call("umereg_pair_match_graph_create_cap", cap_N, n, K, 5.0, 0.05, F, m, d, pr, ws, nws, None, cap.cuda_stream, ctypes.byref(h))
-    for tag, Ns, Nt in (("a", 2400, 1777), ("b", 1025, 2399)):
+    for tag, Ns, Nt in (("a", N, 1777), ("b", 1025, N - 1)):
         a = [G.inp(x)[0] for x in (sp[:Ns], tp[:Nt], sf[:Ns], tf[:Nt], sk % Ns, tk % Nt)]
         G.call("umereg_pair_match_graph_launch_ragged", h, *a, Ns, Nt, prob_h.data_ptr(), G.stream)
         torch.cuda.synchronize()

@@ -2251,7 +2251,8 @@ def test_f1_at_the_benchmarks_own_size_against_sampled_oracle_scores(gpu, shape)
 
         class Spy(orig):
             def feature_corr_hypothesis_test(self, *a_, **k_):
-                fc_holder["inputs"] = a_[:4]
+                names = ("source_pc", "target_pc", "source_feat", "target_feat")
+                fc_holder["inputs"] = tuple(k_[n_] if n_ in k_ else a_[i_] for i_, n_ in enumerate(names))
                 r_ = super().feature_corr_hypothesis_test(*a_, **k_)
                 fc_holder["fc"] = self
                 return r_
