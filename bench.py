@@ -95,6 +95,9 @@ def parse():
     ap.add_argument("--stream-plan", default=None,
                     help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
                          "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
+    ap.add_argument("--plan-check-pairs", type=int, default=96,
+                    help="pairs of the stream-plan self-check (config.stream_plan_check: the shipped plan against plain creation order, "
+                         "after the timed region; 0 = skip)")
     ap.add_argument("--match-pform", action="store_true",
                     help="(experiments) run the P-form coarse kernel of the matcher (umereg_match_opts.variant = 1, per call)")
     ap.add_argument("--match-tuning", default=None,
@@ -282,6 +285,10 @@ def main():
             ops.hypothesis_gates(out.rtume_tform[0], h.entry.gt, leg_counts(h.slot))
 
     roofline_every = a.roofline_every if a.roofline_every else max(1, a.steps // 5)
+    # positions of a sampled step: the first n_alone pairs run alone, pair k_situ is timed inside the pipeline.  Short steps (the K1 tests
+    # run 2-3 pairs per step) keep one alone pair and, from three pairs on, an in-situ one behind it
+    n_alone = 2 if P >= 4 else 1
+    k_situ = max(n_alone, P // 2) if P > n_alone else None
 
     def run(first, n, record):
         pending = []
@@ -294,14 +301,14 @@ def main():
             k = (i - first) % P
             step = (i - first) // P
             sample = record and step % roofline_every == 0
-            if sample and k < 2:          # two pairs alone, one after the other, behind ONE drain (the drain is what a sample costs)
+            if sample and k < n_alone:    # two pairs alone, one after the other, behind ONE drain (the drain is what a sample costs)
                 while pending:
                     finish(pending.pop(0))
                 torch.cuda.synchronize()
                 finish(submit(i, timing))
                 torch.cuda.synchronize()
                 continue
-            pending.append(submit(i, timing_situ if (sample and k == P // 2) else None))
+            pending.append(submit(i, timing_situ if (sample and k == k_situ) else None))
             if len(pending) >= depth:
                 finish(pending.pop(0))
         while pending:
@@ -440,6 +447,31 @@ def main():
         leg.pool = pool
         del rag_pool
 
+    # ---- does the stream plan still pay on THIS runtime?  The pipeline creates its slot streams interleaved with spacer streams ("sd"
+    # per slot) because the HIP runtime deals streams onto its hardware queues in creation order (RegistrationPipeline.__init__): an
+    # unspecified behaviour.  So every run times the same pairs through a pipeline built with the shipped plan and one built in plain
+    # creation order, after the timed region, and records the ratio: a runtime that deals queues differently shows up as a number in
+    # bench_detail.json, not as a silent -20 %. ----
+    plan_check = None
+    if a.plan_check_pairs > 0 and graph_mode != "none":
+        plan_check = {}
+        for tag, plan in (("shipped_plan", a.stream_plan), ("creation_order", "s" * depth)):
+            leg.pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=graph_mode,
+                                                     stream_plan=plan, match_opts=match_opts)
+            leg.pool = pool
+            run(0, a.plan_check_pairs, False)
+            fence()
+            t1 = time.perf_counter()
+            run(a.plan_check_pairs, 2 * a.plan_check_pairs, False)
+            fence()
+            plan_check[tag] = round(2 * a.plan_check_pairs / (time.perf_counter() - t1), 1)
+        leg.pipe, leg.pool = pipe, pool
+        plan_check["ratio_shipped_over_creation_order"] = round(plan_check["shipped_plan"] / max(plan_check["creation_order"], 1e-9), 4)
+        plan_check["note"] = (f"pairs/s over {2 * a.plan_check_pairs} pairs of the pool on rank 0's device, fresh pipelines, after the timed region; "
+                              "shipped plan = '" + (a.stream_plan or "sd" * depth) + "', creation order = '" + "s" * depth + "'")
+        if plan_check["ratio_shipped_over_creation_order"] < 0.97:
+            print(f"[bench] the pipeline's stream plan is SLOWER than plain creation order on this runtime: {plan_check}", file=sys.stderr)
+
     # ---- per-kernel durations measured live with events on the launch stream -----------------------
     def situ(lst):
         v = [s.elapsed_time(e_) for s, e_ in lst]
@@ -474,7 +506,13 @@ def main():
         # config 5 (200 000-point clouds, saturated balls): the feature table (2 x 25.6 MB) no longer sits in an XCD's 4 MiB L2, the gathers are
         # served by the fabric / Infinity Cache, and SURVEY 8(d)'s model -- algorithmic bytes against the HBM peak -- is a utilisation here
         # (< 1).  This is BASELINE.json's "roofline run": the moment kernel is priced the way north_star asks (>= 50 % of the HBM roofline).
+        # `achieved` / `frac` are the bench contract's: ALGORITHMIC bytes (140 n_i + 524 per keypoint) per launch / duration
+        # over the HBM peak.  That is NOT the fabric's utilisation: an XCD's L2 still serves most of the gathers (hit rate 0.86), the
+        # measured fabric bytes are a quarter to a third of the algorithmic ones -- `traffic_frac` below (filled in from the counter
+        # pass: traffic / duration / HBM peak, ~0.2) is the utilisation a profiler sees, and the two must not be confused.
         roof_mom.update({"bound": "hbm", "achieved": round(mom_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mom_gbs / HBM_PEAK_GBS, 4),
+                         "frac_is": "algorithmic bytes (SURVEY 8(d)) / time / HBM peak, as the bench contract defines `achieved`; "
+                                    "the MEASURED fabric utilisation is `traffic_frac`",
                          "mfma_f64_tflops": round(mom_tfs, 2), "mfma_f64_frac": round(mom_tfs / MFMA_F64_PEAK_TFLOPS, 4)})
     if a.precision == "f16r":
         # filter + refine: ONE f16 MFMA product per algorithmic product in the coarse kernel (the timed
@@ -520,6 +558,10 @@ def main():
         counters_match[os.path.basename(pmc)] = tr.get("library_source_hash") == lib_hash
         for r_ in (roof_mom, roof_dist):
             r_["traffic"] = tr.get(r_["kernel"])
+            if r_["traffic"] and r_.get("avg_launch_ms"):
+                # what the fabric really moved per launch over the HBM peak (the profiler's utilisation)
+                r_["traffic_gb_per_s"] = round(float(r_["traffic"]) / (r_["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                r_["traffic_frac"] = round(r_["traffic_gb_per_s"] / HBM_PEAK_GBS, 4)
             r_["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run " \
                                    "of this command; fabric bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)"
     sq = os.path.join(REPO, "profiles", f"sq_summary{suffix}.json")
@@ -561,8 +603,9 @@ def main():
                                 "per pipeline slot (captured at the capacity max_pc_size; a pair = a 64-byte device record + a replay): "
                                 "what a loop like evaluate.py:175 gets" if graph_mode != "none" else "named path a1-a7, pairs/s, plain launches"),
                    "resident_replay": resident_replay, "named_path_on_hard_pairs": hard_named, "named_path_on_ragged_pairs": ragged_named,
-                   "graphs_captured_total": pipe.captures,
+                   "graphs_captured_total": pipe.captures, "stream_plan_check": plan_check,
                    "roofline_sampling_every_n_steps": roofline_every,
+                   "roofline_in_situ_sample": ("none: fewer pairs per step than a sample needs" if k_situ is None else f"pair {k_situ} of a sampled step"),
                    "roofline_sampling": "one pair per sampled step runs alone (pipeline drained before and after, inside the timed region): "
                                         "`avg_launch_ms` / `achieved` are the kernel's own; `in_situ_avg_launch_ms` = one pair per sampled step "
                                         "timed inside the pipeline, beside the kernels of the other pairs in flight", "host_draw_thread": bool(a.threaded_draw), "clouds_per_moment_launch": 2 if a.batch_clouds else 1,
@@ -844,6 +887,22 @@ def main():
     if rr:
         result["cpu_baseline"]["rr_pairs"] = rr["pairs"]
         result["cpu_baseline"]["rr_pairs_with_a_different_gate_outcome"] = len(rr["pairs_with_a_different_gate_outcome_same_draws"])
+    # `recall` of the line = numbers that can DISCRIMINATE: the hard pairs, oracle (port of the reference) and this library side by side on
+    # replayed draws, and the KT-size hard pairs through the library's own loop.  (The plain pairs are exact rigid copies: 100 / 100 / 100
+    # whatever the code does; they stay in `end_to_end` of the detail file.)
+    rec = {"gates": ["1.5deg,0.6m", "1.5deg,0.3m", "1deg,0.1m"]}
+    if rr:
+        rec.update({"hard_reduced_size_pairs": rr["pairs"], "reference_port_rr_percent": rr["cpu_rr_percent"],
+                    "this_library_same_draws_rr_percent": rr["hip_same_draws_rr_percent"],
+                    "pairs_with_a_different_gate_outcome": len(rr["pairs_with_a_different_gate_outcome_same_draws"]),
+                    "reference_port_mRRE_mRTE": rr["cpu_mRRE_mRTE"], "this_library_mRRE_mRTE": rr["hip_same_draws_mRRE_mRTE"]})
+    if e2h:
+        rec["hard_full_size_pairs"] = {"pairs": e2h["pairs"], "rr_percent": [e2h["rr_1.5deg_0.6m"], e2h["rr_1.5deg_0.3m"], e2h["rr_1deg_0.1m"]],
+                                       "mRRE_deg": e2h["mRRE_deg"], "mRTE_m": e2h["mRTE_m"],
+                                       "evaluate_pairs_NP_SP_percent": [e2h.get("evaluate_pairs_loop", {}).get("rank0_N.P_percent"),
+                                                                        e2h.get("evaluate_pairs_loop", {}).get("rank0_S.P_percent")]}
+    if rr or e2h:
+        result["recall"] = rec
     cm = dict(result.get("counters_match_library_by_file") or {})
     if (f1s.get("plain") or {}).get("counters_match_library") is not None:
         cm["f1_sq_summary.json"] = f1s["plain"]["counters_match_library"]

@@ -395,6 +395,17 @@ size_t umereg_knn_workspace_bytes(int B, int n2);
 int umereg_knn_points_f32(const float* p1, const float* p2, int B, int n1, int n2, int K, float* dists,
                           int64_t* idx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The K = 1 feature transfer of BOTH clouds of a pair in one pass -- evaluate.py:272-275:
+ *   knn_points(src_pts_raw, src_pts, K=1) and knn_points(tgt_pts_raw, tgt_pts, K=1)
+ * Four clouds of four sizes on a real pair (the collate dilutes source and target independently, datasets/kitti/kitti_dataset.py:
+ * 568-569; the voxel thinning keeps what it keeps): q_src [nq_src,3] searches p_src [n_src,3], q_tgt [nq_tgt,3] searches p_tgt
+ * [n_tgt,3]; idx_* int64 [nq_*] (the nearest point, lower index on ties: umereg_knn_points_f32 with K = 1), dist_* f32 [nq_*]
+ * squared distances (may be NULL).  One structure build and one query launch for both clouds. */
+size_t umereg_nn1_pair_workspace_bytes(int n_src, int n_tgt);
+int umereg_nn1_pair_f32(const float* q_src, const float* q_tgt, const float* p_src, const float* p_tgt, int nq_src, int nq_tgt,
+                        int n_src, int n_tgt, int64_t* idx_src, int64_t* idx_tgt, float* dist_src, float* dist_tgt,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* feature_spatial_var(pts, feat, knn)   -- utils/loc_utils.py:579-585
  * out[b,i] = mean over the knn-1 nearest OTHER points j of |feat[b,i] - feat[b,j]|_2 (self-kNN,
  * idx[:, :, 1:]); fused kNN + gather + norm, nothing of size [N,knn,32] is formed.

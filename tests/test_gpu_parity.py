@@ -722,7 +722,7 @@ def test_other_configs_full_size_properties(gpu, config):
     R = a.rtume_tform[0, :, :3, :3]
     assert float((R @ R.transpose(1, 2) - torch.eye(3, device=gpu)).abs().max()) < 1e-4
     # the one-call path equals the layered one
-    F = ops.ume_moments(pair.pts, None, pair.feat, 750, 5.0, kp_index=pair.inds)
+    F = ops.ume_moments(torch.cat(clouds[0:2]), None, torch.cat(clouds[2:4]), 750, 5.0, kp_index=pair.inds)
     m2, d2 = ops.ume_match(F[0:1], F[1:2], precision="f16r")
     assert torch.equal(F[0:1], a.ume_src) and torch.equal(m2, a.match) and torch.equal(d2, a.match_d)
     # moment matrices against the oracle on a sample (saturated balls included for SY)

@@ -284,6 +284,10 @@ def _canned_bench_result():
     }
 
 
+def prose_of(full):
+    return full["config"]["value_is"]
+
+
 def test_bench_line_is_bounded_and_complete(tmp_path):
     """the ONE line bench.py prints: < 4 KB whatever the full result holds (the driver keeps an 8 KB stdout tail; round 4's 22 KB
     line did not parse), strict JSON, every key of the bench contract; the full result goes to the detail file"""
@@ -309,7 +313,22 @@ def test_bench_line_is_bounded_and_complete(tmp_path):
     assert d["cpu_baseline"]["value"] == 1.965 and d["cpu_baseline"]["cores"] == 256 and d["cpu_baseline"]["kind"] == "port"
     assert d["cpu_baseline"]["rr_pairs"] == 128 and d["cpu_baseline"]["rr_pairs_with_a_different_gate_outcome"] == 0
     assert d["recall"]["mRTE_m"] is None                         # NaN -> null, not a bare NaN token
+    assert "rigid copies" in d["recall"]["pairs_are"]            # (no hard-pair leg in this result: the fallback says what its pairs are)
     assert d["detail"] == "gpurun_out/bench_detail.json"
+    # with the hard-pair legs on record, `recall` is THEIR numbers (the reference's port and this library side by side), ragged leg included
+    rich = dict(full, recall={"gates": ["1.5deg,0.6m", "1.5deg,0.3m", "1deg,0.1m"], "hard_reduced_size_pairs": 128,
+                              "reference_port_rr_percent": [79.7, 75.8, 75.8], "this_library_same_draws_rr_percent": [79.7, 75.8, 75.8],
+                              "pairs_with_a_different_gate_outcome": 0})
+    rich["config"] = dict(full["config"], named_path_on_ragged_pairs={"pairs_per_s": 3900.0, "ratio_to_value": 1.08,
+                                                                      "graphs_captured_during_the_leg": 0, "note": prose_of(full)})
+    s2 = benchline.line(rich, "x.json")
+    d2 = json.loads(s2)
+    assert len(s2.encode()) < 4096 and d2["recall"]["reference_port_rr_percent"] == [79.7, 75.8, 75.8]
+    assert d2["config"]["named_path_on_ragged_pairs"] == {"pairs_per_s": 3900.0, "ratio_to_value": 1.08, "graphs_captured_during_the_leg": 0}
+    # a result that cannot be formatted still yields a line with the contract's keys (rank 0 must not die before the others' barrier)
+    broken = dict(full, rooflines={"k": float("nan")})
+    d3 = json.loads(benchline.safe_line(broken, "x.json"))
+    assert d3["value"] == 3595.123 and all(k in d3 for k in benchline.REQUIRED_KEYS)
     assert json.load(open(path))["f1_selection"]["plain"]["kernels"]["k3"]["note"]     # nothing is lost: it is in the file
     # N > 1 (no CPU leg) and the tracked round-4 result (the one whose line was too long) go through as well
     many = dict(full, cpu_baseline=None, n_gpus=8)

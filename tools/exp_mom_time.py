@@ -18,7 +18,7 @@ if cfg == "HARD":       # KT-size half-overlapping pair (two 240-degree sectors:
 else:
     p = synth_pair_cfg(1, cfg)
 t = lambda a: torch.from_numpy(a).to(dev)
-pair = evaluate.PairBatch.from_clouds(t(p.src_pts)[None], t(p.tgt_pts)[None], t(p.src_feat)[None], t(p.tgt_feat)[None], t(p.src_inds), t(p.tgt_inds))
+pair = evaluate.PairBatch(torch.stack([t(p.src_pts), t(p.tgt_pts)]), torch.stack([t(p.src_feat), t(p.tgt_feat)]), torch.stack([t(p.src_inds), t(p.tgt_inds)]))
 for search in ["default"]:
   tm = []
   for it in range(25):

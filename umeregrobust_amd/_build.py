@@ -72,12 +72,14 @@ def toolchain_id():
     return d
 
 
-def source_hash():
+def source_hash(extra_flags=()):
     """sha256 over the names and contents of every dependency and the compiler flags: the identity of a build.
     It is compiled INTO the library (-DUMEREG_SOURCE_HASH, exported as umereg_build_source_hash()), so a shared object can
-    be checked against the tree it claims to come from."""
+    be checked against the tree it claims to come from.  extra_flags: the `-D...` switches of an A/B variant (build_native(extra_flags=
+    ..., out=tools/lib*.so)) are part of ITS identity: a counter pass taken on a variant library carries another hash than the product's
+    and cannot pass for a profile of the product (bench.py's counters_match_library)."""
     h = hashlib.sha256()
-    h.update(" ".join(CFLAGS + ["-shared"]).encode())    # (without the -I path: the same sources build the same anywhere)
+    h.update(" ".join(CFLAGS + list(extra_flags) + ["-shared"]).encode())    # (without the -I path: the same sources build the same anywhere)
     for f in dependencies():
         h.update(os.path.basename(f).encode() + b"\0" + _file_digest(f).encode() + b"\0")
     return h.hexdigest()
@@ -151,7 +153,7 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None):
         raise ValueError("build_native(extra_flags=...) builds an A/B variant: give it its own `out` (e.g. tools/lib<name>.so), not the product library")
     if out == LIB_PATH and not extra_flags and not force and not is_stale():
         return LIB_PATH
-    want = source_hash()
+    want = source_hash(extra_flags)
     obj_dir_default = OBJ_DIR
     if out != LIB_PATH or extra_flags:
         OBJ_DIR = os.path.join(CSRC, ".obj-" + hashlib.sha256((out + " ".join(extra_flags)).encode()).hexdigest()[:12])

@@ -112,6 +112,9 @@ SIGNATURES = {
     "umereg_knn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "umereg_knn_points_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "umereg_nn1_pair_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "umereg_nn1_pair_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_feature_spatial_var_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                                c_size_t, c_void_p]),
     "umereg_corr_weighted_features_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -22,7 +22,7 @@ def _roof(r):
     if not r:
         return None
     out = {k: r.get(k) for k in ROOFLINE_KEYS}
-    for k in ("counters_match_library", "peak_source"):
+    for k in ("counters_match_library", "peak_source", "traffic_frac"):
         if k in r:
             out[k] = r[k]
     return out
@@ -52,6 +52,7 @@ def compact(result, detail_path=None):
         "end_to_end_pairs_per_s": e2e,
         "named_path_on_hard_pairs": {"pairs_per_s": hard.get("pairs_per_s")} if hard else None,
         "named_path_on_ragged_pairs": {k: rag.get(k) for k in ("pairs_per_s", "ratio_to_value", "graphs_captured_during_the_leg")} if rag else None,
+        "stream_plan_check": (cfg.get("stream_plan_check") or {}).get("ratio_shipped_over_creation_order"),
         "world": {"ranks": world.get("ranks"), "backend": world.get("backend"), "launched_by": world.get("launched_by")},
     }
     out["roofline"] = _roof(result.get("roofline"))
@@ -65,9 +66,14 @@ def compact(result, detail_path=None):
                 out["cpu_baseline"][k] = cb[k]
     else:
         out["cpu_baseline"] = None      # (N > 1, or --no-cpu-baseline: rank 0 at N = 1 only, by the bench contract)
+    # recall: the discriminating numbers (hard pairs: the reference's port and this library on replayed draws, the KT-size hard pairs);
+    # a run without those legs (N > 1: no CPU leg) falls back to the end-to-end leg's own pairs, labelled as what they are
     e = result.get("end_to_end") or {}
-    if e:
-        out["recall"] = {k: e.get(k) for k in ("rr_1.5deg_0.6m", "rr_1.5deg_0.3m", "rr_1deg_0.1m", "mRRE_deg", "mRTE_m")}
+    if result.get("recall"):
+        out["recall"] = result["recall"]
+    elif e:
+        out["recall"] = {"pairs_are": "exact rigid copies (cannot fail)",
+                         **{k: e.get(k) for k in ("rr_1.5deg_0.6m", "rr_1.5deg_0.3m", "rr_1deg_0.1m", "mRRE_deg", "mRTE_m")}}
     if "counters_match_library" in result:
         out["counters_match_library"] = result["counters_match_library"]
     out["detail"] = detail_path

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void knn_points_kernel(const char* __restrict_
                                                          const float* __restrict__ p1, int n1, int n2, int K, int cap,
                                                          int ordered, float* __restrict__ dists, int64_t* __restrict__ idx);
 __global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ p1, int n1, int n2,
-                                                         float* __restrict__ dists, int64_t* __restrict__ idx);
+                                                         float* __restrict__ dists, int64_t* __restrict__ idx, const QueryDesc* __restrict__ dq);
 template <class IdxT>
 __global__ __launch_bounds__(256) void spatial_var_kernel(const char* __restrict__ ws, size_t ws_stride,
                                                           const float4* __restrict__ feat4, int N, int K, int cap,

@@ -74,9 +74,11 @@ template __global__ __launch_bounds__(256) void knn_points_kernel<unsigned int>(
 // raw points of a KITTI pair against ~25 here.
 constexpr int kNn1Lanes = 8;
 __global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ p1, int n1, int n2,
-                                                         float* __restrict__ dists, int64_t* __restrict__ idx)
+                                                         float* __restrict__ dists, int64_t* __restrict__ idx, const QueryDesc* __restrict__ dq)
 {
     const int b = blockIdx.y;
+    // dq (a ragged pair, umereg_nn1_pair_f32): batch element b asks ITS queries and writes ITS outputs; n1 is then the launch's capacity
+    if (dq) { n1 = dq->n_q[b]; p1 = dq->q[b] - (size_t)b * n1 * 3; idx = dq->idx[b] - (size_t)b * n1; dists = dq->dist[b] ? dq->dist[b] - (size_t)b * n1 : nullptr; }
     const GridWs w = grid_ws(n2);
     const char* wb = ws + b * ws_stride;
     const float4* __restrict__ P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict_
     }
     (void)lane;
     if (live && sub == 0) {
-        dists[(size_t)b * n1 + q] = m != ~0ull ? __uint_as_float((unsigned int)(m >> 32)) : 0.f;
+        if (dists) dists[(size_t)b * n1 + q] = m != ~0ull ? __uint_as_float((unsigned int)(m >> 32)) : 0.f;
         idx[(size_t)b * n1 + q] = m != ~0ull ? (int64_t)(unsigned int)(m & 0xffffffffull) : (int64_t)-1;
     }
 }
@@ -321,7 +323,7 @@ UMEREG_API int umereg_knn_points_f32(const float* p1, const float* p2, int B, in
     if (int rc = launch_prep(p2, (char*)workspace, B, n2, -(float)K, st)) return rc;
     if (K == 1) {
         hipLaunchKernelGGL(nn1_points_kernel, dim3((n1 + 256 / kNn1Lanes - 1) / (256 / kNn1Lanes), B), dim3(256), 0, st, (const char*)workspace,
-                           grid_ws(n2).total, p1, n1, n2, dists, idx);
+                           grid_ws(n2).total, p1, n1, n2, dists, idx, (const QueryDesc*)nullptr);
         UMEREG_CHECK_LAUNCH("nn1_points_kernel");
         return UMEREG_OK;
     }
@@ -340,6 +342,45 @@ UMEREG_API int umereg_knn_points_f32(const float* p1, const float* p2, int B, in
         hipLaunchKernelGGL(knn_points_kernel<unsigned int>, dim3((n1 + qpb - 1) / qpb, B), dim3(qpb), lds, st,
                            (const char*)workspace, grid_ws(n2).total, p1, n1, n2, K, cap, ordered, dists, idx);
     UMEREG_CHECK_LAUNCH("knn_points_kernel");
+    return UMEREG_OK;
+}
+
+// ---- the K = 1 feature transfer of BOTH clouds of a pair in one pass (evaluate.py:272-275) -----------------------------------------
+// knn_points(src_pts_raw, src_pts, K=1) and knn_points(tgt_pts_raw, tgt_pts, K=1): four clouds of four sizes on a real pair (the
+// collate dilutes source and target independently, kitti_dataset.py:568-569; the voxel thinning keeps what it keeps).  One search
+// structure build for both network clouds (batch of two at the capacity max(n_src, n_tgt), per-cloud lengths through a PairDesc) and
+// one query launch (per-cloud query sets through a QueryDesc): half the launches of two umereg_knn_points_f32 calls, the same indices.
+UMEREG_API size_t umereg_nn1_pair_workspace_bytes(int n_src, int n_tgt)
+{
+    if (n_src <= 0 || n_tgt <= 0) return 0;
+    return 2 * grid_ws(n_src > n_tgt ? n_src : n_tgt).total + 256;
+}
+
+UMEREG_API int umereg_nn1_pair_f32(const float* q_src, const float* q_tgt, const float* p_src, const float* p_tgt, int nq_src, int nq_tgt,
+                                   int n_src, int n_tgt, int64_t* idx_src, int64_t* idx_tgt, float* dist_src, float* dist_tgt,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    UMEREG_REQUIRE(q_src && q_tgt && p_src && p_tgt && idx_src && idx_tgt, "nn1_pair: null pointer");
+    UMEREG_REQUIRE(nq_src > 0 && nq_tgt > 0 && n_src > 0 && n_tgt > 0, "nn1_pair: sizes must be positive (got %d, %d queries into %d, %d points)",
+                   nq_src, nq_tgt, n_src, n_tgt);
+    if (int rc = check_device()) return rc;
+    const size_t need = umereg_nn1_pair_workspace_bytes(n_src, n_tgt);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+        set_error("nn1_pair: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+        return UMEREG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int N = n_src > n_tgt ? n_src : n_tgt, nq = nq_src > nq_tgt ? nq_src : nq_tgt;
+    PairDesc* dp = (PairDesc*)((char*)workspace + need - 256);
+    QueryDesc* dq = (QueryDesc*)((char*)workspace + need - 128);
+    const PairDesc vp = {{p_src, p_tgt}, {nullptr, nullptr}, {nullptr, nullptr}, {n_src, n_tgt}, 0, 0};
+    const QueryDesc vq = {{q_src, q_tgt}, {idx_src, idx_tgt}, {dist_src, dist_tgt}, {nq_src, nq_tgt}, {0, 0}};
+    if (int rc = write_record(dp, vp, st)) return rc;
+    if (int rc = write_record(dq, vq, st)) return rc;
+    if (int rc = launch_prep(nullptr, (char*)workspace, 2, N, -1.0f, st, 0, dp)) return rc;
+    hipLaunchKernelGGL(nn1_points_kernel, dim3((nq + 256 / kNn1Lanes - 1) / (256 / kNn1Lanes), 2), dim3(256), 0, st, (const char*)workspace,
+                       grid_ws(N).total, (const float*)nullptr, nq, N, (float*)nullptr, (int64_t*)nullptr, (const QueryDesc*)dq);
+    UMEREG_CHECK_LAUNCH("nn1_points_kernel");
     return UMEREG_OK;
 }
 

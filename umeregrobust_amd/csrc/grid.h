@@ -32,6 +32,29 @@ struct PairDesc {
 };
 static_assert(sizeof(PairDesc) == 64, "PairDesc is a 64-byte device record");
 
+// the queries of a two-cloud search whose query sets differ in size (the K = 1 feature transfer of evaluate.py:272-275 on a ragged
+// pair): batch element b asks n_q[b] queries q[b] and writes idx[b] / dist[b] (dist may be null)
+struct QueryDesc {
+    const float* q[2];          // [n_q[b], 3]
+    int64_t* idx[2];            // [n_q[b]]
+    float* dist[2];             // [n_q[b]] or null
+    int n_q[2];
+    int reserved[2];
+};
+static_assert(sizeof(QueryDesc) == 64, "QueryDesc is a 64-byte device record");
+
+// a device record written by a one-thread kernel that takes the VALUE as its argument: nothing on the host has to outlive the call
+// (a hipMemcpyAsync from pageable memory would stage, one from pinned memory would tie a host buffer to the stream)
+template <class T>
+__global__ void record_write_kernel(T* __restrict__ d, T v) { *d = v; }
+template <class T>
+inline int write_record(T* dev, const T& v, hipStream_t st)
+{
+    hipLaunchKernelGGL(record_write_kernel<T>, dim3(1), dim3(1), 0, st, dev, v);
+    UMEREG_CHECK_LAUNCH("record_write_kernel");
+    return UMEREG_OK;
+}
+
 // ---- workspace carve-up (per batch element) ---------------------------------------------------
 struct GridWs {
     size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_tot, off_bbox, off_kperm, off_box, total;

@@ -1427,14 +1427,7 @@ UMEREG_API int umereg_pair_match_f32(const float* pts, const float* feat, const 
 // written outside the graph, before every replay).
 static PairDesc* desc_of(void* workspace, size_t need) { return (PairDesc*)((char*)workspace + need - 256); }
 
-__global__ void pair_desc_write_kernel(PairDesc* __restrict__ d, PairDesc v) { *d = v; }
-
-static int write_pair_desc(PairDesc* dev, const PairDesc& v, hipStream_t st)
-{
-    hipLaunchKernelGGL(pair_desc_write_kernel, dim3(1), dim3(1), 0, st, dev, v);
-    UMEREG_CHECK_LAUNCH("pair_desc_write_kernel");
-    return UMEREG_OK;
-}
+static int write_pair_desc(PairDesc* dev, const PairDesc& v, hipStream_t st) { return write_record(dev, v, st); }
 
 static int ragged_args(const PairDesc& v, int N_cap, int n_kp, const char* who)
 {

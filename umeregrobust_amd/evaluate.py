@@ -180,11 +180,12 @@ def select_hypothesis(src_pts_raw, tgt_pts_raw, src_pts, tgt_pts, src_feat, tgt_
     tgt_sel = _index_tensor(choice_uniform_noreplace(rng, n_tgt, min(args.pc_corr_max_size, n_tgt)), dev)          # :283-284
     src_pts_raw = src_pts_raw[src_inds[src_sel]][None].contiguous()
     tgt_pts_raw = tgt_pts_raw[tgt_inds[tgt_sel]][None].contiguous()
-    if src_pts_raw.shape == tgt_pts_raw.shape and src_pts.shape == tgt_pts.shape:
-        # both clouds as one batch of two through the grid build and the search (same arithmetic per cloud, half the launches)
-        ind = ops.knn_points(torch.cat([src_pts_raw, tgt_pts_raw], 0), torch.cat([src_pts, tgt_pts], 0), K=1)[1]    # :272, :274
-        src_feat_corr = src_feat[0][ind[0, :, 0]][None]                                                          # knn_gather(...)[:, :, 0, :]
-        tgt_feat_corr = tgt_feat[0][ind[1, :, 0]][None]
+    if src_pts_raw.is_cuda and all(x.dtype == torch.float32 for x in (src_pts_raw, tgt_pts_raw, src_pts, tgt_pts)):
+        # both clouds as one batch of two through the grid build and the search (same arithmetic per cloud, half the launches), whatever
+        # the four sizes are: the collate dilutes source and target independently (kitti_dataset.py:568-569), the thinning keeps what it keeps
+        i_s, i_t = ops.nn1_pair(src_pts_raw, tgt_pts_raw, src_pts.contiguous(), tgt_pts.contiguous())                 # :272, :274
+        src_feat_corr = src_feat[0][i_s][None]                                                                   # knn_gather(...)[:, :, 0, :]
+        tgt_feat_corr = tgt_feat[0][i_t][None]
     else:
         ind = ops.knn_points(src_pts_raw, src_pts, K=1)                                                          # :272
         src_feat_corr = src_feat[0][ind[1][0, :, 0]][None]                                                       # knn_gather(...)[:, :, 0, :]

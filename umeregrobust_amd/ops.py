@@ -492,6 +492,26 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, return_nn=False, **_ig
     return KNN(dists, idx, nn)
 
 
+def nn1_pair(q_src, q_tgt, p_src, p_tgt):
+    """The K = 1 feature transfer of both clouds of a pair (reference evaluate.py:272-275: knn_points(src_pts_raw, src_pts, K=1) and
+    knn_points(tgt_pts_raw, tgt_pts, K=1)) in one native call: one structure build, one query launch, whatever the four sizes are.
+    q_src [nq_s,3], q_tgt [nq_t,3], p_src [n_s,3], p_tgt [n_t,3] ([1,n,3] accepted) -> (idx_src int64 [nq_s], idx_tgt int64 [nq_t]):
+    knn_points(...).idx[0, :, 0] of the two calls."""
+    lib = _lib.load()
+    qs, qt, ps, pt = _cloud2(q_src, "q_src", 3), _cloud2(q_tgt, "q_tgt", 3), _cloud2(p_src, "p_src", 3), _cloud2(p_tgt, "p_tgt", 3)
+    if min(qs.shape[0], qt.shape[0], ps.shape[0], pt.shape[0]) == 0:
+        raise ValueError("nn1_pair: empty cloud")
+    dev = qs.device
+    i_s = torch.empty(qs.shape[0], dtype=torch.int64, device=dev)
+    i_t = torch.empty(qt.shape[0], dtype=torch.int64, device=dev)
+    ws = _workspace(dev, lib.umereg_nn1_pair_workspace_bytes(ps.shape[0], pt.shape[0]), "nn1pair")
+    with torch.cuda.device(dev):
+        rc = lib.umereg_nn1_pair_f32(_ptr(qs), _ptr(qt), _ptr(ps), _ptr(pt), qs.shape[0], qt.shape[0], ps.shape[0], pt.shape[0],
+                                     _ptr(i_s), _ptr(i_t), None, None, _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_nn1_pair_f32")
+    return i_s, i_t
+
+
 def feature_spatial_var(pts, feat, knn=10):
     """reference utils/loc_utils.py:579-585, fused.  pts [B,N,3], feat [B,N,32] -> [B,N].  2 <= knn <= min(64, N)
     (the reference default is 10, FeatureCorrelator uses 50)."""
@@ -686,6 +706,12 @@ class IcpJob:
             self.launched = 0
             self._enqueue(True, 4)
         except BaseException:
+            # the native call may have enqueued kernels before it failed (and no event is recorded behind them): nothing of this job
+            # -- its workspace slot, its pinned state -- goes back before the stream has drained
+            try:
+                self.stream.synchronize()
+            except Exception:   # noqa: BLE001
+                pass
             self._release(reuse_state=False)
             raise
 
@@ -724,6 +750,8 @@ class IcpJob:
     def result(self):
         if self._res is not None:
             return self._res
+        if self.state is None:
+            raise RuntimeError("IcpJob.result: this job was released after an error (its earlier result() raised); it has no result")
         import numpy as np
         from types import SimpleNamespace
         lib = _lib.load()
@@ -740,10 +768,14 @@ class IcpJob:
                     break
                 self._enqueue(False, 8)
         except BaseException:
-            self.event.synchronize()
+            # (an _enqueue that raised has no event behind its kernels: wait for the stream itself, and do not recycle the pinned state)
+            try:
+                self.stream.synchronize()
+            except Exception:   # noqa: BLE001
+                pass
+            self._release(reuse_state=False)
             raise
-        finally:
-            self._release()
+        self._release()
         self._res = SimpleNamespace(transformation=T, fitness=float(out[0]), inlier_rmse=float(out[1]), iterations=int(iters[0]))
         return self._res
 
