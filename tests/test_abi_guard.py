@@ -29,7 +29,7 @@ HOST_ONLY = {
     "umereg_ume_cdist_workspace_bytes", "umereg_ume_match_workspace_bytes", "umereg_ume_match_workspace_bytes_ex",
     "umereg_ume_match_q_scratch_bytes", "umereg_ume_match_q_scratch_bytes_ex", "umereg_pair_match_workspace_bytes",
     "umereg_pair_match_workspace_bytes_ex", "umereg_voxel_first_index_workspace_bytes", "umereg_knn_workspace_bytes",
-    "umereg_corr_workspace_bytes", "umereg_corr_workspace_bytes_ex", "umereg_icp_workspace_bytes", "umereg_icp_state_bytes",
+    "umereg_corr_workspace_bytes", "umereg_corr_workspace_bytes_ex", "umereg_nn1_pair_workspace_bytes", "umereg_icp_workspace_bytes", "umereg_icp_state_bytes",
     "umereg_icp_state_decode", "umereg_host_choice_round", "umereg_host_choice_check", "umereg_host_choice_mt19937",
     "umereg_host_permutation_mt19937",
 }
@@ -424,6 +424,15 @@ def case_knn(G):
         ws, nws = G.ws(G.lib.umereg_knn_workspace_bytes(B, n2))
         G.call("umereg_knn_points_f32", a1, a2, B, n1, n2, K, d, i, ws, nws, G.stream)
         out[f"d{K}"], out[f"i{K}"] = td, ti
+    # the K = 1 transfer of both clouds of a ragged pair in one pass: four sizes
+    nqs, nqt, ns, nt = 333, 207, 1301, 1024
+    qs, qt, ps, pt = (G.inp(cloud(rng, k))[0] for k in (nqs, nqt, ns, nt))
+    i_s, tis = G.out((nqs,), torch.int64, "idx_src")
+    i_t, tit = G.out((nqt,), torch.int64, "idx_tgt")
+    d_s, tds = G.out((nqs,), torch.float32, "dist_src")
+    ws, nws = G.ws(G.lib.umereg_nn1_pair_workspace_bytes(ns, nt))
+    G.call("umereg_nn1_pair_f32", qs, qt, ps, pt, nqs, nqt, ns, nt, i_s, i_t, d_s, None, ws, nws, G.stream)
+    out["nn1_pair.idx_src"], out["nn1_pair.idx_tgt"], out["nn1_pair.dist_src"] = tis, tit, tds
     ft = np.stack([feats(rng, n2), feats(rng, n2)])
     o, to = G.out((B, n2), torch.float32, "fsv")
     ws, nws = G.ws(G.lib.umereg_knn_workspace_bytes(B, n2))

@@ -1400,6 +1400,24 @@ def test_knn_points_vs_oracle(gpu, n1, n2, K):
     assert np.array_equal(N_(out.knn[0]), p2[ref.idx[0]])
 
 
+def test_nn1_pair_equals_the_two_knn_calls(gpu):
+    """evaluate.py:272-275 on a pair whose four clouds have four sizes (raw and network clouds of source and target: the collate
+    dilutes independently, kitti_dataset.py:568-569): ops.nn1_pair = knn_points(K=1) per cloud = the oracle, lattice ties included
+    (lower index), and select_hypothesis on a ragged pair equals its per-cloud form."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(3)
+    for nqs, nqt, ns, nt, lat in ((5000, 3777, 9000, 7431, 0.3), (100, 1, 1, 257, 0.0), (1025, 1024, 50000, 41300, 0.3)):
+        mk = lambda n: (np.round(rng.uniform(-30, 30, (n, 3)) * [1, 1, 0.1] / lat) * lat if lat else rng.uniform(-30, 30, (n, 3))).astype(np.float32)   # noqa: E731
+        qs, qt, ps, pt = mk(nqs), mk(nqt), mk(ns), mk(nt)
+        i_s, i_t = ops.nn1_pair(T_(qs, gpu), T_(qt, gpu), T_(ps, gpu)[None], T_(pt, gpu)[None])
+        a = ops.knn_points(T_(qs, gpu)[None], T_(ps, gpu)[None], K=1).idx[0, :, 0]
+        b = ops.knn_points(T_(qt, gpu)[None], T_(pt, gpu)[None], K=1).idx[0, :, 0]
+        assert torch.equal(i_s, a) and torch.equal(i_t, b)
+        if ns <= 10000:
+            assert np.array_equal(N_(i_s), orc.knn_points(qs[None], ps[None], K=1).idx[0, :, 0])
+            assert np.array_equal(N_(i_t), orc.knn_points(qt[None], pt[None], K=1).idx[0, :, 0])
+
+
 def test_knn_points_lattice_ties(gpu):
     """Points on a lattice produce many exactly equal distances: ties must resolve towards the lower index."""
     from umeregrobust_amd import ops
