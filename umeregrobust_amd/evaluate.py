@@ -668,7 +668,11 @@ class RegistrationPipeline:
             if self.args.filter_by_ume_dist_cond:
                 c = np.asarray(cond, dtype=np.int64)
                 n = c.size
-                if self.host_cond[k] is None or self.host_cond[k].numel() != n:
+                if self.host_cond[k] is None or self.host_cond[k].numel() != n or self.host_cond_np[k] is None \
+                        or self.cond_dev[k] is None or self.cond_dev[k].numel() != n:
+                    # (the plain-launch branch below allocates host_cond[k] alone: a slot that served a timed pair first has no views yet)
+                    if self.cond_uploaded[k] is not None:
+                        self.cond_uploaded[k].synchronize()
                     self.host_cond[k] = torch.empty(n, dtype=torch.int64, pin_memory=True)
                     self.host_cond_np[k] = self.host_cond[k].numpy()
                     self.cond_dev[k] = torch.empty(n, dtype=torch.int64, device=self.dev)
@@ -698,6 +702,7 @@ class RegistrationPipeline:
                 k = a.slot
                 if self.host_cond[k] is None or self.host_cond[k].numel() != c.size:
                     self.host_cond[k] = torch.empty(c.size, dtype=torch.int64, pin_memory=True)
+                    self.host_cond_np[k] = None
                 elif self.cond_uploaded[k] is not None:
                     self.cond_uploaded[k].synchronize()        # the previous pair's async upload out of this buffer is done
                 self.host_cond[k].numpy()[:] = c
