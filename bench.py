@@ -93,8 +93,8 @@ def parse():
                     help="pairs in flight: 2 overlaps the host RNG draw of pair i with the GPU work of pair i+1; 1 = serial.  Measured (round 5, "
                          "same box, three repetitions, pairs/s): 2: 3 420, 3: 3 750-3 780, 4: 3 560-3 600, 5: 3 590-3 620, 8: 3 400")
     ap.add_argument("--stream-plan", default=None,
-                    help="creation order of the pipeline's HIP streams ('s' = next slot, 'd' = spacer; default 'sd' per slot): the "
-                         "runtime deals streams onto its hardware queues in creation order, see RegistrationPipeline")
+                    help="default: the pipeline's slot streams are chosen by measurement (streams that run side by side, none on the null "
+                         "stream's hardware queue); a string of 's' (next slot) / 'd' (spacer) = plain creation order of rounds 3-5")
     ap.add_argument("--plan-check-pairs", type=int, default=96,
                     help="pairs of the stream-plan self-check (config.stream_plan_check: the shipped plan against plain creation order, "
                          "after the timed region; 0 = skip)")
@@ -455,7 +455,7 @@ def main():
     plan_check = None
     if a.plan_check_pairs > 0 and graph_mode != "none":
         plan_check = {}
-        for tag, plan in (("shipped_plan", a.stream_plan), ("creation_order", "s" * depth)):
+        for tag, plan in (("shipped_plan", a.stream_plan), ("creation_order", "s" * depth), ("round5_sd_plan", "sd" * depth)):
             leg.pipe = evaluate.RegistrationPipeline(args, dev, depth=depth, rng=None, threaded_draw=a.threaded_draw, use_graphs=graph_mode,
                                                      stream_plan=plan, match_opts=match_opts)
             leg.pool = pool
@@ -467,8 +467,11 @@ def main():
             plan_check[tag] = round(2 * a.plan_check_pairs / (time.perf_counter() - t1), 1)
         leg.pipe, leg.pool = pipe, pool
         plan_check["ratio_shipped_over_creation_order"] = round(plan_check["shipped_plan"] / max(plan_check["creation_order"], 1e-9), 4)
+        from umeregrobust_amd import streams as _st
+        plan_check["measured_stream_classes"] = _st.report(dev)
         plan_check["note"] = (f"pairs/s over {2 * a.plan_check_pairs} pairs of the pool on rank 0's device, fresh pipelines, after the timed region; "
-                              "shipped plan = '" + (a.stream_plan or "sd" * depth) + "', creation order = '" + "s" * depth + "'")
+                              "shipped plan = '" + (a.stream_plan or "measured: slot streams chosen by the side-by-side probe (umeregrobust_amd/streams.py)")
+                              + "', creation order = '" + "s" * depth + "', rounds 3-5 = '" + "sd" * depth + "'")
         if plan_check["ratio_shipped_over_creation_order"] < 0.97:
             print(f"[bench] the pipeline's stream plan is SLOWER than plain creation order on this runtime: {plan_check}", file=sys.stderr)
 
@@ -633,7 +636,8 @@ def main():
         waiting = [None for _ in range(n_fl)]
         sel_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
         ref_counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(n_fl)]
-        streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
+        from umeregrobust_amd import streams as _st
+        streams = _st.concurrent_streams(dev, n_fl)         # (measured to run side by side, none on the null stream's hardware queue)
         eye = torch.eye(4, device=dev)
 
         def draws(i):

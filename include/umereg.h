@@ -62,6 +62,12 @@ const char* umereg_last_error(void);
 /* number of visible HIP devices; fills name (may be NULL) with device 0's gcnArchName */
 int umereg_device_count(char* arch_name, size_t arch_name_len);
 
+/* Do two HIP streams of this process run SIDE BY SIDE?  (Runtime plumbing of the loops that keep several pairs in flight,
+ * evaluate.py:175: the HIP runtime multiplexes streams onto a few hardware queues by a rule a caller cannot read back; two streams on
+ * one queue execute one after the other.)  A spin kernel of spin_ms on stream_a, a one-thread kernel on stream_b, both timed by
+ * events: *side_by_side_host = 1 if b's kernel completed while a's was still spinning.  Synchronises both streams; host outputs. */
+int umereg_streams_run_side_by_side(void* stream_a, void* stream_b, float spin_ms, int* side_by_side_host, float* waited_ms_host);
+
 /* ---------------------------------------------------------------------------------------------
  * a1  pytorch3d.ops.ball_query(p1, p2, lengths1, lengths2, K, radius, return_nn)
  *     reference call sites: evaluate.py:51, utils/loc_utils.py:38,72,100,114,167,184,383-384.

@@ -24,7 +24,7 @@ CANARY = 0xA5
 
 # entry points without device buffers: size queries, identification, host-side RNG helpers (tests/test_host_logic.py covers those)
 HOST_ONLY = {
-    "umereg_abi_version", "umereg_build_source_hash", "umereg_last_error", "umereg_device_count",
+    "umereg_abi_version", "umereg_build_source_hash", "umereg_last_error", "umereg_device_count", "umereg_streams_run_side_by_side",
     "umereg_ball_query_workspace_bytes", "umereg_ume_moments_workspace_bytes", "umereg_qbasis_bytes",
     "umereg_ume_cdist_workspace_bytes", "umereg_ume_match_workspace_bytes", "umereg_ume_match_workspace_bytes_ex",
     "umereg_ume_match_q_scratch_bytes", "umereg_ume_match_q_scratch_bytes_ex", "umereg_pair_match_workspace_bytes",

@@ -2310,3 +2310,29 @@ def test_f1_at_the_benchmarks_own_size_against_sampled_oracle_scores(gpu, shape)
     gt = p.gt_tform
     cosang = np.clip((np.trace(Tw[:3, :3] @ gt[:3, :3].T) - 1) / 2, -1, 1)
     assert np.degrees(np.arccos(cosang)) <= 1.5 and np.linalg.norm(Tw[:3, 3] - gt[:3, 3]) <= 0.6
+
+
+def test_overlap_streams_are_chosen_by_measurement(gpu):
+    """The streams the loops overlap pairs on (evaluate_pairs: two, RegistrationPipeline: depth) are measured to run SIDE BY SIDE and to
+    stay off the null stream's hardware queue (umeregrobust_amd/streams.py, umereg_streams_run_side_by_side): a stream runs beside a
+    stream of another class and not beside itself / a stream of its own class, whatever the process created before."""
+    from umeregrobust_amd import streams
+    for _ in range(5):
+        torch.cuda.Stream(gpu).cuda_stream                  # (disturb the runtime's own dealing order)
+    null = torch.cuda.default_stream(gpu)
+    classes = streams.stream_classes(gpu, want=3, per_class=2)
+    rep = streams.report(gpu)
+    assert classes[0][0].cuda_stream == null.cuda_stream and rep["classes_beside_null"] >= 1
+    a = classes[1][0]
+    assert not streams.run_side_by_side(a, a)
+    if len(classes[1]) > 1:
+        assert not streams.run_side_by_side(a, classes[1][1])
+    if len(classes) > 2:
+        assert streams.run_side_by_side(a, classes[2][0]) and streams.run_side_by_side(classes[2][0], a)
+    assert streams.run_side_by_side(null, a)
+    got = streams.concurrent_streams(gpu, 3)
+    assert len({s.cuda_stream for s in got}) == 3 and all(s.cuda_stream != null.cuda_stream for s in got)
+    if rep["classes_beside_null"] >= 3:
+        assert all(streams.run_side_by_side(got[i], got[j]) for i in range(3) for j in range(3) if i != j)
+        assert all(streams.run_side_by_side(null, s) for s in got)
+    assert [s.cuda_stream for s in streams.concurrent_streams(gpu, 3)] == [s.cuda_stream for s in got]       # cached: the same streams

@@ -24,6 +24,7 @@ SIGNATURES = {
     "umereg_build_source_hash": (ctypes.c_char_p, []),
     "umereg_last_error": (ctypes.c_char_p, []),
     "umereg_device_count": (c_int, [ctypes.c_char_p, c_size_t]),
+    "umereg_streams_run_side_by_side": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "umereg_ball_query_workspace_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ball_query_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

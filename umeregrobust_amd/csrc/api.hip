@@ -64,6 +64,67 @@ UMEREG_API int umereg_device_count(char* arch_name, size_t arch_name_len)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Do two HIP streams of this process run side by side?  The runtime multiplexes its streams onto a few hardware queues (four on this
+// stack) by a rule of its own -- measured here: neither creation order modulo four nor anything a caller can read back -- and two
+// streams on one queue execute strictly one after the other.  A loop that overlaps consecutive pairs on "two streams" gains nothing
+// if the two share a queue (evaluate_pairs: 310 pairs/s against 440), and loses 12 % if one of them shares the NULL stream's queue.
+// So the overlap streams are CHOSEN BY MEASUREMENT (umeregrobust_amd/streams.py): a spin kernel of `spin_ms` on stream a, behind an
+// event a one-thread kernel on stream b; b's kernel done long before the spin ends <=> different queues.  Synchronises both streams.
+namespace umereg {
+__global__ void probe_spin_kernel(unsigned long long ticks, unsigned int* sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned int n = 0;
+    while (wall_clock64() - t0 < ticks) ++n;
+    if (sink && n == 0xffffffffu) *sink = n;       // (keeps the loop)
+}
+__global__ void probe_touch_kernel(unsigned int* sink) { if (sink && threadIdx.x == 12345u) *sink = 1u; }
+}  // namespace umereg
+
+UMEREG_API int umereg_streams_run_side_by_side(void* stream_a, void* stream_b, float spin_ms, int* side_by_side_host, float* waited_ms_host)
+{
+    UMEREG_REQUIRE(side_by_side_host, "streams_run_side_by_side: null output");
+    UMEREG_REQUIRE(spin_ms > 0.f && spin_ms <= 50.f, "streams_run_side_by_side: spin_ms must be in (0, 50] (got %g)", (double)spin_ms);
+    if (int rc = umereg::check_device()) return rc;
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) {
+        if (ea) (void)hipEventDestroy(ea);
+        (void)hipGetLastError();
+        umereg::set_error("streams_run_side_by_side: hipEventCreate failed");
+        return UMEREG_ELAUNCH;
+    }
+    int wall_khz = 0;
+    if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0) != hipSuccess || wall_khz <= 0) {
+        (void)hipGetLastError();
+        wall_khz = 100000;                                   // gfx9: 100 MHz constant clock
+    }
+    const unsigned long long ticks = (unsigned long long)((double)spin_ms * (double)wall_khz);
+    int rc = UMEREG_OK;
+    float ms = 0.f;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) rc = UMEREG_ELAUNCH;
+    if (rc == UMEREG_OK) {
+        (void)hipEventRecord(ea, a);
+        hipLaunchKernelGGL(umereg::probe_spin_kernel, dim3(1), dim3(64), 0, a, ticks, (unsigned int*)nullptr);
+        hipLaunchKernelGGL(umereg::probe_touch_kernel, dim3(1), dim3(64), 0, b, (unsigned int*)nullptr);
+        (void)hipEventRecord(eb, b);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+            hipEventElapsedTime(&ms, ea, eb) != hipSuccess)
+            rc = UMEREG_ELAUNCH;
+    }
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    if (rc != UMEREG_OK) {
+        (void)hipGetLastError();
+        umereg::set_error("streams_run_side_by_side: HIP runtime error");
+        return rc;
+    }
+    *side_by_side_host = ms < 0.5f * spin_ms ? 1 : 0;
+    if (waited_ms_host) *waited_ms_host = ms;
+    return UMEREG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // HOST helper for the one host-side step of the path: np.random.choice(n, size, replace=False, p=prob)
 // at reference evaluate.py:238.  numpy's legacy algorithm (numpy/random/mtrand.pyx, RandomState.choice)
 // runs rounds of { x = rand(size - n_uniq); p[found] = 0; cdf = cumsum(p); cdf /= cdf[-1];

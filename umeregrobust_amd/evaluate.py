@@ -11,7 +11,7 @@ import contextlib
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, streams as _streams
 from .host_rng import choice_noreplace, choice_uniform_noreplace
 from .utils.eval_utils import relative_rotation_error  # noqa: F401
 from .utils.loc_utils import (FeatureCorrelator, batch_estimate_transform_ume_old, ume_cdist,  # noqa: F401
@@ -498,20 +498,26 @@ class RegistrationPipeline:
             from concurrent.futures import ThreadPoolExecutor
             self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="umereg-draw")
         self.dev = torch.device(device)
-        # The HIP runtime deals its streams round-robin onto 4 hardware queues in creation order, and which slot streams share a
-        # queue decides how the pairs' kernels overlap: all four slots on one queue 2 820 pairs/s, four separate queues 3 280-3 610
-        # depending on which other stream of the process they fall beside, slots {0,2} and {1,3} sharing a queue each 3 480-3 555
-        # whatever the offset (measured, KT shape, depth 4).  So the slot streams are created HERE, each followed by a spacer
-        # stream: slot i and slot i+2 then share a queue, and nothing depends on when torch would have created them lazily.
+        # Which slot streams share a HARDWARE QUEUE decides how the pairs' kernels overlap: the HIP runtime multiplexes all streams of the
+        # process onto four queues by a rule a caller cannot read back, and two streams on one queue run strictly one after the other
+        # (all slots on one queue 2 820 pairs/s, KT shape; a slot on the NULL stream's queue costs ~10 %).  Rounds 3-5 steered that by
+        # creation order ("sd": a spacer stream behind every slot stream) -- which holds only until the process creates one stream more
+        # somewhere else (BENCH r05 -> r06: evaluate_pairs 446 -> 375 pairs/s on unchanged code).  Now the slot streams are CHOSEN BY
+        # MEASUREMENT (streams.concurrent_streams: a spin kernel on one stream, a one-thread kernel on the other): consecutive slots on
+        # different queues, none on the null stream's.  stream_plan = a string of 's' / 'd' keeps the creation-order form (bench.py times
+        # both after every run: config.stream_plan_check).
         self.streams, self._spacers = [], []
+        self.stream_plan = stream_plan or "measured"
         with torch.cuda.device(self.dev):
-            plan = stream_plan if stream_plan else "sd" * depth          # 's' = the next slot's stream, 'd' = a spacer
-            for tok in plan + "s" * depth:
-                if tok == "s" and len(self.streams) >= depth:
-                    continue
-                s_ = torch.cuda.Stream(self.dev)
-                s_.cuda_stream                          # creates the HIP stream now
-                (self.streams if tok == "s" else self._spacers).append(s_)
+            if stream_plan in (None, "measured", "auto"):
+                self.streams = list(_streams.concurrent_streams(self.dev, depth))
+            else:
+                for tok in stream_plan + "s" * depth:           # 's' = the next slot's stream, 'd' = a spacer
+                    if tok == "s" and len(self.streams) >= depth:
+                        continue
+                    s_ = torch.cuda.Stream(self.dev)
+                    s_.cuda_stream                          # creates the HIP stream now
+                    (self.streams if tok == "s" else self._spacers).append(s_)
         self.host_prob = [None] * depth
         self.host_cond = [None] * depth
         self.cond_uploaded = [None] * depth     # event: the H2D copy out of host_cond[k] has completed
@@ -767,7 +773,9 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
                 # (kept per device: the native workspaces are per stream, a fresh pair of streams per call would allocate anew)
                 streams = _OVERLAP_STREAMS.get(dev)
                 if streams is None:
-                    streams = _OVERLAP_STREAMS[dev] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+                    # two streams MEASURED to run side by side, neither on the null stream's hardware queue (streams.py: which queue
+                    # the runtime gives a new stream depends on what the process created before -- 440 / 380 / 310 pairs/s here)
+                    streams = _OVERLAP_STREAMS[dev] = list(_streams.concurrent_streams(dev, 2))
             st = streams[k % 2]
             st.wait_stream(torch.cuda.current_stream(dev))      # the pair's tensors were made on the caller's stream
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
