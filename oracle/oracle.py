@@ -43,7 +43,7 @@ def lib():
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_SO)
-        for name in ("orc_ball_query_f32", "orc_ume_moments_f32", "orc_orthobasis_f64",
+        for name in ("orc_ball_query_f32", "orc_ball_query_fma_f32", "orc_ume_moments_f32", "orc_orthobasis_f64",
                      "orc_ume_cdist_f64", "orc_knn_points_f32", "orc_pc_corr_cost_f32"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
@@ -64,10 +64,12 @@ KNN = namedtuple("KNN", "dists idx knn")
 # ---------------------------------------------------------------------------------------------
 # a1  pytorch3d.ops.ball_query (reference call sites evaluate.py:51, utils/loc_utils.py:383-384)
 # ---------------------------------------------------------------------------------------------
-def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True):
+def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True, fma=False):
     """First K points of p2 *in index order* with |p1-p2|^2 < radius^2 (strict, fp32).
     p1 [B,n1,3], p2 [B,n2,3] -> dists f32 [B,n1,K] (0 pad), idx i64 [B,n1,K] (-1 pad),
-    knn f32 [B,n1,K,3] (0 pad) or None."""
+    knn f32 [B,n1,K,3] (0 pad) or None.
+    fma=True: the squared distance contracted as nvcc compiles pytorch3d's CUDA kernel (orc_ball_query_fma_f32) -- the checker of
+    the library's opt-in UMEREG_BALL_FMA mode; the default is the uncontracted CPU form `north_star` asks for."""
     p1 = _f32(p1); p2 = _f32(p2)
     B, n1, _ = p1.shape
     n2 = p2.shape[1]
@@ -77,7 +79,7 @@ def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_n
     for b in range(B):
         l1 = -1 if lengths1 is None else int(lengths1[b])
         l2 = -1 if lengths2 is None else int(lengths2[b])
-        rc = lib().orc_ball_query_f32(_p(p1[b]), _p(p2[b]), ctypes.c_int64(n1), ctypes.c_int64(n2),
+        rc = (lib().orc_ball_query_fma_f32 if fma else lib().orc_ball_query_f32)(_p(p1[b]), _p(p2[b]), ctypes.c_int64(n1), ctypes.c_int64(n2),
                                       ctypes.c_int64(l1), ctypes.c_int64(l2), ctypes.c_int(K),
                                       ctypes.c_float(radius), _p(idx[b]), _p(dists[b]),
                                       _p(nn[b]) if return_nn else None)

@@ -81,6 +81,49 @@ ORC_API int orc_ball_query_f32(const float* p1, const float* p2, int64_t n1, int
 }
 
 /* --------------------------------------------------------------------------
+ * a1, CONTRACTED form: the same scan with the squared distance as nvcc compiles pytorch3d's CUDA kernel
+ * (csrc/ball_query/ball_query.cu: `dist2 += diff * diff` over the three coordinates, -fmad=true by default):
+ *   d2 = fma(dz, dz, fma(dy, dy, dx * dx))
+ * -- one rounding less per term than the CPU form above.  The reference's published numbers were produced by
+ * this form (a CUDA build of pytorch3d); `north_star` asks for the CPU form, which is the default everywhere.
+ * Checker of the opt-in UMEREG_BALL_FMA / UMEREG_MOMENTS_FMA_DIST modes of the library only.
+ * -------------------------------------------------------------------------- */
+ORC_API int orc_ball_query_fma_f32(const float* p1, const float* p2, int64_t n1, int64_t n2,
+                                   int64_t len1, int64_t len2, int K, float radius,
+                                   int64_t* idx, float* dists, float* nn)
+{
+    const float r2 = radius * radius;
+    if (len1 < 0 || len1 > n1) len1 = n1;
+    if (len2 < 0 || len2 > n2) len2 = n2;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n1; ++i) {
+        int64_t* oi = idx + i * K;
+        for (int k = 0; k < K; ++k) oi[k] = -1;
+        if (dists) memset(dists + i * K, 0, sizeof(float) * (size_t)K);
+        if (nn) memset(nn + i * K * 3, 0, sizeof(float) * (size_t)K * 3);
+        if (i >= len1) continue;
+        const float qx = p1[3 * i], qy = p1[3 * i + 1], qz = p1[3 * i + 2];
+        int cnt = 0;
+        for (int64_t j = 0; j < len2 && cnt < K; ++j) {
+            const float dx = qx - p2[3 * j];
+            const float dy = qy - p2[3 * j + 1];
+            const float dz = qz - p2[3 * j + 2];
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));      /* (fmaf: correctly rounded whatever the target supports) */
+            if (d2 < r2) {
+                oi[cnt] = j;
+                if (dists) dists[i * K + cnt] = d2;
+                if (nn) {
+                    float* o = nn + (i * K + cnt) * 3;
+                    o[0] = p2[3 * j]; o[1] = p2[3 * j + 1]; o[2] = p2[3 * j + 2];
+                }
+                ++cnt;
+            }
+        }
+    }
+    return 0;
+}
+
+/* --------------------------------------------------------------------------
  * a1+a2  evaluate.py:50-60  my_ume_generation
  *   F1 = sum_k f_k p_k^T (32x3),  F0 = sum_k f_k (32x1),
  *   F = [F0,F1] / (sum_c F0[c] + 1e-6)                -> f32 [n_kp, d, 4]

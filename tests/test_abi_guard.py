@@ -137,7 +137,10 @@ def case_ball_query(G):
     nn, t_nn = G.out((B, n1, K, 3), torch.float32, "nn")
     ws, nws = G.ws(G.lib.umereg_ball_query_workspace_bytes(B, n2))
     G.call("umereg_ball_query_f32", a1, a2, l1, l2, B, n1, n2, K, 5.0, idx, dst, nn, ws, nws, G.stream)
-    return {"idx": t_idx, "dists": t_d, "nn": t_nn}
+    idx2, t_idx2 = G.out((B, n1, K), torch.int64, "idx")
+    ws, nws = G.ws(G.lib.umereg_ball_query_workspace_bytes(B, n2))
+    G.call("umereg_ball_query_ex_f32", a1, a2, None, None, B, n1, n2, K, 5.0, 1, idx2, None, None, ws, nws, G.stream)   # UMEREG_BALL_FMA
+    return {"idx": t_idx, "dists": t_d, "nn": t_nn, "idx_fma": t_idx2}
 
 
 def _moment_inputs(G, rng, B, N, n_kp):

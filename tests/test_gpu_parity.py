@@ -2336,3 +2336,44 @@ def test_overlap_streams_are_chosen_by_measurement(gpu):
         assert all(streams.run_side_by_side(got[i], got[j]) for i in range(3) for j in range(3) if i != j)
         assert all(streams.run_side_by_side(null, s) for s in got)
     assert [s.cuda_stream for s in streams.concurrent_streams(gpu, 3)] == [s.cuda_stream for s in got]       # cached: the same streams
+
+
+def test_contracted_distance_mode_reproduces_the_cuda_form(gpu):
+    """Opt-in UMEREG_BALL_FMA / UMEREG_MOMENTS_FMA_DIST: the squared distance as nvcc contracts pytorch3d's CUDA `ball_query`
+    (reference evaluate.py:51; d2 = fma(dz, dz, fma(dy, dy, dx dx))) -- the build that produced the reference's published numbers.
+    Bit-exact against the oracle's contracted variant (idx, dists, nn; the moment kernel's neighbourhoods) on a cloud made to sit ON
+    the boundary: points at distances whose two roundings straddle r^2, so that the two forms really select different neighbours; the
+    default stays the uncontracted CPU form and keeps matching ITS oracle on the same inputs."""
+    from umeregrobust_amd import ops
+    rng = np.random.RandomState(12)
+    r = np.float32(5.0)
+    r2 = r * r
+    # queries at generic positions; for each, candidates on a thin shell around radius r (|d| - r ~ U(-3e-6, 3e-6) m: a few ulps of d2)
+    nq, per = 200, 400
+    q = rng.uniform(-30, 30, (nq, 3)).astype(np.float32)
+    dirs = rng.standard_normal((nq, per, 3)); dirs /= np.linalg.norm(dirs, axis=2, keepdims=True)
+    rad = 5.0 + rng.uniform(-3e-6, 3e-6, (nq, per, 1))
+    shell = (q[:, None, :].astype(np.float64) + dirs * rad).astype(np.float32).reshape(-1, 3)
+    fill = rng.uniform(-40, 40, (20000, 3)).astype(np.float32)
+    pts = np.concatenate([shell, fill])[rng.permutation(shell.shape[0] + fill.shape[0])]
+    # the two predicates disagree somewhere on this cloud (else the test would prove nothing)
+    d = q[:, None, :] - pts[None, :, :]
+    un = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    d64 = d.astype(np.float64)
+    inner = (d64[..., 0] * d64[..., 0]).astype(np.float32).astype(np.float64)              # fl(dx dx)
+    mid = (d64[..., 1] * d64[..., 1] + inner).astype(np.float32).astype(np.float64)         # fma(dy, dy, .): one rounding
+    co = (d64[..., 2] * d64[..., 2] + mid).astype(np.float32)                                # fma(dz, dz, .)
+    assert int(((un < r2) != (co < r2)).sum()) >= 20
+    K = 750
+    for fma in (False, True):
+        ref = orc.ball_query(q[None], pts[None], K=K, radius=5.0, fma=fma)
+        out = ops.ball_query(T_(q, gpu)[None], T_(pts, gpu)[None], K=K, radius=5.0, fma=fma)
+        assert np.array_equal(N_(out.idx), ref.idx) and np.array_equal(N_(out.dists), ref.dists) and np.array_equal(N_(out.knn), ref.knn)
+        feat = rng.standard_normal((pts.shape[0], 32)).astype(np.float32)
+        F, cnt, nidx = ops.ume_moments(T_(pts, gpu)[None], T_(q, gpu)[None], T_(feat, gpu)[None], K, 5.0, return_count=True,
+                                       return_idx=True, fma_dist=fma)
+        assert np.array_equal(N_(nidx)[0], ref.idx[0]) and np.array_equal(N_(cnt)[0], (ref.idx[0] >= 0).sum(1))
+    a, b = orc.ball_query(q[None], pts[None], K=K, radius=5.0).idx, orc.ball_query(q[None], pts[None], K=K, radius=5.0, fma=True).idx
+    assert not np.array_equal(a, b)                                  # the mode is not a no-op here
+    with pytest.raises(RuntimeError, match="FMA_DIST"):
+        ops.ume_moments(T_(pts, gpu)[None], T_(q, gpu)[None], T_(feat, gpu)[None], K, 5.0, acc="f64valu", fma_dist=True)

@@ -281,3 +281,33 @@ def test_full_pipeline_oracle_on_a_hard_pair():
     a = orc.evaluate_pair_full(h.src_pts, h.tgt_pts, h.src_feat, h.tgt_feat, h.gt_tform, np.random.RandomState(4), **kw)
     b = orc.evaluate_pair_full(h.src_pts, h.tgt_pts, h.src_feat, h.tgt_feat, h.gt_tform, np.random.RandomState(4), **kw)
     assert np.array_equal(a["T_est"], b["T_est"]) and np.isfinite(a["T_est"]).all()
+
+
+def test_contracted_ball_query_variant_against_numpy():
+    """oracle.ball_query(fma=True) -- the checker of the library's opt-in UMEREG_BALL_FMA mode (pytorch3d's CUDA kernel as nvcc
+    contracts it: d2 = fma(dz, dz, fma(dy, dy, dx dx))) -- against an independent numpy evaluation of both predicates (fp64 products
+    rounded once per fused step) on a cloud built to sit on the boundary, where the two forms select different neighbours."""
+    rng = np.random.RandomState(12)
+    r2 = np.float32(5.0) * np.float32(5.0)
+    nq, per = 60, 300
+    q = rng.uniform(-30, 30, (nq, 3)).astype(np.float32)
+    dirs = rng.standard_normal((nq, per, 3))
+    dirs /= np.linalg.norm(dirs, axis=2, keepdims=True)
+    shell = (q[:, None, :].astype(np.float64) + dirs * (5.0 + rng.uniform(-3e-6, 3e-6, (nq, per, 1)))).astype(np.float32).reshape(-1, 3)
+    pts = np.concatenate([shell, rng.uniform(-40, 40, (5000, 3)).astype(np.float32)])
+    pts = pts[rng.permutation(pts.shape[0])]
+    d = q[:, None, :] - pts[None, :, :]
+    un = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    d64 = d.astype(np.float64)
+    inner = (d64[..., 0] * d64[..., 0]).astype(np.float32).astype(np.float64)
+    mid = (d64[..., 1] * d64[..., 1] + inner).astype(np.float32).astype(np.float64)
+    co = (d64[..., 2] * d64[..., 2] + mid).astype(np.float32)
+    assert int(((un < r2) != (co < r2)).sum()) >= 20
+    K = 64
+    for fma, pred in ((False, un < r2), (True, co < r2)):
+        got = orc.ball_query(q[None], pts[None], K=K, radius=5.0, fma=fma)
+        for i in range(nq):
+            want = np.flatnonzero(pred[i])[:K]
+            assert np.array_equal(got.idx[0, i][:want.size], want) and (got.idx[0, i][want.size:] == -1).all()
+        hit = got.idx[0] >= 0
+        assert np.array_equal(got.dists[0][hit], np.take_along_axis(co if fma else un, np.where(hit, got.idx[0], 0), 1)[hit])

@@ -28,6 +28,8 @@ SIGNATURES = {
     "umereg_ball_query_workspace_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ball_query_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "umereg_ball_query_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umereg_ume_moments_workspace_bytes": (c_size_t, [c_int, c_int]),
     "umereg_ume_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -363,6 +363,21 @@ __device__ __forceinline__ int keep_k_smallest(int* lst, int cnt, int K, int nbi
 
 // Grid search for one query.  Returns min(#hits, K); the kept ORIGINAL indices are in
 // lst[0..count) in unspecified (deterministic) order.  lst has capacity cap >= K + (kScanUnroll + 1) * 64 (lds_plan).
+// kFma (opt-in, UMEREG_BALL_FMA / UMEREG_MOMENTS_FMA_DIST): the squared distance as nvcc contracts pytorch3d's CUDA kernel
+// (`dist2 += diff * diff` under -fmad=true): d2 = fma(dz, dz, fma(dy, dy, dx * dx)).  The reference's published numbers come from
+// that build; the default (kFma = false) is the uncontracted CPU form `north_star` names.  The two differ in one neighbour of one
+// ball in ~1e5 on off-lattice clouds (tools/soak_fma_boundary.py); the cell ranges' 1e-4 inflation covers either rounding.
+template <bool kFma>
+__device__ __forceinline__ float dist2_as_the_reference(float dx, float dy, float dz)
+{
+    if (kFma) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    return d2;
+}
+
+template <bool kFma = false>
 __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, const int* __restrict__ start,
                                                 const Grid& g, float qx, float qy, float qz, float r2, int K,
                                                 int n_eff, int nbits, int* lst, int cap, int lane)
@@ -423,9 +438,7 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                     const float dx = qx - p.x;
                     const float dy = qy - p.y;
                     const float dz = qz - p.z;
-                    float d2 = dx * dx;
-                    d2 = d2 + dy * dy;
-                    d2 = d2 + dz * dz;
+                    const float d2 = dist2_as_the_reference<kFma>(dx, dy, dz);
                     const bool hit = (pos < end) && (d2 < r2) && (oi <= thr);
                     const unsigned long long m = __ballot(hit);
                     if (m != 0ull) {   // wave-uniform
@@ -478,6 +491,7 @@ __device__ __forceinline__ void sort_kept(int* lst, int count, int lane)
 }
 
 // ---- a1: ball query with idx / dists / nn outputs ---------------------------------------------
+template <bool kFma>
 __global__ __launch_bounds__(256) void ball_query_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ p1,
     const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int n1, int n2, int K, int cap,
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
     const float r2 = radius * radius;
     const int nbits = 32 - __clz(n2 > 1 ? n2 - 1 : 1);
     int count = 0;
-    if (i < len1 && len2 > 0) count = ball_search_grid(P4s, start, g, qx, qy, qz, r2, K, len2, nbits, lst, cap, lane);
+    if (i < len1 && len2 > 0) count = ball_search_grid<kFma>(P4s, start, g, qx, qy, qz, r2, K, len2, nbits, lst, cap, lane);
     sort_kept(lst, count, lane);   // pytorch3d emits the kept indices in ascending order
     const size_t row = ((size_t)b * n1 + i) * K;
     for (int e = lane; e < K; e += kWave) {
@@ -514,9 +528,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
             const int jj = lst[e];
             const float4 p = P4o[jj];
             const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-            d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
+            d2 = dist2_as_the_reference<kFma>(dx, dy, dz);
             x = p.x; y = p.y; z = p.z;
             j = jj;
         }
@@ -635,7 +647,7 @@ constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 me
 // each) instead of 16 FMA + 7 conversions + 6 broadcast moves per lane; 4 accumulator registers pairs instead of 16; the fold of the
 // two halves is one exchange across lane bit 3.  The matrix pipe's f64 rate equals the vector pipe's on this part (64.6 TFLOP/s
 // measured), so what is saved is the conversions and moves, not the FMAs: see DESIGN 3.1 for the measurement.
-template <int kAcc>
+template <int kAcc, bool kFma = false>
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
@@ -690,7 +702,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     }
     const int nbits = 32 - __clz(N > 1 ? N - 1 : 1);
 
-    const int count = ball_search_grid(P4s, start, g, qx, qy, qz, radius * radius, K, n_live, nbits, lst, cap, lane);
+    const int count = ball_search_grid<kFma>(P4s, start, g, qx, qy, qz, radius * radius, K, n_live, nbits, lst, cap, lane);
 
     if (nn_count && lane == 0) nn_count[(size_t)b * n_kp + kp] = count;
     if (nn_idx) {   // optional parity output, ascending like ball_query
@@ -933,10 +945,19 @@ UMEREG_API int umereg_ball_query_f32(const float* p1, const float* p2, const int
                                      float radius, int64_t* idx, float* dists, float* nn,
                                      void* workspace, size_t workspace_bytes, void* stream)
 {
+    return umereg_ball_query_ex_f32(p1, p2, lengths1, lengths2, B, n1, n2, K, radius, 0, idx, dists, nn, workspace, workspace_bytes, stream);
+}
+
+UMEREG_API int umereg_ball_query_ex_f32(const float* p1, const float* p2, const int64_t* lengths1,
+                                        const int64_t* lengths2, int B, int n1, int n2, int K,
+                                        float radius, int flags, int64_t* idx, float* dists, float* nn,
+                                        void* workspace, size_t workspace_bytes, void* stream)
+{
     UMEREG_REQUIRE(p1 && p2 && idx, "ball_query: null pointer (p1/p2/idx)");
     UMEREG_REQUIRE(B > 0 && n1 > 0 && n2 > 0, "ball_query: B, n1, n2 must be positive (got %d, %d, %d)", B, n1, n2);
     UMEREG_REQUIRE(K > 0 && K <= 7680, "ball_query: K must be in [1, 7680] (got %d)", K);
     UMEREG_REQUIRE(radius > 0.f, "ball_query: radius must be positive");
+    UMEREG_REQUIRE((flags & ~UMEREG_BALL_FMA) == 0, "ball_query: unknown flags 0x%x", flags);
     if (int rc = check_device()) return rc;
     if (!workspace || workspace_bytes < umereg_ball_query_workspace_bytes(B, n2) || ((uintptr_t)workspace & 15)) {
         set_error("ball_query: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
@@ -948,9 +969,14 @@ UMEREG_API int umereg_ball_query_f32(const float* p1, const float* p2, const int
     int cap, waves;
     lds_plan(K, &cap, &waves);
     dim3 grid((n1 + waves - 1) / waves, B);
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int), st,
-                       (const char*)workspace, grid_ws(n2).total, p1, lengths1, lengths2, n1, n2, K, cap, radius,
-                       idx, dists, nn);
+    if (flags & UMEREG_BALL_FMA)
+        hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int), st,
+                           (const char*)workspace, grid_ws(n2).total, p1, lengths1, lengths2, n1, n2, K, cap, radius,
+                           idx, dists, nn);
+    else
+        hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int), st,
+                           (const char*)workspace, grid_ws(n2).total, p1, lengths1, lengths2, n1, n2, K, cap, radius,
+                           idx, dists, nn);
     UMEREG_CHECK_LAUNCH("ball_query_kernel");
     return UMEREG_OK;
 }
@@ -992,7 +1018,13 @@ int launch_moments(const void* packed, const float* kpts, const int64_t* kp_inde
     lds_plan(K, &cap, &waves);
     dim3 grid((n_kp + waves - 1) / waves, B);
     UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_VALU)), "ume_moments: ACC_F32 and ACC_VALU exclude each other");
-    if (!(flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)))
+    UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_FMA_DIST) && (flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU))),
+                   "ume_moments: FMA_DIST goes with the default accumulation only");
+    if (flags & UMEREG_MOMENTS_FMA_DIST)     // (opt-in: its own instantiation of the default accumulation, nothing added to the product kernel)
+        hipLaunchKernelGGL((ume_moments_kernel<2, true>), grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
+                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
+                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+    else if (!(flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)))
         hipLaunchKernelGGL(ume_moments_kernel<2>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
                            st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
                            n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);

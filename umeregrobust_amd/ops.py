@@ -65,9 +65,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True):
+def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True, fma=False):
     """pytorch3d.ops.ball_query drop-in (reference evaluate.py:51; utils/loc_utils.py:383-384).
-    p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] f32 0-pad, idx [B,n1,K] i64 -1-pad, knn [B,n1,K,3] | None)."""
+    p1 [B,n1,3], p2 [B,n2,3] -> (dists [B,n1,K] f32 0-pad, idx [B,n1,K] i64 -1-pad, knn [B,n1,K,3] | None).
+    fma (opt-in, UMEREG_BALL_FMA): the squared distance contracted the way nvcc compiles pytorch3d's CUDA kernel,
+    fma(dz, dz, fma(dy, dy, dx dx)), instead of the uncontracted CPU form (the default, what `north_star` names)."""
     lib = _lib.load()
     p1 = _dev(p1, "p1"); p2 = _dev(p2, "p2")
     if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3 or p1.shape[0] != p2.shape[0]:
@@ -88,9 +90,9 @@ def ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_n
     need = lib.umereg_ball_query_workspace_bytes(B, n2)
     ws = _workspace(dev, need, "bq")
     with torch.cuda.device(dev):
-        rc = lib.umereg_ball_query_f32(_ptr(p1), _ptr(p2), _ptr(l1), _ptr(l2), B, n1, n2, int(K), float(radius),
-                                       _ptr(idx), _ptr(dists), _ptr(nn), _ptr(ws), ws.numel(), _stream_ptr(dev))
-    _lib.check(rc, "umereg_ball_query_f32")
+        rc = lib.umereg_ball_query_ex_f32(_ptr(p1), _ptr(p2), _ptr(l1), _ptr(l2), B, n1, n2, int(K), float(radius), BALL_FMA if fma else 0,
+                                          _ptr(idx), _ptr(dists), _ptr(nn), _ptr(ws), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "umereg_ball_query_ex_f32")
     return BallQuery(dists, idx, nn)
 
 
@@ -117,11 +119,12 @@ def _timed_end(timing, ev, dev):
         timing.append(ev)
 
 
-MOMENTS_ORDERED, MOMENTS_RAW, MOMENTS_ACC_F32, MOMENTS_ACC_VALU = 1, 2, 4, 8      # include/umereg.h
+MOMENTS_ORDERED, MOMENTS_RAW, MOMENTS_ACC_F32, MOMENTS_ACC_VALU, MOMENTS_FMA_DIST = 1, 2, 4, 8, 16      # include/umereg.h
+BALL_FMA = 1
 
 
 def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False, timing=None, kp_index=None,
-                normalize=True, acc="f64"):
+                normalize=True, acc="f64", fma_dist=False):
     """Fused ball query + gather + UME moment matrix (reference evaluate.py:50-60).
     pts [B,N,3], kpts [B,n,3], feat [B,N,32] -> F [B,n,32,4] (+ nn_count i32 [B,n], nn_idx i64 [B,n,K]).
     timing: optional list; receives a (start, end) event pair bracketing the moment kernel alone.
@@ -130,7 +133,8 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
     normalize=False: the un-normalised matrix of generate_ume_from_keypoints2 (utils/loc_utils.py:160-162).
     acc: "f64" (default) -- every term accumulated in fp64, on the matrix pipe (v_mfma_f64_4x4x4_4b_f64); "f64valu" -- the same sums on the
     vector pipe (the kernel of rounds 1-3: bit-identical results, 13 % slower; kept for A/B); "f32" -- neighbour sums in packed fp32 on keypoint-centred
-    coordinates, everything after them in fp64 (UMEREG_MOMENTS_ACC_F32: 9 % faster, 2.6e-5 instead of correctly rounded)."""
+    coordinates, everything after them in fp64 (UMEREG_MOMENTS_ACC_F32: 9 % faster, 2.6e-5 instead of correctly rounded).
+    fma_dist (opt-in, acc="f64" only): the ball search with the contracted squared distance of pytorch3d's CUDA kernel (see ball_query)."""
     if acc not in ("f32", "f64", "f64valu"):
         raise ValueError(f"ume_moments: acc must be 'f64' (default: fp64 sums on the matrix pipe), 'f64valu' (the same on the vector "
                          f"pipe) or 'f32' (got {acc!r})")
@@ -170,7 +174,8 @@ def ume_moments(pts, kpts, feat, K, radius, return_count=False, return_idx=False
             ev = _timed(timing, dev)
             rc = lib.umereg_ume_moments_packed_f32(_ptr(ws), _ptr(kpts), _ptr(kp_index), _ptr(feat), B, N, n, d, int(K),
                                                    float(radius), ordered | (0 if normalize else MOMENTS_RAW) |
-                                                   (MOMENTS_ACC_F32 if acc == "f32" else MOMENTS_ACC_VALU if acc == "f64valu" else 0), _ptr(F), _ptr(cnt), _ptr(nidx),
+                                                   (MOMENTS_ACC_F32 if acc == "f32" else MOMENTS_ACC_VALU if acc == "f64valu" else 0) |
+                                                   (MOMENTS_FMA_DIST if fma_dist else 0), _ptr(F), _ptr(cnt), _ptr(nidx),
                                                    _stream_ptr(dev))
             _lib.check(rc, "umereg_ume_moments_packed_f32")
             _timed_end(timing, ev, dev)
