@@ -60,6 +60,17 @@ __global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __res
         }
         out[j] = v;
     }
+    if (desc && desc->kp[b]) {
+        // a ragged pair's keypoint indices, int64 lists wherever the caller keeps them -> int32 at a fixed place of the workspace (n_kp <=
+        // Npad: the pair chain checks).  Anything outside int32 becomes -1: "outside the cloud", which the moment kernel answers with NaN.
+        const int64_t* __restrict__ kp = desc->kp[b];
+        int* __restrict__ kpi = reinterpret_cast<int*>(ws + b * ws_stride + w.off_kpi);
+        const int n_kp = desc->n_kp < w.Npad ? desc->n_kp : w.Npad;
+        for (int k = blockIdx.x * kPackWG + threadIdx.x; k < n_kp; k += gridDim.x * kPackWG) {
+            const int64_t i = kp[k];
+            kpi[k] = (i < 0 || i > 0x7fffffffLL) ? -1 : (int)i;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -566,10 +577,11 @@ __global__ __launch_bounds__(1024) void kp_order_kernel(char* __restrict__ ws, s
     for (int c = threadIdx.x; c < kMaxCells; c += 1024) cnt[c] = 0;
     __syncthreads();
     const int n_live = desc ? desc->n_pts[b] : N;
-    const int64_t* __restrict__ kpi = desc ? desc->kp[b] : (kp_index ? kp_index + (size_t)b * n_kp : nullptr);
+    const int64_t* __restrict__ kpi = kp_index ? kp_index + (size_t)b * n_kp : nullptr;
+    const int* __restrict__ kpi32 = reinterpret_cast<const int*>(wb + w.off_kpi);       // (a ragged pair's, written by pack_points_kernel)
     auto cell_of_kp = [&](int k) {
-        if (kpi) {   // the point's cell, from the hist pass (an out-of-range index only affects the ORDER here: clamped)
-            const int64_t i = kpi[k];
+        if (desc || kpi) {   // the point's cell, from the hist pass (an out-of-range index only affects the ORDER here: clamped)
+            const int64_t i = desc ? (int64_t)kpi32[k] : kpi[k];
             return cell_of[i < 0 ? 0 : (i >= n_live ? n_live - 1 : i)];
         }
         const float* q = kpts + ((size_t)b * n_kp + k) * 3;
@@ -680,12 +692,14 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
     const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     // a ragged pair (desc): this cloud's feature table and keypoint indices where the caller left them, n_live <= N points
-    const int n_live = desc ? desc->n_pts[b] : N;
-    const float4* fb = desc ? reinterpret_cast<const float4*>(desc->feat[b]) : feat4 + (size_t)b * N * 8;
-    const int64_t* __restrict__ kpi = desc ? desc->kp[b] : (kp_index ? kp_index + (size_t)b * n_kp : nullptr);
+    const int n_live = desc ? uniform_int(desc->n_pts[b]) : N;
+    const float4* fb = desc ? uniform_ptr(reinterpret_cast<const float4*>(desc->feat[b])) : feat4 + (size_t)b * N * 8;
     float qx, qy, qz;
-    if (kpi) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
-        const int64_t ki = kpi[kp];
+    if (desc || kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
+        // (one load through whichever base applies: a SELECTED base pointer cost the kernel 9 vector registers and its seventh wavefront)
+        // (a ragged pair's indices come from the int32 copy in the workspace, not through the record's pointer: loading the list's base
+        // out of the record cost this kernel 9 vector registers and its seventh wavefront per SIMD -- 108.7 against 104.4 us per KT pair)
+        const int64_t ki = desc ? (int64_t)reinterpret_cast<const int*>(wb + w.off_kpi)[kp] : kp_index[(size_t)b * n_kp + kp];
         if (ki < 0 || ki >= n_live) {
             // an index outside the cloud (stale, or the -1 padding the reference's own code produces) must not read out of
             // bounds: the keypoint's matrix is all NaN -- loud downstream, where torch indexing would have raised

@@ -32,6 +32,18 @@ struct PairDesc {
 };
 static_assert(sizeof(PairDesc) == 64, "PairDesc is a 64-byte device record");
 
+// a pointer / an int that is the same in every lane, pinned to scalar registers: the fields of a device record are loaded through a
+// pointer the compiler cannot prove read-only, so without this they (and everything derived from them: the feature table's base, the
+// keypoint list) live in VECTOR registers -- the moment kernel went from 57 to 66 VGPRs and lost its seventh wavefront per SIMD
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // the queries of a two-cloud search whose query sets differ in size (the K = 1 feature transfer of evaluate.py:272-275 on a ragged
 // pair): batch element b asks n_q[b] queries q[b] and writes idx[b] / dist[b] (dist may be null)
 struct QueryDesc {
@@ -57,7 +69,7 @@ inline int write_record(T* dev, const T& v, hipStream_t st)
 
 // ---- workspace carve-up (per batch element) ---------------------------------------------------
 struct GridWs {
-    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_tot, off_bbox, off_kperm, off_box, total;
+    size_t off_p4o, off_p4s, off_cell, off_counts, off_bases, off_start, off_tot, off_bbox, off_kperm, off_kpi, off_box, total;
     int Npad, n_wg;
 };
 
@@ -76,6 +88,8 @@ __host__ __device__ inline GridWs grid_ws(int N)
     w.off_tot = o;    o += (size_t)kMaxCells * 4;      // points per cell (grid_scan_kernel), turned into start[] by every scatter workgroup
     w.off_bbox = o;   o += 64;
     w.off_kperm = o;  o += (size_t)w.Npad * 4;   // keypoint processing order (n_kp <= Npad)
+    w.off_kpi = o;    o += (size_t)w.Npad * 4;   // a ragged pair's keypoint indices as int32 (pack_points_kernel copies them out of the record's
+                                                 // int64 lists: the moment kernel then reads a fixed workspace address, see there)
     o = (o + 15) / 16 * 16;
     w.off_box = o;    o += (size_t)(w.Npad / 64) * 32;   // bounding boxes of the sorted table's 64-point chunks (corr.hip)
     w.total = (o + 255) / 256 * 256;

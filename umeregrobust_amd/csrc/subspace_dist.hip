@@ -1454,6 +1454,8 @@ static int pair_match_chain(const float* pts, const float* feat, const int64_t* 
     UMEREG_REQUIRE(K > 0 && K <= 7680, "%s: K must be in [1, 7680] (got %d)", who, K);
     UMEREG_REQUIRE(radius > 0.f, "%s: radius must be positive", who);
     UMEREG_REQUIRE(!prob || tau > 0.f, "%s: tau must be positive when prob is requested", who);
+    UMEREG_REQUIRE(!ragged || n_kp <= grid_ws(N).Npad, "%s: n_kp (%d) exceeds the capacity's keypoint buffer (%d): the reference draws "
+                   "min(10000, N_src, N_tgt) keypoints (evaluate.py:197)", who, n_kp, grid_ws(N).Npad);
     UMEREG_REQUIRE(((uintptr_t)F & 15) == 0 && (ragged || ((uintptr_t)feat & 15) == 0), "%s: feat and F must be 16-byte aligned", who);
     if (int rc = check_device()) return rc;
     const size_t need = umereg_pair_match_workspace_bytes_ex(N, n_kp, opts);
