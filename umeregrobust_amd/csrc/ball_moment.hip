@@ -45,14 +45,14 @@ __global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __res
     const int b = blockIdx.y;
     // (a ragged pair: cloud b where the caller left it, n_live <= N points of it; the table is padded to the capacity)
     const int n_live = desc ? desc->n_pts[b] : N;
-    const float* __restrict__ src = desc ? desc->pts[b] : pts + (size_t)b * N * 3;
+    const UMEREG_GLOBAL_AS float* __restrict__ src = global_ptr(desc ? desc->pts[b] : pts + (size_t)b * N * 3);
     float4* out = reinterpret_cast<float4*>(ws + b * ws_stride + w.off_p4o);
     unsigned int* bbox = reinterpret_cast<unsigned int*>(ws + b * ws_stride + w.off_bbox);
     unsigned int e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     for (int j = blockIdx.x * kPackWG + threadIdx.x; j < w.Npad; j += gridDim.x * kPackWG) {
         float4 v = make_float4(kFar, kFar, kFar, 0.f);
         if (j < n_live) {
-            const float* p = src + (size_t)j * 3;
+            const UMEREG_GLOBAL_AS float* p = src + (size_t)j * 3;
             v = make_float4(p[0], p[1], p[2], 0.f);
             const unsigned int ex = enc_ord(v.x), ey = enc_ord(v.y), ez = enc_ord(v.z);
             e[0] = max(e[0], ~ex); e[1] = max(e[1], ~ey); e[2] = max(e[2], ~ez);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kPackWG) void pack_points_kernel(const float* __res
     if (desc && desc->kp[b]) {
         // a ragged pair's keypoint indices, int64 lists wherever the caller keeps them -> int32 at a fixed place of the workspace (n_kp <=
         // Npad: the pair chain checks).  Anything outside int32 becomes -1: "outside the cloud", which the moment kernel answers with NaN.
-        const int64_t* __restrict__ kp = desc->kp[b];
+        const UMEREG_GLOBAL_AS int64_t* __restrict__ kp = global_ptr(desc->kp[b]);
         int* __restrict__ kpi = reinterpret_cast<int*>(ws + b * ws_stride + w.off_kpi);
         const int n_kp = desc->n_kp < w.Npad ? desc->n_kp : w.Npad;
         for (int k = blockIdx.x * kPackWG + threadIdx.x; k < n_kp; k += gridDim.x * kPackWG) {
@@ -693,7 +693,11 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
     // a ragged pair (desc): this cloud's feature table and keypoint indices where the caller left them, n_live <= N points
     const int n_live = desc ? uniform_int(desc->n_pts[b]) : N;
-    const float4* fb = desc ? uniform_ptr(reinterpret_cast<const float4*>(desc->feat[b])) : feat4 + (size_t)b * N * 8;
+    // (a native vector type: HIP's float4 is a class, whose assignment cannot bind a reference into address space 1)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const UMEREG_GLOBAL_AS f4v* fb = global_ptr(desc ? uniform_ptr(reinterpret_cast<const f4v*>(desc->feat[b]))
+                                                     : reinterpret_cast<const f4v*>(feat4) + (size_t)b * N * 8);
+    auto feat_slice = [&](size_t k) __attribute__((always_inline)) { const f4v t = fb[k]; return make_float4(t.x, t.y, t.z, t.w); };
     float qx, qy, qz;
     if (desc || kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
         // (one load through whichever base applies: a SELECTED base pointer cost the kernel 9 vector registers and its seventh wavefront)
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const unsigned int jn = (unsigned int)lst[min(e0 + u * 8 + mns, count - 1)];
-                ff[u] = fb[(size_t)jn * 8 + mcq];
+                ff[u] = feat_slice((size_t)jn * 8 + mcq);
                 pc[u] = Pf[(size_t)jn * 4 + (mj > 0 ? mj - 1 : 0)];
             }
 #pragma unroll
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
             // wave instead of 1 KiB), the others get them by two DPP moves per word (lane 0 of the quad, then quad 0 -> quad 1)
             pp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (qd == 0) pp[u] = Pb[jj[u]];
-            ff[u] = fb[(size_t)jj[u] * 8 + qd];
+            ff[u] = feat_slice((size_t)jj[u] * 8 + qd);
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {

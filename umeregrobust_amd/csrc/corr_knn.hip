@@ -74,11 +74,15 @@ template __global__ __launch_bounds__(256) void knn_points_kernel<unsigned int>(
 // raw points of a KITTI pair against ~25 here.
 constexpr int kNn1Lanes = 8;
 __global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ p1, int n1, int n2,
-                                                         float* __restrict__ dists, int64_t* __restrict__ idx, const QueryDesc* __restrict__ dq)
+                                                         float* __restrict__ dists_, int64_t* __restrict__ idx_, const QueryDesc* __restrict__ dq)
 {
     const int b = blockIdx.y;
-    // dq (a ragged pair, umereg_nn1_pair_f32): batch element b asks ITS queries and writes ITS outputs; n1 is then the launch's capacity
-    if (dq) { n1 = dq->n_q[b]; p1 = dq->q[b] - (size_t)b * n1 * 3; idx = dq->idx[b] - (size_t)b * n1; dists = dq->dist[b] ? dq->dist[b] - (size_t)b * n1 : nullptr; }
+    // dq (a ragged pair, umereg_nn1_pair_f32): batch element b asks ITS queries and writes ITS outputs; n1 is then the launch's capacity.
+    // (the record's pointers are global memory: said explicitly, or every access through them is a flat instruction)
+    if (dq) n1 = dq->n_q[b];
+    const UMEREG_GLOBAL_AS float* pq_base = global_ptr(dq ? dq->q[b] : p1 + (size_t)b * n1 * 3);
+    UMEREG_GLOBAL_AS int64_t* idx = global_ptr(dq ? dq->idx[b] : idx_ + (size_t)b * n1);
+    UMEREG_GLOBAL_AS float* dists = global_ptr(dq ? dq->dist[b] : (dists_ ? dists_ + (size_t)b * n1 : nullptr));
     const GridWs w = grid_ws(n2);
     const char* wb = ws + b * ws_stride;
     const float4* __restrict__ P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict_
     const int sub = threadIdx.x & (kNn1Lanes - 1);
     const int q = blockIdx.x * (256 / kNn1Lanes) + (int)(threadIdx.x / kNn1Lanes);
     const bool live = q < n1;
-    const float* pq = p1 + ((size_t)b * n1 + (live ? q : 0)) * 3;
+    const UMEREG_GLOBAL_AS float* pq = pq_base + (size_t)(live ? q : 0) * 3;
     const float fx = pq[0], fy = pq[1], fz = pq[2];
     float rho = 0.75f * fminf(1.0f / g.invx, fminf(1.0f / g.invy, 1.0f / g.invz));
     unsigned long long m = ~0ull;
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(256) void nn1_points_kernel(const char* __restrict_
     }
     (void)lane;
     if (live && sub == 0) {
-        if (dists) dists[(size_t)b * n1 + q] = m != ~0ull ? __uint_as_float((unsigned int)(m >> 32)) : 0.f;
-        idx[(size_t)b * n1 + q] = m != ~0ull ? (int64_t)(unsigned int)(m & 0xffffffffull) : (int64_t)-1;
+        if (dists) dists[q] = m != ~0ull ? __uint_as_float((unsigned int)(m >> 32)) : 0.f;
+        idx[q] = m != ~0ull ? (int64_t)(unsigned int)(m & 0xffffffffull) : (int64_t)-1;
     }
 }
 

@@ -32,6 +32,15 @@ struct PairDesc {
 };
 static_assert(sizeof(PairDesc) == 64, "PairDesc is a 64-byte device record");
 
+// A pointer that was LOADED from memory (a record's field) carries no address space: every access through it is a flat_load, which
+// the hardware issues against both the LDS and the memory counters -- the moment kernel's feature gathers became flat_load_dwordx4 and
+// the kernel 4 % slower (108.7 against 104.4 us per KT pair, same box).  These casts say what the record's pointers are: global memory.
+#define UMEREG_GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const UMEREG_GLOBAL_AS T* global_ptr(const T* p) { return (const UMEREG_GLOBAL_AS T*)p; }
+template <class T>
+__device__ __forceinline__ UMEREG_GLOBAL_AS T* global_ptr(T* p) { return (UMEREG_GLOBAL_AS T*)p; }
+
 // a pointer / an int that is the same in every lane, pinned to scalar registers: the fields of a device record are loaded through a
 // pointer the compiler cannot prove read-only, so without this they (and everything derived from them: the feature table's base, the
 // keypoint list) live in VECTOR registers -- the moment kernel went from 57 to 66 VGPRs and lost its seventh wavefront per SIMD
