@@ -164,7 +164,16 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(char* __restrict__ ws, s
     int* __restrict__ tot = reinterpret_cast<int*>(wb + w.off_tot);
     unsigned int* bbox = reinterpret_cast<unsigned int*>(wb + w.off_bbox);
     const Grid gg = load_grid_compute(bbox, radius, desc ? desc->n_pts[blockIdx.y] : N);      // (the density of the LIVE points, kNN mode)
-    if (blockIdx.x == 0 && threadIdx.x == 0) store_grid(bbox, gg);     // for every later kernel
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        store_grid(bbox, gg);     // for every later kernel
+        if (desc) {
+            // a ragged pair: what the moment kernel needs of the record -- the cloud's size and its feature table -- beside the geometry, in
+            // the 64 bytes every wavefront of that kernel loads anyway (a load THROUGH the record at the head of every wavefront: +2.6 us per pair)
+            const unsigned long long fp = (unsigned long long)desc->feat[blockIdx.y];
+            bbox[6] = (unsigned int)fp; bbox[7] = (unsigned int)(fp >> 32);
+            bbox[15] = (unsigned int)desc->n_pts[blockIdx.y];
+        }
+    }
     // cells beyond this are never populated (curve positions of an order-only structure: any of the 4096)
     const int n_cells = ((order_only >> blockIdx.y) & 1) ? kMaxCells : gg.nx * gg.ny * gg.nz;
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -659,12 +668,14 @@ constexpr int kMomUnroll = 4;  // 4 x 8 = 32 neighbours in flight per wave (8 me
 // each) instead of 16 FMA + 7 conversions + 6 broadcast moves per lane; 4 accumulator registers pairs instead of 16; the fold of the
 // two halves is one exchange across lane bit 3.  The matrix pipe's f64 rate equals the vector pipe's on this part (64.6 TFLOP/s
 // measured), so what is saved is the conversions and moves, not the FMAs: see DESIGN 3.1 for the measurement.
-template <int kAcc, bool kFma = false>
+// kDesc: the two clouds of a ragged pair (PairDesc, grid.h): size and feature table of cloud b from words 15 / 6-7 of its bounding-box
+// record (grid_scan_kernel put them there), keypoint indices from the int32 copy pack_points_kernel made; feat4 / kp_index are unused.
+template <int kAcc, bool kFma = false, bool kDesc = false>
 __global__ __launch_bounds__(256) void ume_moments_kernel(
     const char* __restrict__ ws, size_t ws_stride, const float* __restrict__ kpts,
     const int64_t* __restrict__ kp_index, const float4* __restrict__ feat4, int N, int n_kp, int K, int cap,
     float radius, int flags, float* __restrict__ F, int32_t* __restrict__ nn_count,
-    int64_t* __restrict__ nn_idx, const PairDesc* __restrict__ desc)
+    int64_t* __restrict__ nn_idx)
 {
     const bool ordered = flags & UMEREG_MOMENTS_ORDERED;
     extern __shared__ int lds[];
@@ -691,19 +702,19 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
     const float4* P4s = reinterpret_cast<const float4*>(wb + w.off_p4s);
     const int* start = reinterpret_cast<const int*>(wb + w.off_start);
     const Grid g = load_grid(reinterpret_cast<const unsigned int*>(wb + w.off_bbox), radius, N);
-    // a ragged pair (desc): this cloud's feature table and keypoint indices where the caller left them, n_live <= N points
-    const int n_live = desc ? uniform_int(desc->n_pts[b]) : N;
+    // a ragged pair (kDesc): this cloud's feature table where the caller left it, n_live <= N points
+    const unsigned int* __restrict__ rec = reinterpret_cast<const unsigned int*>(wb + w.off_bbox);
+    const int n_live = kDesc ? (int)rec[15] : N;
     // (a native vector type: HIP's float4 is a class, whose assignment cannot bind a reference into address space 1)
     typedef float f4v __attribute__((ext_vector_type(4)));
-    const UMEREG_GLOBAL_AS f4v* fb = global_ptr(desc ? uniform_ptr(reinterpret_cast<const f4v*>(desc->feat[b]))
-                                                     : reinterpret_cast<const f4v*>(feat4) + (size_t)b * N * 8);
+    const UMEREG_GLOBAL_AS f4v* fb = global_ptr(kDesc ? reinterpret_cast<const f4v*>(((unsigned long long)rec[7] << 32) | rec[6])
+                                                      : reinterpret_cast<const f4v*>(feat4) + (size_t)b * N * 8);
     auto feat_slice = [&](size_t k) __attribute__((always_inline)) { const f4v t = fb[k]; return make_float4(t.x, t.y, t.z, t.w); };
     float qx, qy, qz;
-    if (desc || kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
-        // (one load through whichever base applies: a SELECTED base pointer cost the kernel 9 vector registers and its seventh wavefront)
-        // (a ragged pair's indices come from the int32 copy in the workspace, not through the record's pointer: loading the list's base
-        // out of the record cost this kernel 9 vector registers and its seventh wavefront per SIMD -- 108.7 against 104.4 us per KT pair)
-        const int64_t ki = desc ? (int64_t)reinterpret_cast<const int*>(wb + w.off_kpi)[kp] : kp_index[(size_t)b * n_kp + kp];
+    if (kDesc || kp_index) {   // keypoint = point kp_index[kp] of this cloud (fused gather, evaluate.py:201-202)
+        // (a ragged pair's indices: the int32 copy in the workspace, not the record's int64 list -- a base pointer loaded out of a record
+        // cost this kernel 9 vector registers and its seventh wavefront per SIMD)
+        const int64_t ki = kDesc ? (int64_t)reinterpret_cast<const int*>(wb + w.off_kpi)[kp] : kp_index[(size_t)b * n_kp + kp];
         if (ki < 0 || ki >= n_live) {
             // an index outside the cloud (stale, or the -1 padding the reference's own code produces) must not read out of
             // bounds: the keypoint's matrix is all NaN -- loud downstream, where torch indexing would have raised
@@ -1038,22 +1049,23 @@ int launch_moments(const void* packed, const float* kpts, const int64_t* kp_inde
     UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_ACC_F32) && (flags & UMEREG_MOMENTS_ACC_VALU)), "ume_moments: ACC_F32 and ACC_VALU exclude each other");
     UMEREG_REQUIRE(!((flags & UMEREG_MOMENTS_FMA_DIST) && (flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU))),
                    "ume_moments: FMA_DIST goes with the default accumulation only");
-    if (flags & UMEREG_MOMENTS_FMA_DIST)     // (opt-in: its own instantiation of the default accumulation, nothing added to the product kernel)
-        hipLaunchKernelGGL((ume_moments_kernel<2, true>), grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+#define UMEREG_LAUNCH_MOMENTS(...)                                                                                                    \
+    hipLaunchKernelGGL((ume_moments_kernel<__VA_ARGS__>), grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int), st,               \
+                       (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N, n_kp, K, cap, radius, flags, F,   \
+                       nn_count, nn_idx)
+    UMEREG_REQUIRE(!desc || !(flags & (UMEREG_MOMENTS_FMA_DIST | UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)),
+                   "ume_moments: a ragged pair runs the default kernel only");
+    if (desc)                                     // (the record itself was consumed by the structure build: see kDesc)
+        UMEREG_LAUNCH_MOMENTS(2, false, true);
+    else if (flags & UMEREG_MOMENTS_FMA_DIST)     // (opt-in: its own instantiation of the default accumulation, nothing added to the product kernel)
+        UMEREG_LAUNCH_MOMENTS(2, true);
     else if (!(flags & (UMEREG_MOMENTS_ACC_F32 | UMEREG_MOMENTS_ACC_VALU)))
-        hipLaunchKernelGGL(ume_moments_kernel<2>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+        UMEREG_LAUNCH_MOMENTS(2);
     else if (!(flags & UMEREG_MOMENTS_ACC_F32))
-        hipLaunchKernelGGL(ume_moments_kernel<1>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+        UMEREG_LAUNCH_MOMENTS(1);
     else
-        hipLaunchKernelGGL(ume_moments_kernel<0>, grid, dim3(kWave * waves), (size_t)waves * cap * sizeof(int),
-                           st, (const char*)packed, grid_ws(N).total, kpts, kp_index, (const float4*)feat, N,
-                           n_kp, K, cap, radius, flags, F, nn_count, nn_idx, desc);
+        UMEREG_LAUNCH_MOMENTS(0);
+#undef UMEREG_LAUNCH_MOMENTS
     UMEREG_CHECK_LAUNCH("ume_moments_kernel");
     return UMEREG_OK;
 }
