@@ -742,7 +742,10 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 
     constexpr bool kF64 = kAcc != 0;
 #ifndef UMEREG_MOM_ABLATE
-#define UMEREG_MOM_ABLATE 0   // timing experiments only: 1 = no gather / accumulation (search cost alone)
+#define UMEREG_MOM_ABLATE 0   // timing experiments only (results are wrong by construction): 1 = no gather / accumulation (the search alone);
+                              // matrix-pipe path: 2 = the accumulate loop without its gathers (list reads, conversions and MFMAs on made-up
+                              // operands), 4 = with the gathers but without conversions / MFMAs (five fp32 adds per group instead), 6 = both
+                              // (the loop's list reads and control flow alone) -- profiles/r06/mom_split.txt
 #endif
 #ifndef UMEREG_MOM_MFMA_UNROLL
 #define UMEREG_MOM_MFMA_UNROLL 4      // groups of 8 neighbours whose loads are in flight together (tools/exp_mom_acc.py measures alternatives)
@@ -760,8 +763,21 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const unsigned int jn = (unsigned int)lst[min(e0 + u * 8 + mns, count - 1)];
+                if (UMEREG_MOM_ABLATE & 2) {
+                    const float v = __uint_as_float(0x3f800000u | (jn & 0xffffu));
+                    ff[u] = make_float4(v, v + 1.f, v + 2.f, v + 3.f);
+                    pc[u] = v;
+                    continue;
+                }
                 ff[u] = feat_slice((size_t)jn * 8 + mcq);
                 pc[u] = Pf[(size_t)jn * 4 + (mj > 0 ? mj - 1 : 0)];
+            }
+            if (UMEREG_MOM_ABLATE & 4) {
+                float t = 0.f;
+#pragma unroll
+                for (int u = 0; u < kU; ++u) t += ((ff[u].x + ff[u].y) + (ff[u].z + ff[u].w)) + pc[u];
+                acc[0] += (double)t;
+                return;
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
@@ -777,10 +793,62 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
                 acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].w, bq, acc[3], 0, 0, 0);
             }
         };
+#ifndef UMEREG_MOM_PIPE
+#define UMEREG_MOM_PIPE 0     // 1: the loop software-pipelined in half-trips (A/B, profiles/r06/mom_split.txt); same groups in the same order
+#endif
+#if UMEREG_MOM_PIPE
+        // Two register sets of kMU / 2 groups each: while the MFMAs of one half-trip run, the gathers of the NEXT half-trip are in flight
+        // (issued before them; the memory counter waits in issue order, so the first set's data can be awaited with the second set's
+        // loads outstanding).  The trip-at-a-time loop below has no load of its own wavefront in flight while it converts and
+        // multiplies.  Groups are accumulated in the same order by the same instructions: bit-identical sums.
+        constexpr int kH = kMU / 2 > 0 ? kMU / 2 : 1;
+        auto load_half = [&](int e0, float4 (&ff)[kH], float (&pc)[kH]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < kH; ++u) {
+                if (e0 + u * 8 < count) {                                                   // (wave-uniform)
+                    const unsigned int jn = (unsigned int)lst[min(e0 + u * 8 + mns, count - 1)];
+                    ff[u] = feat_slice((size_t)jn * 8 + mcq);
+                    pc[u] = Pf[(size_t)jn * 4 + (mj > 0 ? mj - 1 : 0)];
+                }
+            }
+        };
+        auto fma_half = [&](int e0, float4 (&ff)[kH], float (&pc)[kH]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < kH; ++u) {
+                if (e0 + u * 8 < count) {                                                   // (wave-uniform)
+                    if (e0 + u * 8 + 8 > count) {                                           // the one ragged group
+                        const bool v = e0 + u * 8 + mns < count;
+                        ff[u].x = v ? ff[u].x : 0.f; ff[u].y = v ? ff[u].y : 0.f;
+                        ff[u].z = v ? ff[u].z : 0.f; ff[u].w = v ? ff[u].w : 0.f;
+                    }
+                    const double bq = mj == 0 ? 1.0 : (double)pc[u];
+                    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].x, bq, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].y, bq, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].z, bq, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ff[u].w, bq, acc[3], 0, 0, 0);
+                }
+            }
+        };
+        {
+            float4 fa[kH], fc[kH];
+            float pa[kH], pq[kH];
+            const int step = 8 * kH;
+            const int n_half = (UMEREG_MOM_ABLATE & 1) ? 0 : (count + step - 1) / step;
+            if (n_half > 0) load_half(0, fa, pa);
+            for (int h = 0; h < n_half; h += 2) {
+                if (h + 1 < n_half) load_half((h + 1) * step, fc, pq);
+                fma_half(h * step, fa, pa);
+                if (h + 2 < n_half) load_half((h + 2) * step, fa, pa);
+                if (h + 1 < n_half) fma_half((h + 1) * step, fc, pq);
+            }
+        }
+        (void)mtrip;
+#else
         const int mfull = (UMEREG_MOM_ABLATE & 1) ? 0 : (count / (8 * kMU)) * (8 * kMU);
         for (int e0 = 0; e0 < mfull; e0 += 8 * kMU) mtrip(e0, false, std::integral_constant<int, kMU>{});
         if (!(UMEREG_MOM_ABLATE & 1))
         for (int e0 = mfull; e0 < count; e0 += 8) mtrip(e0, e0 + 8 > count, std::integral_constant<int, 1>{});
+#endif
         // D lane = 16 i + 4 b + j: channel 4 ((4 b + i) & 7) + m, column j, the neighbour half b >> 1 -- the halves differ in lane bit 3
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] += shfl_xor_f64(acc[m], 8);
