@@ -401,6 +401,7 @@ def main():
     # and target independently; evaluate.py:195-204), and which `value`'s equally large clouds are the special case of.  A pair of
     # another shape costs a 64-byte record written on the device before the replay: `graphs_captured_during_the_leg` must be 0. ----
     ragged_named = None
+    rag_pool = None
     if a.ragged_steps is None:
         a.ragged_steps = 0 if a.config == "K1" else 3
     if a.ragged_steps > 0 and a.batch_clouds:
@@ -445,7 +446,6 @@ def main():
                                 "evaluate.py:195-204.  Same pipeline and per-slot graphs as `value` (captured once at the capacity "
                                 "args.max_pc_size; a pair of another shape = a 64-byte device record, no re-capture, no staging copy)"}
         leg.pool = pool
-        del rag_pool
 
     # ---- does the stream plan still pay on THIS runtime?  The pipeline creates its slot streams interleaved with spacer streams ("sd"
     # per slot) because the HIP runtime deals streams onto its hardware queues in creation order (RegistrationPipeline.__init__): an
@@ -810,6 +810,11 @@ def main():
         if a.e2e_side_by_side > a.e2e_in_flight:
             result["end_to_end"]["side_by_side"] = side_by_side(e2e_leg(pool, a.e2e_pairs, 500000, "", a.e2e_side_by_side))
         result["end_to_end"]["evaluate_pairs_loop"] = api_loop(pool, a.e2e_pairs, 510000)
+    if not a.no_e2e and a.e2e_pairs > 0 and rag_pool:
+        # the library's own loop (keypoint draws, a1-a7, K = 1 transfer of both clouds in one pass, f1, f2) over the RAGGED pairs
+        result["end_to_end_ragged"] = {"evaluate_pairs_loop": api_loop(rag_pool, min(a.e2e_pairs, 2 * len(rag_pool)), 520000),
+                                       "workload": "the ragged pairs of config.named_path_on_ragged_pairs (N_src != N_tgt, exact rigid twins where both clouds kept the point)"}
+    rag_pool = None
     hard_pool = hard_pool_first = None
     if not a.no_e2e and a.e2e_hard_pairs > 0:
         n_hard = min(4, a.e2e_hard_pairs)      # (the same pairs as the named-path leg's hard pool, when that ran)
@@ -875,12 +880,14 @@ def main():
         result["cpu_baseline"]["rr_check"] = rr_check(a, orc, evaluate, ops, torch, dev, args, synth_pair_hard)
     # the numbers a user of evaluate.py feels, where the driver's parser keeps them (it drops unknown top-level keys)
     e2e, e2h = result.get("end_to_end"), result.get("end_to_end_hard")
+    e2r = result.get("end_to_end_ragged")
     f1s = result.get("f1_selection") or {}
     result["config"]["end_to_end_pairs_per_s"] = {
         "plain_pair_by_pair": e2e and e2e["pairs_per_s"], "plain_evaluate_pairs": e2e and e2e.get("evaluate_pairs_loop", {}).get("pairs_per_s"),
         "plain_side_by_side": e2e and e2e.get("side_by_side", {}).get("pairs_per_s"),
         "hard_pair_by_pair": e2h and e2h["pairs_per_s"], "hard_evaluate_pairs": e2h and e2h.get("evaluate_pairs_loop", {}).get("pairs_per_s"),
         "hard_side_by_side": e2h and e2h.get("side_by_side", {}).get("pairs_per_s"),
+        "ragged_evaluate_pairs": e2r and e2r.get("evaluate_pairs_loop", {}).get("pairs_per_s"),
         "f1_ms_plain": f1s.get("plain", {}).get("stage_ms", {}).get("total"), "f1_ms_hard": f1s.get("hard", {}).get("stage_ms", {}).get("total"),
         "what": "a1-a7 + raw-cloud prep + f1 hypothesis selection + f2 ICP per pair (evaluate.py:195-309), whole job"}
     # the dominant kernel of a REGISTRATION (not of the named path): the consensus pass of f1

@@ -121,6 +121,48 @@ def soak_ball(rng):
     return f"ball N={N} n1={n1} K={K} r={r}"
 
 
+def soak_pair(rng):
+    """a1..a5 of a RAGGED pair in one call (clouds of two sizes read through the device record) against the per-cloud entry points (bit
+    for bit), the oracle's neighbourhoods (bit-exact) and its fp64 moment matrices; every other trial through a capacity graph replayed
+    for a second pair of other sizes"""
+    Ns, Nt = rand_size(rng, 30000), rand_size(rng, 30000)
+    n = int(min(Ns, Nt, rand_size(rng, 3000)))
+    K = int(rng.choice([5, 64, 750]))
+    r = float(rng.choice([2.0, 5.0]))
+
+    def one(Ns, Nt):
+        sp, tp = cloud(rng, Ns), cloud(rng, Nt)
+        sf, tf = rng.standard_normal((Ns, 32)).astype(np.float32), rng.standard_normal((Nt, 32)).astype(np.float32)
+        sk, tk = rng.choice(Ns, n, replace=n > Ns).astype(np.int64), rng.choice(Nt, n, replace=n > Nt).astype(np.int64)
+        return sp, tp, sf, tf, sk, tk
+    h = one(Ns, Nt)
+    d = [T_(x) for x in h]
+    F, m, dd, prob = ops.pair_match_ragged(*d, K, r, tau=0.05)
+    Fs = ops.ume_moments(d[0][None], None, d[2][None], K, r, kp_index=d[4])
+    Ft, idx_t = ops.ume_moments(d[1][None], None, d[3][None], K, r, kp_index=d[5], return_idx=True)
+    assert torch.equal(F[0], Fs[0]) and torch.equal(F[1], Ft[0]), f"ragged one-call F differs from the per-cloud call (Ns={Ns}, Nt={Nt}, n={n}, K={K})"
+    m2, d2 = ops.ume_match(Fs, Ft)
+    assert torch.equal(m, m2) and torch.equal(dd, d2), "ragged one-call match differs"
+    sel = np.arange(0, n, max(1, n // 32))
+    ref = orc.ball_query(h[1][h[5][sel]][None], h[1][None], K=K, radius=r, return_nn=False)
+    assert np.array_equal(N_(idx_t)[0][sel], ref.idx[0]), "ragged neighbourhoods differ from the oracle"
+    Fo = orc.ume_moments(h[0], h[0][h[4][sel]], h[2], K=K, radius=r)
+    scale = np.abs(Fo).max(axis=(1, 2), keepdims=True) + 1e-30
+    assert (np.abs(N_(F[0])[sel] - Fo) / scale).max() < 3e-6, "ragged moments differ from the oracle"
+    if rng.rand() < 0.5:
+        g = ops.PairMatchCapGraph(DEV, max(Ns, Nt), n, K, r, 0.05)
+        st = torch.cuda.current_stream(DEV).cuda_stream
+        Ns2, Nt2 = max(n, int(Ns * rng.uniform(0.5, 1.0))), max(n, int(Nt * rng.uniform(0.5, 1.0)))
+        h2 = one(Ns2, Nt2)
+        d2_ = [T_(x) for x in h2]
+        for dev_in in (d2_, d):
+            g.launch(*dev_in, 0, st)
+            torch.cuda.synchronize()
+            want = ops.pair_match_ragged(*dev_in, K, r, tau=0.05)
+            assert torch.equal(g.F, want[0]) and torch.equal(g.m, want[1]) and torch.equal(g.prob, want[3]), "capacity graph replay differs"
+    return f"pair Ns={Ns} Nt={Nt} n={n} K={K} r={r}"
+
+
 def soak_knn(rng):
     n2, n1 = rand_size(rng, 12000), rand_size(rng, 3000)
     K = int(min(n2, rng.choice([1, 5, 20, 50, 64])))
@@ -245,7 +287,7 @@ def main():
     a = ap.parse_args()
     global BIG
     BIG = a.big
-    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr, "voxel": soak_voxel, "matchp": soak_match_pform}
+    kinds = {"match": soak_match, "ball": soak_ball, "knn": soak_knn, "rtume": soak_rtume, "corr": soak_corr, "voxel": soak_voxel, "matchp": soak_match_pform, "pair": soak_pair}
     if a.only:
         kinds = {k: v for k, v in kinds.items() if k in a.only.split(",")}
     t0 = time.time()
