@@ -159,7 +159,19 @@ def soak_pair(rng):
             g.launch(*dev_in, 0, st)
             torch.cuda.synchronize()
             want = ops.pair_match_ragged(*dev_in, K, r, tau=0.05)
-            assert torch.equal(g.F, want[0]) and torch.equal(g.m, want[1]) and torch.equal(g.prob, want[3]), "capacity graph replay differs"
+            if not (torch.equal(g.F, want[0]) and torch.equal(g.m, want[1]) and torch.equal(g.prob, want[3])):
+                got = (g.F.clone(), g.m.clone(), g.prob.clone())
+                g.launch(*dev_in, 0, st)
+                torch.cuda.synchronize()
+                again = (g.F.clone(), g.m.clone(), g.prob.clone())
+                want2 = ops.pair_match_ragged(*dev_in, K, r, tau=0.05)
+                torch.cuda.synchronize()
+                raise AssertionError(f"capacity graph replay differs (sizes {[tuple(x.shape) for x in dev_in[:2]]}, n={n}, K={K}, r={r}, cap {g.capacity}): "
+                                     f"F {int((got[0] != want[0]).sum())} m {int((got[1] != want[1]).sum())} prob {int((got[2] != want[3]).sum())} entries; "
+                                     f"graph relaunch equals first launch: {torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])}, "
+                                     f"one-call recomputed equals itself: {torch.equal(want2[0], want[0]) and torch.equal(want2[1], want[1])}, "
+                                     f"relaunch equals one-call: {torch.equal(again[0], want2[0]) and torch.equal(again[1], want2[1])}; "
+                                     f"NaN in F: graph {int(torch.isnan(got[0]).sum())} one-call {int(torch.isnan(want[0]).sum())}")
     return f"pair Ns={Ns} Nt={Nt} n={n} K={K} r={r}"
 
 

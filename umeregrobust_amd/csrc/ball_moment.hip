@@ -977,14 +977,28 @@ __global__ __launch_bounds__(256) void ume_moments_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* __restrict__ p, unsigned int words_per_row, size_t stride_words)
+{
+    unsigned int* row = p + blockIdx.y * stride_words;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < words_per_row; i += gridDim.x * 256u) row[i] = 0u;
+}
+
+int launch_zero(void* p, size_t row_bytes, int rows, size_t stride, hipStream_t st)
+{
+    if (row_bytes == 0 || rows <= 0) return UMEREG_OK;
+    const unsigned int words = (unsigned int)(row_bytes / 4);
+    unsigned int nb = (words + 255u) / 256u;
+    nb = nb > 256u ? 256u : nb;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(nb, rows), dim3(256), 0, st, (unsigned int*)p, words, stride / 4);
+    UMEREG_CHECK_LAUNCH("zero_words_kernel");
+    return UMEREG_OK;
+}
+
 int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only, const PairDesc* desc)
 {
     const GridWs w = grid_ws(N);
     // the B bounding-box records (64 B each, one per cloud's workspace slice) in one call
-    if ((B == 1 ? hipMemsetAsync(ws + w.off_bbox, 0, 64, st) : hipMemset2DAsync(ws + w.off_bbox, w.total, 0, 64, B, st)) != hipSuccess) {
-        set_error("hipMemsetAsync(bbox) failed");
-        return UMEREG_ELAUNCH;
-    }
+    if (int rc = launch_zero(ws + w.off_bbox, 64, B, w.total, st)) return rc;
     {
         int nb = (w.Npad + kPackWG - 1) / kPackWG;
         nb = nb > kPackMaxBlocks ? kPackMaxBlocks : nb;

@@ -228,6 +228,11 @@ int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStrea
 int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,
                        hipStream_t st, const PairDesc* desc = nullptr);
 
+// zero `rows` runs of `row_bytes` bytes (a multiple of 4), `stride` bytes apart -- by a KERNEL, not hipMemsetAsync: inside a captured
+// hipGraph a memset node followed by a short kernel was seen to be reordered / overlapped by the runtime on tiny problems (the matcher's
+// per-row limits zeroed while the coarse pass already ran: wrong matches in ~3 % of randomised small pairs, tools/soak_parity.py `pair`)
+int launch_zero(void* p, size_t row_bytes, int rows, size_t stride, hipStream_t st);
+
 // the fused search + gather + moment kernel over a structure built by launch_prep (arguments as umereg_ume_moments_packed_f32)
 int launch_moments(const void* packed, const float* kpts, const int64_t* kp_index, const float* feat, int B, int N, int n_kp, int K,
                    float radius, int flags, float* F, int32_t* nn_count, int64_t* nn_idx, hipStream_t st, const PairDesc* desc = nullptr);

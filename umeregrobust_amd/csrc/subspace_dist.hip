@@ -1143,11 +1143,7 @@ UMEREG_API int umereg_ume_match_reset_f16(void* scratch, size_t scratch_bytes, i
         return UMEREG_EWORKSPACE;
     }
     // the per-row limits start at 0; everything else in the scratch is written before it is read
-    if (hipMemsetAsync(scratch, 0, (size_t)n1 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) {
-        set_error("ume_match_reset_f16: hipMemsetAsync failed");
-        return UMEREG_ELAUNCH;
-    }
-    return UMEREG_OK;
+    return launch_zero(scratch, (size_t)n1 * sizeof(unsigned int), 1, 0, (hipStream_t)stream);
 }
 
 UMEREG_API int umereg_ume_match_coarse_f16_ex(const void* Q1_rows_h, const void* Q2_cols_h, int n1, int n2, void* scratch,
