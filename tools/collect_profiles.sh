@@ -24,7 +24,7 @@ timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT
 f=$(ls $OUT/stats/*/run_kernel_stats.csv $OUT/stats/run_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
 rm -rf $OUT/stats $OUT/stats_detail.json
 fi
-SMALL="--config $CFG --steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e --pool 4 --resident-steps 0 --hard-steps 0 --detail $OUT/small_detail.json"
+SMALL="--config $CFG --steps 2 --warmup 1 --pairs-per-step 8 --depth 1 --no-cpu-baseline --no-e2e --pool 4 --resident-steps 0 --hard-steps 0 --ragged-steps 0 --plan-check-pairs 0 --detail $OUT/small_detail.json"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py $SMALL > $OUT/pmc_$c.log 2>&1
   f=$(ls $OUT/pmc_$c/*/pmc_counter_collection.csv $OUT/pmc_$c/pmc_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/pmc_$c.csv
