@@ -753,8 +753,12 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
     max_it = int(getattr(args, "icp_max_iteration", 200))
 
     def read_back(p):
-        R_hat, t_hat, st, _keep, T_dev, job = p     # _keep: the pair's input tensors stay alive until its last kernel is done
+        R_hat, t_hat, st, _keep, T_dev, job, clouds = p     # _keep: the pair's input tensors stay alive until its last kernel is done
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            if job is None and refine:
+                # (no job could be enqueued for this pair -- one pair at a time on the caller's stream, or clouds the job does not take:
+                # the synchronous form, here, so that a loop over 1 475 pairs never holds more than two pairs of raw clouds)
+                refined.append(refine_registration(R_hat, t_hat, args, [clouds], tform_dev=T_dev if T_dev.is_cuda else None)[0][0])
             if job is not None:
                 # The reference refines all pairs after the loop (:301).  The ICP consumes no random numbers and touches nothing but
                 # its own pair: its whole chain was enqueued right behind the pair's hypothesis selection (ops.IcpJob: it starts from
@@ -794,10 +798,10 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
             job = None
             if refine and st is not None and src_raw.is_cuda and src_raw.dtype == torch.float32 and tgt_raw.dtype == torch.float32:
                 job = ops.IcpJob(src_raw, tgt_raw, T_dev[0].contiguous(), max_corr, max_it)                              # :63-96
-        raw.append((src_raw, tgt_raw, pair["gt_tform"]))
+        raw.append(pair["gt_tform"])
         if pending is not None:
             read_back(pending)        # the previous pair's result: its scores ran beside everything above
-        pending = (R_hat, t_hat, st, pair, T_dev, job)
+        pending = (R_hat, t_hat, st, pair, T_dev, job, (src_raw, tgt_raw, pair["gt_tform"]))
         if st is None:
             read_back(pending)
             pending = None
@@ -808,18 +812,15 @@ def evaluate_pairs(pairs, args, rng=np.random, refine=True, verbose=False, overl
         for st in streams:
             torch.cuda.current_stream(streams[0].device).wait_stream(st)
     R_sel, t_sel = torch.cat(R_sel, dim=0), torch.cat(t_sel, dim=0)
-    if refine and len(refined) != R_sel.shape[0]:
-        T_est, rre, rte = refine_registration(R_sel, t_sel, args, raw)                                             # :301
+    if refine:
+        T_est = torch.stack(refined)                                                                               # :301 (refined inside the loop)
     else:
-        if refine:
-            T_est = torch.stack(refined)                                                                           # (refined inside the loop)
-        else:
-            T_est = torch.eye(4)[None].repeat(R_sel.shape[0], 1, 1)
-            T_est[:, :3, :3], T_est[:, :3, 3] = R_sel, t_sel
-        gts = torch.stack([g.detach().cpu().float() if isinstance(g, torch.Tensor) else torch.as_tensor(g).float() for _, _, g in raw])
-        dev = raw[0][0].device
-        rre = relative_rotation_error(T_est[:, :3, :3].to(dev).contiguous(), gts[:, :3, :3].to(dev).contiguous()).cpu()
-        rte = (T_est[:, :3, 3] - gts[:, :3, 3]).norm(dim=-1)
+        T_est = torch.eye(4)[None].repeat(R_sel.shape[0], 1, 1)
+        T_est[:, :3, :3], T_est[:, :3, 3] = R_sel, t_sel
+    gts = torch.stack([g.detach().cpu().float() if isinstance(g, torch.Tensor) else torch.as_tensor(g).float() for g in raw])
+    dev = R_hat.device
+    rre = relative_rotation_error(T_est[:, :3, :3].to(dev).contiguous(), gts[:, :3, :3].to(dev).contiguous()).cpu()           # :100-107
+    rte = (T_est[:, :3, 3] - gts[:, :3, 3]).norm(dim=-1)
     rr_np = float(((rre <= 1.5) & (rte <= 0.6)).float().mean())                                                   # :304-305
     rr_sp = float(((rre <= 1) & (rte <= 0.1)).float().mean())
     res = dict(R_sel=R_sel, t_sel=t_sel, T_est=T_est, rre=rre, rte=rte, rr_np=rr_np, rr_sp=rr_sp,
@@ -918,8 +919,14 @@ def main(argv=None):
         pairs = synthetic_pairs(cli.benchmark, shard_indices(cli.synthetic, rank, world), device)
     metrics = RegistrationMetrics()
     with torch.no_grad():
-        for pair in pairs:
-            res = evaluate_pairs([pair], args, rng=rng, refine=not cli.no_refine)
+        # the whole (lazy) stream of pairs through ONE evaluate_pairs loop per chunk: consecutive pairs overlap on two streams and a
+        # pair's ICP is read one pair later (a call per pair, as until round 5, gave all of that away: 330 against 440 pairs/s)
+        it = iter(pairs)
+        while True:
+            chunk = list(__import__("itertools").islice(it, 64))
+            if not chunk:
+                break
+            res = evaluate_pairs(chunk, args, rng=rng, refine=not cli.no_refine)
             metrics.update(res["rre"].numpy(), res["rte"].numpy())
     s = metrics.all_reduce(device).summary()
     if rank == 0:
