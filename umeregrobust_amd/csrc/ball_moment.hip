@@ -434,72 +434,6 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                 my_end = start[cbase + cell_axis(qx + sx, g.minx, g.invx, g.nx) + 1];
             }
         }
-        // room for a whole trip is made BEFORE its loads are issued (keep the K smallest; cap >= K + kScanUnroll chunks): the
-        // selection then runs with none of the trip's points in registers
-        auto make_room = [&](int chunks) __attribute__((always_inline)) {
-            if (cnt > cap - chunks * kWave) {
-                __builtin_amdgcn_wave_barrier();
-                cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
-            }
-        };
-#ifndef UMEREG_SCAN_BATCH
-#define UMEREG_SCAN_BATCH 1
-#endif
-#if UMEREG_SCAN_BATCH
-        // The rows' runs as ONE sequence of 64-point chunks, kScanUnroll of them per trip whatever rows they belong to.  Until round 5
-        // every row was a trip of its own (rows hold 100-250 points with the half-radius cells: 2-4 chunks): 8-12 DEPENDENT round trips
-        // to L2 per keypoint, and the search -- 37 of the kernel's 104 us at KITTI size -- waited for memory most of its life.  The
-        // chunks are visited in the same order as before (row by row, front to back): the kept list is the same list.
-        int nch = (my_end > my_beg) ? (my_end - my_beg + kWave - 1) >> 6 : 0;            // (lane = row; lanes past the last row hold 0)
-        int incl = nch;
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-            const int o = __shfl_up(incl, m, kWave);
-            if (lane >= m) incl += o;
-        }
-        const int excl = incl - nch;
-        const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
-        auto trip = [&](int c0, auto U_) __attribute__((always_inline)) {
-            constexpr int U = decltype(U_)::value;
-            int cb[U], ce[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u;
-                const bool live = c < total;                                                 // (wave-uniform)
-                const int r = (int)__popcll(__ballot(incl <= (live ? c : total - 1)));       // the row chunk c belongs to
-                const int ex = __builtin_amdgcn_readlane(excl, r);
-                const int e = __builtin_amdgcn_readlane(my_end, r);
-                const int bb = __builtin_amdgcn_readlane(my_beg, r) + (((live ? c : total - 1) - ex) << 6);
-                cb[u] = bb;
-                ce[u] = live ? e : bb;                                                       // (a dead slot of the last trip: nothing passes `pos < end`)
-            }
-            float4 pv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pos = cb[u] + lane;
-                pv[u] = P4s[pos < ce[u] ? pos : cb[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pos = cb[u] + lane;
-                const float4 p = pv[u];
-                const int oi = __float_as_int(p.w);
-                const float dx = qx - p.x;
-                const float dy = qy - p.y;
-                const float dz = qz - p.z;
-                const float d2 = dist2_as_the_reference<kFma>(dx, dy, dz);
-                const bool hit = (pos < ce[u]) && (d2 < r2) && (oi <= thr);
-                const unsigned long long m = __ballot(hit);
-                if (m != 0ull) {   // wave-uniform
-                    if (hit) lst[cnt + mbcnt(m)] = oi;
-                    cnt += __popcll(m);
-                }
-            }
-        };
-        int c0 = 0;
-        for (; total - c0 > 2; c0 += kScanUnroll) { make_room(kScanUnroll); trip(c0, std::integral_constant<int, kScanUnroll>{}); }
-        if (c0 < total) { make_room(2); trip(c0, std::integral_constant<int, 2>{}); }
-#else
         const int n_here = min(kWave, n_rows - r0);
         for (int rr = 0; rr < n_here; ++rr) {
             const int beg = __builtin_amdgcn_readlane(my_beg, rr);
@@ -533,11 +467,18 @@ __device__ __forceinline__ int ball_search_grid(const float4* __restrict__ P4s, 
                     }
                 }
             };
+            // room for a whole trip is made BEFORE its loads are issued (keep the K smallest; cap >= K + kScanUnroll chunks): the
+            // selection then runs with none of the trip's points in registers
+            auto make_room = [&](int chunks) __attribute__((always_inline)) {
+                if (cnt > cap - chunks * kWave) {
+                    __builtin_amdgcn_wave_barrier();
+                    cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
+                }
+            };
             int base = beg;
             for (; end - base > 2 * kWave; base += kWave * kScanUnroll) { make_room(kScanUnroll); scan(base, std::integral_constant<int, kScanUnroll>{}); }
             if (base < end) { make_room(2); scan(base, std::integral_constant<int, 2>{}); }
         }
-#endif
     }
     __builtin_amdgcn_wave_barrier();
     if (cnt > K) cnt = keep_k_smallest(lst, cnt, K, nbits, cap, lane, thr);
