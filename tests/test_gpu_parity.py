@@ -2317,6 +2317,9 @@ def test_overlap_streams_are_chosen_by_measurement(gpu):
     stay off the null stream's hardware queue (umeregrobust_amd/streams.py, umereg_streams_run_side_by_side): a stream runs beside a
     stream of another class and not beside itself / a stream of its own class, whatever the process created before."""
     from umeregrobust_amd import streams
+
+    def beside(x, y):                                       # (majority of three probes: one can be disturbed by whatever else the box runs)
+        return sum(streams.run_side_by_side(x, y) for _ in range(3)) >= 2
     for _ in range(5):
         torch.cuda.Stream(gpu).cuda_stream                  # (disturb the runtime's own dealing order)
     null = torch.cuda.default_stream(gpu)
@@ -2324,17 +2327,17 @@ def test_overlap_streams_are_chosen_by_measurement(gpu):
     rep = streams.report(gpu)
     assert classes[0][0].cuda_stream == null.cuda_stream and rep["classes_beside_null"] >= 1
     a = classes[1][0]
-    assert not streams.run_side_by_side(a, a)
+    assert not beside(a, a)
     if len(classes[1]) > 1:
-        assert not streams.run_side_by_side(a, classes[1][1])
+        assert not beside(a, classes[1][1])
     if len(classes) > 2:
-        assert streams.run_side_by_side(a, classes[2][0]) and streams.run_side_by_side(classes[2][0], a)
-    assert streams.run_side_by_side(null, a)
+        assert beside(a, classes[2][0]) and beside(classes[2][0], a)
+    assert beside(null, a)
     got = streams.concurrent_streams(gpu, 3)
     assert len({s.cuda_stream for s in got}) == 3 and all(s.cuda_stream != null.cuda_stream for s in got)
     if rep["classes_beside_null"] >= 3:
-        assert all(streams.run_side_by_side(got[i], got[j]) for i in range(3) for j in range(3) if i != j)
-        assert all(streams.run_side_by_side(null, s) for s in got)
+        assert all(beside(got[i], got[j]) for i in range(3) for j in range(3) if i != j)
+        assert all(beside(null, s) for s in got)
     assert [s.cuda_stream for s in streams.concurrent_streams(gpu, 3)] == [s.cuda_stream for s in got]       # cached: the same streams
 
 
