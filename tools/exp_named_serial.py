@@ -3,6 +3,11 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
+if os.environ.get('ALTLIB'):
+    import umeregrobust_amd._build as _b
+    _b.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ['ALTLIB'])
+    import umeregrobust_amd._lib as _L
+    _L.LIB_PATH = _b.LIB_PATH
 from types import SimpleNamespace
 from umeregrobust_amd import evaluate, ops
 from umeregrobust_amd.synth import synth_pair_cfg, synth_pair, ragged_sizes
