@@ -994,9 +994,7 @@ int launch_zero(void* p, size_t row_bytes, int rows, size_t stride, hipStream_t 
     return UMEREG_OK;
 }
 
-// the structure build in two parts: everything up to the cells' totals and the geometry record (what kp_order_kernel needs), then the
-// scatter -- a caller may run the keypoint order beside the scatter (pair_match_chain: a fork of the captured graph)
-int launch_prep_head(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only, const PairDesc* desc)
+int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only, const PairDesc* desc)
 {
     const GridWs w = grid_ws(N);
     // the B bounding-box records (64 B each, one per cloud's workspace slice) in one call
@@ -1011,21 +1009,9 @@ int launch_prep_head(const float* pts, char* ws, int B, int N, float radius, hip
     UMEREG_CHECK_LAUNCH("grid_hist_kernel");
     hipLaunchKernelGGL(grid_scan_kernel, dim3(kScanWGs, B), dim3(256), 0, st, ws, w.total, N, radius, order_only, desc);
     UMEREG_CHECK_LAUNCH("grid_scan_kernel");
-    return UMEREG_OK;
-}
-
-int launch_prep_tail(char* ws, int B, int N, hipStream_t st, const PairDesc* desc)
-{
-    const GridWs w = grid_ws(N);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(w.n_wg, B), dim3(kSortWG), 0, st, ws, w.total, N, desc);
     UMEREG_CHECK_LAUNCH("grid_scatter_kernel");
     return UMEREG_OK;
-}
-
-int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only, const PairDesc* desc)
-{
-    if (int rc = launch_prep_head(pts, ws, B, N, radius, st, order_only, desc)) return rc;
-    return launch_prep_tail(ws, B, N, st, desc);
 }
 
 int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,

@@ -224,8 +224,6 @@ __device__ __forceinline__ int cell_axis(float p, float mn, float inv, int n)
 // the cells where the grid has one layer); it must not be searched (see grid_hist_kernel)
 // desc (optional, device pointer): per-cloud sources and lengths of a ragged pair (B = 2; `pts` is then unused, N is the capacity)
 int launch_prep(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only = 0, const PairDesc* desc = nullptr);
-int launch_prep_head(const float* pts, char* ws, int B, int N, float radius, hipStream_t st, int order_only = 0, const PairDesc* desc = nullptr);
-int launch_prep_tail(char* ws, int B, int N, hipStream_t st, const PairDesc* desc = nullptr);
 // cell-sorted processing order of n_q query points (kpts [B,n_q,3] or indices into pts) -> ws.off_kperm
 int launch_query_order(char* ws, const float* kpts, const int64_t* kp_index, int B, int N, int n_q, float radius,
                        hipStream_t st, const PairDesc* desc = nullptr);

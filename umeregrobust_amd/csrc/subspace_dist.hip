@@ -1437,32 +1437,6 @@ static int ragged_args(const PairDesc& v, int N_cap, int n_kp, const char* who)
     return UMEREG_OK;
 }
 
-// ---- a side stream per (host thread, device, launch stream) for the one fork of the chain ------------------------------------------
-#ifndef UMEREG_CHAIN_FORK
-#define UMEREG_CHAIN_FORK 1
-#endif
-struct SideLane { hipStream_t main; int device; hipStream_t s; hipEvent_t fork, join; };
-static const hipStream_t kCaptureLane = (hipStream_t)(intptr_t)-1;
-static SideLane* side_lane(hipStream_t main)
-{
-    constexpr int kLanes = 16;
-    static thread_local SideLane lanes[kLanes] = {};
-    static thread_local int n_lanes = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    for (int i = 0; i < n_lanes; ++i)
-        if (lanes[i].main == main && lanes[i].device == dev) return &lanes[i];
-    if (n_lanes == kLanes) return nullptr;            // (more launch streams than that on one thread: the chain stays serial there)
-    SideLane l = {main, dev, nullptr, nullptr, nullptr};
-    if (hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    lanes[n_lanes] = l;
-    return &lanes[n_lanes++];
-}
-
 static int pair_match_chain(const float* pts, const float* feat, const int64_t* kp_index, const PairDesc* desc_vals, bool write_desc,
                             bool ragged, int N, int n_kp, int K, float radius, float tau, float* F, int64_t* match_idx,
                             float* match_dist, float* prob, void* workspace, size_t workspace_bytes, const umereg_match_opts* opts,
@@ -1494,31 +1468,10 @@ static int pair_match_chain(const float* pts, const float* feat, const int64_t* 
         if (int rc = ragged_args(*desc_vals, N, n_kp, who)) return rc;
         if (int rc = write_pair_desc(desc_of(workspace, need), *desc_vals, st)) return rc;
     }
-    // The keypoint order (one workgroup per cloud, 19 us) needs the cells' geometry and the points' cell numbers, not the sorted table:
-    // it runs BESIDE the scatter (20 us, ~100 workgroups) on a side stream forked off `stream` by an event -- in a captured graph that is
-    // a branch of the graph, in plain launches two streams.  (UMEREG_CHAIN_FORK=0: one after the other, the chain of rounds 2-5.)
-    if (int rc = launch_prep_head(pts, ws_mom, 2, N, radius, st, 0, desc)) return rc;
+    if (int rc = launch_prep(pts, ws_mom, 2, N, radius, st, 0, desc)) return rc;
     const int ordered = n_kp <= grid_ws(N).Npad && n_kp >= 64;
-    // (while a graph is being captured the branch goes through ONE lane per thread and device, created before the capture began: the
-    // capture stream is a different one for every graph, and nothing but the node dependencies survives the capture)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    SideLane* side = (ordered && UMEREG_CHAIN_FORK) ? side_lane(cs == hipStreamCaptureStatusActive ? kCaptureLane : st) : nullptr;
-    if (side) {
-        if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("%s: fork of the side stream failed", who);
-            return UMEREG_ELAUNCH;
-        }
-        if (int rc = launch_query_order(ws_mom, nullptr, kp_index, 2, N, n_kp, radius, side->s, desc)) return rc;
-        if (hipEventRecord(side->join, side->s) != hipSuccess) { (void)hipGetLastError(); set_error("%s: join record failed", who); return UMEREG_ELAUNCH; }
-    }
-    if (int rc = launch_prep_tail(ws_mom, 2, N, st, desc)) return rc;
-    if (side) {
-        if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) { (void)hipGetLastError(); set_error("%s: join of the side stream failed", who); return UMEREG_ELAUNCH; }
-    } else if (ordered) {
+    if (ordered)
         if (int rc = launch_query_order(ws_mom, nullptr, kp_index, 2, N, n_kp, radius, st, desc)) return rc;
-    }
     if (int rc = launch_moments(ws_mom, nullptr, kp_index, feat, 2, N, n_kp, K, radius, ordered ? UMEREG_MOMENTS_ORDERED : 0, F, nullptr,
                                 nullptr, st, desc))
         return rc;
@@ -1593,7 +1546,6 @@ UMEREG_API int umereg_pair_match_graph_create_ex(const float* pts, const float* 
     *graph_out = nullptr;
     if (int rc = check_device()) return rc;
     hipStream_t st = (hipStream_t)stream;
-    (void)side_lane(kCaptureLane);          // (streams and events are created outside the capture)
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         set_error("pair_match_graph_create: hipStreamBeginCapture failed");
@@ -1637,7 +1589,6 @@ UMEREG_API int umereg_pair_match_graph_create_cap(int N_cap, int n_kp, int K, fl
     *graph_out = nullptr;
     if (int rc = check_device()) return rc;
     hipStream_t st = (hipStream_t)stream;
-    (void)side_lane(kCaptureLane);          // (streams and events are created outside the capture)
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         set_error("pair_match_graph_create_cap: hipStreamBeginCapture failed");
