@@ -2380,3 +2380,26 @@ def test_contracted_distance_mode_reproduces_the_cuda_form(gpu):
     assert not np.array_equal(a, b)                                  # the mode is not a no-op here
     with pytest.raises(RuntimeError, match="FMA_DIST"):
         ops.ume_moments(T_(pts, gpu)[None], T_(q, gpu)[None], T_(feat, gpu)[None], K, 5.0, acc="f64valu", fma_dist=True)
+
+
+def test_documented_ctypes_binding_of_the_ragged_entry(gpu):
+    """INTEGRATION.md section 3 shows a maintainer's own ctypes binding of `umereg_pair_match_ragged_f32` (evaluate.py:206-236 for a pair of
+    two cloud sizes).  The snippet is executed AS PRINTED there (extracted from the file) and must give what the ops layer gives."""
+    import ctypes
+    import re
+    from types import SimpleNamespace
+    from umeregrobust_amd import _build, ops
+    from umeregrobust_amd.synth import synth_pair
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(def pair_match\(.*?)```", text, re.S).group(1)
+    lib = ctypes.CDLL(_build.LIB_PATH)
+    lib.umereg_last_error.restype = ctypes.c_char_p
+    ns = {"ctypes": ctypes, "torch": torch, "lib": lib}
+    exec(code, ns)
+    p = synth_pair(77, n_src=6100, n_tgt=4321, n_kp=700)
+    c = [T_(x, gpu) for x in (p.src_pts, p.tgt_pts, p.src_feat, p.tgt_feat, p.src_inds, p.tgt_inds)]
+    args = SimpleNamespace(ume_max_nn=750, ume_r_nn=5.0, tau=0.05)
+    with torch.cuda.device(gpu):
+        F, m, d, prob = ns["pair_match"](*c, args)
+    want = ops.pair_match_ragged(*c, 750, 5.0, tau=0.05)
+    assert torch.equal(F, want[0]) and torch.equal(m, want[1][0]) and torch.equal(d, want[2][0]) and torch.equal(prob, want[3])
