@@ -385,3 +385,39 @@ def test_valu_issue_floor_prices_every_instruction_once():
         floor_s, cls = bench.valu_issue_floor_s(k["counters"], json.load(open(vr)))
         dur_s = k["duration_shader_clocks"] / 2.4e9                              # (at most this long: the clock is <= 2.4 GHz)
         assert 0.3 * dur_s < floor_s < dur_s and cls["packed_f32"][0] > 0
+
+
+def test_ragged_synthetic_pairs_contract():
+    """synth_pair / synth_pair_hard with n_src != n_tgt (what the reference's collate produces: datasets/kitti/kitti_dataset.py:568-569
+    dilutes the two clouds independently; evaluate.py:195-204 draws min(10000, N_src, N_tgt) keypoints from each): sizes, keypoint rule,
+    twins really are the same scene point under the ground-truth transform -- and the equal-size generators are untouched (same arrays as
+    before the ragged form existed: the goldens and the bench's pair pool depend on them)."""
+    import hashlib
+    from umeregrobust_amd.synth import ragged_sizes, synth_pair, synth_pair_hard
+    for f in (synth_pair, synth_pair_hard):
+        p = f(3, n_src=5000, n_tgt=4130, n_kp=10000)
+        assert p.src_pts.shape == (5000, 3) and p.tgt_pts.shape == (4130, 3) and p.src_feat.shape == (5000, 32) and p.tgt_feat.shape == (4130, 32)
+        assert p.src_inds.shape == p.tgt_inds.shape == (4130,) and p.src_inds.max() < 5000 and p.tgt_inds.max() < 4130
+        assert len(np.unique(p.src_inds)) == 4130 and p.tgt_twin_of_src.shape == (5000,) and p.tgt_twin_of_src.max() < 4130
+        ok = p.tgt_twin_of_src >= 0
+        assert 0.2 < ok.mean() < 0.95
+        moved = p.src_pts[ok] @ p.gt_tform[:3, :3].T + p.gt_tform[:3, 3]
+        assert np.abs(moved - p.tgt_pts[p.tgt_twin_of_src[ok]]).max() < (1e-4 if f is synth_pair else 0.2)       # (hard pairs carry 2 cm noise)
+    q = synth_pair(9, n_src=3000, n_tgt=7000, n_kp=800)
+    assert q.src_inds.shape == (800,) and q.src_pts.shape[0] == 3000 and q.tgt_pts.shape[0] == 7000
+    sizes = [ragged_sizes(i) for i in range(64)]
+    assert all(35000 <= a <= 50000 and 35000 <= b <= 50000 for a, b in sizes) and len({a for a, _ in sizes}) > 50 and sizes == [ragged_sizes(i) for i in range(64)]
+    assert sum(a != b for a, b in sizes) >= 63
+    # the equal-size generators: byte-identical to rounds 1-5 (pinned digests)
+    assert hashlib.sha1(synth_pair(3, N=4096, n_kp=256).tgt_pts.tobytes()).hexdigest()[:12] == "4a5c3b6e64d6"
+    assert hashlib.sha1(synth_pair_hard(3, N=4096, n_kp=256).tgt_pts.tobytes()).hexdigest()[:12] == "b66a5c7db172"
+
+
+def test_variant_builds_carry_their_own_source_hash():
+    """An A/B build of the library (`-D...` switches, tools/lib*.so) embeds a hash that covers its flags: a counter pass taken on it cannot
+    pass for a profile of the product library (bench.py: counters_match_library)."""
+    from umeregrobust_amd import _build
+    a, b = _build.source_hash(), _build.source_hash(["-DUMEREG_MOM_ABLATE=1"])
+    assert a != b and a == _build.source_hash(()) and len(b) == 64
+    with pytest.raises(ValueError, match="its own `out`"):
+        _build.build_native(extra_flags=["-DUMEREG_MOM_ABLATE=1"])
